@@ -1,0 +1,171 @@
+"""The CPU oracle against the golden vectors produced from the reference's own function bodies
+(tests/golden/make_goldens.py).  No GPU."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import bm25_ref, dense_ref, rerank_ref
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _load(name):
+    with open(os.path.join(G, name), encoding="utf-8") as f:
+        return json.load(f)
+
+
+# ------------------------------------------------------------------ BM25 known answers
+@pytest.mark.parametrize("case", _load("bm25_kat.json"), ids=lambda c: c["name"])
+def test_bm25_known_answers(case):
+    postings = {t: [tuple(p) for p in pl] for t, pl in case["postings"].items()}
+    doc_len = {int(d): l for d, l in case["doc_len"].items()}
+    ix, vocab = bm25_ref.index_from_tables(postings, doc_len, case["idf_f32"], case["avgdl_f32"])
+    urls_db = {int(d): tuple(v) for d, v in case["urls_db"].items()}
+    for q in case["queries"]:
+        ids = [vocab.get(t, -1) for t in q["terms"]]
+        for fn in (bm25_ref.topk, bm25_ref.topk_literal):
+            idx, sc = fn(ix, ids, 10 ** 6, q["min_score"], case["k1"], case["b"])
+            assert len(idx) == len(set(idx.tolist()))
+        got = bm25_ref.search(ix, ids, q["top_k"], q["min_score"], urls_db, case["k1"], case["b"])
+        assert got == q["expected"], (case["name"], q["terms"])     # bitwise: float64 == float64
+
+
+@pytest.mark.parametrize("name", ["bm25_random_a", "bm25_random_b"])
+def test_bm25_random_corpus(name):
+    ix = dict(np.load(os.path.join(G, name + ".npz")))
+    meta = _load(name + ".json")
+    missing = set(meta["missing_from_urlsdb"])
+    urls_db = {int(d): ("t", "x") for d in ix["doc_ids"] if int(d) not in missing}
+    for qi, q in enumerate(meta["queries"]):
+        got = bm25_ref.search(ix, q["terms"], q["top_k"], q["min_score"], urls_db)
+        assert [r["doc_id"] for r in got] == q["doc_id"]
+        assert [r["score"] for r in got] == q["score"]            # exact float64 equality
+        if qi % 9 == 0:                                             # literal form agrees too
+            a = bm25_ref.topk(ix, q["terms"], q["top_k"], q["min_score"])
+            b = bm25_ref.topk_literal(ix, q["terms"], q["top_k"], q["min_score"])
+            assert a[0].tolist() == b[0].tolist() and a[1].tolist() == b[1].tolist()
+
+
+# ------------------------------------------------------------------ cosine
+def test_cosine_matches_sklearn_float32():
+    z = np.load(os.path.join(G, "cosine.npz"))
+    assert str(z["expected_dtype"]) == "float32"
+    got = rerank_ref.cosine_f32(z["q"], z["E"])
+    assert got.dtype == np.float32
+    np.testing.assert_allclose(got, z["expected"], rtol=0, atol=1e-6)
+    assert got[7] == 0.0                                            # zero row -> 0, not NaN
+    assert abs(float(got[123]) - float(z["single_123"])) < 1e-6
+
+
+# ------------------------------------------------------------------ rerank chain
+def _case_tables(c):
+    z = np.load(os.path.join(G, f"rerank_{c['case']}.npz"))
+    urls = {int(u[0]): (u[1], u[2], u[3]) for u in c["urls"]}
+    order = np.lexsort((z["chunk_id"], z["chunk_doc"]))
+    return urls, z["chunk_id"][order], z["chunk_doc"][order], z["emb"][order], z["q"]
+
+
+def _assert_ranked_equal(got, exp, tol):
+    """Same documents in the same order, except inside groups of (near-)equal scores."""
+    assert len(got) == len(exp)
+    gs = np.array([g[1] for g in got]); es = np.array([e[1] for e in exp])
+    np.testing.assert_allclose(gs, es, rtol=0, atol=tol)
+    i = 0
+    while i < len(exp):
+        j = i + 1
+        while j < len(exp) and abs(es[j] - es[j - 1]) <= 2 * tol:
+            j += 1
+        assert sorted(g[0] for g in got[i:j]) == sorted(e[0] for e in exp[i:j]), (i, j)
+        i = j
+
+
+@pytest.mark.parametrize("c", _load("rerank_chain.json")["cases"], ids=lambda c: f"case{c['case']}")
+def test_rerank_chain(c):
+    urls, cid, cdoc, emb, q = _case_tables(c)
+    st = {}
+    names = ["cos", "cos_norm", "bm25_norm", "blend", None, "positional"]
+    chunk_stages = [s for s in c["stages"] if s["target"] != "reranked_documents"]
+    assert len(chunk_stages) == len(names)
+    for div in (False, True):
+        resp, stages = rerank_ref.rerank(urls, cid, cdoc, emb, q, c["doc_ids"], c["similarities"],
+                                         diversification=div, return_stages=True)
+        exp = c["response"]["div" if div else "nodiv"]
+        assert resp["total_documents"] == exp["total_documents"] and resp["total_windows"] == exp["total_windows"]
+        _assert_ranked_equal([(d["doc_id"], d["similarity_score"]) for d in resp["document_scores"]],
+                             [(d["doc_id"], d["similarity_score"]) for d in exp["document_scores"]], 2e-6)
+        gmap = {d["doc_id"]: d for d in resp["document_scores"]}
+        for e in exp["document_scores"]:
+            g = gmap[e["doc_id"]]
+            assert (g["title"], g["url"], g["window_index"]) == (e["title"], e["url"], e["window_index"])
+            assert abs(g["original_similarity"] - e["original_similarity"]) < 1e-12
+        wmap = {w["doc_id"]: w for w in resp["top_windows"]}
+        for w in exp["top_windows"]:
+            assert abs(wmap[w["doc_id"]]["similarity_score"] - w["similarity_score"]) < 2e-6
+            assert wmap[w["doc_id"]]["window_index"] == w["window_index"]
+    # chunk-level stages: reference rows are ordered (doc_id, chunk_id) before AND after the groupby
+    rows = stages["rows"]
+    for name, s in zip(names, chunk_stages):
+        if name is None:
+            continue
+        assert list(zip(s["doc_id"], s["chunk_id"])) == rows
+        col = "old_similarity" if name == "bm25_norm" else "new_similarity"
+        np.testing.assert_allclose(stages[name], s[col], rtol=0, atol=2e-6)
+    pooled = c["stages"][-1]
+    _assert_ranked_equal([(p[0], p[2]) for p in stages["pooled"]],
+                         list(zip(pooled["doc_id"], pooled["new_similarity"])), 2e-6)
+
+
+def test_rerank_empty_is_401():
+    assert _load("rerank_chain.json")["empty_error"] == {"type": "HTTPException", "status_code": 401}
+    with pytest.raises(LookupError):
+        rerank_ref.rerank({}, np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros((0, 768), np.float32),
+                          np.ones(768, np.float32), ["1", "2"], [1.0, 0.5])
+
+
+# ------------------------------------------------------------------ diversification / windows
+def test_diversification():
+    d = _load("diversification.json")
+    for c in d["cases"]:
+        docs = [{"doc_id": str(i), "url": u, "similarity_score": s} for i, u, s in c["input"]]
+        got = rerank_ref.hybrid_diversification(docs, top_k=c["top_k"])
+        assert [[int(x["doc_id"]), x["similarity_score"]] for x in got] == c["expected"]
+    for c in d["domain_cap"]:
+        docs = [{"doc_id": i, "url": u, "similarity_score": s} for i, u, s in c["input"]]
+        kept, dropped = rerank_ref.apply_domain_cap(docs, 2)
+        assert [x["doc_id"] for x in kept] == c["kept"] and [x["doc_id"] for x in dropped] == c["dropped"]
+    for u, dom in d["extract_domain"]:
+        assert rerank_ref.extract_domain(u) == dom
+
+
+def test_sliding_windows():
+    for c in _load("windows.json"):
+        wins = rerank_ref.create_sliding_windows(list(range(c["n"])), c["window"], c["step"])
+        assert [w[0] if w else -1 for w in wins] == c["starts"]
+        assert [len(w) for w in wins] == c["lens"]
+
+
+# ------------------------------------------------------------------ dense full scan (self-consistency)
+def test_dense_quick_search_matches_bruteforce():
+    rng = np.random.default_rng(3)
+    n = rng.integers(0, 7, size=200)
+    doc_off = np.zeros(201, np.int64); doc_off[1:] = np.cumsum(n)
+    emb = rng.standard_normal((int(doc_off[-1]), 768)).astype(np.float32)
+    emb /= np.linalg.norm(emb, axis=1, keepdims=True)
+    q = rng.standard_normal(768).astype(np.float32) * 4
+    for mc in (0, 3):
+        idx, sc, arg = dense_ref.quick_search(emb, doc_off, q, 20, mc)
+        cos = rerank_ref.cosine_f32(q, emb)
+        brute = []
+        for d in range(200):
+            lo, hi = doc_off[d], doc_off[d + 1]
+            if mc:
+                hi = min(hi, lo + mc)
+            if hi > lo:
+                j = lo + int(np.argmax(cos[lo:hi]))
+                brute.append((-float(cos[j]), d, j))
+        brute.sort()
+        assert idx.tolist() == [b[1] for b in brute[:20]]
+        assert arg.tolist() == [b[2] for b in brute[:20]]
+        assert np.all(np.diff(sc) <= 0)
