@@ -1,0 +1,148 @@
+/*
+ * msretr.h -- C ABI of the MI355X-native two-stage retriever (libmsretr.so).
+ *
+ * The reference (StephenTaf/Modern-Search-Engines-Project) has no FFI / plugin interface: its query path
+ * is three Python call sites.  Each entry point below replaces one of them and is what a binding for that
+ * call site would bind (see INTEGRATION.md for the ctypes stubs):
+ *
+ *   msr_bm25_topk   <- BM25.search scoring loop + sort + cut      indexer/bm25_indexer.py:434-488
+ *   msr_dense_topk  <- Retriever.quick_search (dense full scan)   search_api.py:60,87 (retriever.py absent;
+ *                      cosine reranker/reranker_api.py:285, per-doc max :370, report p.2)
+ *   msr_rerank      <- /rerank endpoint arithmetic                reranker/reranker_api.py:27-63,273-334,357-372
+ *   msr_merge_topk  <- (new) merge of per-shard top-k after the RCCL all-gather; no reference counterpart
+ *   msr_bind_*      <- the per-query SQL fetches, done ONCE        bm25_indexer.py:413-448, reranker_api.py:36-61
+ *
+ * Conventions
+ *   - Every function returns 0 on success or a negative msr_status; it never throws and never returns
+ *     memory the caller has to free.  msr_last_error() gives the text of the last failure.
+ *   - All array arguments are DEVICE pointers into HBM of the engine's device unless marked [host].
+ *     The caller owns them (typically torch tensors: tensor.data_ptr()) and must keep the bound index
+ *     arrays alive until msr_destroy / the next msr_bind_*.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).  Work is only
+ *     enqueued; nothing synchronises.  Results are valid once the stream has drained.
+ *   - A document is addressed by its dense index: the rank of its doc_id in ascending order, so
+ *     "ascending index" == "ascending doc_id" (the reference's tie order, bm25_indexer.py:445,484).
+ *     A shard adds `doc_base` to its local indices before the merge.
+ *   - One engine per (device, stream); an engine is not thread-safe, distinct engines are independent.
+ */
+#ifndef MSRETR_H
+#define MSRETR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSR_ABI_VERSION 1
+#define MSR_DIM 768               /* config.py:2 EMBEDDING_DIMENSION */
+#define MSR_MAX_K 1024            /* config.py:13 TOP_K_RETRIEVAL = 1000 */
+#define MSR_MAX_QUERY_TERMS 64
+#define MSR_RERANK_MAX_CHUNKS 10  /* reranker_api.py:58 */
+
+typedef enum msr_status {
+    MSR_OK = 0,
+    MSR_ERR_INVALID = -1,    /* bad argument (null pointer, size out of range, wrong dim) */
+    MSR_ERR_NOT_BOUND = -2,  /* the index part this call needs has not been bound */
+    MSR_ERR_HIP = -3,        /* a HIP runtime call failed; text in msr_last_error */
+    MSR_ERR_NOMEM = -4       /* scratch allocation failed */
+} msr_status;
+
+typedef struct msr_engine msr_engine;
+
+typedef struct msr_config {
+    int32_t struct_size;      /* sizeof(msr_config), for forward compatibility */
+    int32_t device;           /* HIP device ordinal */
+    int32_t dim;              /* must be MSR_DIM */
+    int32_t max_queries;      /* queries processed per internal slice; scratch is sized for this many */
+    int32_t max_k;            /* largest k any call will ask for, <= MSR_MAX_K */
+    int32_t rerank_max_docs;  /* largest candidate list per query for msr_rerank, <= 1024 */
+    int32_t scan_layout;      /* 0 = row-major embeddings; 1 = 16-row interleaved */
+    int32_t reserved;
+} msr_config;
+
+/* BM25 parameters travel with the postings (bm25_indexer.py:57 k1=1.2, b=0.75). */
+typedef struct msr_rerank_params {
+    double smoothing;          /* reranker/config.yaml:28   0.15 */
+    double max_boost;          /* reranker_api.py:317       0.10 */
+    double max_decay;          /* reranker_api.py:318       0.05 */
+    int32_t max_chunks;        /* reranker_api.py:58        10   */
+    int32_t reserved;
+} msr_rerank_params;
+
+int msr_abi_version(void);
+int msr_create(const msr_config* cfg, msr_engine** out);
+int msr_destroy(msr_engine* e);
+/* e may be NULL: returns the text of the last failed msr_create on this thread. */
+const char* msr_last_error(const msr_engine* e);
+
+/* Stage-1 index: CSR postings over the dense doc index, sorted by doc inside each term.
+ *   term_off[n_terms+1] i64, post_doc[n_postings] i32, post_tf[n_postings] i32   bm25_term_freq  (:97-104)
+ *   doc_len[n_docs] i32                                                          bm25_doc_stats  (:88-94)
+ *   idf[n_terms] f32 (as stored: REAL, may be negative)                          bm25_term_stats (:106-113)
+ *   avgdl f32 (REAL)                                                             bm25_corpus_stats (:116-122)
+ */
+int msr_bind_postings(msr_engine* e, const int64_t* term_off, int64_t n_terms, const int32_t* post_doc,
+                      const int32_t* post_tf, int64_t n_postings, const int32_t* doc_len, int64_t n_docs,
+                      const float* idf, float avgdl, double k1, double b, void* stream);
+
+/* Stage-2 index: chunk embeddings sorted by (doc index, chunk_id); doc d owns rows
+ * [doc_off[d], doc_off[d+1]).  emb is f32 [n_chunks][768] row-major (scan_layout 0) or the interleaved
+ * image produced by msr_interleave_rows (scan_layout 1).  inv_norm[n_chunks] f32 = 1/||row|| (0-norm -> 1),
+ * or NULL to have the engine compute it.       indexer/embedder.py:31-52, indexer/indexer.py:165 */
+int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks, const int32_t* doc_off,
+                    int64_t n_docs, const float* inv_norm, void* stream);
+
+/* Per-document metadata the rerank stage needs: url_group[n_docs] i32 = id of the document's URL with
+ * the query string removed, or -1 when the document is not in urlsDB.   reranker_api.py:38-47 */
+int msr_bind_doc_meta(msr_engine* e, const int32_t* url_group, int64_t n_docs, void* stream);
+
+/* Re-order row-major rows into the 16-row interleaved scan layout (dst may not alias src).
+ * n_rows is padded up to a multiple of 16 in dst (pad rows zero): dst holds ceil16(n_rows)*768 floats. */
+int msr_interleave_rows(msr_engine* e, const float* src, int64_t n_rows, float* dst, void* stream);
+
+/* BM25 top-k for Q queries.  Query q owns q_terms/q_qtf[q_term_off[q] .. q_term_off[q+1]): its UNIQUE
+ * term ids in first-occurrence order and how often each occurs in the query (bm25_indexer.py:405-409);
+ * ids outside [0, n_terms) or with empty posting lists are skipped (:430).  Scores are float64 and
+ * bit-identical to the reference's accumulation order (:466-478).  A document is a candidate only if at
+ * least one posting touched it and score >= min_score (:461,480).  Output row q holds out_n[q] <= k
+ * entries ordered by (score desc, doc index asc) (:484-485); the rest of the row is -1 / -inf. */
+int msr_bm25_topk(msr_engine* e, const int32_t* q_term_off, const int32_t* q_terms, const int32_t* q_qtf,
+                  int32_t n_queries, int32_t k, double min_score, int32_t* out_doc, double* out_score,
+                  int32_t* out_n, void* stream);
+
+/* Dense full scan for Q queries: score(d) = max over the document's first `max_chunks_per_doc` chunks
+ * (0 = all) of cosine(q, chunk), cosine as sklearn computes it in float32 (reranker_api.py:285).
+ * q is [n_queries][768] f32, NOT normalised (reranker_api.py:355).  Output rows as for msr_bm25_topk,
+ * with float32 scores and out_chunk = row index of the arg-max chunk (first maximum). */
+int msr_dense_topk(msr_engine* e, const float* q, int32_t n_queries, int32_t k, int32_t max_chunks_per_doc,
+                   int32_t* out_doc, float* out_score, int32_t* out_chunk, int32_t* out_n, void* stream);
+
+/* Rerank/fuse of stage-1 candidates, reranker_api.py:337-372.  Query qi has cand_n[qi] <= max_cand
+ * candidates in row qi of cand_doc / cand_bm25 (any order).  Candidates not in urlsDB, losing the URL
+ * dedup (MIN(id) wins) or without chunks are dropped; the others come back ordered by
+ * (new_similarity desc, doc index asc): out_doc, out_score (new_similarity), out_orig (min-max
+ * normalised BM25 of the winning row), out_chunk (row index of the winning chunk), out_n, and
+ * out_rows[qi] = number of chunk rows that took part (RerankResponse.total_documents, :410). */
+int msr_rerank(msr_engine* e, const float* q, int32_t n_queries, const int32_t* cand_doc,
+               const double* cand_bm25, const int32_t* cand_n, int32_t max_cand,
+               const msr_rerank_params* params, int32_t* out_doc, double* out_score, double* out_orig,
+               int32_t* out_chunk, int32_t* out_n, int32_t* out_rows, void* stream);
+
+/* Merge n_parts per-shard top-k lists (the payload of the RCCL all-gather) into the global top-k.
+ * in_doc [n_parts][n_queries][k] i32 GLOBAL doc indices, in_score same shape (score_bits = 32: f32,
+ * 64: f64), in_n [n_parts][n_queries].  Order: score desc, doc index asc -- identical on every rank. */
+int msr_merge_topk(msr_engine* e, const int32_t* in_doc, const void* in_score, const int32_t* in_n,
+                   int32_t n_parts, int32_t n_queries, int32_t k, int32_t score_bits, int32_t* out_doc,
+                   void* out_score, int32_t* out_n, void* stream);
+
+/* Timing hooks for bench.py: hipEvent-bracketed duration of the dominant kernel of the last
+ * msr_dense_topk / msr_bm25_topk call, recorded on the caller's stream.  msr_kernel_time_ms blocks on
+ * the stop event.  which: 0 = dense scan kernel, 1 = BM25 TAAT kernel. */
+int msr_set_timing(msr_engine* e, int32_t enabled);
+int msr_kernel_time_ms(msr_engine* e, int32_t which, float* out_ms, int32_t* out_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSRETR_H */

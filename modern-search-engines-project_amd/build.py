@@ -1,0 +1,66 @@
+"""Build recipe for libmsretr.so (HIP, gfx950 only) -- plain hipcc, no cmake.
+
+    python -m msretr.build            # or: from msretr.build import build_library; build_library()
+
+The shared library is written next to the sources (csrc/libmsretr.so) so that it travels with the tree.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "libmsretr.so")
+ARCH = "gfx950"
+
+# translation unit -> extra flags.  The float64 paths must not fuse a*b+c (Python does not).
+UNITS = {
+    "msr_engine.hip": [],
+    "msr_topk.hip": [],
+    "msr_bm25.hip": ["-ffp-contract=off"],
+    "msr_dense.hip": [],
+    "msr_rerank.hip": ["-ffp-contract=off"],
+}
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force=False, verbose=False, save_temps=False):
+    hipcc = _hipcc()
+    headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
+    headers.append(os.path.join(HERE, "..", "include", "msretr.h"))
+    objs = []
+    for src, extra in UNITS.items():
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            cmd = [hipcc] + COMMON + extra + ["-c", s, "-o", o]
+            if save_temps:
+                cmd.insert(1, "-save-temps=obj")
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True, cwd=CSRC)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True, save_temps="--save-temps" in sys.argv))

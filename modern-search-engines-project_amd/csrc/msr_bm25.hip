@@ -1,0 +1,117 @@
+// K1 -- BM25 term-at-a-time scoring over HBM-resident CSR postings (gfx950).
+//
+// Replaces the per-query SQL fetch + Python grouping + scoring loop of the reference
+// (indexer/bm25_indexer.py:434-481).  The dense doc index is cut into tiles of TILE documents; one
+// workgroup owns one (tile, query) pair and keeps the tile's float64 accumulators in LDS.  For each query
+// term, IN QUERY ORDER, it locates the tile's slice of the term's posting list (wave-wide 64-ary search)
+// and streams it with coalesced loads; a document occurs at most once per posting list
+// (PRIMARY KEY (doc_id, term), :100-104), so the read-modify-write of acc[doc] needs no atomics, and a
+// barrier between terms makes the float64 summation order equal to the reference's (:466-478).
+// The arithmetic is written operation by operation as Python evaluates it and this file is compiled with
+// -ffp-contract=off, so scores are bit-identical to the oracle.
+//
+// HBM traffic per query: 8 B per posting of the query's terms + 4 B per document (doc_len) + 8 B per
+// document (dense float64 score row consumed by the top-k select).
+#include "msr_common.h"
+#include "msr_internal.h"
+
+namespace {
+
+constexpr int BM25_TILE = 4096;
+constexpr int BM25_THREADS = 256;
+constexpr uint64_t UNTOUCHED = 0x7FF8DEADBEEF0001ull;   // a quiet-NaN payload no computation produces
+
+// First index in [s, e) with a[idx] >= target (e if none).  Executed by one full wave.
+__device__ __forceinline__ int64_t wave_lower_bound(const int32_t* __restrict__ a, int64_t s, int64_t e,
+                                                    int32_t target) {
+    const int lane = threadIdx.x & 63;
+    while (e - s > 64) {
+        const int64_t len = e - s;
+        const int64_t chunk = (len + 63) >> 6;
+        int64_t idx = s + (int64_t)(lane + 1) * chunk - 1;
+        if (idx > e - 1) idx = e - 1;
+        const bool ge = a[idx] >= target;
+        const unsigned long long m = __ballot(ge);
+        if (m == 0) return e;
+        const int f = __ffsll((long long)m) - 1;
+        const int64_t idx_f = __shfl(idx, f);
+        const int64_t idx_p = __shfl(idx, f > 0 ? f - 1 : 0);
+        if (f > 0) s = idx_p + 1;
+        e = idx_f;                                   // a[idx_f] >= target: the answer is in [s, idx_f]
+        if (e <= s) return s;
+    }
+    const int64_t i = s + lane;
+    const bool ge = i < e && a[i] >= target;
+    const unsigned long long m = __ballot(ge);
+    if (m == 0) return e;
+    return s + (__ffsll((long long)m) - 1);
+}
+
+__global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
+                                                                  const int32_t* __restrict__ q_term_off,
+                                                                  const int32_t* __restrict__ q_terms,
+                                                                  const int32_t* __restrict__ q_qtf,
+                                                                  int q_first, double min_score,
+                                                                  double* __restrict__ scores) {
+    __shared__ double acc[BM25_TILE];
+    __shared__ int32_t dl[BM25_TILE];
+    __shared__ int64_t slice[2];
+    const int tid = threadIdx.x;
+    const int q = blockIdx.y;                        // row of `scores`
+    const int64_t lo = (int64_t)blockIdx.x * BM25_TILE;
+    const int64_t hi = lo + BM25_TILE < ix.n_docs ? lo + BM25_TILE : ix.n_docs;
+    const int n = (int)(hi - lo);
+    for (int i = tid; i < BM25_TILE; i += BM25_THREADS) {
+        acc[i] = __longlong_as_double((long long)UNTOUCHED);
+        dl[i] = i < n ? ix.doc_len[lo + i] : 0;
+    }
+    const double k1 = ix.k1, b = ix.b, avgdl = ix.avgdl;
+    const double k1p1 = k1 + 1.0;                    // self.k1 + 1
+    const double omb = 1.0 - b;                      // 1 - self.b
+    const int t0 = q_term_off[q_first + q], t1 = q_term_off[q_first + q + 1];
+    __syncthreads();
+    for (int j = t0; j < t1; ++j) {
+        const int32_t t = q_terms[j];
+        if (t < 0 || t >= ix.n_terms) continue;      // block-uniform
+        const int64_t s = ix.term_off[t], e = ix.term_off[t + 1];
+        if (e <= s) continue;
+        if (tid < 64) {
+            const int64_t ps = wave_lower_bound(ix.post_doc, s, e, (int32_t)lo);
+            const int64_t pe = wave_lower_bound(ix.post_doc, ps, e, (int32_t)hi);
+            if (tid == 0) { slice[0] = ps; slice[1] = pe; }
+        }
+        __syncthreads();
+        const int64_t ps = slice[0], pe = slice[1];
+        const double idf = (double)ix.idf[t];
+        const double qtf = (double)q_qtf[j];
+        for (int64_t i = ps + tid; i < pe; i += BM25_THREADS) {
+            const int d = ix.post_doc[i] - (int32_t)lo;
+            const double tf = (double)ix.post_tf[i];
+            const double dlen = (double)dl[d];
+            // tf_component = (tf * (k1 + 1)) / (tf + k1 * (1 - b + b * doc_length / avg_doc_length))
+            const double comp = (tf * k1p1) / (tf + k1 * (omb + (b * dlen) / avgdl));
+            // term_score = idf * tf_component * query_term_freq[term]; bm25_score += term_score
+            const double c = (idf * comp) * qtf;
+            const double a = acc[d];
+            acc[d] = ((uint64_t)__double_as_longlong(a) == UNTOUCHED ? 0.0 : a) + c;
+        }
+        __syncthreads();
+    }
+    double* row = scores + (int64_t)q * ix.n_docs + lo;
+    for (int i = tid; i < n; i += BM25_THREADS) {
+        const double a = acc[i];
+        const bool touched = (uint64_t)__double_as_longlong(a) != UNTOUCHED;
+        row[i] = (touched && a >= min_score) ? a : -__builtin_inf();
+    }
+}
+
+}  // namespace
+
+hipError_t msr_bm25_scores(const Bm25Index& ix, const int32_t* q_term_off, const int32_t* q_terms,
+                           const int32_t* q_qtf, int q_first, int nq, double min_score, double* scores,
+                           hipStream_t stream) {
+    if (nq <= 0 || ix.n_docs <= 0) return hipSuccess;
+    dim3 grid((unsigned)((ix.n_docs + BM25_TILE - 1) / BM25_TILE), (unsigned)nq);
+    bm25_taat_kernel<<<grid, BM25_THREADS, 0, stream>>>(ix, q_term_off, q_terms, q_qtf, q_first, min_score, scores);
+    return hipGetLastError();
+}

@@ -1,0 +1,333 @@
+// K2 + K3 -- query x chunk cosine over the whole embedding matrix with a fused per-document max-pool.
+//
+// Replaces the reference's cosine_similarity calls (reranker/reranker_api.py:273-287) and per-document
+// arg-max (:370) at full-corpus scale, i.e. the missing Retriever.quick_search (search_api.py:60,87).
+//
+// Shape of the work: E is [C][768] f32 (15.36 GB at C = 5 M) and is read exactly once per launch for up to
+// 32 queries -> HBM-bound (arithmetic intensity Q/2 flop/B).  The dot products run on the exact-f32 matrix
+// cores: v_mfma_f32_16x16x4_f32 with 16 chunk rows as the A operand and 16 queries as the B operand, so
+// each lane needs ONE f32 of E per MFMA and a 16 B/lane global load feeds four MFMAs.  The k index of an
+// MFMA is only a label: lane (i = lane & 15, g = lane >> 4) loads E[row i][16t + 4g .. +3] and the query
+// image in LDS is stored in the same permuted order, so no data ever moves between lanes.
+//
+// Work decomposition: the document range is cut into `n_spans` spans with equal chunk counts, at
+// document boundaries; one persistent workgroup (16 waves) per span.  Inside a span a super-tile is
+// 16 waves x 16 rows = 256 chunk rows: each wave multiplies its 16 rows against all queries, writes the
+// 16 x Q scores to LDS, and after a barrier the workgroup reduces the chunk scores to per-document maxima
+// (segments are contiguous; a document that crosses a super-tile boundary is carried in LDS).  Documents
+// never cross spans, so no inter-workgroup communication exists.
+#include "msr_common.h"
+#include "msr_internal.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SCAN_WAVES = 16;
+constexpr int SCAN_THREADS = SCAN_WAVES * 64;
+constexpr int ST_ROWS = SCAN_WAVES * 16;            // rows per super-tile
+constexpr int KSTEPS = MSR_DIM / 16;                // 48 float4 per lane per row group
+
+template <int QB> struct ScanLds {
+    static constexpr int NQP = 16 * QB;                         // padded query count
+    static constexpr int SROW = NQP + 1;                        // sbuf row stride in floats (bank spread)
+    static constexpr size_t q_bytes = (size_t)QB * KSTEPS * 64 * 16;
+    static constexpr size_t s_bytes = (size_t)ST_ROWS * SROW * 4;
+    static constexpr size_t c_bytes = (size_t)2 * NQP * 4;
+    static constexpr size_t total = q_bytes + ((s_bytes + 15) & ~(size_t)15) + c_bytes;
+};
+
+template <int QB, bool TILED>
+__global__ __launch_bounds__(SCAN_THREADS) void dense_scan_kernel(DenseIndex ix, const float* __restrict__ qn,
+                                                                   int nq, int max_chunks,
+                                                                   float* __restrict__ docscore) {
+    using L = ScanLds<QB>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* Qs = (f32x4*)smem;                                   // [QB][KSTEPS][64] fragment order
+    float* sbuf = (float*)(smem + L::q_bytes);                  // [ST_ROWS][SROW]
+    float* carry = (float*)(smem + L::q_bytes + ((L::s_bytes + 15) & ~(size_t)15));   // [2][NQP]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = tid >> 6;
+    const int li = lane & 15;                                   // row inside the wave's 16-row group
+    const int lg = lane >> 4;                                   // k sub-block 0..3
+
+    // Query image: Qs[qb][t][l] = qn[16 qb + (l & 15)][16 t + 4 (l >> 4) .. +3]
+    for (int idx = tid; idx < QB * KSTEPS * 64; idx += SCAN_THREADS) {
+        const int l = idx & 63;
+        const int t = (idx >> 6) % KSTEPS;
+        const int qb = idx / (KSTEPS * 64);
+        Qs[idx] = *(const f32x4*)(qn + (size_t)(16 * qb + (l & 15)) * MSR_DIM + 16 * t + 4 * (l >> 4));
+    }
+    __syncthreads();
+
+    const int64_t N = ix.n_docs;
+    const int64_t C = ix.n_chunks;
+    const float NEG_INF = -__builtin_inff();
+
+    for (int s = blockIdx.x; s < ix.n_spans; s += gridDim.x) {
+        const int d0 = ix.span_doc[s], d1 = ix.span_doc[s + 1];
+        const int64_t c0 = ix.doc_off[d0], c1 = ix.doc_off[d1];
+        // chunk-less documents get -inf for every query
+        for (int d = d0 + tid; d < d1; d += SCAN_THREADS)
+            if (ix.doc_off[d + 1] == ix.doc_off[d])
+                for (int qq = 0; qq < nq; ++qq) docscore[(int64_t)qq * N + d] = NEG_INF;
+        int parity = 0;
+        for (int64_t st = c0 & ~(int64_t)15; st < c1; st += ST_ROWS) {
+            // ---- phase 1: 16 rows x NQP queries per wave on the f32 matrix cores -------------------
+            const int64_t row0 = st + 16 * w;
+            if (row0 < c1) {                                     // wave-uniform
+                const f32x4* p;
+                if (TILED) {
+                    p = (const f32x4*)(ix.emb + (size_t)(row0 >> 4) * (16 * MSR_DIM)) + lane;
+                } else {
+                    int64_t r = row0 + li;
+                    if (r > C - 1) r = C - 1;                    // clamp: masked out in phase 2
+                    p = (const f32x4*)(ix.emb + (size_t)r * MSR_DIM) + lg;
+                }
+                constexpr int PSTRIDE = TILED ? 64 : 4;          // f32x4 units between k-steps
+                f32x4 acc[QB];
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) acc[qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                // Register double buffer of LB k-steps: the loads of batch n+1 are in flight while the
+                // matrix cores consume batch n (a 16 B/lane global load is asynchronous until its wait).
+                constexpr int LB = 8;
+                constexpr int NBATCH = KSTEPS / LB;
+                f32x4 buf0[LB], buf1[LB];
+#pragma unroll
+                for (int u = 0; u < LB; ++u) buf0[u] = p[(size_t)u * PSTRIDE];
+                __builtin_amdgcn_sched_barrier(0);               // keep the loads ahead of the MFMAs
+#pragma unroll
+                for (int nb = 0; nb < NBATCH; ++nb) {
+                    if (nb + 1 < NBATCH) {
+#pragma unroll
+                        for (int u = 0; u < LB; ++u) {
+                            const f32x4 x = p[(size_t)((nb + 1) * LB + u) * PSTRIDE];
+                            if (nb & 1) buf0[u] = x; else buf1[u] = x;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < LB; ++u) {
+                        const f32x4 a = (nb & 1) ? buf1[u] : buf0[u];
+                        const int t = nb * LB + u;
+#pragma unroll
+                        for (int qb = 0; qb < QB; ++qb) {
+                            const f32x4 bq = Qs[(qb * KSTEPS + t) * 64 + lane];
+                            acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq.x, acc[qb], 0, 0, 0);
+                            acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq.y, acc[qb], 0, 0, 0);
+                            acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq.z, acc[qb], 0, 0, 0);
+                            acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq.w, acc[qb], 0, 0, 0);
+                        }
+                    }
+                }
+                // D layout: lane holds rows 4*lg + reg, column (query) li
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    int64_t r = row0 + 4 * lg + reg;
+                    if (r > C - 1) r = C - 1;
+                    const float inv = ix.inv_norm[r];
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb)
+                        sbuf[(16 * w + 4 * lg + reg) * L::SROW + 16 * qb + li] = acc[qb][reg] * inv;
+                }
+            }
+            __syncthreads();
+            // ---- phase 2: per-document max over the rows of this super-tile -------------------------
+            {
+                const int pr = tid & (ST_ROWS - 1);
+                const int qg = tid >> 8;                         // 4 query groups of NQP/4
+                const int64_t r = st + pr;
+                const int64_t lo_valid = st > c0 ? st : c0;
+                const int64_t tile_end = st + ST_ROWS < c1 ? st + ST_ROWS : c1;
+                if (r >= lo_valid && r < tile_end) {
+                    const int d = ix.chunk_doc[r];
+                    const int64_t ds = ix.doc_off[d], de = ix.doc_off[d + 1];
+                    const int64_t first = ds > lo_valid ? ds : lo_valid;
+                    if (r == first) {                            // leader of document d in this tile
+                        const int64_t de_eff = (max_chunks > 0 && ds + max_chunks < de) ? ds + max_chunks : de;
+                        int64_t stop = de < tile_end ? de : tile_end;
+                        if (de_eff < stop) stop = de_eff;
+                        const bool continued = ds < lo_valid;    // started in an earlier super-tile
+                        const bool finished = de <= tile_end;
+                        constexpr int QPT = L::NQP / 4;
+#pragma unroll 1
+                        for (int u = 0; u < QPT; ++u) {
+                            const int qq = qg * QPT + u;
+                            if (qq >= nq) break;
+                            float m = continued ? carry[parity * L::NQP + qq] : NEG_INF;
+                            for (int64_t rr = r; rr < stop; ++rr)
+                                m = fmaxf(m, sbuf[(int)(rr - st) * L::SROW + qq]);
+                            if (finished) docscore[(int64_t)qq * N + d] = m;
+                            else carry[(parity ^ 1) * L::NQP + qq] = m;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            parity ^= 1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restrict__ q, int nq,
+                                                            float* __restrict__ qn, int nq_pad) {
+    // one wave per (padded) query row: qn = q / ||q||, zero norm -> divide by 1 (sklearn normalize)
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= nq_pad) return;
+    float v[12];
+    float ss = 0.f;
+    for (int j = 0; j < 12; ++j) {
+        v[j] = row < nq ? q[(size_t)row * MSR_DIM + lane + 64 * j] : 0.f;
+        ss += v[j] * v[j];
+    }
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    float nrm = sqrtf(ss);
+    if (nrm == 0.f) nrm = 1.f;
+    for (int j = 0; j < 12; ++j) qn[(size_t)row * MSR_DIM + lane + 64 * j] = v[j] / nrm;
+}
+
+__global__ void fill_chunk_doc_kernel(const int32_t* __restrict__ doc_off, int64_t n_docs,
+                                      int32_t* __restrict__ chunk_doc) {
+    const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_docs) return;
+    for (int64_t c = doc_off[d]; c < doc_off[d + 1]; ++c) chunk_doc[c] = (int32_t)d;
+}
+
+__global__ __launch_bounds__(256) void row_inv_norm_kernel(const float* __restrict__ emb, int64_t n_rows,
+                                                            float* __restrict__ inv_norm) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n_rows) return;
+    const f32x4* p = (const f32x4*)(emb + (size_t)row * MSR_DIM);
+    float ss = 0.f;
+    for (int j = 0; j < 3; ++j) {
+        const f32x4 v = p[lane + 64 * j];
+        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    float nrm = sqrtf(ss);
+    if (nrm == 0.f) nrm = 1.f;
+    if (lane == 0) inv_norm[row] = 1.0f / nrm;
+}
+
+// dst block (group, t) is 64 lanes x float4: lane l = 16 g + i holds src[16 group + i][16 t + 4 g .. +3]
+__global__ __launch_bounds__(256) void interleave_kernel(const float* __restrict__ src, int64_t n_rows,
+                                                          float* __restrict__ dst, int64_t n_vec) {
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n_vec;
+         v += (int64_t)gridDim.x * blockDim.x) {
+        const int l = (int)(v & 63);
+        const int64_t bt = v >> 6;
+        const int t = (int)(bt % KSTEPS);
+        const int64_t grp = bt / KSTEPS;
+        const int64_t r = grp * 16 + (l & 15);
+        f32x4 x = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (r < n_rows) x = *(const f32x4*)(src + (size_t)r * MSR_DIM + 16 * t + 4 * (l >> 4));
+        ((f32x4*)dst)[v] = x;
+    }
+}
+
+// One wave per (query, winner): recompute the winner's chunk cosines and report the first maximum.
+template <bool TILED>
+__global__ __launch_bounds__(64) void best_chunk_kernel(DenseIndex ix, const float* __restrict__ qn, int k,
+                                                         int max_chunks, const int32_t* __restrict__ out_doc,
+                                                         const int32_t* __restrict__ out_n,
+                                                         int32_t* __restrict__ out_chunk) {
+    const int q = blockIdx.y, r = blockIdx.x, lane = threadIdx.x;
+    if (r >= out_n[q]) {
+        if (lane == 0) out_chunk[(int64_t)q * k + r] = -1;
+        return;
+    }
+    const int d = out_doc[(int64_t)q * k + r];
+    const int64_t ds = ix.doc_off[d];
+    int64_t de = ix.doc_off[d + 1];
+    if (max_chunks > 0 && ds + max_chunks < de) de = ds + max_chunks;
+    float qv[12];
+    for (int j = 0; j < 12; ++j) qv[j] = qn[(size_t)q * MSR_DIM + lane + 64 * j];
+    float best = -__builtin_inff();
+    int64_t arg = -1;
+    for (int64_t c = ds; c < de; ++c) {
+        float s = 0.f;
+        for (int j = 0; j < 12; ++j) {
+            const int dim = lane + 64 * j;
+            size_t off;
+            if (TILED) {
+                const int t = dim >> 4, g = (dim >> 2) & 3, e = dim & 3;
+                off = (size_t)(c >> 4) * (16 * MSR_DIM) + ((size_t)t * 64 + g * 16 + (c & 15)) * 4 + e;
+            } else {
+                off = (size_t)c * MSR_DIM + dim;
+            }
+            s += ix.emb[off] * qv[j];
+        }
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        s *= ix.inv_norm[c];
+        if (s > best) { best = s; arg = c; }
+    }
+    if (lane == 0) out_chunk[(int64_t)q * k + r] = (int32_t)arg;
+}
+
+template <int QB, bool TILED>
+hipError_t launch_scan(const DenseIndex& ix, const float* qn, int nq, int max_chunks, float* docscore,
+                       hipStream_t stream) {
+    const size_t lds = ScanLds<QB>::total;
+    hipError_t err = hipFuncSetAttribute((const void*)dense_scan_kernel<QB, TILED>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (err != hipSuccess) return err;
+    int grid = ix.n_spans;
+    dense_scan_kernel<QB, TILED><<<grid, SCAN_THREADS, lds, stream>>>(ix, qn, nq, max_chunks, docscore);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t msr_dense_scan(const DenseIndex& ix, const float* qn, int nq, int max_chunks, float* docscore,
+                          hipStream_t stream) {
+    if (nq <= 0 || ix.n_docs <= 0) return hipSuccess;
+    if (nq > 32) return hipErrorInvalidValue;
+    const bool tiled = ix.layout == 1;
+    if (nq <= 16)
+        return tiled ? launch_scan<1, true>(ix, qn, nq, max_chunks, docscore, stream)
+                     : launch_scan<1, false>(ix, qn, nq, max_chunks, docscore, stream);
+    return tiled ? launch_scan<2, true>(ix, qn, nq, max_chunks, docscore, stream)
+                 : launch_scan<2, false>(ix, qn, nq, max_chunks, docscore, stream);
+}
+
+hipError_t msr_prep_queries(const float* q, int nq, float* qn, int nq_pad, hipStream_t stream) {
+    if (nq_pad <= 0) return hipSuccess;
+    prep_queries_kernel<<<(nq_pad + 3) / 4, 256, 0, stream>>>(q, nq, qn, nq_pad);
+    return hipGetLastError();
+}
+
+hipError_t msr_fill_chunk_doc(const int32_t* doc_off, int64_t n_docs, int32_t* chunk_doc, hipStream_t stream) {
+    if (n_docs <= 0) return hipSuccess;
+    fill_chunk_doc_kernel<<<(unsigned)((n_docs + 255) / 256), 256, 0, stream>>>(doc_off, n_docs, chunk_doc);
+    return hipGetLastError();
+}
+
+hipError_t msr_row_inv_norm(const float* emb, int64_t n_rows, float* inv_norm, hipStream_t stream) {
+    if (n_rows <= 0) return hipSuccess;
+    row_inv_norm_kernel<<<(unsigned)((n_rows + 3) / 4), 256, 0, stream>>>(emb, n_rows, inv_norm);
+    return hipGetLastError();
+}
+
+hipError_t msr_interleave(const float* src, int64_t n_rows, float* dst, hipStream_t stream) {
+    if (n_rows <= 0) return hipSuccess;
+    const int64_t n_vec = ((n_rows + 15) / 16) * KSTEPS * 64;
+    int64_t blocks = (n_vec + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    interleave_kernel<<<(unsigned)blocks, 256, 0, stream>>>(src, n_rows, dst, n_vec);
+    return hipGetLastError();
+}
+
+hipError_t msr_best_chunk(const DenseIndex& ix, const float* qn, int nq, int k, int max_chunks,
+                          const int32_t* out_doc, const int32_t* out_n, int32_t* out_chunk, hipStream_t stream) {
+    if (nq <= 0 || k <= 0) return hipSuccess;
+    dim3 grid((unsigned)k, (unsigned)nq);
+    if (ix.layout == 1)
+        best_chunk_kernel<true><<<grid, 64, 0, stream>>>(ix, qn, k, max_chunks, out_doc, out_n, out_chunk);
+    else
+        best_chunk_kernel<false><<<grid, 64, 0, stream>>>(ix, qn, k, max_chunks, out_doc, out_n, out_chunk);
+    return hipGetLastError();
+}

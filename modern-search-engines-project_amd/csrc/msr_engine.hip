@@ -1,0 +1,365 @@
+// C ABI of libmsretr (see include/msretr.h): engine object, scratch, argument checks, kernel sequencing.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "../../include/msretr.h"
+#include "msr_internal.h"
+
+struct msr_engine {
+    msr_config cfg;
+    char err[512];
+    // bound index parts (borrowed device pointers)
+    Bm25Index bm25;
+    bool have_postings = false;
+    DenseIndex dense;
+    bool have_chunks = false;
+    const int32_t* url_group = nullptr;
+    int64_t url_group_n = 0;
+    // engine-owned device memory
+    int32_t* chunk_doc = nullptr;
+    float* inv_norm_own = nullptr;
+    int32_t* span_doc = nullptr;
+    float* qn = nullptr;              // [32][768] normalised queries of the current slice
+    void* score_rows = nullptr;       // max_queries rows of n_docs float64 (reused as float32 rows)
+    size_t score_rows_bytes = 0;
+    SelScratch sel{};
+    float* rerank_cos = nullptr;
+    int n_cus = 256;
+    // timing
+    bool timing = false;
+    hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    bool ev_valid[2] = {false, false};
+    int ev_launches[2] = {0, 0};
+};
+
+static thread_local char g_create_err[512] = "";
+
+static int fail(msr_engine* e, int code, const char* fmt, ...) {
+    char* dst = e ? e->err : g_create_err;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(e, call)                                                                          \
+    do {                                                                                          \
+        hipError_t _err = (call);                                                                 \
+        if (_err != hipSuccess) return fail(e, MSR_ERR_HIP, "%s: %s", #call, hipGetErrorString(_err)); \
+    } while (0)
+
+static void free_dev(void* p) {
+    if (p) (void)hipFree(p);
+}
+
+extern "C" int msr_abi_version(void) { return MSR_ABI_VERSION; }
+
+extern "C" const char* msr_last_error(const msr_engine* e) { return e ? e->err : g_create_err; }
+
+extern "C" int msr_create(const msr_config* cfg, msr_engine** out) {
+    if (!cfg || !out) return fail(nullptr, MSR_ERR_INVALID, "msr_create: null argument");
+    *out = nullptr;
+    if (cfg->struct_size != (int32_t)sizeof(msr_config))
+        return fail(nullptr, MSR_ERR_INVALID, "msr_create: struct_size %d != %zu", cfg->struct_size, sizeof(msr_config));
+    if (cfg->dim != MSR_DIM) return fail(nullptr, MSR_ERR_INVALID, "msr_create: dim must be %d", MSR_DIM);
+    if (cfg->max_queries < 1 || cfg->max_queries > 4096)
+        return fail(nullptr, MSR_ERR_INVALID, "msr_create: max_queries out of range [1, 4096]");
+    if (cfg->max_k < 1 || cfg->max_k > MSR_MAX_K)
+        return fail(nullptr, MSR_ERR_INVALID, "msr_create: max_k out of range [1, %d]", MSR_MAX_K);
+    if (cfg->rerank_max_docs < 0 || cfg->rerank_max_docs > 1024)
+        return fail(nullptr, MSR_ERR_INVALID, "msr_create: rerank_max_docs out of range [0, 1024]");
+    if (cfg->scan_layout != 0 && cfg->scan_layout != 1)
+        return fail(nullptr, MSR_ERR_INVALID, "msr_create: scan_layout must be 0 or 1");
+    int ndev = 0;
+    hipError_t herr = hipGetDeviceCount(&ndev);
+    if (herr != hipSuccess || ndev <= 0)
+        return fail(nullptr, MSR_ERR_HIP, "msr_create: no HIP device available (%s)",
+                    herr == hipSuccess ? "device count is 0" : hipGetErrorString(herr));
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(nullptr, MSR_ERR_INVALID, "msr_create: device %d out of range (have %d)", cfg->device, ndev);
+    msr_engine* e = new (std::nothrow) msr_engine();
+    if (!e) return fail(nullptr, MSR_ERR_NOMEM, "msr_create: out of host memory");
+    e->cfg = *cfg;
+    e->err[0] = 0;
+    memset(&e->bm25, 0, sizeof(e->bm25));
+    memset(&e->dense, 0, sizeof(e->dense));
+    auto bail = [&](int code, const char* what, hipError_t he) {
+        fail(nullptr, code, "msr_create: %s: %s", what, hipGetErrorString(he));
+        msr_destroy(e);
+        return code;
+    };
+    if ((herr = hipSetDevice(cfg->device)) != hipSuccess) return bail(MSR_ERR_HIP, "hipSetDevice", herr);
+    hipDeviceProp_t prop;
+    if ((herr = hipGetDeviceProperties(&prop, cfg->device)) != hipSuccess) return bail(MSR_ERR_HIP, "hipGetDeviceProperties", herr);
+    e->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const size_t nq = (size_t)cfg->max_queries;
+    if ((herr = hipMalloc((void**)&e->qn, 32 * MSR_DIM * sizeof(float))) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc qn", herr);
+    if ((herr = hipMalloc((void**)&e->sel.hist, nq * MSR_SEL_BINS * sizeof(uint32_t))) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc hist", herr);
+    if ((herr = hipMalloc((void**)&e->sel.state, nq * sizeof(SelState))) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc state", herr);
+    if ((herr = hipMalloc((void**)&e->sel.cand_hi, nq * MSR_SEL_CAP * sizeof(uint64_t))) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc cand_hi", herr);
+    if ((herr = hipMalloc((void**)&e->sel.cand_lo, nq * MSR_SEL_CAP * sizeof(uint32_t))) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc cand_lo", herr);
+    if ((herr = hipMalloc((void**)&e->sel.cand_n, nq * sizeof(int32_t))) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc cand_n", herr);
+    if ((herr = hipMemset(e->sel.hist, 0, nq * MSR_SEL_BINS * sizeof(uint32_t))) != hipSuccess) return bail(MSR_ERR_HIP, "hipMemset hist", herr);
+    if ((herr = hipMemset(e->sel.cand_n, 0, nq * sizeof(int32_t))) != hipSuccess) return bail(MSR_ERR_HIP, "hipMemset cand_n", herr);
+    if (cfg->rerank_max_docs > 0) {
+        const size_t bytes = nq * (size_t)cfg->rerank_max_docs * MSR_RERANK_MAX_CHUNKS * sizeof(float);
+        if ((herr = hipMalloc((void**)&e->rerank_cos, bytes)) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc rerank_cos", herr);
+    }
+    for (int w = 0; w < 2; ++w)
+        for (int j = 0; j < 2; ++j)
+            if ((herr = hipEventCreate(&e->ev[w][j])) != hipSuccess) return bail(MSR_ERR_HIP, "hipEventCreate", herr);
+    *out = e;
+    return MSR_OK;
+}
+
+extern "C" int msr_destroy(msr_engine* e) {
+    if (!e) return MSR_OK;
+    free_dev(e->chunk_doc); free_dev(e->inv_norm_own); free_dev(e->span_doc); free_dev(e->qn);
+    free_dev(e->score_rows); free_dev(e->sel.hist); free_dev(e->sel.state); free_dev(e->sel.cand_hi);
+    free_dev(e->sel.cand_lo); free_dev(e->sel.cand_n); free_dev(e->rerank_cos);
+    for (int w = 0; w < 2; ++w)
+        for (int j = 0; j < 2; ++j)
+            if (e->ev[w][j]) (void)hipEventDestroy(e->ev[w][j]);
+    delete e;
+    return MSR_OK;
+}
+
+// (Re)size the per-slice score rows: max_queries rows of n_docs float64.
+static int ensure_score_rows(msr_engine* e, int64_t n_docs) {
+    const size_t need = (size_t)e->cfg.max_queries * (size_t)n_docs * sizeof(double);
+    if (need <= e->score_rows_bytes) return MSR_OK;
+    free_dev(e->score_rows);
+    e->score_rows = nullptr;
+    e->score_rows_bytes = 0;
+    hipError_t herr = hipMalloc(&e->score_rows, need);
+    if (herr != hipSuccess) return fail(e, MSR_ERR_NOMEM, "score rows (%zu bytes): %s", need, hipGetErrorString(herr));
+    e->score_rows_bytes = need;
+    return MSR_OK;
+}
+
+extern "C" int msr_bind_postings(msr_engine* e, const int64_t* term_off, int64_t n_terms, const int32_t* post_doc,
+                                 const int32_t* post_tf, int64_t n_postings, const int32_t* doc_len, int64_t n_docs,
+                                 const float* idf, float avgdl, double k1, double b, void* stream) {
+    (void)stream;
+    if (!e) return MSR_ERR_INVALID;
+    if (!term_off || !doc_len || !idf || n_terms < 0 || n_postings < 0 || n_docs <= 0 || n_docs >= (1ll << 31) ||
+        (n_postings > 0 && (!post_doc || !post_tf)))
+        return fail(e, MSR_ERR_INVALID, "msr_bind_postings: bad argument");
+    if (e->have_chunks && e->dense.n_docs != n_docs)
+        return fail(e, MSR_ERR_INVALID, "msr_bind_postings: n_docs %lld differs from bound chunks (%lld)",
+                    (long long)n_docs, (long long)e->dense.n_docs);
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    int rc = ensure_score_rows(e, n_docs);
+    if (rc) return rc;
+    e->bm25 = Bm25Index{term_off, post_doc, post_tf, doc_len, idf, n_terms, n_postings, n_docs,
+                        (double)avgdl, k1, b};
+    e->have_postings = true;
+    return MSR_OK;
+}
+
+extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks, const int32_t* doc_off,
+                               int64_t n_docs, const float* inv_norm, void* stream) {
+    if (!e) return MSR_ERR_INVALID;
+    if (!emb || !doc_off || n_chunks <= 0 || n_chunks >= (1ll << 31) || n_docs <= 0 || n_docs >= (1ll << 31))
+        return fail(e, MSR_ERR_INVALID, "msr_bind_chunks: bad argument");
+    if (e->have_postings && e->bm25.n_docs != n_docs)
+        return fail(e, MSR_ERR_INVALID, "msr_bind_chunks: n_docs %lld differs from bound postings (%lld)",
+                    (long long)n_docs, (long long)e->bm25.n_docs);
+    if (e->cfg.scan_layout == 1 && !inv_norm)
+        return fail(e, MSR_ERR_INVALID, "msr_bind_chunks: inv_norm is required with the interleaved layout");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    int rc = ensure_score_rows(e, n_docs);
+    if (rc) return rc;
+    // spans need the document offsets on the host (one-time, at bind)
+    std::vector<int32_t> h_off((size_t)n_docs + 1);
+    HIP_TRY(e, hipMemcpyAsync(h_off.data(), doc_off, (size_t)(n_docs + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(e, hipStreamSynchronize(st));
+    if (h_off[0] != 0 || (int64_t)h_off[n_docs] != n_chunks)
+        return fail(e, MSR_ERR_INVALID, "msr_bind_chunks: doc_off[0]=%d, doc_off[n_docs]=%d, n_chunks=%lld",
+                    h_off[0], h_off[n_docs], (long long)n_chunks);
+    for (int64_t d = 0; d < n_docs; ++d)
+        if (h_off[d + 1] < h_off[d]) return fail(e, MSR_ERR_INVALID, "msr_bind_chunks: doc_off not monotone at %lld", (long long)d);
+    // equal-chunk-count spans cut at document boundaries; one persistent workgroup each
+    int target_spans = e->n_cus;
+    const int64_t min_rows = 256;                         // at least one super-tile of work per span
+    if ((int64_t)target_spans * min_rows > n_chunks) target_spans = (int)std::max<int64_t>(1, n_chunks / min_rows);
+    std::vector<int32_t> spans;
+    spans.push_back(0);
+    for (int s = 1; s < target_spans; ++s) {
+        const int64_t want = n_chunks * s / target_spans;
+        // first document whose first chunk is >= want
+        int64_t d = std::lower_bound(h_off.begin(), h_off.end(), (int32_t)want) - h_off.begin();
+        if (d > n_docs) d = n_docs;
+        if (d > spans.back()) spans.push_back((int32_t)d);
+    }
+    if (spans.back() != (int32_t)n_docs) spans.push_back((int32_t)n_docs);
+    const int n_spans = (int)spans.size() - 1;
+
+    free_dev(e->chunk_doc); e->chunk_doc = nullptr;
+    free_dev(e->inv_norm_own); e->inv_norm_own = nullptr;
+    free_dev(e->span_doc); e->span_doc = nullptr;
+    hipError_t herr;
+    if ((herr = hipMalloc((void**)&e->chunk_doc, (size_t)n_chunks * sizeof(int32_t))) != hipSuccess)
+        return fail(e, MSR_ERR_NOMEM, "chunk_doc: %s", hipGetErrorString(herr));
+    if ((herr = hipMalloc((void**)&e->span_doc, spans.size() * sizeof(int32_t))) != hipSuccess)
+        return fail(e, MSR_ERR_NOMEM, "span_doc: %s", hipGetErrorString(herr));
+    HIP_TRY(e, hipMemcpyAsync(e->span_doc, spans.data(), spans.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(e, msr_fill_chunk_doc(doc_off, n_docs, e->chunk_doc, st));
+    if (!inv_norm) {
+        if ((herr = hipMalloc((void**)&e->inv_norm_own, (size_t)n_chunks * sizeof(float))) != hipSuccess)
+            return fail(e, MSR_ERR_NOMEM, "inv_norm: %s", hipGetErrorString(herr));
+        HIP_TRY(e, msr_row_inv_norm(emb, n_chunks, e->inv_norm_own, st));
+        inv_norm = e->inv_norm_own;
+    }
+    HIP_TRY(e, hipStreamSynchronize(st));                 // spans vector goes out of scope
+    e->dense = DenseIndex{emb, doc_off, e->chunk_doc, inv_norm, e->span_doc, n_chunks, n_docs, n_spans,
+                          e->cfg.scan_layout};
+    e->have_chunks = true;
+    return MSR_OK;
+}
+
+extern "C" int msr_bind_doc_meta(msr_engine* e, const int32_t* url_group, int64_t n_docs, void* stream) {
+    (void)stream;
+    if (!e) return MSR_ERR_INVALID;
+    if (url_group && e->have_chunks && n_docs != e->dense.n_docs)
+        return fail(e, MSR_ERR_INVALID, "msr_bind_doc_meta: n_docs mismatch");
+    e->url_group = url_group;
+    e->url_group_n = n_docs;
+    return MSR_OK;
+}
+
+extern "C" int msr_interleave_rows(msr_engine* e, const float* src, int64_t n_rows, float* dst, void* stream) {
+    if (!e) return MSR_ERR_INVALID;
+    if (!src || !dst || n_rows <= 0 || src == dst) return fail(e, MSR_ERR_INVALID, "msr_interleave_rows: bad argument");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, msr_interleave(src, n_rows, dst, (hipStream_t)stream));
+    return MSR_OK;
+}
+
+extern "C" int msr_set_timing(msr_engine* e, int32_t enabled) {
+    if (!e) return MSR_ERR_INVALID;
+    e->timing = enabled != 0;
+    e->ev_valid[0] = e->ev_valid[1] = false;
+    return MSR_OK;
+}
+
+extern "C" int msr_kernel_time_ms(msr_engine* e, int32_t which, float* out_ms, int32_t* out_launches) {
+    if (!e || which < 0 || which > 1 || !out_ms) return e ? fail(e, MSR_ERR_INVALID, "msr_kernel_time_ms: bad argument") : MSR_ERR_INVALID;
+    if (!e->ev_valid[which]) return fail(e, MSR_ERR_INVALID, "msr_kernel_time_ms: no timed launch recorded");
+    HIP_TRY(e, hipEventSynchronize(e->ev[which][1]));
+    HIP_TRY(e, hipEventElapsedTime(out_ms, e->ev[which][0], e->ev[which][1]));
+    if (out_launches) *out_launches = e->ev_launches[which];
+    return MSR_OK;
+}
+
+extern "C" int msr_bm25_topk(msr_engine* e, const int32_t* q_term_off, const int32_t* q_terms, const int32_t* q_qtf,
+                             int32_t n_queries, int32_t k, double min_score, int32_t* out_doc, double* out_score,
+                             int32_t* out_n, void* stream) {
+    if (!e) return MSR_ERR_INVALID;
+    if (!e->have_postings) return fail(e, MSR_ERR_NOT_BOUND, "msr_bm25_topk: postings not bound");
+    if (n_queries < 0 || k < 1 || k > e->cfg.max_k || !q_term_off || !out_doc || !out_score || !out_n)
+        return fail(e, MSR_ERR_INVALID, "msr_bm25_topk: bad argument (k=%d, max_k=%d)", k, e->cfg.max_k);
+    if (n_queries == 0) return MSR_OK;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    const int slice = e->cfg.max_queries;
+    const int64_t N = e->bm25.n_docs;
+    // only the LAST slice's kernel is bracketed when timing (one launch per event pair)
+    for (int q0 = 0; q0 < n_queries; q0 += slice) {
+        const int nq = std::min(slice, n_queries - q0);
+        const bool timed = e->timing && q0 + nq >= n_queries;
+        if (timed) HIP_TRY(e, hipEventRecord(e->ev[1][0], st));
+        HIP_TRY(e, msr_bm25_scores(e->bm25, q_term_off, q_terms, q_qtf, q0, nq, min_score, (double*)e->score_rows, st));
+        if (timed) {
+            HIP_TRY(e, hipEventRecord(e->ev[1][1], st));
+            e->ev_valid[1] = true; e->ev_launches[1] = 1;
+        }
+        HIP_TRY(e, msr_select_topk(64, e->score_rows, N, N, nq, k, e->sel, out_doc + (int64_t)q0 * k,
+                                   out_score + (int64_t)q0 * k, out_n + q0, st));
+    }
+    return MSR_OK;
+}
+
+extern "C" int msr_dense_topk(msr_engine* e, const float* q, int32_t n_queries, int32_t k, int32_t max_chunks_per_doc,
+                              int32_t* out_doc, float* out_score, int32_t* out_chunk, int32_t* out_n, void* stream) {
+    if (!e) return MSR_ERR_INVALID;
+    if (!e->have_chunks) return fail(e, MSR_ERR_NOT_BOUND, "msr_dense_topk: chunks not bound");
+    if (n_queries < 0 || k < 1 || k > e->cfg.max_k || max_chunks_per_doc < 0 || !q || !out_doc || !out_score || !out_n)
+        return fail(e, MSR_ERR_INVALID, "msr_dense_topk: bad argument (k=%d, max_k=%d)", k, e->cfg.max_k);
+    if (n_queries == 0) return MSR_OK;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    const int slice = std::min(32, e->cfg.max_queries);   // one sweep of E serves up to 32 queries
+    const int64_t N = e->dense.n_docs;
+    for (int q0 = 0; q0 < n_queries; q0 += slice) {
+        const int nq = std::min(slice, n_queries - q0);
+        const int nq_pad = nq <= 16 ? 16 : 32;
+        const bool timed = e->timing && q0 + nq >= n_queries;
+        HIP_TRY(e, msr_prep_queries(q + (int64_t)q0 * MSR_DIM, nq, e->qn, nq_pad, st));
+        if (timed) HIP_TRY(e, hipEventRecord(e->ev[0][0], st));
+        HIP_TRY(e, msr_dense_scan(e->dense, e->qn, nq, max_chunks_per_doc, (float*)e->score_rows, st));
+        if (timed) {
+            HIP_TRY(e, hipEventRecord(e->ev[0][1], st));
+            e->ev_valid[0] = true; e->ev_launches[0] = 1;
+        }
+        HIP_TRY(e, msr_select_topk(32, e->score_rows, N, N, nq, k, e->sel, out_doc + (int64_t)q0 * k,
+                                   out_score + (int64_t)q0 * k, out_n + q0, st));
+        if (out_chunk)
+            HIP_TRY(e, msr_best_chunk(e->dense, e->qn, nq, k, max_chunks_per_doc, out_doc + (int64_t)q0 * k,
+                                      out_n + q0, out_chunk + (int64_t)q0 * k, st));
+    }
+    return MSR_OK;
+}
+
+extern "C" int msr_rerank(msr_engine* e, const float* q, int32_t n_queries, const int32_t* cand_doc,
+                          const double* cand_bm25, const int32_t* cand_n, int32_t max_cand,
+                          const msr_rerank_params* params, int32_t* out_doc, double* out_score, double* out_orig,
+                          int32_t* out_chunk, int32_t* out_n, int32_t* out_rows, void* stream) {
+    if (!e) return MSR_ERR_INVALID;
+    if (!e->have_chunks) return fail(e, MSR_ERR_NOT_BOUND, "msr_rerank: chunks not bound");
+    if (n_queries < 0 || !q || !cand_doc || !cand_bm25 || !cand_n || !params || !out_doc || !out_score || !out_orig ||
+        !out_chunk || !out_n || !out_rows || max_cand < 1 || max_cand > e->cfg.rerank_max_docs)
+        return fail(e, MSR_ERR_INVALID, "msr_rerank: bad argument (max_cand=%d, rerank_max_docs=%d)", max_cand,
+                    e->cfg.rerank_max_docs);
+    if (params->max_chunks < 1 || params->max_chunks > MSR_RERANK_MAX_CHUNKS)
+        return fail(e, MSR_ERR_INVALID, "msr_rerank: max_chunks out of range [1, %d]", MSR_RERANK_MAX_CHUNKS);
+    if (e->url_group && e->url_group_n != e->dense.n_docs)
+        return fail(e, MSR_ERR_INVALID, "msr_rerank: doc meta bound for %lld docs, chunks for %lld",
+                    (long long)e->url_group_n, (long long)e->dense.n_docs);
+    if (n_queries == 0) return MSR_OK;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    const RerankParams p{params->smoothing, params->max_boost, params->max_decay, params->max_chunks};
+    const int slice = std::min(32, e->cfg.max_queries);   // qn holds 32 normalised queries
+    for (int q0 = 0; q0 < n_queries; q0 += slice) {
+        const int nq = std::min(slice, n_queries - q0);
+        HIP_TRY(e, msr_prep_queries(q + (int64_t)q0 * MSR_DIM, nq, e->qn, nq, st));
+        const int64_t o = (int64_t)q0 * max_cand;
+        HIP_TRY(e, msr_rerank_run(e->dense, e->url_group, e->qn, nq, cand_doc + o, cand_bm25 + o, cand_n + q0,
+                                  max_cand, p, e->rerank_cos, out_doc + o, out_score + o, out_orig + o,
+                                  out_chunk + o, out_n + q0, out_rows + q0, st));
+    }
+    return MSR_OK;
+}
+
+extern "C" int msr_merge_topk(msr_engine* e, const int32_t* in_doc, const void* in_score, const int32_t* in_n,
+                              int32_t n_parts, int32_t n_queries, int32_t k, int32_t score_bits, int32_t* out_doc,
+                              void* out_score, int32_t* out_n, void* stream) {
+    if (!e) return MSR_ERR_INVALID;
+    if (!in_doc || !in_score || !in_n || !out_doc || !out_score || !out_n || n_parts < 1 || n_parts > 64 ||
+        n_queries < 0 || k < 1 || k > MSR_MAX_K || (score_bits != 32 && score_bits != 64) || (int64_t)n_parts * k > 8192)
+        return fail(e, MSR_ERR_INVALID, "msr_merge_topk: bad argument (n_parts=%d, k=%d)", n_parts, k);
+    if (n_queries == 0) return MSR_OK;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, msr_merge_lists(score_bits, in_doc, in_score, in_n, n_parts, n_queries, k, out_doc, out_score, out_n,
+                               (hipStream_t)stream));
+    return MSR_OK;
+}

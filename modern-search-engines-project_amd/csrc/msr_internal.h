@@ -1,0 +1,87 @@
+// Internal (C++) interfaces between the translation units of libmsretr.  Not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MSR_DIM 768
+#define MSR_SEL_BINS 4096      // 12-bit radix digits
+#define MSR_SEL_CAP 4096       // candidate capacity per query of the exact final sort
+
+// ---- K4: radix-select top-k over a dense score row per query -------------------------------------
+struct SelState {
+    uint64_t pref_hi, mask_hi;   // resolved digits of the score part of the key
+    uint32_t pref_lo, mask_lo;   // resolved digits of the (~doc index) part of the key
+    int32_t k_rem;               // how many more are needed from inside the current tie bin
+    int32_t n_above;             // elements strictly above the resolved prefix
+    int32_t done;
+    int32_t n_sel;               // number of entries that will be emitted (min(k, #valid))
+};
+
+struct SelScratch {
+    uint32_t* hist;      // [nq][MSR_SEL_BINS], all zero between calls
+    SelState* state;     // [nq]
+    uint64_t* cand_hi;   // [nq][MSR_SEL_CAP]
+    uint32_t* cand_lo;   // [nq][MSR_SEL_CAP]
+    int32_t* cand_n;     // [nq], all zero between calls
+};
+
+// Select the top-k of scores[q][0..n) (row stride `stride` elements) for q in [0, nq).
+// score_bits 32: float scores / float out_score; 64: double.  Rows of out_* have stride k.
+// Order: score desc, index asc.  Entries past out_n[q] are (-1, -inf).
+hipError_t msr_select_topk(int score_bits, const void* scores, int64_t n, int64_t stride, int nq, int k,
+                           const SelScratch& sc, int32_t* out_doc, void* out_score, int32_t* out_n,
+                           hipStream_t stream);
+
+// Merge lists: in_* [n_parts][nq][k]; see msretr.h msr_merge_topk.
+hipError_t msr_merge_lists(int score_bits, const int32_t* in_doc, const void* in_score, const int32_t* in_n,
+                           int n_parts, int nq, int k, int32_t* out_doc, void* out_score, int32_t* out_n,
+                           hipStream_t stream);
+
+// ---- K1: BM25 term-at-a-time ----------------------------------------------------------------------
+struct Bm25Index {
+    const int64_t* term_off;
+    const int32_t* post_doc;
+    const int32_t* post_tf;
+    const int32_t* doc_len;
+    const float* idf;
+    int64_t n_terms, n_postings, n_docs;
+    double avgdl, k1, b;
+};
+// scores[q][n_docs] (row stride n_docs) <- BM25 score, or -inf for documents that are not candidates.
+hipError_t msr_bm25_scores(const Bm25Index& ix, const int32_t* q_term_off, const int32_t* q_terms,
+                           const int32_t* q_qtf, int q_first, int nq, double min_score, double* scores,
+                           hipStream_t stream);
+
+// ---- K2/K3: dense scan + per-document max ---------------------------------------------------------
+struct DenseIndex {
+    const float* emb;          // row-major [n_chunks][768] or interleaved image
+    const int32_t* doc_off;    // [n_docs+1]
+    const int32_t* chunk_doc;  // [n_chunks]
+    const float* inv_norm;     // [n_chunks]
+    const int32_t* span_doc;   // [n_spans+1] document boundaries of the work spans
+    int64_t n_chunks, n_docs;
+    int32_t n_spans;
+    int32_t layout;            // 0 row-major, 1 interleaved
+};
+// qn: [ceil16(nq)][768] normalised queries (zero rows as padding).
+// docscore[q][n_docs] <- max cosine over the document's chunks (-inf for chunk-less documents).
+hipError_t msr_dense_scan(const DenseIndex& ix, const float* qn, int nq, int max_chunks, float* docscore,
+                          hipStream_t stream);
+hipError_t msr_prep_queries(const float* q, int nq, float* qn, int nq_pad, hipStream_t stream);
+hipError_t msr_fill_chunk_doc(const int32_t* doc_off, int64_t n_docs, int32_t* chunk_doc, hipStream_t stream);
+hipError_t msr_row_inv_norm(const float* emb, int64_t n_rows, float* inv_norm, hipStream_t stream);
+hipError_t msr_interleave(const float* src, int64_t n_rows, float* dst, hipStream_t stream);
+// For each (q, r < out_n[q]): out_chunk[q][r] = row of the first maximum cosine among the winner's chunks.
+hipError_t msr_best_chunk(const DenseIndex& ix, const float* qn, int nq, int k, int max_chunks,
+                          const int32_t* out_doc, const int32_t* out_n, int32_t* out_chunk, hipStream_t stream);
+
+// ---- K6: rerank / fuse ----------------------------------------------------------------------------
+struct RerankParams {
+    double smoothing, max_boost, max_decay;
+    int32_t max_chunks;
+};
+hipError_t msr_rerank_run(const DenseIndex& ix, const int32_t* url_group, const float* qn, int nq,
+                          const int32_t* cand_doc, const double* cand_bm25, const int32_t* cand_n, int max_cand,
+                          const RerankParams& p, float* cos_scratch /*[nq][max_cand][10]*/,
+                          int32_t* out_doc, double* out_score, double* out_orig, int32_t* out_chunk,
+                          int32_t* out_n, int32_t* out_rows, hipStream_t stream);

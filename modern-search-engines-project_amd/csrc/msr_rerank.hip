@@ -1,0 +1,244 @@
+// K6 -- rerank / fuse of the stage-1 candidates (gfx950).  Compiled with -ffp-contract=off.
+//
+// Replaces the arithmetic of the /rerank endpoint (reranker/reranker_api.py):
+//   candidate fetch   URL dedup (MIN(id) per URL-without-query-string), first <=10 chunks   :27-63
+//   cosine            sklearn cosine_similarity, float32                                     :273-287
+//   min-max           over ALL chunk rows of the request, python floats (float64)            :289-296, 360-361
+//   blend             new*(1-smoothing) + old*smoothing                                      :362
+//   positional        boost/decay of each document's best chunk                              :299-334
+//   pool + order      per-document first maximum, descending                                 :370-372
+// Two kernels: (A) one wave per (query, candidate) gathers the candidate's chunk rows and computes the
+// cosines (HBM-bound gather of <= 10 x 3 KiB rows); (B) one workgroup per query runs the float64 chain on
+// <= 1024 candidates entirely in LDS.
+#include "msr_common.h"
+#include "msr_internal.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int RR_MAXC = 10;           // scratch slots per candidate (MSR_RERANK_MAX_CHUNKS)
+constexpr int RR_THREADS = 1024;
+constexpr int RR_MAXM = 1024;
+
+template <bool TILED>
+__global__ __launch_bounds__(64) void rerank_cos_kernel(DenseIndex ix, const float* __restrict__ qn,
+                                                         const int32_t* __restrict__ cand_doc,
+                                                         const int32_t* __restrict__ cand_n, int max_cand,
+                                                         int max_chunks, float* __restrict__ cos_out) {
+    const int q = blockIdx.y, m = blockIdx.x, lane = threadIdx.x;
+    if (m >= cand_n[q]) return;
+    const int d = cand_doc[(int64_t)q * max_cand + m];
+    if (d < 0 || d >= ix.n_docs) return;
+    const int64_t ds = ix.doc_off[d];
+    int64_t de = ix.doc_off[d + 1];
+    if (ds + max_chunks < de) de = ds + max_chunks;
+    const f32x4* q4 = (const f32x4*)(qn + (size_t)q * MSR_DIM);
+    const f32x4 qa = q4[lane], qb = q4[lane + 64], qc = q4[lane + 128];
+    float* out = cos_out + ((int64_t)q * max_cand + m) * RR_MAXC;
+    for (int64_t c = ds; c < de; ++c) {
+        f32x4 a, b, e;
+        if (TILED) {
+            const f32x4* base = (const f32x4*)(ix.emb + (size_t)(c >> 4) * (16 * MSR_DIM));
+            const int i = (int)(c & 15);
+            // float4 number v of the row (dims 4v..4v+3) lives at block t = v >> 2, lane 16 (v & 3) + i
+            const int v0 = lane, v1 = lane + 64, v2 = lane + 128;
+            a = base[(v0 >> 2) * 64 + (v0 & 3) * 16 + i];
+            b = base[(v1 >> 2) * 64 + (v1 & 3) * 16 + i];
+            e = base[(v2 >> 2) * 64 + (v2 & 3) * 16 + i];
+        } else {
+            const f32x4* p = (const f32x4*)(ix.emb + (size_t)c * MSR_DIM);
+            a = p[lane]; b = p[lane + 64]; e = p[lane + 128];
+        }
+        float s = a.x * qa.x + a.y * qa.y + a.z * qa.z + a.w * qa.w;
+        s += b.x * qb.x + b.y * qb.y + b.z * qb.z + b.w * qb.w;
+        s += e.x * qc.x + e.y * qc.y + e.z * qc.z + e.w * qc.w;
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) out[c - ds] = s * ix.inv_norm[c];
+    }
+}
+
+// Bitonic sort of (hi, lo) keys with a 32-bit payload; ascending if ASC else descending.
+template <bool ASC>
+__device__ void bitonic_kv(uint64_t* khi, uint32_t* klo, uint32_t* val, int P) {
+    for (int kk = 2; kk <= P; kk <<= 1) {
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int idx = threadIdx.x; idx < (P >> 1); idx += RR_THREADS) {
+                const int i = ((idx & ~(j - 1)) << 1) | (idx & (j - 1));
+                const int p = i | j;
+                const bool up = ((i & kk) == 0) == ASC;          // this pair must end ascending
+                const uint64_t ah = khi[i], bh = khi[p];
+                const uint32_t al = klo[i], bl = klo[p];
+                const bool a_gt_b = ah > bh || (ah == bh && al > bl);
+                const bool a_lt_b = ah < bh || (ah == bh && al < bl);
+                if (up ? a_gt_b : a_lt_b) {
+                    khi[i] = bh; klo[i] = bl; khi[p] = ah; klo[p] = al;
+                    const uint32_t t = val[i]; val[i] = val[p]; val[p] = t;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__device__ __forceinline__ double block_reduce(double v, bool is_min, double* red) {
+    // red: LDS scratch of RR_THREADS/64 doubles
+    for (int o = 32; o > 0; o >>= 1) {
+        const double u = __shfl_xor(v, o);
+        v = is_min ? (u < v ? u : v) : (u > v ? u : v);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = red[0];
+    for (int i = 1; i < RR_THREADS / 64; ++i) {
+        const double u = red[i];
+        r = is_min ? (u < r ? u : r) : (u > r ? u : r);
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(RR_THREADS) void rerank_fuse_kernel(
+    DenseIndex ix, const int32_t* __restrict__ url_group, const int32_t* __restrict__ cand_doc,
+    const double* __restrict__ cand_bm25, const int32_t* __restrict__ cand_n, int max_cand, RerankParams prm,
+    const float* __restrict__ cos_in, int32_t* __restrict__ out_doc, double* __restrict__ out_score,
+    double* __restrict__ out_orig, int32_t* __restrict__ out_chunk, int32_t* __restrict__ out_n,
+    int32_t* __restrict__ out_rows) {
+    __shared__ uint64_t khi[RR_MAXM];
+    __shared__ uint32_t klo[RR_MAXM];
+    __shared__ uint32_t val[RR_MAXM];
+    __shared__ double sc[RR_MAXM];
+    __shared__ double og[RR_MAXM];
+    __shared__ int32_t ch[RR_MAXM];
+    __shared__ uint8_t keep[RR_MAXM];
+    __shared__ double red[RR_THREADS / 64];
+    __shared__ int cnt[2];
+
+    const int q = blockIdx.x, tid = threadIdx.x;
+    int n = cand_n[q];
+    if (n > max_cand) n = max_cand;
+    if (n > RR_MAXM) n = RR_MAXM;
+    int P = 64;
+    while (P < n) P <<= 1;
+    const int32_t* cd = cand_doc + (int64_t)q * max_cand;
+    const double* cb = cand_bm25 + (int64_t)q * max_cand;
+
+    // 1. sort candidates by (url group, doc) so the first entry of each group is MIN(id)   (:38-47)
+    for (int i = tid; i < P; i += RR_THREADS) {
+        uint64_t key = ~0ull;
+        if (i < n) {
+            const int d = cd[i];
+            if (d >= 0 && d < ix.n_docs) {
+                const int g = url_group ? url_group[d] : d;
+                if (g >= 0) key = ((uint64_t)(uint32_t)g << 32) | (uint32_t)d;
+            }
+        }
+        khi[i] = key; klo[i] = 0; val[i] = (uint32_t)i;
+    }
+    if (tid < 2) cnt[tid] = 0;
+    __syncthreads();
+    bitonic_kv<true>(khi, klo, val, P);
+
+    // 2. keep = first of its URL group, has at least one chunk row
+    double cmin = __builtin_inf(), cmax = -__builtin_inf(), bmin = __builtin_inf(), bmax = -__builtin_inf();
+    int my_rows = 0;
+    for (int i = tid; i < P; i += RR_THREADS) {                  // at most one iteration
+        bool k = false;
+        const uint64_t key = khi[i];
+        if (key != ~0ull && (i == 0 || (khi[i - 1] >> 32) != (key >> 32))) {
+            const int d = (int)(uint32_t)key;
+            int64_t nr = (int64_t)ix.doc_off[d + 1] - ix.doc_off[d];
+            if (nr > prm.max_chunks) nr = prm.max_chunks;
+            if (nr > 0) {
+                k = true;
+                const int m = (int)val[i];
+                const float* cs = cos_in + ((int64_t)q * max_cand + m) * RR_MAXC;
+                for (int j = 0; j < (int)nr; ++j) {
+                    const double c = (double)cs[j];
+                    cmin = c < cmin ? c : cmin; cmax = c > cmax ? c : cmax;
+                }
+                const double bm = cb[m];
+                bmin = bm < bmin ? bm : bmin; bmax = bm > bmax ? bm : bmax;
+                my_rows += (int)nr;
+            }
+        }
+        keep[i] = k ? 1 : 0;
+    }
+    cmin = block_reduce(cmin, true, red);
+    cmax = block_reduce(cmax, false, red);
+    bmin = block_reduce(bmin, true, red);
+    bmax = block_reduce(bmax, false, red);
+    if (my_rows) atomicAdd(&cnt[0], my_rows);
+    __syncthreads();
+
+    // 3. per kept document: normalise, blend, positional weighting, first maximum
+    const double one_m_s = 1.0 - prm.smoothing;
+    if (tid < P) {                                               // P <= RR_THREADS: one entry per thread
+        const int i = tid;
+        uint64_t shi = 0; uint32_t slo = 0;
+        if (keep[i]) {
+            const int d = (int)(uint32_t)khi[i];
+            const int m = (int)val[i];
+            int nr = (int)(ix.doc_off[d + 1] - ix.doc_off[d]);
+            if (nr > prm.max_chunks) nr = prm.max_chunks;
+            const float* cs = cos_in + ((int64_t)q * max_cand + m) * RR_MAXC;
+            const double old = (bmax == bmin) ? 0.0 : (cb[m] - bmin) / (bmax - bmin);
+            double v[RR_MAXC];
+            int best = 0;
+            for (int j = 0; j < nr; ++j) {
+                const double nw = (cmax == cmin) ? 0.0 : ((double)cs[j] - cmin) / (cmax - cmin);
+                v[j] = nw * one_m_s + old * prm.smoothing;
+                if (v[j] > v[best]) best = j;
+            }
+            if (nr > 1) {
+                const double ratio = (double)best / (double)(nr - 1);
+                const double adj = prm.max_boost - (prm.max_boost + prm.max_decay) * ratio;
+                double a = v[best] + adj;
+                a = a < 1.0 ? a : 1.0;                           // min(1.0, adjusted)
+                a = a > 0.0 ? a : 0.0;                           // max(0.0, ...)
+                v[best] = a;
+                best = 0;
+                for (int j = 1; j < nr; ++j)
+                    if (v[j] > v[best]) best = j;
+            }
+            sc[i] = v[best]; og[i] = old; ch[i] = (int32_t)(ix.doc_off[d] + best);
+            shi = msr_ord64(v[best]); slo = ~(uint32_t)d;
+            atomicAdd(&cnt[1], 1);
+        }
+        khi[i] = shi; klo[i] = slo; val[i] = (uint32_t)i;
+    }
+    __syncthreads();
+    // 4. order by (score desc, doc asc)
+    bitonic_kv<false>(khi, klo, val, P);
+    const int n_keep = cnt[1];
+    for (int i = tid; i < max_cand; i += RR_THREADS) {
+        const int64_t o = (int64_t)q * max_cand + i;
+        if (i < n_keep) {
+            const int src = (int)val[i];
+            out_doc[o] = (int32_t)~klo[i]; out_score[o] = sc[src]; out_orig[o] = og[src]; out_chunk[o] = ch[src];
+        } else {
+            out_doc[o] = -1; out_score[o] = -__builtin_inf(); out_orig[o] = 0.0; out_chunk[o] = -1;
+        }
+    }
+    if (tid == 0) { out_n[q] = n_keep; out_rows[q] = cnt[0]; }
+}
+
+}  // namespace
+
+hipError_t msr_rerank_run(const DenseIndex& ix, const int32_t* url_group, const float* qn, int nq,
+                          const int32_t* cand_doc, const double* cand_bm25, const int32_t* cand_n, int max_cand,
+                          const RerankParams& p, float* cos_scratch, int32_t* out_doc, double* out_score,
+                          double* out_orig, int32_t* out_chunk, int32_t* out_n, int32_t* out_rows,
+                          hipStream_t stream) {
+    if (nq <= 0) return hipSuccess;
+    if (max_cand <= 0 || max_cand > RR_MAXM || p.max_chunks <= 0 || p.max_chunks > RR_MAXC)
+        return hipErrorInvalidValue;
+    dim3 grid((unsigned)max_cand, (unsigned)nq);
+    if (ix.layout == 1)
+        rerank_cos_kernel<true><<<grid, 64, 0, stream>>>(ix, qn, cand_doc, cand_n, max_cand, p.max_chunks, cos_scratch);
+    else
+        rerank_cos_kernel<false><<<grid, 64, 0, stream>>>(ix, qn, cand_doc, cand_n, max_cand, p.max_chunks, cos_scratch);
+    rerank_fuse_kernel<<<nq, RR_THREADS, 0, stream>>>(ix, url_group, cand_doc, cand_bm25, cand_n, max_cand, p,
+                                                      cos_scratch, out_doc, out_score, out_orig, out_chunk, out_n,
+                                                      out_rows);
+    return hipGetLastError();
+}

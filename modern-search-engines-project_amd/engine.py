@@ -1,0 +1,184 @@
+"""DeviceEngine: the index resident in HBM + the libmsretr handle.
+
+PyTorch is plumbing here: it owns the device allocations and the stream; every computation on the path is
+a HIP kernel in csrc/ reached through the C ABI (include/msretr.h).  There is no fallback: without a GPU
+or without the built library, construction raises.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _abi
+from .index import DIM, CorpusIndex
+
+RERANK_DEFAULTS = dict(smoothing=0.15, max_boost=0.1, max_decay=0.05, max_chunks=10)   # reranker/config.yaml:28,
+#                                                                                        reranker_api.py:58,317-318
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class DeviceEngine:
+    def __init__(self, index: CorpusIndex, device=0, max_queries=32, max_k=1000, rerank_max_docs=1000,
+                 scan_layout=0):
+        if not torch.cuda.is_available():
+            raise _abi.MsrError(-102, "no GPU visible: the retrieval path runs on MI355X only (no CPU fallback)")
+        self.lib = _abi.load()
+        self.index = index
+        self.device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        self.max_k = int(max_k)
+        self.scan_layout = int(scan_layout)
+        self.rerank_max_docs = int(rerank_max_docs)
+        cfg = _abi.MsrConfig(C.sizeof(_abi.MsrConfig), self.device.index or 0, DIM, int(max_queries), int(max_k),
+                             int(rerank_max_docs), int(scan_layout), 0)
+        self.handle = C.c_void_p()
+        rc = self.lib.msr_create(C.byref(cfg), C.byref(self.handle))
+        if rc != 0:
+            raise _abi.MsrError(rc, (self.lib.msr_last_error(None) or b"?").decode())
+        self._t = {}          # device tensors that the engine borrows: keep them alive
+        self._bind(index)
+
+    # ------------------------------------------------------------------ plumbing
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, x, dtype):
+        if x is None:
+            return None
+        if torch.is_tensor(x):
+            return x.to(device=self.device, dtype=dtype).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(x)).to(device=self.device, dtype=dtype)
+
+    def _check(self, rc):
+        _abi.check(self.handle, rc)
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle.value:
+            torch.cuda.synchronize(self.device)
+            self.lib.msr_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _bind(self, ix):
+        t = self._t
+        with torch.cuda.device(self.device):
+            if ix.term_off is not None:
+                t["term_off"] = self._dev(ix.term_off, torch.int64)
+                t["post_doc"] = self._dev(ix.post_doc, torch.int32)
+                t["post_tf"] = self._dev(ix.post_tf, torch.int32)
+                t["doc_len"] = self._dev(ix.doc_len, torch.int32)
+                t["idf"] = self._dev(ix.idf, torch.float32)
+                self._check(self.lib.msr_bind_postings(
+                    self.handle, _ptr(t["term_off"]), ix.n_terms, _ptr(t["post_doc"]), _ptr(t["post_tf"]),
+                    int(t["post_doc"].numel()), _ptr(t["doc_len"]), ix.n_docs, _ptr(t["idf"]),
+                    C.c_float(ix.avgdl), C.c_double(ix.k1), C.c_double(ix.b), self._stream()))
+            if ix.doc_off is not None and ix.emb is not None:
+                t["doc_off"] = self._dev(ix.doc_off, torch.int32)
+                emb = self._dev(ix.emb, torch.float32)
+                n_chunks = int(emb.shape[0])
+                inv = None
+                if self.scan_layout == 1:
+                    nrm = torch.linalg.vector_norm(emb, dim=1)
+                    inv = (1.0 / torch.where(nrm == 0, torch.ones_like(nrm), nrm)).contiguous()
+                    pad = (n_chunks + 15) // 16 * 16
+                    tiled = torch.empty((pad, DIM), dtype=torch.float32, device=self.device)
+                    self._check(self.lib.msr_interleave_rows(self.handle, _ptr(emb), n_chunks, _ptr(tiled), self._stream()))
+                    torch.cuda.synchronize(self.device)
+                    del emb
+                    emb = tiled
+                t["emb"], t["inv_norm"] = emb, inv
+                self._check(self.lib.msr_bind_chunks(self.handle, _ptr(emb), n_chunks, _ptr(t["doc_off"]),
+                                                     ix.n_docs, _ptr(inv), self._stream()))
+                t["url_group"] = self._dev(ix.url_group(), torch.int32)
+                self._check(self.lib.msr_bind_doc_meta(self.handle, _ptr(t["url_group"]), ix.n_docs, self._stream()))
+            torch.cuda.synchronize(self.device)
+
+    # ------------------------------------------------------------------ stage 1
+    def pack_queries(self, term_lists):
+        """list of term-id lists (repeats allowed, any unknown id < 0) -> device CSR of UNIQUE terms in
+        first-occurrence order with their query frequencies (bm25_indexer.py:405-409)."""
+        off, terms, qtf = [0], [], []
+        for tl in term_lists:
+            cnt = {}
+            for t in tl:
+                cnt[int(t)] = cnt.get(int(t), 0) + 1
+            for t, c in cnt.items():
+                terms.append(t)
+                qtf.append(c)
+            off.append(len(terms))
+        mk = lambda a: torch.tensor(a if a else [0], dtype=torch.int32, device=self.device)
+        return mk(off), mk(terms), mk(qtf), len(term_lists)
+
+    def bm25_topk(self, term_lists, k=1000, min_score=0.0, packed=None):
+        """-> (doc index int32 [Q, k], score float64 [Q, k], n int32 [Q]) device tensors."""
+        q_off, q_terms, q_qtf, Q = packed if packed is not None else self.pack_queries(term_lists)
+        out_doc = torch.empty((Q, k), dtype=torch.int32, device=self.device)
+        out_score = torch.empty((Q, k), dtype=torch.float64, device=self.device)
+        out_n = torch.empty((Q,), dtype=torch.int32, device=self.device)
+        self._check(self.lib.msr_bm25_topk(self.handle, _ptr(q_off), _ptr(q_terms), _ptr(q_qtf), Q, k,
+                                           C.c_double(min_score), _ptr(out_doc), _ptr(out_score), _ptr(out_n),
+                                           self._stream()))
+        return out_doc, out_score, out_n
+
+    # ------------------------------------------------------------------ stage 2 (full scan)
+    def dense_topk(self, qvec, k=100, max_chunks_per_doc=0, want_chunk=True):
+        """qvec float32 [Q, 768] (not normalised) -> (doc [Q,k] i32, score [Q,k] f32, chunk row [Q,k] i32, n [Q])."""
+        q = self._dev(qvec, torch.float32).reshape(-1, DIM)
+        Q = int(q.shape[0])
+        out_doc = torch.empty((Q, k), dtype=torch.int32, device=self.device)
+        out_score = torch.empty((Q, k), dtype=torch.float32, device=self.device)
+        out_chunk = torch.empty((Q, k), dtype=torch.int32, device=self.device) if want_chunk else None
+        out_n = torch.empty((Q,), dtype=torch.int32, device=self.device)
+        self._check(self.lib.msr_dense_topk(self.handle, _ptr(q), Q, k, int(max_chunks_per_doc), _ptr(out_doc),
+                                            _ptr(out_score), _ptr(out_chunk), _ptr(out_n), self._stream()))
+        return out_doc, out_score, out_chunk, out_n
+
+    # ------------------------------------------------------------------ rerank / fuse
+    def rerank(self, qvec, cand_doc, cand_bm25, cand_n, **params):
+        """cand_doc int32 [Q, M] dense indices, cand_bm25 float64 [Q, M], cand_n int32 [Q]
+        -> (doc, new_similarity f64, normalised bm25 f64, chunk row, n, rows) device tensors [Q, M] / [Q]."""
+        p = dict(RERANK_DEFAULTS)
+        p.update(params)
+        q = self._dev(qvec, torch.float32).reshape(-1, DIM)
+        cand_doc = self._dev(cand_doc, torch.int32)
+        cand_bm25 = self._dev(cand_bm25, torch.float64)
+        cand_n = self._dev(cand_n, torch.int32)
+        Q, M = int(cand_doc.shape[0]), int(cand_doc.shape[1])
+        prm = _abi.MsrRerankParams(p["smoothing"], p["max_boost"], p["max_decay"], int(p["max_chunks"]), 0)
+        mk = lambda dt: torch.empty((Q, M), dtype=dt, device=self.device)
+        out_doc, out_score, out_orig, out_chunk = mk(torch.int32), mk(torch.float64), mk(torch.float64), mk(torch.int32)
+        out_n = torch.empty((Q,), dtype=torch.int32, device=self.device)
+        out_rows = torch.empty((Q,), dtype=torch.int32, device=self.device)
+        self._check(self.lib.msr_rerank(self.handle, _ptr(q), Q, _ptr(cand_doc), _ptr(cand_bm25), _ptr(cand_n), M,
+                                        C.byref(prm), _ptr(out_doc), _ptr(out_score), _ptr(out_orig),
+                                        _ptr(out_chunk), _ptr(out_n), _ptr(out_rows), self._stream()))
+        return out_doc, out_score, out_orig, out_chunk, out_n, out_rows
+
+    # ------------------------------------------------------------------ shard merge
+    def merge_topk(self, docs, scores, ns, k):
+        """docs int32 [G, Q, k] GLOBAL indices, scores f32/f64 [G, Q, k], ns int32 [G, Q] -> merged top-k."""
+        G, Q = int(docs.shape[0]), int(docs.shape[1])
+        bits = 64 if scores.dtype == torch.float64 else 32
+        out_doc = torch.empty((Q, k), dtype=torch.int32, device=self.device)
+        out_score = torch.empty((Q, k), dtype=scores.dtype, device=self.device)
+        out_n = torch.empty((Q,), dtype=torch.int32, device=self.device)
+        self._check(self.lib.msr_merge_topk(self.handle, _ptr(docs.contiguous()), _ptr(scores.contiguous()),
+                                            _ptr(ns.contiguous()), G, Q, k, bits, _ptr(out_doc), _ptr(out_score),
+                                            _ptr(out_n), self._stream()))
+        return out_doc, out_score, out_n
+
+    # ------------------------------------------------------------------ timing hooks (bench.py)
+    def set_timing(self, on):
+        self._check(self.lib.msr_set_timing(self.handle, 1 if on else 0))
+
+    def kernel_time_ms(self, which):
+        ms, n = C.c_float(), C.c_int32()
+        self._check(self.lib.msr_kernel_time_ms(self.handle, which, C.byref(ms), C.byref(n)))
+        return ms.value, n.value

@@ -1,0 +1,251 @@
+"""Host-side index container: the DuckDB tables of the reference, read ONCE into contiguous arrays.
+
+Reference schema this mirrors (all read per query through SQL in the reference):
+  urlsDB(id, url, title, text)                        crawler/databaseManagement.py:18-51
+  bm25_doc_stats / bm25_term_freq / bm25_term_stats / bm25_corpus_stats    indexer/bm25_indexer.py:86-126
+  chunks_optimized(chunk_id, doc_id, chunk_text), embeddings(chunk_id, FLOAT[768])   indexer/embedder.py:31-52
+
+Layout: documents are numbered by the rank of their doc_id in ascending order ("dense index"); postings
+are CSR by term with documents ascending inside a term; chunk rows are sorted by (doc, chunk_id) so a
+document's chunks are one contiguous row range [doc_off[d], doc_off[d+1]).
+"""
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import numpy as np
+
+DIM = 768
+
+
+def _np(x):
+    if x is None:
+        return None
+    if hasattr(x, "detach"):
+        return x.detach().cpu().numpy()
+    return np.asarray(x)
+
+
+@dataclass
+class CorpusIndex:
+    doc_ids: object                     # int64 [N] ascending
+    doc_len: object = None              # int32 [N]
+    term_off: object = None             # int64 [V+1]
+    post_doc: object = None             # int32 [P]
+    post_tf: object = None              # int32 [P]
+    idf: object = None                  # float32 [V]  (as stored: REAL, may be negative)
+    avgdl: float = 1.0                  # float32-rounded (REAL)
+    total_docs: int = 0                 # N of the WHOLE corpus (replicated on shards)
+    k1: float = 1.2                     # bm25_indexer.py:57
+    b: float = 0.75
+    vocab: Optional[Dict[str, int]] = None
+    doc_off: object = None              # int32 [N+1]
+    chunk_ids: object = None            # int64 [C]
+    emb: object = None                  # float32 [C, 768] row-major (numpy array or torch tensor)
+    urls: Optional[List[Optional[str]]] = None     # None entry => document not in urlsDB
+    titles: Optional[List[Optional[str]]] = None
+    texts: Optional[List[Optional[str]]] = None
+    doc_base: int = 0                   # first global dense index of this shard
+    n_docs_global: int = 0
+    _url_group: object = field(default=None, repr=False)
+
+    # ------------------------------------------------------------------ basic properties
+    @property
+    def n_docs(self):
+        return int(len(self.doc_ids))
+
+    @property
+    def n_terms(self):
+        return 0 if self.term_off is None else int(len(self.term_off) - 1)
+
+    @property
+    def n_chunks(self):
+        return 0 if self.doc_off is None else int(_np(self.doc_off[-1:])[0])
+
+    def term_ids(self, terms):
+        """Map term strings (or ints) to ids; unknown -> -1."""
+        out = []
+        for t in terms:
+            if isinstance(t, (int, np.integer)):
+                out.append(int(t))
+            else:
+                out.append(self.vocab.get(t, -1) if self.vocab else -1)
+        return out
+
+    def url_group(self):
+        """int32[N]: id of the URL with its query string removed (reranker_api.py:43-46); -1 if the
+        document has no urlsDB row.  Without URL metadata every document is its own group."""
+        if self._url_group is None:
+            if self.urls is None:
+                self._url_group = np.arange(self.n_docs, dtype=np.int32)
+            else:
+                ids, out = {}, np.empty(self.n_docs, np.int32)
+                for i, u in enumerate(self.urls):
+                    if u is None:
+                        out[i] = -1
+                    else:
+                        key = u[: u.index("?")] if "?" in u else u
+                        out[i] = ids.setdefault(key, len(ids))
+                self._url_group = out
+        return self._url_group
+
+    # ------------------------------------------------------------------ construction helpers
+    @staticmethod
+    def from_tables(postings, doc_len, idf, avgdl, total_docs=None, chunks=None, emb=None, urls_db=None,
+                    k1=1.2, b=0.75):
+        """Build from reference-style tables: postings {term: [(doc_id, tf)]}, doc_len {doc_id: len},
+        idf {term: float|None}, chunks [(chunk_id, doc_id)], emb {chunk_id: vec} or array aligned with
+        sorted chunks, urls_db {doc_id: (url, title, text)}.  Documents = keys of doc_len (the inner JOIN
+        with bm25_doc_stats, bm25_indexer.py:443) united with chunk owners and urlsDB ids."""
+        ids = set(int(d) for d in doc_len)
+        if chunks:
+            ids |= {int(d) for _, d in chunks}
+        if urls_db:
+            ids |= {int(d) for d in urls_db}
+        doc_ids = np.array(sorted(ids), np.int64)
+        rank = {int(d): i for i, d in enumerate(doc_ids)}
+        vocab = {t: i for i, t in enumerate(postings)}
+        term_off = np.zeros(len(vocab) + 1, np.int64)
+        pd_, ptf = [], []
+        for t, i in vocab.items():
+            pl = sorted((rank[int(d)], int(tf)) for d, tf in postings[t] if int(d) in doc_len)
+            pd_ += [p[0] for p in pl]
+            ptf += [p[1] for p in pl]
+            term_off[i + 1] = len(pd_)
+        ix = CorpusIndex(doc_ids=doc_ids,
+                         doc_len=np.array([doc_len.get(int(d), 0) for d in doc_ids], np.int32),
+                         term_off=term_off, post_doc=np.array(pd_, np.int32), post_tf=np.array(ptf, np.int32),
+                         idf=np.array([(idf[t] or 0.0) for t in vocab], np.float32),   # NULL -> 0.0 (:426)
+                         avgdl=float(np.float32(avgdl)), total_docs=int(total_docs or len(doc_len)),
+                         k1=k1, b=b, vocab=vocab)
+        if chunks is not None:
+            ch = sorted(((rank[int(d)], int(c)) for c, d in chunks))
+            cnt = np.bincount(np.array([d for d, _ in ch], np.int64), minlength=len(doc_ids))
+            ix.doc_off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+            ix.chunk_ids = np.array([c for _, c in ch], np.int64)
+            if isinstance(emb, dict):
+                ix.emb = np.stack([np.asarray(emb[c], np.float32) for c in ix.chunk_ids]) if len(ch) else np.zeros((0, DIM), np.float32)
+            else:
+                ix.emb = emb
+        if urls_db is not None:
+            ix.urls = [urls_db[int(d)][0] if int(d) in urls_db else None for d in doc_ids]
+            ix.titles = [urls_db[int(d)][1] if int(d) in urls_db else None for d in doc_ids]
+            ix.texts = [urls_db[int(d)][2] if int(d) in urls_db else None for d in doc_ids]
+        ix.n_docs_global = ix.n_docs
+        return ix
+
+    # ------------------------------------------------------------------ snapshot (raw arrays)
+    def save(self, path):
+        arrs = dict(doc_ids=_np(self.doc_ids), doc_len=_np(self.doc_len), term_off=_np(self.term_off),
+                    post_doc=_np(self.post_doc), post_tf=_np(self.post_tf), idf=_np(self.idf),
+                    scalars=np.array([self.avgdl, self.total_docs, self.k1, self.b, self.doc_base,
+                                      self.n_docs_global], np.float64))
+        if self.doc_off is not None:
+            arrs.update(doc_off=_np(self.doc_off), chunk_ids=_np(self.chunk_ids), emb=_np(self.emb))
+        if self.vocab is not None:
+            arrs["vocab_terms"] = np.array(list(self.vocab.keys()), dtype=np.str_)
+        np.savez(path, **{k: v for k, v in arrs.items() if v is not None})
+
+    @staticmethod
+    def load(path, mmap=False):
+        z = np.load(path, mmap_mode="r" if mmap else None, allow_pickle=False)
+        s = z["scalars"]
+        ix = CorpusIndex(doc_ids=z["doc_ids"], doc_len=z["doc_len"], term_off=z["term_off"],
+                         post_doc=z["post_doc"], post_tf=z["post_tf"], idf=z["idf"], avgdl=float(s[0]),
+                         total_docs=int(s[1]), k1=float(s[2]), b=float(s[3]), doc_base=int(s[4]),
+                         n_docs_global=int(s[5]))
+        if "doc_off" in z:
+            ix.doc_off, ix.chunk_ids, ix.emb = z["doc_off"], z["chunk_ids"], z["emb"]
+        if "vocab_terms" in z:
+            ix.vocab = {str(t): i for i, t in enumerate(z["vocab_terms"])}
+        return ix
+
+    # ------------------------------------------------------------------ DuckDB (the reference's store)
+    @staticmethod
+    def from_duckdb(db_path, with_text=True):
+        """Read the reference's tables once.  `duckdb` is not installable in the build container, so this
+        loader is written against the DDL cited in the module docstring and has not been executed there."""
+        import duckdb  # noqa: deliberately unguarded: fails loudly where duckdb is absent
+        con = duckdb.connect(db_path, read_only=True)
+        docs = con.execute("SELECT doc_id, doc_length FROM bm25_doc_stats ORDER BY doc_id").fetchnumpy()
+        stats = dict(con.execute("SELECT stat_name, stat_value FROM bm25_corpus_stats").fetchall())
+        terms = con.execute("SELECT term, idf_score FROM bm25_term_stats ORDER BY term").fetchall()
+        vocab = {t: i for i, (t, _) in enumerate(terms)}
+        url_rows = con.execute("SELECT id, url, title, text FROM urlsDB ORDER BY id").fetchall() if with_text else \
+            con.execute("SELECT id, url, title, NULL FROM urlsDB ORDER BY id").fetchall()
+        ch = con.execute("SELECT c.chunk_id, c.doc_id FROM chunks_optimized c ORDER BY c.doc_id, c.chunk_id").fetchnumpy()
+        all_ids = np.union1d(np.union1d(docs["doc_id"].astype(np.int64), ch["doc_id"].astype(np.int64)),
+                             np.array([r[0] for r in url_rows], np.int64))
+        rank = {int(d): i for i, d in enumerate(all_ids)}
+        doc_len = np.zeros(len(all_ids), np.int32)
+        doc_len[[rank[int(d)] for d in docs["doc_id"]]] = docs["doc_length"].astype(np.int32)
+        tf = con.execute("SELECT tf.term, tf.doc_id, tf.freq FROM bm25_term_freq tf JOIN bm25_doc_stats ds "
+                         "ON tf.doc_id = ds.doc_id ORDER BY tf.term, tf.doc_id").fetchnumpy()
+        t_id = np.array([vocab.get(t, -1) for t in tf["term"]], np.int64)
+        keep = t_id >= 0
+        t_id, p_doc, p_tf = t_id[keep], tf["doc_id"][keep], tf["freq"][keep]
+        order = np.lexsort((p_doc, t_id))
+        t_id, p_doc, p_tf = t_id[order], p_doc[order], p_tf[order]
+        term_off = np.zeros(len(vocab) + 1, np.int64)
+        term_off[1:] = np.cumsum(np.bincount(t_id, minlength=len(vocab)))
+        emb_rows = con.execute("SELECT e.embedding FROM embeddings e JOIN chunks_optimized c ON e.chunk_id = c.chunk_id "
+                               "ORDER BY c.doc_id, c.chunk_id").fetchnumpy()["embedding"]
+        cnt = np.bincount(np.array([rank[int(d)] for d in ch["doc_id"]], np.int64), minlength=len(all_ids))
+        umap = {int(r[0]): r for r in url_rows}
+        ix = CorpusIndex(doc_ids=all_ids, doc_len=doc_len, term_off=term_off,
+                         post_doc=np.array([rank[int(d)] for d in p_doc], np.int32), post_tf=p_tf.astype(np.int32),
+                         idf=np.array([0.0 if v is None else v for _, v in terms], np.float32),
+                         avgdl=float(np.float32(stats.get("avg_doc_length", 1.0))),
+                         total_docs=int(stats.get("total_docs", len(docs["doc_id"]))), vocab=vocab,
+                         doc_off=np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32),
+                         chunk_ids=ch["chunk_id"].astype(np.int64),
+                         emb=np.stack([np.asarray(v, np.float32) for v in emb_rows]) if len(emb_rows) else np.zeros((0, DIM), np.float32),
+                         urls=[umap[int(d)][1] if int(d) in umap else None for d in all_ids],
+                         titles=[umap[int(d)][2] if int(d) in umap else None for d in all_ids],
+                         texts=[umap[int(d)][3] if int(d) in umap else None for d in all_ids])
+        ix.n_docs_global = ix.n_docs
+        return ix
+
+    # ------------------------------------------------------------------ doc-range sharding
+    def shard_bounds(self, world):
+        """Document boundaries of `world` shards balanced by chunk count (dense cost); falls back to
+        document count when no chunks are present."""
+        N = self.n_docs
+        if self.doc_off is not None and self.n_chunks > 0:
+            off = _np(self.doc_off).astype(np.int64)
+            want = (off[-1] * np.arange(1, world)) // world
+            cuts = np.searchsorted(off, want, side="left")
+        else:
+            cuts = (N * np.arange(1, world)) // world
+        b = np.concatenate([[0], np.minimum(cuts, N), [N]]).astype(np.int64)
+        return np.maximum.accumulate(b)
+
+    def shard(self, rank, world):
+        """Shard `rank` of `world`: its documents, its slice of every posting list, its chunk rows.
+        idf / avgdl / total_docs stay GLOBAL so scores are bit-identical to the unsharded index."""
+        b = self.shard_bounds(world)
+        d0, d1 = int(b[rank]), int(b[rank + 1])
+        sub = CorpusIndex(doc_ids=_np(self.doc_ids)[d0:d1], avgdl=self.avgdl, total_docs=self.total_docs,
+                          k1=self.k1, b=self.b, vocab=self.vocab, doc_base=self.doc_base + d0,
+                          n_docs_global=self.n_docs_global or self.n_docs)
+        if self.term_off is not None:
+            pdoc = _np(self.post_doc)
+            keep = (pdoc >= d0) & (pdoc < d1)
+            csum = np.concatenate([[0], np.cumsum(keep, dtype=np.int64)])
+            sub.term_off = csum[_np(self.term_off)]
+            sub.post_doc = (pdoc[keep] - d0).astype(np.int32)
+            sub.post_tf = _np(self.post_tf)[keep]
+            sub.doc_len = _np(self.doc_len)[d0:d1]
+            sub.idf = _np(self.idf)
+        if self.doc_off is not None:
+            off = _np(self.doc_off).astype(np.int64)
+            c0, c1 = int(off[d0]), int(off[d1])
+            sub.doc_off = (off[d0:d1 + 1] - c0).astype(np.int32)
+            sub.chunk_ids = _np(self.chunk_ids)[c0:c1] if self.chunk_ids is not None else None
+            sub.emb = self.emb[c0:c1]
+        for name in ("urls", "titles", "texts"):
+            v = getattr(self, name)
+            if v is not None:
+                setattr(sub, name, v[d0:d1])
+        if self._url_group is not None or self.urls is not None:
+            sub._url_group = self.url_group()[d0:d1]        # group ids stay global
+        return sub

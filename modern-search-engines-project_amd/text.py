@@ -1,0 +1,82 @@
+"""Host-side text helpers of the query path (strings never reach the GPU).
+
+Mirrors, by behaviour, /root/reference/search_api.py:155-166 (preprocess_query), :168-201
+(extract_domain_topic), reranker/reranker_api.py:170-176 (extract_domain), :239-260
+(create_sliding_windows) and the batch line format of search_api.py:290.
+"""
+import re
+from urllib.parse import urlparse
+
+CITY = "tübingen"
+
+
+def preprocess_query(query: str) -> str:
+    """Lower-case, map the ASCII spellings of the city to 'tübingen', append the city when the query does
+    not mention it (search_api.py:155-166)."""
+    q = query.strip().lower()
+    if "tuebingen" in q or "tubingen" in q or CITY in q:
+        q = q.replace("tuebingen", CITY).replace("tubingen", CITY)
+    else:
+        q = f"{q} {CITY}"
+    return q.replace("tuebingen", CITY).replace("tubingen", CITY).strip().lower()
+
+
+def extract_domain(url) -> str:
+    try:
+        return urlparse(url).netloc.lower()
+    except Exception:
+        return "defaultdomain"
+
+
+def extract_domain_topic(url) -> str:
+    if not url or url == "#":
+        return "unknown"
+    try:
+        domain = re.sub(r"^www\.", "", urlparse(url).netloc.lower())
+        parts = domain.split(".")
+        main = (parts[0] if len(parts) == 2 else parts[-2]) if len(parts) >= 2 else domain
+        main = re.sub(r"[^a-zA-Z0-9-]", "", main)
+        return main if main else "unknown"
+    except Exception:
+        return "unknown"
+
+
+def create_sliding_windows(tokens, window_size=512, step_size=450):
+    """Token windows used to cut documents into chunks (config.py:10-11; embedder.py:65-87)."""
+    if len(tokens) <= window_size:
+        return [tokens]
+    windows = [tokens[i:i + window_size] for i in range(0, len(tokens) - window_size + 1, step_size)]
+    last = len(tokens) - window_size
+    if last >= 0 and last % step_size != 0:
+        windows.append(tokens[last:last + window_size])
+    return windows
+
+
+_WORD = re.compile(r"[^\W\d_]+", re.UNICODE)
+
+
+def simple_tokenize(text: str):
+    """Stand-in for BM25._tokenize (bm25_indexer.py:149-155).  The reference lemmatises with spaCy
+    `en_core_web_sm` and drops stop words; spaCy and its model are not available offline, so this only
+    lower-cases and keeps alphabetic tokens.  Pass `tokenizer=` to BM25 / Retriever to plug in the real
+    one; with identical term lists the engine's results are identical to the reference's."""
+    return [m.group(0).lower() for m in _WORD.finditer(text)]
+
+
+def format_result_line(query_num, rank, url, score) -> str:
+    """search_api.py:290"""
+    return f"{query_num}\t{rank}\t{url}\t{score:.3f}"
+
+
+def read_queries_file(path):
+    """queries.txt: 'query_num<TAB>query_text' per line (search_api.py:214-235)."""
+    out = []
+    with open(path, "r", encoding="utf-8") as f:
+        for line in f:
+            line = line.strip()
+            if not line:
+                continue
+            parts = line.split("\t")
+            if len(parts) >= 2:
+                out.append((parts[0].strip(), parts[1].strip()))
+    return out

@@ -1,0 +1,279 @@
+"""HIP path vs the CPU oracle and vs the reference-generated goldens.  Every call goes through the C ABI
+(libmsretr.so).  Run on the GPU box: pytest -m gpu."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _load(name):
+    with open(os.path.join(G, name), encoding="utf-8") as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import msretr
+    from msretr.engine import DeviceEngine
+    from msretr.index import CorpusIndex
+    from oracle import bm25_ref, dense_ref, rerank_ref
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return dict(DeviceEngine=DeviceEngine, CorpusIndex=CorpusIndex, bm25_ref=bm25_ref, dense_ref=dense_ref,
+                rerank_ref=rerank_ref, msretr=msretr)
+
+
+def _ix_from_npz(CorpusIndex, z):
+    return CorpusIndex(doc_ids=z["doc_ids"], doc_len=z["doc_len"], term_off=z["term_off"], post_doc=z["post_doc"],
+                       post_tf=z["post_tf"], idf=z["idf"], avgdl=float(z["avgdl"]), total_docs=int(z["total_docs"]))
+
+
+# ------------------------------------------------------------------------------------------------ BM25
+@pytest.mark.parametrize("name", ["bm25_random_a", "bm25_random_b"])
+def test_bm25_golden_random(mods, name):
+    z = dict(np.load(os.path.join(G, name + ".npz")))
+    meta = _load(name + ".json")
+    ix = _ix_from_npz(mods["CorpusIndex"], z)
+    eng = mods["DeviceEngine"](ix, max_queries=8, max_k=1000)
+    missing = set(meta["missing_from_urlsdb"])
+    for min_score in sorted({q["min_score"] for q in meta["queries"]}):
+        for top_k in sorted({q["top_k"] for q in meta["queries"]}):
+            qs = [q for q in meta["queries"] if q["top_k"] == top_k and q["min_score"] == min_score]
+            if not qs:
+                continue
+            doc, score, n = eng.bm25_topk([q["terms"] for q in qs], k=top_k, min_score=min_score)
+            doc, score, n = doc.cpu().numpy(), score.cpu().numpy(), n.cpu().numpy()
+            for i, q in enumerate(qs):
+                ids = [int(z["doc_ids"][d]) for d in doc[i, :n[i]]]
+                sc = [float(s) for s in score[i, :n[i]]]
+                # engine level == oracle before the urlsDB join (bitwise float64)
+                oi, os_ = mods["bm25_ref"].topk(z, q["terms"], top_k, min_score)
+                assert doc[i, :n[i]].tolist() == oi.tolist()
+                assert sc == os_.tolist()
+                assert np.all(doc[i, n[i]:] == -1) and np.all(np.isneginf(score[i, n[i]:]))
+                # reference golden == engine result after dropping documents absent from urlsDB
+                keep = [(d, s) for d, s in zip(ids, sc) if d not in missing]
+                assert [d for d, _ in keep] == q["doc_id"]
+                assert [s for _, s in keep] == q["score"]
+    eng.close()
+
+
+def test_bm25_known_answers(mods):
+    from msretr.bm25 import BM25
+    for case in _load("bm25_kat.json"):
+        postings = {t: [tuple(p) for p in pl] for t, pl in case["postings"].items()}
+        doc_len = {int(d): l for d, l in case["doc_len"].items()}
+        urls_db = {int(d): ("http://x/%s" % d, v[0], v[1]) for d, v in case["urls_db"].items()}
+        ix = mods["CorpusIndex"].from_tables(postings, doc_len, case["idf_f32"], case["avgdl_f32"],
+                                              total_docs=case["total_docs"], urls_db=urls_db,
+                                              k1=case["k1"], b=case["b"])
+        bm = BM25(ix, k1=case["k1"], b=case["b"], tokenizer=lambda s: s.split(), max_queries=4, max_k=16)
+        for q in case["queries"]:
+            got = bm.search(" ".join(q["terms"]), top_k=min(q["top_k"], 16), min_score=q["min_score"])
+            assert got == q["expected"], (case["name"], q["terms"])
+        bm.engine.close()
+
+
+def test_bm25_synthetic_vs_oracle(mods):
+    from msretr.synthetic import synthetic_corpus, synthetic_queries
+    ix = synthetic_corpus(30000, n_chunks=0, n_terms=20000, seed=5)
+    terms, _ = synthetic_queries(ix, 40, seed=6)
+    terms[3] = [7, 7, 7, 0, 19999, 250000, -1]          # repeats, rare, out-of-range and negative ids
+    terms[4] = []                                        # empty query
+    terms[5] = [0]                                       # only the negative-idf term
+    z = {k: (getattr(ix, k).cpu().numpy() if torch.is_tensor(getattr(ix, k)) else getattr(ix, k))
+         for k in ("doc_ids", "doc_len", "term_off", "post_doc", "post_tf", "idf")}
+    z["avgdl"] = ix.avgdl
+    eng = mods["DeviceEngine"](ix, max_queries=16, max_k=1000)      # 40 queries -> 3 internal slices
+    for k, ms in ((1000, 0.0), (100, 0.0), (7, -50.0), (1000, 2.5)):
+        doc, score, n = eng.bm25_topk(terms, k=k, min_score=ms)
+        doc, score, n = doc.cpu().numpy(), score.cpu().numpy(), n.cpu().numpy()
+        for i, t in enumerate(terms):
+            oi, os_ = mods["bm25_ref"].topk(z, t, k, ms)
+            assert n[i] == len(oi), (i, k, ms)
+            assert doc[i, :n[i]].tolist() == oi.tolist(), (i, k, ms)
+            assert score[i, :n[i]].tolist() == os_.tolist(), (i, k, ms)
+    eng.close()
+
+
+def test_bm25_massive_ties(mods):
+    """All documents identical => every score equal: the k lowest doc indices must come back in order."""
+    N = 20000
+    ix = mods["CorpusIndex"](doc_ids=np.arange(N, dtype=np.int64) * 3 + 5, doc_len=np.full(N, 10, np.int32),
+                             term_off=np.array([0, N], np.int64), post_doc=np.arange(N, dtype=np.int32),
+                             post_tf=np.ones(N, np.int32), idf=np.array([1.5], np.float32), avgdl=10.0, total_docs=N)
+    eng = mods["DeviceEngine"](ix, max_queries=2, max_k=1000)
+    doc, score, n = eng.bm25_topk([[0], [0, 0]], k=1000)
+    doc, score, n = doc.cpu().numpy(), score.cpu().numpy(), n.cpu().numpy()
+    assert n.tolist() == [1000, 1000]
+    assert doc[0].tolist() == list(range(1000)) and doc[1].tolist() == list(range(1000))
+    assert len(set(score[0].tolist())) == 1
+    eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ dense
+def _rand_chunked(rng, n_docs, max_ch, big=()):
+    n = rng.integers(0, max_ch + 1, size=n_docs)
+    for pos, size in big:
+        n[pos] = size
+    doc_off = np.zeros(n_docs + 1, np.int64); doc_off[1:] = np.cumsum(n)
+    C = int(doc_off[-1])
+    emb = rng.standard_normal((C, 768)).astype(np.float32)
+    emb /= np.linalg.norm(emb, axis=1, keepdims=True)
+    return doc_off, emb
+
+
+def _check_dense(mods, eng, doc_off, emb, q, k, mc, got):
+    doc, score, chunk, n = [x.cpu().numpy() for x in got]
+    for i in range(q.shape[0]):
+        best, arg = mods["dense_ref"].doc_scores(emb, doc_off, q[i], mc)
+        oi, os_, oa = mods["dense_ref"].quick_search(emb, doc_off, q[i], k, mc)
+        assert n[i] == len(oi)
+        np.testing.assert_allclose(score[i, :n[i]], os_, rtol=0, atol=1e-5)        # north_star: 1e-5 fp32
+        np.testing.assert_allclose(score[i, :n[i]], best[doc[i, :n[i]]], rtol=0, atol=1e-5)
+        assert np.all(np.diff(score[i, :n[i]]) <= 0)
+        # same documents, except for swaps among scores closer than the tolerance
+        diff = set(doc[i, :n[i]].tolist()) ^ set(oi.tolist())
+        for d in diff:
+            assert abs(best[d] - os_[-1]) <= 2e-5
+        # ties broken by ascending index where the scores are exactly equal
+        for j in range(1, n[i]):
+            if score[i, j] == score[i, j - 1]:
+                assert doc[i, j] > doc[i, j - 1]
+        # arg-max chunk row
+        for j in range(n[i]):
+            d = doc[i, j]
+            c = chunk[i, j]
+            lo, hi = doc_off[d], doc_off[d + 1]
+            if mc:
+                hi = min(hi, lo + mc)
+            assert lo <= c < hi
+            cos_c = float(mods["rerank_ref"].cosine_f32(q[i], emb[c:c + 1])[0])
+            assert abs(cos_c - best[d]) <= 2e-5
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+def test_dense_scan_vs_oracle(mods, layout):
+    rng = np.random.default_rng(17 + layout)
+    doc_off, emb = _rand_chunked(rng, 700, 9, big=((5, 70), (300, 300), (301, 0), (699, 33)))
+    ix = mods["CorpusIndex"](doc_ids=np.arange(700, dtype=np.int64) * 2 + 11, doc_off=doc_off.astype(np.int32),
+                             chunk_ids=np.arange(doc_off[-1], dtype=np.int64), emb=emb, total_docs=700)
+    eng = mods["DeviceEngine"](ix, max_queries=32, max_k=200, scan_layout=layout)
+    for Q in (1, 5, 16, 17, 32, 40):
+        q = (rng.standard_normal((Q, 768)) * rng.uniform(0.5, 9)).astype(np.float32)
+        q[0] = emb[123] * 4.0                                  # an exact hit
+        for (k, mc) in ((100, 0), (200, 10), (7, 3)):
+            got = eng.dense_topk(q, k=k, max_chunks_per_doc=mc)
+            _check_dense(mods, eng, doc_off, emb, q, k, mc, got)
+    eng.close()
+
+
+def test_dense_tiny_and_ragged(mods):
+    rng = np.random.default_rng(2)
+    for n_docs, max_ch in ((1, 1), (3, 2), (40, 1), (17, 40)):
+        doc_off, emb = _rand_chunked(rng, n_docs, max_ch)
+        if doc_off[-1] == 0:
+            continue
+        ix = mods["CorpusIndex"](doc_ids=np.arange(n_docs, dtype=np.int64), doc_off=doc_off.astype(np.int32),
+                                 chunk_ids=np.arange(doc_off[-1], dtype=np.int64), emb=emb, total_docs=n_docs)
+        eng = mods["DeviceEngine"](ix, max_queries=4, max_k=64)
+        q = rng.standard_normal((3, 768)).astype(np.float32)
+        q[1] = 0.0                                              # zero query: cosine 0 everywhere (sklearn)
+        got = eng.dense_topk(q, k=64)
+        _check_dense(mods, eng, doc_off, emb, q, 64, 0, got)
+        eng.close()
+
+
+def test_dense_cosine_golden(mods):
+    """One chunk per document: the engine's scores are the reference's cosine_similarity values."""
+    z = np.load(os.path.join(G, "cosine.npz"))
+    E, q, exp = z["E"], z["q"], z["expected"]
+    n = len(E)
+    ix = mods["CorpusIndex"](doc_ids=np.arange(n, dtype=np.int64), doc_off=np.arange(n + 1, dtype=np.int32),
+                             chunk_ids=np.arange(n, dtype=np.int64), emb=E, total_docs=n)
+    for layout in (0, 1):
+        eng = mods["DeviceEngine"](ix, max_queries=4, max_k=1000, scan_layout=layout)
+        doc, score, chunk, cnt = [x.cpu().numpy() for x in eng.dense_topk(q[None, :], k=1000)]
+        assert cnt[0] == n
+        got = np.empty(n, np.float32); got[doc[0]] = score[0]
+        np.testing.assert_allclose(got, exp, rtol=0, atol=1e-5)
+        assert chunk[0].tolist() == doc[0].tolist()
+        eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ rerank
+def _rerank_case_index(mods, c):
+    z = np.load(os.path.join(G, f"rerank_{c['case']}.npz"))
+    urls_db = {int(u[0]): (u[1], u[2], u[3]) for u in c["urls"]}
+    chunks = list(zip(z["chunk_id"].tolist(), z["chunk_doc"].tolist()))
+    emb = {int(cid): z["emb"][i] for i, cid in enumerate(z["chunk_id"])}
+    doc_len = {int(u[0]): 1 for u in c["urls"]}
+    ix = mods["CorpusIndex"].from_tables({}, doc_len, {}, 1.0, chunks=chunks, emb=emb, urls_db=urls_db)
+    return ix, z["q"]
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+def test_rerank_chain_golden(mods, layout):
+    for c in _load("rerank_chain.json")["cases"]:
+        ix, q = _rerank_case_index(mods, c)
+        pos = {int(d): i for i, d in enumerate(ix.doc_ids)}
+        eng = mods["DeviceEngine"](ix, max_queries=4, max_k=16, rerank_max_docs=256, scan_layout=layout)
+        M = 256
+        cand = np.full((2, M), -1, np.int32); bm = np.zeros((2, M), np.float64)
+        ids = [int(d) for d in c["doc_ids"]]
+        known = [(pos[d], s) for d, s in zip(ids, c["similarities"]) if d in pos]
+        for r in range(2):                                       # same request twice: rows are independent
+            cand[r, :len(known)] = [k[0] for k in known]
+            bm[r, :len(known)] = [k[1] for k in known]
+        n = np.array([len(known)] * 2, np.int32)
+        out = [x.cpu().numpy() for x in eng.rerank(np.stack([q, q]), cand, bm, n)]
+        doc, score, orig, chunk, cnt, rows = out
+        pooled = c["stages"][-1]
+        exp = {d: (ch, s, o) for d, ch, s, o in zip(pooled["doc_id"], pooled["chunk_id"], pooled["new_similarity"],
+                                                    pooled["old_similarity"])}
+        for r in range(2):
+            assert cnt[r] == len(exp)
+            assert rows[r] == c["response"]["div"]["total_documents"]
+            got_ids = [int(ix.doc_ids[d]) for d in doc[r, :cnt[r]]]
+            assert sorted(got_ids) == sorted(exp)
+            assert np.all(np.diff(score[r, :cnt[r]]) <= 0)
+            for j, d in enumerate(got_ids):
+                ch, s, o = exp[d]
+                assert abs(score[r, j] - s) < 5e-6, (d, score[r, j], s)
+                assert abs(orig[r, j] - o) < 1e-12
+                assert int(ix.chunk_ids[chunk[r, j]]) == ch
+        eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ merge
+@pytest.mark.parametrize("bits", [32, 64])
+def test_merge_topk(mods, bits):
+    rng = np.random.default_rng(9)
+    ix = mods["CorpusIndex"](doc_ids=np.arange(4, dtype=np.int64), doc_len=np.ones(4, np.int32),
+                             term_off=np.array([0, 1], np.int64), post_doc=np.zeros(1, np.int32),
+                             post_tf=np.ones(1, np.int32), idf=np.ones(1, np.float32), avgdl=1.0, total_docs=4)
+    eng = mods["DeviceEngine"](ix, max_queries=2, max_k=16)
+    dt = np.float32 if bits == 32 else np.float64
+    for G_, Q, k in ((2, 3, 10), (8, 5, 100), (8, 2, 1000), (1, 1, 1)):
+        docs = np.full((G_, Q, k), -1, np.int32); sc = np.full((G_, Q, k), -np.inf, dt); ns = np.zeros((G_, Q), np.int32)
+        for g in range(G_):
+            for qi in range(Q):
+                m = int(rng.integers(0, k + 1))
+                s = np.sort(rng.integers(0, 50, size=m).astype(dt) / 7)[::-1]     # many exact ties
+                d = rng.choice(np.arange(g * 100000, (g + 1) * 100000), size=m, replace=False).astype(np.int32)
+                o = np.lexsort((d, -s.astype(np.float64)))
+                docs[g, qi, :m], sc[g, qi, :m], ns[g, qi] = d[o], s[o], m
+        t = lambda a: torch.as_tensor(a).cuda()
+        od, os_, on = [x.cpu().numpy() for x in eng.merge_topk(t(docs), t(sc), t(ns), k)]
+        for qi in range(Q):
+            parts = [(docs[g, qi, :ns[g, qi]].astype(np.int64), sc[g, qi, :ns[g, qi]]) for g in range(G_)]
+            ei, es = mods["dense_ref"].merge_topk(parts, k)
+            assert on[qi] == len(ei)
+            assert od[qi, :on[qi]].tolist() == ei.tolist()
+            assert os_[qi, :on[qi]].tolist() == es.tolist()
+    eng.close()
