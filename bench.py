@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""Headline benchmark: queries/sec (and single-query p50 latency) of the two-stage retriever, top-100 on a
+synthetic 1 M-document / 5 M x 768 f32-chunk corpus resident in HBM (BASELINE.json metric / configs[2]).
+
+A STEP = one pass of the whole hot path over one batch of `--queries-per-step` queries:
+    stage 1  BM25 term-at-a-time + top-1000                        (msr_bm25_topk)
+    stage 2  dense full scan: q x chunk cosine, per-doc max-pool, top-100   (msr_dense_topk; one sweep of E)
+    fuse     reference rerank chain on the stage-1 candidates -> top-100     (msr_rerank_gather + _fuse)
+With N > 1 GPUs the corpus is doc-sharded (strong scaling: the corpus is fixed); per step one all-gather of
+the per-shard top-k lists and one bit-OR all-reduce of the candidates' cosines cross xGMI.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      dense-scan kernel: algorithmic bytes per launch / mean launch duration (hipEvents recorded on
+                the launch stream inside the timed region) against the 8 TB/s HBM peak
+  cpu_baseline  the C restatement in oracle/ (kind "port") timed on the host cores on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_shard(args, rank, world, dev, n_queries):
+    from msretr.synthetic import SEED, synthetic_corpus, synthetic_queries
+    t0 = time.time()
+    # postings + chunk layout of the WHOLE corpus (same seed on every rank => identical), embeddings only
+    # for this rank's rows (they are i.i.d., so a shard-local stream is the same distribution)
+    full = synthetic_corpus(args.docs, n_chunks=args.chunks, n_terms=args.terms, seed=SEED, device=dev,
+                            with_embeddings=False)
+    # query terms come from the GLOBAL document frequencies, so every rank draws the same queries
+    terms, _ = synthetic_queries(full, n_queries, seed=777, device="cpu")
+    shard = full.shard(rank, world) if world > 1 else full
+    if world > 1:
+        del full
+    C = shard.n_chunks
+    g = torch.Generator(device=dev)
+    g.manual_seed(SEED + 7919 * (rank + 1))
+    emb = torch.empty((C, 768), dtype=torch.float32, device=dev)
+    blk = 1 << 18
+    for s in range(0, C, blk):
+        x = torch.randn((min(blk, C - s), 768), generator=g, device=dev)
+        emb[s:s + len(x)] = x / x.norm(dim=1, keepdim=True)
+    shard.emb = emb
+    torch.cuda.synchronize()
+    log(f"[rank {rank}] corpus: {shard.n_docs} docs, {C} chunks, {int(shard.post_doc.numel())} postings "
+        f"(doc_base {shard.doc_base}) in {time.time() - t0:.1f}s")
+    return shard, terms
+
+
+def make_query_vectors(n, dev, seed):
+    """Same vectors on every rank: seeded CPU stream, norm in [5, 15] (the encoder output is not normalised)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    v = torch.randn((n, 768), generator=g)
+    v = v / v.norm(dim=1, keepdim=True) * torch.empty(n, 1).uniform_(5.0, 15.0, generator=g)
+    return v.to(dev)
+
+
+def cpu_baseline(args, shard, terms, qvec):
+    """C restatement (oracle/) on the host cores: BM25 over the full postings + dense scan over the first
+    `frac` of the chunk rows, extrapolated to the full corpus.  Returns the cpu_baseline object."""
+    from oracle import bm25_ref, c_oracle
+    nq = min(args.cpu_queries, len(terms))
+    frac = args.cpu_sample_frac
+    n_docs_s = max(1, int(shard.n_docs * frac))
+    doc_off = shard.doc_off[: n_docs_s + 1].cpu().numpy().astype(np.int32)
+    c_s = int(doc_off[-1])
+    t0 = time.time()
+    emb_s = shard.emb[:c_s].cpu().numpy()
+    ix = {k: getattr(shard, k).cpu().numpy() for k in ("term_off", "post_doc", "post_tf", "doc_len", "idf")}
+    ix["avgdl"] = shard.avgdl
+    log(f"[cpu baseline] host copy of postings + {c_s} chunk rows: {time.time() - t0:.1f}s")
+    q_host = qvec[:nq].cpu().numpy()
+    t_b = t_d = 0.0
+    results = []
+    for i in range(nq):
+        ut, qtf = bm25_ref.prepare_query(terms[i], ix["term_off"])
+        t0 = time.perf_counter()
+        r = c_oracle.bm25_topk(ix, ut, qtf, args.k1, 0.0, shard.k1, shard.b)
+        t_b += time.perf_counter() - t0
+        results.append(r)
+        t0 = time.perf_counter()
+        c_oracle.dense_topk(emb_s, doc_off, q_host[i], args.k2)
+        t_d += time.perf_counter() - t0
+    per_query = t_b / nq + (t_d / nq) * (shard.n_chunks / max(1, c_s))
+    threads = c_oracle.threads()
+    obj = {"value": 1.0 / per_query, "unit": "queries/sec", "cores": threads, "kind": "port",
+           "sample": f"{nq} queries: BM25 top-{args.k1} over all {int(ix['post_doc'].size)} postings (1 thread, C) "
+                     f"{1e3 * t_b / nq:.1f} ms/query + dense cosine/max-pool/top-{args.k2} over the first {c_s} of "
+                     f"{shard.n_chunks} chunk rows ({threads} OpenMP threads, C) {1e3 * t_d / nq:.1f} ms/query, "
+                     f"extrapolated linearly to all rows; rerank/fuse stage not included (favours the CPU)"}
+    return obj, results
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--docs", type=int, default=1_000_000)
+    ap.add_argument("--chunks", type=int, default=5_000_000)
+    ap.add_argument("--terms", type=int, default=1_000_000)
+    ap.add_argument("--queries-per-step", type=int, default=32)
+    ap.add_argument("--k1", type=int, default=1000, help="stage-1 candidates (config.py:13)")
+    ap.add_argument("--k2", type=int, default=100, help="final top-k (reranker/config.yaml:30)")
+    ap.add_argument("--scan-layout", type=int, default=0)
+    ap.add_argument("--cpu-queries", type=int, default=16)
+    ap.add_argument("--cpu-sample-frac", type=float, default=0.125)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--latency-queries", type=int, default=20)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from msretr.distributed import ShardedEngine
+    from msretr.engine import DeviceEngine
+
+    Q = args.queries_per_step
+    n_pool = Q * 8
+    shard, terms = build_shard(args, rank, world, dev, n_pool)
+    qvec = make_query_vectors(n_pool, dev, seed=778)
+    eng = DeviceEngine(shard, device=local_rank, max_queries=max(Q, 1), max_k=max(args.k1, args.k2),
+                       rerank_max_docs=args.k1, scan_layout=args.scan_layout)
+    se = ShardedEngine(eng, shard.doc_base, shard.row_base)
+    batches = []
+    for b in range(n_pool // Q):
+        tl = [shard.term_ids(t) for t in terms[b * Q:(b + 1) * Q]]
+        batches.append((eng.pack_queries(tl), qvec[b * Q:(b + 1) * Q].contiguous()))
+
+    def step(i):
+        packed, qv = batches[i % len(batches)]
+        return se.search(None, qv, k1=args.k1, k2=args.k2, packed=packed)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    eng.set_timing(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    scan_ms, scan_n = eng.kernel_time_ms(0)
+    bm_ms, bm_n = eng.kernel_time_ms(1)
+    eng.set_timing(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # single-query latency (p50), same path with a batch of one
+    lat = []
+    one = [(eng.pack_queries([shard.term_ids(terms[i])]), qvec[i:i + 1].contiguous()) for i in range(args.latency_queries)]
+    for rep in range(2):
+        for packed, qv in one:
+            fence()
+            t1 = time.perf_counter()
+            se.search(None, qv, k1=args.k1, k2=args.k2, packed=packed)
+            torch.cuda.synchronize()
+            if rep:
+                lat.append(time.perf_counter() - t1)
+    p50_ms = 1e3 * float(np.median(lat)) if lat else None
+
+    # sanity of the last step's outputs (cheap, outside the timed region)
+    b_doc, b_score, b_n = out["bm25"]
+    d_doc, d_score, d_chunk, d_n = out["dense"]
+    r_doc, r_score, r_orig, r_chunk, r_n, r_rows = out["rerank"]
+    ok = bool((d_n == args.k2).all().item()) and bool((torch.diff(d_score, dim=1) <= 0).all().item())
+    ok = ok and bool((b_n > 0).all().item()) and bool((r_n > 0).all().item())
+
+    if rank == 0:
+        n_ch = shard.n_chunks
+        alg_bytes = n_ch * 768 * 4 + (shard.n_docs + 1) * 4 + Q * 768 * 4
+        per_launch_ms = scan_ms / max(1, scan_n)
+        achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "dense_scan_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes, "launches": scan_n, "ms_per_launch": per_launch_ms,
+                "bm25_taat_ms_per_launch": bm_ms / max(1, bm_n)}
+        line = {
+            "metric": "queries/sec, two-stage retrieval top-100 (BM25 top-1000 + dense full scan + rerank/fuse)",
+            "value": Q * args.steps / elapsed, "unit": "queries/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32 (dense cosine) / f64 (BM25, fuse)",
+            "data": "synthetic",
+            "config": {"workload": f"hybrid two-stage retrieval, {args.docs} docs / {args.chunks} x 768 f32 chunks, "
+                                   f"{Q} queries per step, doc-sharded x{world}",
+                       "n_docs": args.docs, "n_chunks": args.chunks, "n_terms": args.terms,
+                       "queries_per_step": Q, "k_stage1": args.k1, "k_final": args.k2,
+                       "scan_layout": args.scan_layout},
+            "p50_latency_ms_single_query": p50_ms, "outputs_sane": ok, "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                cb, cres = cpu_baseline(args, shard, terms, qvec)
+                line["cpu_baseline"] = cb
+                # BM25 parity of the GPU path against the C restatement on the same queries (bitwise)
+                tl = [shard.term_ids(t) for t in terms[:len(cres)]]
+                gd, gs, gn = [x.cpu().numpy() for x in eng.bm25_topk(tl, k=args.k1)]
+                line["bm25_parity_vs_cpu"] = all(
+                    gd[i, :gn[i]].tolist() == cres[i][0].tolist() and gs[i, :gn[i]].tolist() == cres[i][1].tolist()
+                    for i in range(len(cres)))
+            except Exception as ex:  # the baseline must never take the GPU numbers down with it
+                line["cpu_baseline"] = {"error": repr(ex)}
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -129,6 +129,23 @@ int msr_rerank(msr_engine* e, const float* q, int32_t n_queries, const int32_t* 
                const msr_rerank_params* params, int32_t* out_doc, double* out_score, double* out_orig,
                int32_t* out_chunk, int32_t* out_n, int32_t* out_rows, void* stream);
 
+/* The two halves of msr_rerank, for a doc-sharded index (the reference-exact hybrid needs a
+ * second exchange).  cand_doc holds GLOBAL document indices and is identical on every rank.
+ *   msr_rerank_gather: for the candidates this shard owns (doc_base <= doc < doc_base + n_docs) writes the
+ *     cosines of their first <= max_chunks chunks into out_cos[q][m][0..10) and
+ *     out_meta[q][m] = (rows, url_group + 2, row_base + first row); everything else is written as 0.
+ *     Summing out_cos / out_meta over the shards (one RCCL all-reduce) yields the arrays of the whole
+ *     candidate list, because exactly one shard contributes a non-zero entry.
+ *   msr_rerank_fuse: the float64 chain of reranker_api.py:360-372 on those arrays; touches no index, so
+ *     every rank computes the same result.  Outputs as msr_rerank (out_doc are global indices). */
+int msr_rerank_gather(msr_engine* e, const float* q, int32_t n_queries, const int32_t* cand_doc,
+                      const int32_t* cand_n, int32_t max_cand, int32_t doc_base, int32_t row_base,
+                      int32_t max_chunks, float* out_cos, int32_t* out_meta, void* stream);
+int msr_rerank_fuse(msr_engine* e, int32_t n_queries, const int32_t* cand_doc, const double* cand_bm25,
+                    const int32_t* cand_n, int32_t max_cand, const float* cos, const int32_t* meta,
+                    const msr_rerank_params* params, int32_t* out_doc, double* out_score, double* out_orig,
+                    int32_t* out_chunk, int32_t* out_n, int32_t* out_rows, void* stream);
+
 /* Merge n_parts per-shard top-k lists (the payload of the RCCL all-gather) into the global top-k.
  * in_doc [n_parts][n_queries][k] i32 GLOBAL doc indices, in_score same shape (score_bits = 32: f32,
  * 64: f64), in_n [n_parts][n_queries].  Order: score desc, doc index asc -- identical on every rank. */
@@ -136,9 +153,10 @@ int msr_merge_topk(msr_engine* e, const int32_t* in_doc, const void* in_score, c
                    int32_t n_parts, int32_t n_queries, int32_t k, int32_t score_bits, int32_t* out_doc,
                    void* out_score, int32_t* out_n, void* stream);
 
-/* Timing hooks for bench.py: hipEvent-bracketed duration of the dominant kernel of the last
- * msr_dense_topk / msr_bm25_topk call, recorded on the caller's stream.  msr_kernel_time_ms blocks on
- * the stop event.  which: 0 = dense scan kernel, 1 = BM25 TAAT kernel. */
+/* Timing hooks for bench.py: while enabled, every launch of the dominant kernels is bracketed by a
+ * hipEvent pair recorded on the caller's stream (ring of 256 launches per kernel).  msr_kernel_time_ms
+ * blocks on the recorded events and returns the SUM of the launch durations and the number of launches
+ * since msr_set_timing(e, 1).  which: 0 = dense scan kernel, 1 = BM25 TAAT kernel. */
 int msr_set_timing(msr_engine* e, int32_t enabled);
 int msr_kernel_time_ms(msr_engine* e, int32_t which, float* out_ms, int32_t* out_launches);
 

@@ -30,12 +30,14 @@ struct msr_engine {
     size_t score_rows_bytes = 0;
     SelScratch sel{};
     float* rerank_cos = nullptr;
+    int32_t* rerank_meta = nullptr;
     int n_cus = 256;
     // timing
     bool timing = false;
-    hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-    bool ev_valid[2] = {false, false};
-    int ev_launches[2] = {0, 0};
+    static constexpr int EV_RING = 256;
+    hipEvent_t ev_start[2][EV_RING] = {};
+    hipEvent_t ev_stop[2][EV_RING] = {};
+    int ev_count[2] = {0, 0};          // launches recorded since msr_set_timing(1)
 };
 
 static thread_local char g_create_err[512] = "";
@@ -111,10 +113,14 @@ extern "C" int msr_create(const msr_config* cfg, msr_engine** out) {
     if (cfg->rerank_max_docs > 0) {
         const size_t bytes = nq * (size_t)cfg->rerank_max_docs * MSR_RERANK_MAX_CHUNKS * sizeof(float);
         if ((herr = hipMalloc((void**)&e->rerank_cos, bytes)) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc rerank_cos", herr);
+        if ((herr = hipMalloc((void**)&e->rerank_meta, nq * (size_t)cfg->rerank_max_docs * 3 * sizeof(int32_t))) != hipSuccess)
+            return bail(MSR_ERR_NOMEM, "hipMalloc rerank_meta", herr);
     }
     for (int w = 0; w < 2; ++w)
-        for (int j = 0; j < 2; ++j)
-            if ((herr = hipEventCreate(&e->ev[w][j])) != hipSuccess) return bail(MSR_ERR_HIP, "hipEventCreate", herr);
+        for (int j = 0; j < msr_engine::EV_RING; ++j) {
+            if ((herr = hipEventCreate(&e->ev_start[w][j])) != hipSuccess) return bail(MSR_ERR_HIP, "hipEventCreate", herr);
+            if ((herr = hipEventCreate(&e->ev_stop[w][j])) != hipSuccess) return bail(MSR_ERR_HIP, "hipEventCreate", herr);
+        }
     *out = e;
     return MSR_OK;
 }
@@ -123,10 +129,12 @@ extern "C" int msr_destroy(msr_engine* e) {
     if (!e) return MSR_OK;
     free_dev(e->chunk_doc); free_dev(e->inv_norm_own); free_dev(e->span_doc); free_dev(e->qn);
     free_dev(e->score_rows); free_dev(e->sel.hist); free_dev(e->sel.state); free_dev(e->sel.cand_hi);
-    free_dev(e->sel.cand_lo); free_dev(e->sel.cand_n); free_dev(e->rerank_cos);
+    free_dev(e->sel.cand_lo); free_dev(e->sel.cand_n); free_dev(e->rerank_cos); free_dev(e->rerank_meta);
     for (int w = 0; w < 2; ++w)
-        for (int j = 0; j < 2; ++j)
-            if (e->ev[w][j]) (void)hipEventDestroy(e->ev[w][j]);
+        for (int j = 0; j < msr_engine::EV_RING; ++j) {
+            if (e->ev_start[w][j]) (void)hipEventDestroy(e->ev_start[w][j]);
+            if (e->ev_stop[w][j]) (void)hipEventDestroy(e->ev_stop[w][j]);
+        }
     delete e;
     return MSR_OK;
 }
@@ -247,16 +255,23 @@ extern "C" int msr_interleave_rows(msr_engine* e, const float* src, int64_t n_ro
 extern "C" int msr_set_timing(msr_engine* e, int32_t enabled) {
     if (!e) return MSR_ERR_INVALID;
     e->timing = enabled != 0;
-    e->ev_valid[0] = e->ev_valid[1] = false;
+    e->ev_count[0] = e->ev_count[1] = 0;
     return MSR_OK;
 }
 
 extern "C" int msr_kernel_time_ms(msr_engine* e, int32_t which, float* out_ms, int32_t* out_launches) {
     if (!e || which < 0 || which > 1 || !out_ms) return e ? fail(e, MSR_ERR_INVALID, "msr_kernel_time_ms: bad argument") : MSR_ERR_INVALID;
-    if (!e->ev_valid[which]) return fail(e, MSR_ERR_INVALID, "msr_kernel_time_ms: no timed launch recorded");
-    HIP_TRY(e, hipEventSynchronize(e->ev[which][1]));
-    HIP_TRY(e, hipEventElapsedTime(out_ms, e->ev[which][0], e->ev[which][1]));
-    if (out_launches) *out_launches = e->ev_launches[which];
+    const int n = std::min(e->ev_count[which], (int)msr_engine::EV_RING);
+    if (n <= 0) return fail(e, MSR_ERR_INVALID, "msr_kernel_time_ms: no timed launch recorded");
+    float total = 0.f;
+    for (int j = 0; j < n; ++j) {
+        float ms = 0.f;
+        HIP_TRY(e, hipEventSynchronize(e->ev_stop[which][j]));
+        HIP_TRY(e, hipEventElapsedTime(&ms, e->ev_start[which][j], e->ev_stop[which][j]));
+        total += ms;
+    }
+    *out_ms = total;
+    if (out_launches) *out_launches = n;
     return MSR_OK;
 }
 
@@ -272,15 +287,15 @@ extern "C" int msr_bm25_topk(msr_engine* e, const int32_t* q_term_off, const int
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     const int slice = e->cfg.max_queries;
     const int64_t N = e->bm25.n_docs;
-    // only the LAST slice's kernel is bracketed when timing (one launch per event pair)
     for (int q0 = 0; q0 < n_queries; q0 += slice) {
         const int nq = std::min(slice, n_queries - q0);
-        const bool timed = e->timing && q0 + nq >= n_queries;
-        if (timed) HIP_TRY(e, hipEventRecord(e->ev[1][0], st));
+        // every kernel launch gets its own event pair (ring of EV_RING; later launches are not recorded)
+        const bool timed = e->timing && e->ev_count[1] < msr_engine::EV_RING;
+        if (timed) HIP_TRY(e, hipEventRecord(e->ev_start[1][e->ev_count[1]], st));
         HIP_TRY(e, msr_bm25_scores(e->bm25, q_term_off, q_terms, q_qtf, q0, nq, min_score, (double*)e->score_rows, st));
         if (timed) {
-            HIP_TRY(e, hipEventRecord(e->ev[1][1], st));
-            e->ev_valid[1] = true; e->ev_launches[1] = 1;
+            HIP_TRY(e, hipEventRecord(e->ev_stop[1][e->ev_count[1]], st));
+            e->ev_count[1]++;
         }
         HIP_TRY(e, msr_select_topk(64, e->score_rows, N, N, nq, k, e->sel, out_doc + (int64_t)q0 * k,
                                    out_score + (int64_t)q0 * k, out_n + q0, st));
@@ -302,13 +317,13 @@ extern "C" int msr_dense_topk(msr_engine* e, const float* q, int32_t n_queries, 
     for (int q0 = 0; q0 < n_queries; q0 += slice) {
         const int nq = std::min(slice, n_queries - q0);
         const int nq_pad = nq <= 16 ? 16 : 32;
-        const bool timed = e->timing && q0 + nq >= n_queries;
+        const bool timed = e->timing && e->ev_count[0] < msr_engine::EV_RING;
         HIP_TRY(e, msr_prep_queries(q + (int64_t)q0 * MSR_DIM, nq, e->qn, nq_pad, st));
-        if (timed) HIP_TRY(e, hipEventRecord(e->ev[0][0], st));
+        if (timed) HIP_TRY(e, hipEventRecord(e->ev_start[0][e->ev_count[0]], st));
         HIP_TRY(e, msr_dense_scan(e->dense, e->qn, nq, max_chunks_per_doc, (float*)e->score_rows, st));
         if (timed) {
-            HIP_TRY(e, hipEventRecord(e->ev[0][1], st));
-            e->ev_valid[0] = true; e->ev_launches[0] = 1;
+            HIP_TRY(e, hipEventRecord(e->ev_stop[0][e->ev_count[0]], st));
+            e->ev_count[0]++;
         }
         HIP_TRY(e, msr_select_topk(32, e->score_rows, N, N, nq, k, e->sel, out_doc + (int64_t)q0 * k,
                                    out_score + (int64_t)q0 * k, out_n + q0, st));
@@ -319,33 +334,78 @@ extern "C" int msr_dense_topk(msr_engine* e, const float* q, int32_t n_queries, 
     return MSR_OK;
 }
 
+static int rerank_args_ok(msr_engine* e, const char* fn, int32_t n_queries, int32_t max_cand, int32_t max_chunks) {
+    if (n_queries < 0 || max_cand < 1 || max_cand > e->cfg.rerank_max_docs)
+        return fail(e, MSR_ERR_INVALID, "%s: bad argument (max_cand=%d, rerank_max_docs=%d)", fn, max_cand,
+                    e->cfg.rerank_max_docs);
+    if (max_chunks < 1 || max_chunks > MSR_RERANK_MAX_CHUNKS)
+        return fail(e, MSR_ERR_INVALID, "%s: max_chunks out of range [1, %d]", fn, MSR_RERANK_MAX_CHUNKS);
+    return MSR_OK;
+}
+
+extern "C" int msr_rerank_gather(msr_engine* e, const float* q, int32_t n_queries, const int32_t* cand_doc,
+                                 const int32_t* cand_n, int32_t max_cand, int32_t doc_base, int32_t row_base,
+                                 int32_t max_chunks, float* out_cos, int32_t* out_meta, void* stream) {
+    if (!e) return MSR_ERR_INVALID;
+    if (!e->have_chunks) return fail(e, MSR_ERR_NOT_BOUND, "msr_rerank_gather: chunks not bound");
+    if (!q || !cand_doc || !cand_n || !out_cos || !out_meta) return fail(e, MSR_ERR_INVALID, "msr_rerank_gather: null argument");
+    int rc = rerank_args_ok(e, "msr_rerank_gather", n_queries, max_cand, max_chunks);
+    if (rc) return rc;
+    if (e->url_group && e->url_group_n != e->dense.n_docs)
+        return fail(e, MSR_ERR_INVALID, "msr_rerank_gather: doc meta bound for %lld docs, chunks for %lld",
+                    (long long)e->url_group_n, (long long)e->dense.n_docs);
+    if (n_queries == 0) return MSR_OK;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    for (int q0 = 0; q0 < n_queries; q0 += 32) {            // qn holds 32 normalised queries
+        const int nq = std::min(32, n_queries - q0);
+        HIP_TRY(e, msr_prep_queries(q + (int64_t)q0 * MSR_DIM, nq, e->qn, nq, st));
+        const int64_t o = (int64_t)q0 * max_cand;
+        HIP_TRY(e, msr_rerank_gather(e->dense, e->url_group, e->qn, nq, cand_doc + o, cand_n + q0, max_cand, doc_base,
+                                     row_base, max_chunks, out_cos + o * MSR_RERANK_MAX_CHUNKS, out_meta + o * 3, st));
+    }
+    return MSR_OK;
+}
+
+extern "C" int msr_rerank_fuse(msr_engine* e, int32_t n_queries, const int32_t* cand_doc, const double* cand_bm25,
+                               const int32_t* cand_n, int32_t max_cand, const float* cos, const int32_t* meta,
+                               const msr_rerank_params* params, int32_t* out_doc, double* out_score,
+                               double* out_orig, int32_t* out_chunk, int32_t* out_n, int32_t* out_rows, void* stream) {
+    if (!e) return MSR_ERR_INVALID;
+    if (!cand_doc || !cand_bm25 || !cand_n || !cos || !meta || !params || !out_doc || !out_score || !out_orig ||
+        !out_chunk || !out_n || !out_rows)
+        return fail(e, MSR_ERR_INVALID, "msr_rerank_fuse: null argument");
+    int rc = rerank_args_ok(e, "msr_rerank_fuse", n_queries, max_cand, params->max_chunks);
+    if (rc) return rc;
+    if (n_queries == 0) return MSR_OK;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    const RerankParams p{params->smoothing, params->max_boost, params->max_decay, params->max_chunks};
+    HIP_TRY(e, msr_rerank_fuse_run(n_queries, cand_doc, cand_bm25, cand_n, max_cand, p, cos, meta, out_doc, out_score,
+                                   out_orig, out_chunk, out_n, out_rows, (hipStream_t)stream));
+    return MSR_OK;
+}
+
 extern "C" int msr_rerank(msr_engine* e, const float* q, int32_t n_queries, const int32_t* cand_doc,
                           const double* cand_bm25, const int32_t* cand_n, int32_t max_cand,
                           const msr_rerank_params* params, int32_t* out_doc, double* out_score, double* out_orig,
                           int32_t* out_chunk, int32_t* out_n, int32_t* out_rows, void* stream) {
     if (!e) return MSR_ERR_INVALID;
-    if (!e->have_chunks) return fail(e, MSR_ERR_NOT_BOUND, "msr_rerank: chunks not bound");
-    if (n_queries < 0 || !q || !cand_doc || !cand_bm25 || !cand_n || !params || !out_doc || !out_score || !out_orig ||
-        !out_chunk || !out_n || !out_rows || max_cand < 1 || max_cand > e->cfg.rerank_max_docs)
-        return fail(e, MSR_ERR_INVALID, "msr_rerank: bad argument (max_cand=%d, rerank_max_docs=%d)", max_cand,
-                    e->cfg.rerank_max_docs);
-    if (params->max_chunks < 1 || params->max_chunks > MSR_RERANK_MAX_CHUNKS)
-        return fail(e, MSR_ERR_INVALID, "msr_rerank: max_chunks out of range [1, %d]", MSR_RERANK_MAX_CHUNKS);
-    if (e->url_group && e->url_group_n != e->dense.n_docs)
-        return fail(e, MSR_ERR_INVALID, "msr_rerank: doc meta bound for %lld docs, chunks for %lld",
-                    (long long)e->url_group_n, (long long)e->dense.n_docs);
-    if (n_queries == 0) return MSR_OK;
-    hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(e, hipSetDevice(e->cfg.device));
-    const RerankParams p{params->smoothing, params->max_boost, params->max_decay, params->max_chunks};
-    const int slice = std::min(32, e->cfg.max_queries);   // qn holds 32 normalised queries
+    if (!params) return fail(e, MSR_ERR_INVALID, "msr_rerank: null params");
+    // unsharded convenience: gather (this engine owns every document) + fuse, slice by slice
+    const int slice = std::min(32, e->cfg.max_queries);
     for (int q0 = 0; q0 < n_queries; q0 += slice) {
         const int nq = std::min(slice, n_queries - q0);
-        HIP_TRY(e, msr_prep_queries(q + (int64_t)q0 * MSR_DIM, nq, e->qn, nq, st));
         const int64_t o = (int64_t)q0 * max_cand;
-        HIP_TRY(e, msr_rerank_run(e->dense, e->url_group, e->qn, nq, cand_doc + o, cand_bm25 + o, cand_n + q0,
-                                  max_cand, p, e->rerank_cos, out_doc + o, out_score + o, out_orig + o,
-                                  out_chunk + o, out_n + q0, out_rows + q0, st));
+        int rc = msr_rerank_gather(e, q ? q + (int64_t)q0 * MSR_DIM : nullptr, nq, cand_doc ? cand_doc + o : nullptr,
+                                   cand_n ? cand_n + q0 : nullptr, max_cand, 0, 0, params->max_chunks, e->rerank_cos,
+                                   e->rerank_meta, stream);
+        if (rc) return rc;
+        rc = msr_rerank_fuse(e, nq, cand_doc + o, cand_bm25 ? cand_bm25 + o : nullptr, cand_n + q0, max_cand,
+                             e->rerank_cos, e->rerank_meta, params, out_doc ? out_doc + o : nullptr,
+                             out_score ? out_score + o : nullptr, out_orig ? out_orig + o : nullptr,
+                             out_chunk ? out_chunk + o : nullptr, out_n ? out_n + q0 : nullptr,
+                             out_rows ? out_rows + q0 : nullptr, stream);
+        if (rc) return rc;
     }
     return MSR_OK;
 }

@@ -80,8 +80,13 @@ struct RerankParams {
     double smoothing, max_boost, max_decay;
     int32_t max_chunks;
 };
-hipError_t msr_rerank_run(const DenseIndex& ix, const int32_t* url_group, const float* qn, int nq,
-                          const int32_t* cand_doc, const double* cand_bm25, const int32_t* cand_n, int max_cand,
-                          const RerankParams& p, float* cos_scratch /*[nq][max_cand][10]*/,
-                          int32_t* out_doc, double* out_score, double* out_orig, int32_t* out_chunk,
-                          int32_t* out_n, int32_t* out_rows, hipStream_t stream);
+// (A) cosines + (rows, url group, first row) of the candidates this shard owns; zeros for the others.
+hipError_t msr_rerank_gather(const DenseIndex& ix, const int32_t* url_group, const float* qn, int nq,
+                             const int32_t* cand_doc, const int32_t* cand_n, int max_cand, int doc_base,
+                             int row_base, int max_chunks, float* cos_out /*[nq][max_cand][10]*/,
+                             int32_t* meta /*[nq][max_cand][3]*/, hipStream_t stream);
+// (B) the float64 chain; needs no index.
+hipError_t msr_rerank_fuse_run(int nq, const int32_t* cand_doc, const double* cand_bm25, const int32_t* cand_n,
+                               int max_cand, const RerankParams& p, const float* cos_in, const int32_t* meta,
+                               int32_t* out_doc, double* out_score, double* out_orig, int32_t* out_chunk,
+                               int32_t* out_n, int32_t* out_rows, hipStream_t stream);

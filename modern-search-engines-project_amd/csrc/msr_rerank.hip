@@ -8,8 +8,11 @@
 //   positional        boost/decay of each document's best chunk                              :299-334
 //   pool + order      per-document first maximum, descending                                 :370-372
 // Two kernels: (A) one wave per (query, candidate) gathers the candidate's chunk rows and computes the
-// cosines (HBM-bound gather of <= 10 x 3 KiB rows); (B) one workgroup per query runs the float64 chain on
-// <= 1024 candidates entirely in LDS.
+// cosines (HBM-bound gather of <= 10 x 3 KiB rows) plus three integers per candidate (rows, URL group,
+// first row); (B) one workgroup per query runs the float64 chain on <= 1024 candidates entirely in LDS,
+// reading ONLY the arrays (A) produced.  That split is what lets a doc-sharded index rerank a global
+// candidate list: each shard runs (A) for the documents it owns, the arrays are summed across shards
+// (all other shards contribute zeros), and every rank runs (B) on identical inputs.
 #include "msr_common.h"
 #include "msr_internal.h"
 
@@ -21,20 +24,34 @@ constexpr int RR_THREADS = 1024;
 constexpr int RR_MAXM = 1024;
 
 template <bool TILED>
-__global__ __launch_bounds__(64) void rerank_cos_kernel(DenseIndex ix, const float* __restrict__ qn,
+__global__ __launch_bounds__(64) void rerank_cos_kernel(DenseIndex ix, const int32_t* __restrict__ url_group,
+                                                         const float* __restrict__ qn,
                                                          const int32_t* __restrict__ cand_doc,
                                                          const int32_t* __restrict__ cand_n, int max_cand,
-                                                         int max_chunks, float* __restrict__ cos_out) {
+                                                         int doc_base, int row_base, int max_chunks,
+                                                         float* __restrict__ cos_out, int32_t* __restrict__ meta) {
+    // cand_doc holds GLOBAL document indices; this shard owns [doc_base, doc_base + n_docs).
     const int q = blockIdx.y, m = blockIdx.x, lane = threadIdx.x;
-    if (m >= cand_n[q]) return;
-    const int d = cand_doc[(int64_t)q * max_cand + m];
-    if (d < 0 || d >= ix.n_docs) return;
+    float* out = cos_out + ((int64_t)q * max_cand + m) * RR_MAXC;
+    int32_t* mt = meta + ((int64_t)q * max_cand + m) * 3;
+    const int d = m < cand_n[q] ? cand_doc[(int64_t)q * max_cand + m] - doc_base : -1;
+    if (d < 0 || d >= ix.n_docs) {                       // not a candidate, or owned by another shard
+        if (lane < RR_MAXC) out[lane] = 0.f;
+        if (lane < 3) mt[lane] = 0;
+        return;
+    }
     const int64_t ds = ix.doc_off[d];
     int64_t de = ix.doc_off[d + 1];
     if (ds + max_chunks < de) de = ds + max_chunks;
+    if (lane == 0) {
+        mt[0] = (int32_t)(de - ds);                      // chunk rows that take part (<= max_chunks)
+        // URL group + 2, so that after the cross-shard sum 0 = nobody owns it, 1 = owned, not in urlsDB
+        mt[1] = (url_group ? url_group[d] : d + doc_base) + 2;
+        mt[2] = (int32_t)ds + row_base;                  // global row of the document's first chunk
+    }
+    if (lane >= (int)(de - ds) && lane < RR_MAXC) out[lane] = 0.f;
     const f32x4* q4 = (const f32x4*)(qn + (size_t)q * MSR_DIM);
     const f32x4 qa = q4[lane], qb = q4[lane + 64], qc = q4[lane + 128];
-    float* out = cos_out + ((int64_t)q * max_cand + m) * RR_MAXC;
     for (int64_t c = ds; c < de; ++c) {
         f32x4 a, b, e;
         if (TILED) {
@@ -98,9 +115,9 @@ __device__ __forceinline__ double block_reduce(double v, bool is_min, double* re
 }
 
 __global__ __launch_bounds__(RR_THREADS) void rerank_fuse_kernel(
-    DenseIndex ix, const int32_t* __restrict__ url_group, const int32_t* __restrict__ cand_doc,
-    const double* __restrict__ cand_bm25, const int32_t* __restrict__ cand_n, int max_cand, RerankParams prm,
-    const float* __restrict__ cos_in, int32_t* __restrict__ out_doc, double* __restrict__ out_score,
+    const int32_t* __restrict__ cand_doc, const double* __restrict__ cand_bm25,
+    const int32_t* __restrict__ cand_n, int max_cand, RerankParams prm, const float* __restrict__ cos_in,
+    const int32_t* __restrict__ meta, int32_t* __restrict__ out_doc, double* __restrict__ out_score,
     double* __restrict__ out_orig, int32_t* __restrict__ out_chunk, int32_t* __restrict__ out_n,
     int32_t* __restrict__ out_rows) {
     __shared__ uint64_t khi[RR_MAXM];
@@ -121,16 +138,15 @@ __global__ __launch_bounds__(RR_THREADS) void rerank_fuse_kernel(
     while (P < n) P <<= 1;
     const int32_t* cd = cand_doc + (int64_t)q * max_cand;
     const double* cb = cand_bm25 + (int64_t)q * max_cand;
+    const int32_t* mt = meta + (int64_t)q * max_cand * 3;      // (rows, url group, first row) per candidate
 
     // 1. sort candidates by (url group, doc) so the first entry of each group is MIN(id)   (:38-47)
     for (int i = tid; i < P; i += RR_THREADS) {
         uint64_t key = ~0ull;
         if (i < n) {
             const int d = cd[i];
-            if (d >= 0 && d < ix.n_docs) {
-                const int g = url_group ? url_group[d] : d;
-                if (g >= 0) key = ((uint64_t)(uint32_t)g << 32) | (uint32_t)d;
-            }
+            const int g = mt[3 * i + 1] - 2;
+            if (d >= 0 && g >= 0) key = ((uint64_t)(uint32_t)g << 32) | (uint32_t)d;
         }
         khi[i] = key; klo[i] = 0; val[i] = (uint32_t)i;
     }
@@ -145,12 +161,10 @@ __global__ __launch_bounds__(RR_THREADS) void rerank_fuse_kernel(
         bool k = false;
         const uint64_t key = khi[i];
         if (key != ~0ull && (i == 0 || (khi[i - 1] >> 32) != (key >> 32))) {
-            const int d = (int)(uint32_t)key;
-            int64_t nr = (int64_t)ix.doc_off[d + 1] - ix.doc_off[d];
-            if (nr > prm.max_chunks) nr = prm.max_chunks;
+            const int m = (int)val[i];
+            const int nr = mt[3 * m];
             if (nr > 0) {
                 k = true;
-                const int m = (int)val[i];
                 const float* cs = cos_in + ((int64_t)q * max_cand + m) * RR_MAXC;
                 for (int j = 0; j < (int)nr; ++j) {
                     const double c = (double)cs[j];
@@ -178,8 +192,7 @@ __global__ __launch_bounds__(RR_THREADS) void rerank_fuse_kernel(
         if (keep[i]) {
             const int d = (int)(uint32_t)khi[i];
             const int m = (int)val[i];
-            int nr = (int)(ix.doc_off[d + 1] - ix.doc_off[d]);
-            if (nr > prm.max_chunks) nr = prm.max_chunks;
+            const int nr = mt[3 * m];
             const float* cs = cos_in + ((int64_t)q * max_cand + m) * RR_MAXC;
             const double old = (bmax == bmin) ? 0.0 : (cb[m] - bmin) / (bmax - bmin);
             double v[RR_MAXC];
@@ -200,7 +213,7 @@ __global__ __launch_bounds__(RR_THREADS) void rerank_fuse_kernel(
                 for (int j = 1; j < nr; ++j)
                     if (v[j] > v[best]) best = j;
             }
-            sc[i] = v[best]; og[i] = old; ch[i] = (int32_t)(ix.doc_off[d] + best);
+            sc[i] = v[best]; og[i] = old; ch[i] = mt[3 * m + 2] + best;
             shi = msr_ord64(v[best]); slo = ~(uint32_t)d;
             atomicAdd(&cnt[1], 1);
         }
@@ -224,21 +237,28 @@ __global__ __launch_bounds__(RR_THREADS) void rerank_fuse_kernel(
 
 }  // namespace
 
-hipError_t msr_rerank_run(const DenseIndex& ix, const int32_t* url_group, const float* qn, int nq,
-                          const int32_t* cand_doc, const double* cand_bm25, const int32_t* cand_n, int max_cand,
-                          const RerankParams& p, float* cos_scratch, int32_t* out_doc, double* out_score,
-                          double* out_orig, int32_t* out_chunk, int32_t* out_n, int32_t* out_rows,
-                          hipStream_t stream) {
+hipError_t msr_rerank_gather(const DenseIndex& ix, const int32_t* url_group, const float* qn, int nq,
+                             const int32_t* cand_doc, const int32_t* cand_n, int max_cand, int doc_base,
+                             int row_base, int max_chunks, float* cos_out, int32_t* meta, hipStream_t stream) {
     if (nq <= 0) return hipSuccess;
-    if (max_cand <= 0 || max_cand > RR_MAXM || p.max_chunks <= 0 || p.max_chunks > RR_MAXC)
-        return hipErrorInvalidValue;
+    if (max_cand <= 0 || max_cand > RR_MAXM || max_chunks <= 0 || max_chunks > RR_MAXC) return hipErrorInvalidValue;
     dim3 grid((unsigned)max_cand, (unsigned)nq);
     if (ix.layout == 1)
-        rerank_cos_kernel<true><<<grid, 64, 0, stream>>>(ix, qn, cand_doc, cand_n, max_cand, p.max_chunks, cos_scratch);
+        rerank_cos_kernel<true><<<grid, 64, 0, stream>>>(ix, url_group, qn, cand_doc, cand_n, max_cand, doc_base,
+                                                         row_base, max_chunks, cos_out, meta);
     else
-        rerank_cos_kernel<false><<<grid, 64, 0, stream>>>(ix, qn, cand_doc, cand_n, max_cand, p.max_chunks, cos_scratch);
-    rerank_fuse_kernel<<<nq, RR_THREADS, 0, stream>>>(ix, url_group, cand_doc, cand_bm25, cand_n, max_cand, p,
-                                                      cos_scratch, out_doc, out_score, out_orig, out_chunk, out_n,
-                                                      out_rows);
+        rerank_cos_kernel<false><<<grid, 64, 0, stream>>>(ix, url_group, qn, cand_doc, cand_n, max_cand, doc_base,
+                                                          row_base, max_chunks, cos_out, meta);
+    return hipGetLastError();
+}
+
+hipError_t msr_rerank_fuse_run(int nq, const int32_t* cand_doc, const double* cand_bm25, const int32_t* cand_n,
+                               int max_cand, const RerankParams& p, const float* cos_in, const int32_t* meta,
+                               int32_t* out_doc, double* out_score, double* out_orig, int32_t* out_chunk,
+                               int32_t* out_n, int32_t* out_rows, hipStream_t stream) {
+    if (nq <= 0) return hipSuccess;
+    if (max_cand <= 0 || max_cand > RR_MAXM || p.max_chunks <= 0 || p.max_chunks > RR_MAXC) return hipErrorInvalidValue;
+    rerank_fuse_kernel<<<nq, RR_THREADS, 0, stream>>>(cand_doc, cand_bm25, cand_n, max_cand, p, cos_in, meta, out_doc,
+                                                      out_score, out_orig, out_chunk, out_n, out_rows);
     return hipGetLastError();
 }

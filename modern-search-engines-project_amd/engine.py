@@ -69,7 +69,7 @@ class DeviceEngine:
     def _bind(self, ix):
         t = self._t
         with torch.cuda.device(self.device):
-            if ix.term_off is not None:
+            if ix.term_off is not None and ix.n_terms > 0:
                 t["term_off"] = self._dev(ix.term_off, torch.int64)
                 t["post_doc"] = self._dev(ix.post_doc, torch.int32)
                 t["post_tf"] = self._dev(ix.post_tf, torch.int32)
@@ -159,6 +159,36 @@ class DeviceEngine:
         self._check(self.lib.msr_rerank(self.handle, _ptr(q), Q, _ptr(cand_doc), _ptr(cand_bm25), _ptr(cand_n), M,
                                         C.byref(prm), _ptr(out_doc), _ptr(out_score), _ptr(out_orig),
                                         _ptr(out_chunk), _ptr(out_n), _ptr(out_rows), self._stream()))
+        return out_doc, out_score, out_orig, out_chunk, out_n, out_rows
+
+    def rerank_gather(self, qvec, cand_doc_global, cand_n, doc_base=0, row_base=0, max_chunks=10):
+        """Shard-local half of rerank: (cos float32 [Q, M, 10], meta int32 [Q, M, 3]); zeros for foreign docs."""
+        q = self._dev(qvec, torch.float32).reshape(-1, DIM)
+        cand = self._dev(cand_doc_global, torch.int32)
+        cn = self._dev(cand_n, torch.int32)
+        Q, M = int(cand.shape[0]), int(cand.shape[1])
+        cos = torch.empty((Q, M, _abi.MSR_RERANK_MAX_CHUNKS), dtype=torch.float32, device=self.device)
+        meta = torch.empty((Q, M, 3), dtype=torch.int32, device=self.device)
+        self._check(self.lib.msr_rerank_gather(self.handle, _ptr(q), Q, _ptr(cand), _ptr(cn), M, int(doc_base),
+                                               int(row_base), int(max_chunks), _ptr(cos), _ptr(meta), self._stream()))
+        return cos, meta
+
+    def rerank_fuse(self, cand_doc_global, cand_bm25, cand_n, cos, meta, **params):
+        p = dict(RERANK_DEFAULTS)
+        p.update(params)
+        cand = self._dev(cand_doc_global, torch.int32)
+        bm = self._dev(cand_bm25, torch.float64)
+        cn = self._dev(cand_n, torch.int32)
+        Q, M = int(cand.shape[0]), int(cand.shape[1])
+        prm = _abi.MsrRerankParams(p["smoothing"], p["max_boost"], p["max_decay"], int(p["max_chunks"]), 0)
+        mk = lambda dt: torch.empty((Q, M), dtype=dt, device=self.device)
+        out_doc, out_score, out_orig, out_chunk = mk(torch.int32), mk(torch.float64), mk(torch.float64), mk(torch.int32)
+        out_n = torch.empty((Q,), dtype=torch.int32, device=self.device)
+        out_rows = torch.empty((Q,), dtype=torch.int32, device=self.device)
+        self._check(self.lib.msr_rerank_fuse(self.handle, Q, _ptr(cand), _ptr(bm), _ptr(cn), M, _ptr(cos.contiguous()),
+                                             _ptr(meta.contiguous()), C.byref(prm), _ptr(out_doc), _ptr(out_score),
+                                             _ptr(out_orig), _ptr(out_chunk), _ptr(out_n), _ptr(out_rows),
+                                             self._stream()))
         return out_doc, out_score, out_orig, out_chunk, out_n, out_rows
 
     # ------------------------------------------------------------------ shard merge

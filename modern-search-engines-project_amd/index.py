@@ -45,6 +45,7 @@ class CorpusIndex:
     titles: Optional[List[Optional[str]]] = None
     texts: Optional[List[Optional[str]]] = None
     doc_base: int = 0                   # first global dense index of this shard
+    row_base: int = 0                   # first global chunk row of this shard
     n_docs_global: int = 0
     _url_group: object = field(default=None, repr=False)
 
@@ -221,27 +222,35 @@ class CorpusIndex:
 
     def shard(self, rank, world):
         """Shard `rank` of `world`: its documents, its slice of every posting list, its chunk rows.
-        idf / avgdl / total_docs stay GLOBAL so scores are bit-identical to the unsharded index."""
+        idf / avgdl / total_docs stay GLOBAL so scores are bit-identical to the unsharded index.
+        Works on numpy arrays and on torch tensors (the 1 M-document corpus is sharded on the GPU)."""
         b = self.shard_bounds(world)
         d0, d1 = int(b[rank]), int(b[rank + 1])
-        sub = CorpusIndex(doc_ids=_np(self.doc_ids)[d0:d1], avgdl=self.avgdl, total_docs=self.total_docs,
+        sub = CorpusIndex(doc_ids=self.doc_ids[d0:d1], avgdl=self.avgdl, total_docs=self.total_docs,
                           k1=self.k1, b=self.b, vocab=self.vocab, doc_base=self.doc_base + d0,
                           n_docs_global=self.n_docs_global or self.n_docs)
         if self.term_off is not None:
-            pdoc = _np(self.post_doc)
+            pdoc = self.post_doc
             keep = (pdoc >= d0) & (pdoc < d1)
-            csum = np.concatenate([[0], np.cumsum(keep, dtype=np.int64)])
-            sub.term_off = csum[_np(self.term_off)]
-            sub.post_doc = (pdoc[keep] - d0).astype(np.int32)
-            sub.post_tf = _np(self.post_tf)[keep]
-            sub.doc_len = _np(self.doc_len)[d0:d1]
-            sub.idf = _np(self.idf)
+            if hasattr(pdoc, "detach"):
+                import torch
+                csum = torch.zeros(pdoc.numel() + 1, dtype=torch.int64, device=pdoc.device)
+                csum[1:] = torch.cumsum(keep, 0)
+                sub.term_off = csum[self.term_off.to(torch.int64)]
+                sub.post_doc = (pdoc[keep] - d0).to(torch.int32)
+            else:
+                csum = np.concatenate([[0], np.cumsum(keep, dtype=np.int64)])
+                sub.term_off = csum[np.asarray(self.term_off)]
+                sub.post_doc = (pdoc[keep] - d0).astype(np.int32)
+            sub.post_tf = self.post_tf[keep]
+            sub.doc_len = self.doc_len[d0:d1]
+            sub.idf = self.idf
         if self.doc_off is not None:
-            off = _np(self.doc_off).astype(np.int64)
-            c0, c1 = int(off[d0]), int(off[d1])
-            sub.doc_off = (off[d0:d1 + 1] - c0).astype(np.int32)
-            sub.chunk_ids = _np(self.chunk_ids)[c0:c1] if self.chunk_ids is not None else None
-            sub.emb = self.emb[c0:c1]
+            c0, c1 = int(self.doc_off[d0]), int(self.doc_off[d1])
+            sub.doc_off = self.doc_off[d0:d1 + 1] - c0
+            sub.chunk_ids = self.chunk_ids[c0:c1] if self.chunk_ids is not None else None
+            sub.emb = self.emb[c0:c1] if self.emb is not None else None
+            sub.row_base = c0
         for name in ("urls", "titles", "texts"):
             v = getattr(self, name)
             if v is not None:

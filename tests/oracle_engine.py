@@ -1,0 +1,96 @@
+"""CPU stand-in with the DeviceEngine method surface, backed by the oracle.  Used ONLY by tests to drive
+msretr.distributed.ShardedEngine under gloo (the exchange logic has no GPU dependency; the kernels do)."""
+import numpy as np
+import torch
+
+from oracle import bm25_ref, dense_ref, rerank_ref
+
+
+def _np(x):
+    return x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+
+
+class OracleEngine:
+    def __init__(self, index):
+        self.index = index
+        self.z = {k: _np(getattr(index, k)) for k in ("doc_ids", "doc_len", "term_off", "post_doc", "post_tf", "idf")}
+        self.z["avgdl"] = index.avgdl
+        self.doc_off = _np(index.doc_off).astype(np.int64)
+        self.emb = _np(index.emb)
+        self.url_group = np.asarray(index.url_group())
+
+    def bm25_topk(self, term_lists, k=1000, min_score=0.0, packed=None):
+        Q = len(term_lists)
+        doc = np.full((Q, k), -1, np.int32); sc = np.full((Q, k), -np.inf, np.float64); n = np.zeros(Q, np.int32)
+        for i, t in enumerate(term_lists):
+            a, b = bm25_ref.topk(self.z, t, k, min_score, self.index.k1, self.index.b)
+            doc[i, :len(a)], sc[i, :len(a)], n[i] = a, b, len(a)
+        return torch.as_tensor(doc), torch.as_tensor(sc), torch.as_tensor(n)
+
+    def dense_topk(self, qvec, k=100, max_chunks_per_doc=0, want_chunk=True):
+        q = _np(qvec)
+        Q = len(q)
+        doc = np.full((Q, k), -1, np.int32); sc = np.full((Q, k), -np.inf, np.float32)
+        ch = np.full((Q, k), -1, np.int32); n = np.zeros(Q, np.int32)
+        for i in range(Q):
+            a, b, c = dense_ref.quick_search(self.emb, self.doc_off, q[i], k, max_chunks_per_doc)
+            doc[i, :len(a)], sc[i, :len(a)], ch[i, :len(a)], n[i] = a, b, c, len(a)
+        return torch.as_tensor(doc), torch.as_tensor(sc), torch.as_tensor(ch), torch.as_tensor(n)
+
+    def merge_topk(self, docs, scores, ns, k):
+        docs, scores, ns = _np(docs), _np(scores), _np(ns)
+        G, Q = docs.shape[:2]
+        od = np.full((Q, k), -1, np.int32); os_ = np.full((Q, k), -np.inf, scores.dtype); on = np.zeros(Q, np.int32)
+        for q in range(Q):
+            a, b = dense_ref.merge_topk([(docs[g, q, :ns[g, q]].astype(np.int64), scores[g, q, :ns[g, q]]) for g in range(G)], k)
+            od[q, :len(a)], os_[q, :len(a)], on[q] = a, b, len(a)
+        return torch.as_tensor(od), torch.as_tensor(os_), torch.as_tensor(on)
+
+    def rerank_gather(self, qvec, cand_doc_global, cand_n, doc_base=0, row_base=0, max_chunks=10):
+        q, cand, cn = _np(qvec), _np(cand_doc_global), _np(cand_n)
+        Q, M = cand.shape
+        cos = np.zeros((Q, M, 10), np.float32); meta = np.zeros((Q, M, 3), np.int32)
+        N = len(self.doc_off) - 1
+        for i in range(Q):
+            for m in range(cn[i]):
+                d = cand[i, m] - doc_base
+                if d < 0 or d >= N:
+                    continue
+                lo, hi = self.doc_off[d], min(self.doc_off[d + 1], self.doc_off[d] + max_chunks)
+                if hi > lo:
+                    cos[i, m, :hi - lo] = rerank_ref.cosine_f32(q[i], self.emb[lo:hi])
+                meta[i, m] = (hi - lo, self.url_group[d] + 2, lo + row_base)
+        return torch.as_tensor(cos), torch.as_tensor(meta)
+
+    def rerank_fuse(self, cand_doc_global, cand_bm25, cand_n, cos, meta, smoothing=0.15, max_boost=0.1,
+                    max_decay=0.05, max_chunks=10):
+        cand, bm, cn, cos, meta = map(_np, (cand_doc_global, cand_bm25, cand_n, cos, meta))
+        Q, M = cand.shape
+        out_doc = np.full((Q, M), -1, np.int32); out_score = np.full((Q, M), -np.inf); out_orig = np.zeros((Q, M))
+        out_chunk = np.full((Q, M), -1, np.int32); out_n = np.zeros(Q, np.int32); out_rows = np.zeros(Q, np.int32)
+        for i in range(Q):
+            best_of_group = {}
+            for m in range(cn[i]):
+                g = meta[i, m, 1] - 2
+                if cand[i, m] >= 0 and g >= 0:
+                    if g not in best_of_group or cand[i, m] < cand[i, best_of_group[g]]:
+                        best_of_group[g] = m
+            kept = sorted((m for m in best_of_group.values() if meta[i, m, 0] > 0), key=lambda m: cand[i, m])
+            if not kept:
+                continue
+            flat = [(m, j) for m in kept for j in range(meta[i, m, 0])]
+            new = rerank_ref.normalise([float(cos[i, m, j]) for m, j in flat])
+            old = rerank_ref.normalise([float(bm[i, m]) for m, _ in flat])
+            new = [a * (1 - smoothing) + b * smoothing for a, b in zip(new, old)]
+            res, p = [], 0
+            for m in kept:
+                n = int(meta[i, m, 0])
+                adj = rerank_ref.positional_adjust(new[p:p + n], n)
+                b = max(range(n), key=lambda t: (adj[t], -t))
+                res.append((-adj[b], int(cand[i, m]), adj[b], old[p + b], int(meta[i, m, 2]) + b))
+                p += n
+            res.sort()
+            for r, (_, d, s, o, c) in enumerate(res):
+                out_doc[i, r], out_score[i, r], out_orig[i, r], out_chunk[i, r] = d, s, o, c
+            out_n[i], out_rows[i] = len(res), len(flat)
+        return tuple(torch.as_tensor(x) for x in (out_doc, out_score, out_orig, out_chunk, out_n, out_rows))

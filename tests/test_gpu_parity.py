@@ -277,3 +277,128 @@ def test_merge_topk(mods, bits):
             assert od[qi, :on[qi]].tolist() == ei.tolist()
             assert os_[qi, :on[qi]].tolist() == es.tolist()
     eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ facades
+def _ranked_equal(got, exp, tol):
+    assert len(got) == len(exp)
+    gs = np.array([g[1] for g in got]); es = np.array([e[1] for e in exp])
+    np.testing.assert_allclose(gs, es, rtol=0, atol=tol)
+    i = 0
+    while i < len(exp):
+        j = i + 1
+        while j < len(exp) and abs(es[j] - es[j - 1]) <= 2 * tol:
+            j += 1
+        assert sorted(g[0] for g in got[i:j]) == sorted(e[0] for e in exp[i:j]), (i, j)
+        i = j
+
+
+def test_reranker_facade_matches_reference_response(mods):
+    from msretr.reranker import Reranker, RerankNotFound
+    for c in _load("rerank_chain.json")["cases"]:
+        ix, q = _rerank_case_index(mods, c)
+        for div in (True, False):
+            rr = Reranker(ix, config={"diversification": div}, max_queries=4, max_k=16, rerank_max_docs=256)
+            resp = rr.rerank([str(d) for d in c["doc_ids"]], c["similarities"], query_embedding=q)
+            exp = c["response"]["div" if div else "nodiv"]
+            assert resp["total_documents"] == exp["total_documents"] and resp["total_windows"] == exp["total_windows"]
+            _ranked_equal([(d["doc_id"], d["similarity_score"]) for d in resp["document_scores"]],
+                          [(d["doc_id"], d["similarity_score"]) for d in exp["document_scores"]], 5e-6)
+            emap = {d["doc_id"]: d for d in exp["document_scores"]}
+            for d in resp["document_scores"]:
+                e = emap[d["doc_id"]]
+                assert (d["title"], d["url"]) == (e["title"], e["url"])
+                assert d["most_relevant_window"]["window_index"] == e["window_index"]
+                assert abs(d["original_similarity"] - e["original_similarity"]) < 1e-12
+            assert [w["doc_id"] for w in resp["top_windows"]] == [d["doc_id"] for d in resp["document_scores"]][:100]
+            if c["case"] == 0 and div:
+                with pytest.raises(RerankNotFound):                  # HTTP 401 in the reference
+                    rr.rerank(["999999", "888888"], [1.0, 0.5], query_embedding=q)
+            rr.engine.close()
+
+
+def _small_web_corpus(mods):
+    from msretr.synthetic import synthetic_corpus, synthetic_queries
+    ix = synthetic_corpus(3000, n_chunks=13000, n_terms=2500, seed=31)
+    N = ix.n_docs
+    ix.vocab = {f"t{i}": i for i in range(ix.n_terms)}
+    ix.vocab["tübingen"] = 0
+    ids = ix.doc_ids.numpy()
+    ix.urls = [f"https://site{int(d) % 41}.de/page/{int(d)}" + ("?s=1" if d % 17 == 0 else "") for d in ids]
+    ix.urls[100] = ix.urls[200].split("?")[0] + "?dup=1"
+    ix.urls[7] = None
+    ix.titles = [None if d % 29 == 0 else f"Title {int(d)}" for d in ids]
+    ix.texts = [f"text of {int(d)} " * (30 if d % 5 == 0 else 2) for d in ids]
+    for i, u in enumerate(ix.urls):
+        if u is None:
+            ix.titles[i] = None; ix.texts[i] = None
+    terms, qvec = synthetic_queries(ix, 6, seed=32)
+    return ix, terms, qvec
+
+
+def test_retriever_two_stage_matches_oracle_chain(mods):
+    from msretr.retriever import Retriever
+    ix, terms, qvec = _small_web_corpus(mods)
+    rt = Retriever(indexer=ix, tokenizer=lambda s: s.split(), max_queries=8, max_k=1000, rerank_max_docs=1000)
+    z = {k: getattr(ix, k).numpy() for k in ("doc_ids", "doc_len", "term_off", "post_doc", "post_tf", "idf")}
+    z["avgdl"] = ix.avgdl
+    ids = ix.doc_ids.numpy()
+    urls_db_bm = {int(d): (ix.titles[i], ix.texts[i]) for i, d in enumerate(ids) if ix.urls[i] is not None}
+    urls_rr = {int(d): (ix.urls[i], ix.titles[i], ix.texts[i]) for i, d in enumerate(ids) if ix.urls[i] is not None}
+    chunk_doc = np.repeat(ids, np.diff(ix.doc_off.numpy()))
+    queries = [" ".join("tübingen" if t == 0 else f"t{t}" for t in tl if t != 0) for tl in terms]   # city is appended
+    got = rt.search_batch(queries, query_embeddings=[q.numpy() for q in qvec])
+    for qi, query in enumerate(queries):
+        pq = mods["msretr"].preprocess_query(query)
+        tids = [ix.vocab.get(t, -1) for t in pq.split()]
+        stage1 = mods["bm25_ref"].search(z, tids, 1000, 0.0, urls_db_bm)
+        if not stage1:
+            assert got[qi] == []
+            continue
+        resp = mods["rerank_ref"].rerank(urls_rr, ix.chunk_ids.numpy(), chunk_doc, ix.emb.numpy(), qvec[qi].numpy(),
+                                         [str(r["doc_id"]) for r in stage1], [r["score"] for r in stage1])
+        _ranked_equal([(d["doc_id"], d["score"]) for d in got[qi]],
+                      [(d["doc_id"], d["similarity_score"]) for d in resp["document_scores"]], 1e-5)
+        assert [d["rank"] for d in got[qi]] == list(range(1, len(got[qi]) + 1))
+        assert all(len(d["snippet"]) <= 203 for d in got[qi])
+    lines = rt.batch_search([(str(i + 1), q) for i, q in enumerate(queries)], query_embeddings=[q.numpy() for q in qvec])
+    assert all(re_line.count("\t") == 3 for re_line in (l["formatted_line"] for l in lines))
+    # dense full-scan API
+    qs = rt.quick_search(query_embedding=qvec[0].numpy(), top_k=10)
+    oi, os_, oa = mods["dense_ref"].quick_search(ix.emb.numpy(), ix.doc_off.numpy(), qvec[0].numpy(), 10)
+    assert [r["doc_id"] for r in qs] == [int(ids[i]) for i in oi]
+    rt.engine.close()
+
+
+def test_sharded_on_one_gpu_equals_unsharded(mods):
+    """Three shard engines on the same device + msr_merge_topk / bit-OR of the gather arrays == one engine."""
+    ix, terms, qvec = _small_web_corpus(mods)
+    full = mods["DeviceEngine"](ix, max_queries=8, max_k=300, rerank_max_docs=300)
+    tl = [ix.term_ids(t) for t in terms]
+    fb = [x.cpu() for x in full.bm25_topk(tl, k=300)]
+    fd = [x.cpu() for x in full.dense_topk(qvec, k=50)]
+    fr = [x.cpu() for x in full.rerank(qvec, fb[0], fb[1], fb[2])]
+    world = 3
+    shards = [ix.shard(r, world) for r in range(world)]
+    engs = [mods["DeviceEngine"](s, max_queries=8, max_k=300, rerank_max_docs=300) for s in shards]
+    glob = lambda t, base: torch.where(t >= 0, t + base, t)
+    pb = [e.bm25_topk(tl, k=300) for e in engs]
+    pd_ = [e.dense_topk(qvec, k=50) for e in engs]
+    mb = engs[0].merge_topk(torch.stack([glob(p[0], s.doc_base) for p, s in zip(pb, shards)]),
+                            torch.stack([p[1] for p in pb]), torch.stack([p[2] for p in pb]), 300)
+    md = engs[1].merge_topk(torch.stack([glob(p[0], s.doc_base) for p, s in zip(pd_, shards)]),
+                            torch.stack([p[1] for p in pd_]), torch.stack([p[3] for p in pd_]), 50)
+    for a, b in zip(mb, fb):
+        assert torch.equal(a.cpu(), b)                            # bitwise float64
+    for a, b in zip(md, (fd[0], fd[1], fd[3])):
+        assert torch.equal(a.cpu(), b)
+    parts = [e.rerank_gather(qvec, mb[0], mb[2], doc_base=s.doc_base, row_base=s.row_base) for e, s in zip(engs, shards)]
+    cos = parts[0][0].view(torch.int32)
+    meta = parts[0][1]
+    for c, m in parts[1:]:
+        cos = cos | c.view(torch.int32); meta = meta | m
+    mr = engs[2].rerank_fuse(mb[0], mb[1], mb[2], cos.view(torch.float32), meta)
+    for a, b in zip(mr, fr):
+        assert torch.equal(a.cpu(), b)
+    for e in engs + [full]:
+        e.close()

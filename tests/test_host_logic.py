@@ -1,0 +1,110 @@
+"""Host-side logic and the C-ABI surface, no GPU: text helpers and diversification against the goldens,
+every symbol of include/msretr.h exported by libmsretr.so, error behaviour without a device."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def _load(name):
+    with open(os.path.join(G, name), encoding="utf-8") as f:
+        return json.load(f)
+
+
+def test_text_helpers_match_reference_outputs():
+    from msretr.text import extract_domain, extract_domain_topic, preprocess_query
+    s = _load("search_api.json")
+    for q, exp in s["preprocess_query"]:
+        assert preprocess_query(q) == exp
+    for u, exp in s["extract_domain_topic"]:
+        assert extract_domain_topic(u) == exp
+    for u, exp in _load("diversification.json")["extract_domain"]:
+        assert extract_domain(u) == exp
+
+
+def test_queries_txt_shape(tmp_path):
+    from msretr.text import format_result_line, read_queries_file
+    p = tmp_path / "queries.txt"
+    p.write_text("1\ttübingen attractions\n\n2\tfood and drinks\nbroken line\n", encoding="utf-8")
+    assert read_queries_file(str(p)) == [("1", "tübingen attractions"), ("2", "food and drinks")]
+    assert format_result_line("7", 3, "https://a.de/x", 0.123456) == "7\t3\thttps://a.de/x\t0.123"
+
+
+def test_sliding_windows_match_reference_outputs():
+    from msretr.text import create_sliding_windows
+    for c in _load("windows.json"):
+        wins = create_sliding_windows(list(range(c["n"])), c["window"], c["step"])
+        assert [w[0] if w else -1 for w in wins] == c["starts"] and [len(w) for w in wins] == c["lens"]
+
+
+def test_diversify_matches_reference_outputs():
+    from msretr.reranker import diversify
+    for c in _load("diversification.json")["cases"]:
+        docs = [{"doc_id": str(i), "url": u, "similarity_score": s} for i, u, s in c["input"]]
+        got = diversify(docs, top_k=c["top_k"])
+        assert [[int(x["doc_id"]), x["similarity_score"]] for x in got] == c["expected"]
+
+
+def test_library_exports_every_declared_symbol():
+    from msretr import _abi
+    hdr = open(os.path.join(ROOT, "include", "msretr.h"), encoding="utf-8").read()
+    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(msr_\w+)\s*\(", hdr, flags=re.M))
+    assert declared, "no prototypes found in msretr.h"
+    lib = _abi.load()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in msretr.h but not exported"
+    assert declared == set(_abi.EXPORTS), declared ^ set(_abi.EXPORTS)
+    assert lib.msr_abi_version() == _abi.MSR_ABI_VERSION
+
+
+def test_create_rejects_bad_config_and_reports_why():
+    from msretr import _abi
+    lib = _abi.load()
+    h = C.c_void_p()
+    cfg = _abi.MsrConfig(C.sizeof(_abi.MsrConfig), 0, 512, 8, 100, 100, 0, 0)       # wrong dim
+    assert lib.msr_create(C.byref(cfg), C.byref(h)) == -1
+    assert b"dim" in lib.msr_last_error(None)
+    cfg = _abi.MsrConfig(4, 0, 768, 8, 100, 100, 0, 0)                               # wrong struct size
+    assert lib.msr_create(C.byref(cfg), C.byref(h)) == -1
+    assert lib.msr_destroy(None) == 0
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product path refuses to run (it must never route through the oracle)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from msretr._abi import MsrError
+    from msretr.engine import DeviceEngine
+    from msretr.index import CorpusIndex
+    ix = CorpusIndex(doc_ids=np.arange(3, dtype=np.int64))
+    with pytest.raises(MsrError):
+        DeviceEngine(ix)
+    src = ""
+    pkg = os.path.join(ROOT, "modern-search-engines-project_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src += open(os.path.join(pkg, fn), encoding="utf-8").read()
+    assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_index_roundtrip_and_url_groups(tmp_path):
+    from msretr.index import CorpusIndex
+    ix = CorpusIndex.from_tables({"a": [(5, 1), (9, 2)], "b": [(9, 1)]}, {5: 3, 9: 4, 12: 1}, {"a": 0.5, "b": None}, 3.0,
+                                 chunks=[(100, 9), (101, 9), (50, 5)], emb={100: np.ones(768), 101: np.zeros(768), 50: np.ones(768) * 2},
+                                 urls_db={5: ("http://x.de/a?q=1", "t5", "x"), 9: ("http://x.de/a", None, "y")})
+    assert ix.doc_ids.tolist() == [5, 9, 12] and ix.doc_off.tolist() == [0, 1, 3, 3]
+    assert ix.chunk_ids.tolist() == [50, 100, 101]
+    assert ix.url_group().tolist() == [0, 0, -1]                 # same URL modulo query string; 12 not in urlsDB
+    assert ix.idf.tolist() == [0.5, 0.0]                         # NULL idf -> 0.0
+    p = str(tmp_path / "snap.npz")
+    ix.save(p)
+    jx = CorpusIndex.load(p)
+    assert jx.post_doc.tolist() == ix.post_doc.tolist() and jx.vocab == ix.vocab and jx.avgdl == ix.avgdl
+    assert np.array_equal(jx.emb, ix.emb)

@@ -1,0 +1,86 @@
+"""N > 1 path on CPU: two gloo ranks, each with its document shard, must reproduce the unsharded result
+exactly (bm25 + dense lists after the all-gather + merge; rerank after the bit-OR all-reduce).  The compute
+is the oracle (tests/oracle_engine.py); what is under test is msretr.distributed + CorpusIndex.shard."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _corpus():
+    from msretr.synthetic import synthetic_corpus, synthetic_queries
+    ix = synthetic_corpus(900, n_chunks=4200, n_terms=700, seed=21)
+    terms, qvec = synthetic_queries(ix, 5, seed=22)
+    # make some documents share a URL (dedup must work across shards) and drop one from urlsDB
+    urls = [f"https://h{d % 37}.de/p{d}" for d in range(900)]
+    urls[10] = urls[700].split("?")[0] + "?x=1"
+    urls[700] = urls[700]
+    urls[450] = None
+    ix.urls = urls
+    return ix, terms, qvec
+
+
+def _run(rank, world, port, ret):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from msretr.distributed import ShardedEngine
+        from oracle_engine import OracleEngine
+        ix, terms, qvec = _corpus()
+        sh = ix.shard(rank, world)
+        se = ShardedEngine(OracleEngine(sh), sh.doc_base, sh.row_base)
+        assert se.world == world and se.rank == rank
+        out = se.search([sh.term_ids(t) for t in terms], qvec, k1=200, k2=50)
+        ret[rank] = {k: [x.numpy() for x in v] for k, v in out.items()}
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharded_equals_unsharded():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from msretr.distributed import ShardedEngine
+    from oracle_engine import OracleEngine
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_run, args=(world, port, ret), nprocs=world, join=True)
+    ix, terms, qvec = _corpus()
+    ref = ShardedEngine(OracleEngine(ix), 0, 0).search([ix.term_ids(t) for t in terms], qvec, k1=200, k2=50)
+    ref = {k: [x.numpy() for x in v] for k, v in ref.items()}
+    for r in range(world):
+        got = ret[r]
+        for key in ("bm25", "dense", "rerank"):
+            for a, b in zip(got[key], ref[key]):
+                assert a.shape == b.shape and np.array_equal(a, b), (r, key)
+    # both ranks hold identical results
+    for key in ("bm25", "dense", "rerank"):
+        for a, b in zip(ret[0][key], ret[1][key]):
+            assert np.array_equal(a, b)
+
+
+def test_shard_partition_is_exact():
+    ix, _, _ = _corpus()
+    for world in (1, 2, 3, 8):
+        b = ix.shard_bounds(world)
+        assert b[0] == 0 and b[-1] == ix.n_docs and np.all(np.diff(b) >= 0)
+        P = C = 0
+        for r in range(world):
+            s = ix.shard(r, world)
+            P += int(s.post_doc.numel()); C += s.n_chunks
+            assert s.doc_base == b[r] and s.n_docs == b[r + 1] - b[r]
+            assert s.idf is ix.idf and s.avgdl == ix.avgdl            # global statistics are replicated
+            if s.n_docs:
+                assert int(s.post_doc.max()) < s.n_docs
+        assert P == int(ix.post_doc.numel()) and C == ix.n_chunks
+        # chunk balance within one document of the ideal cut
+        sizes = [ix.shard(r, world).n_chunks for r in range(world)]
+        assert max(sizes) - min(sizes) <= 2 * 64
