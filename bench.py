@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--k1", type=int, default=1000, help="stage-1 candidates (config.py:13)")
     ap.add_argument("--k2", type=int, default=100, help="final top-k (reranker/config.yaml:30)")
     ap.add_argument("--scan-layout", type=int, default=0)
+    ap.add_argument("--scan-variant", type=int, default=0)
     ap.add_argument("--cpu-queries", type=int, default=16)
     ap.add_argument("--cpu-sample-frac", type=float, default=0.125)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -146,7 +147,7 @@ def main():
     shard, terms = build_shard(args, rank, world, dev, n_pool)
     qvec = make_query_vectors(n_pool, dev, seed=778)
     eng = DeviceEngine(shard, device=local_rank, max_queries=max(Q, 1), max_k=max(args.k1, args.k2),
-                       rerank_max_docs=args.k1, scan_layout=args.scan_layout)
+                       rerank_max_docs=args.k1, scan_layout=args.scan_layout, scan_variant=args.scan_variant)
     se = ShardedEngine(eng, shard.doc_base, shard.row_base)
     batches = []
     for b in range(n_pool // Q):
@@ -221,7 +222,7 @@ def main():
                                    f"{Q} queries per step, doc-sharded x{world}",
                        "n_docs": args.docs, "n_chunks": args.chunks, "n_terms": args.terms,
                        "queries_per_step": Q, "k_stage1": args.k1, "k_final": args.k2,
-                       "scan_layout": args.scan_layout},
+                       "scan_layout": args.scan_layout, "scan_variant": args.scan_variant},
             "p50_latency_ms_single_query": p50_ms, "outputs_sane": ok, "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

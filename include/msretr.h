@@ -58,7 +58,7 @@ typedef struct msr_config {
     int32_t max_k;            /* largest k any call will ask for, <= MSR_MAX_K */
     int32_t rerank_max_docs;  /* largest candidate list per query for msr_rerank, <= 1024 */
     int32_t scan_layout;      /* 0 = row-major embeddings; 1 = 16-row interleaved */
-    int32_t reserved;
+    int32_t scan_variant;     /* 0 = default scan kernel; 1..3 select alternatives kept for A/B measurements */
 } msr_config;
 
 /* BM25 parameters travel with the postings (bm25_indexer.py:57 k1=1.2, b=0.75). */

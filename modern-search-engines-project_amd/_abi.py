@@ -22,7 +22,7 @@ class MsrError(RuntimeError):
 class MsrConfig(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("dim", C.c_int32),
                 ("max_queries", C.c_int32), ("max_k", C.c_int32), ("rerank_max_docs", C.c_int32),
-                ("scan_layout", C.c_int32), ("reserved", C.c_int32)]
+                ("scan_layout", C.c_int32), ("scan_variant", C.c_int32)]
 
 
 class MsrRerankParams(C.Structure):

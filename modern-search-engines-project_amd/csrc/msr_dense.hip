@@ -171,6 +171,173 @@ __global__ __launch_bounds__(SCAN_THREADS) void dense_scan_kernel(DenseIndex ix,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Scan kernel, variant 2: every WAVE streams its own span of row groups with no workgroup barrier after the
+// query image is loaded.  Per 16-row group: 48 x 16 B/lane loads (register double buffer that runs ACROSS
+// groups, so the next group's first batch is in flight during this group's epilogue), 48 x 4 x QB MFMAs,
+// then the 16 x Q cosines go through a wave-private LDS tile so that lane q holds query q's column and walks
+// the 16 rows; document boundaries are wave-uniform scalars (v_readlane of chunk_doc), the running maximum
+// of the open document simply stays in a register across groups.  Finished documents are staged in a
+// wave-private LDS buffer and written 32 documents at a time, 128 B per query row.
+constexpr int V2_WAVES = 8;
+constexpr int V2_THREADS = V2_WAVES * 64;
+constexpr int V2_OBUF_DOCS = 32;
+
+template <int QB> struct ScanLdsV2 {
+    static constexpr int NQP = 16 * QB;
+    static constexpr int SROW = NQP + 1;
+    static constexpr size_t q_bytes = (size_t)QB * KSTEPS * 64 * 16;
+    static constexpr size_t t_bytes = (size_t)16 * SROW * 4;                 // per wave: 16 rows x queries
+    static constexpr size_t o_bytes = (size_t)V2_OBUF_DOCS * SROW * 4;       // per wave: staged documents
+    static constexpr size_t wave_bytes = (t_bytes + o_bytes + 15) & ~(size_t)15;
+    static constexpr size_t total = q_bytes + V2_WAVES * wave_bytes;
+};
+
+template <int QB, bool TILED, int LB>
+__global__ __launch_bounds__(V2_THREADS) void dense_scan_v2_kernel(DenseIndex ix, const int32_t* __restrict__ wspan,
+                                                                    int n_wspans, const float* __restrict__ qn,
+                                                                    int nq, int max_chunks,
+                                                                    float* __restrict__ docscore) {
+    using L = ScanLdsV2<QB>;
+    static_assert(KSTEPS % LB == 0 && ((KSTEPS / LB) % 2) == 0, "even number of load batches per group");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* Qs = (f32x4*)smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* T = (float*)(smem + L::q_bytes + (size_t)w * L::wave_bytes);      // [16][SROW]
+    float* OB = T + 16 * L::SROW;                                            // [V2_OBUF_DOCS][SROW]
+    const int li = lane & 15, lg = lane >> 4;
+
+    for (int idx = tid; idx < QB * KSTEPS * 64; idx += V2_THREADS) {
+        const int l = idx & 63;
+        const int t = (idx >> 6) % KSTEPS;
+        const int qb = idx / (KSTEPS * 64);
+        Qs[idx] = *(const f32x4*)(qn + (size_t)(16 * qb + (l & 15)) * MSR_DIM + 16 * t + 4 * (l >> 4));
+    }
+    __syncthreads();                                             // the only workgroup barrier
+
+    const int s = blockIdx.x * V2_WAVES + w;
+    if (s >= n_wspans) return;                                   // wave-uniform
+    const int64_t N = ix.n_docs, C = ix.n_chunks;
+    const float NEG_INF = -__builtin_inff();
+    const int d0 = wspan[s], d1 = wspan[s + 1];
+    const int64_t c0 = ix.doc_off[d0], c1 = ix.doc_off[d1];
+
+    // staged output: documents ob_base .. ob_base + ob_n - 1 (consecutive) for every query
+    int ob_base = d0, ob_n = 0;
+    auto flush = [&]() {
+        // lane -> (query sub-index, document): 64 lanes cover 2 queries x 32 documents per instruction
+        for (int qq0 = 0; qq0 < nq; qq0 += 2) {
+            const int qq = qq0 + (lane >> 5), dd = lane & 31;
+            if (qq < nq && dd < ob_n) docscore[(int64_t)qq * N + ob_base + dd] = OB[dd * L::SROW + qq];
+        }
+        ob_base += ob_n;
+        ob_n = 0;
+    };
+    auto emit = [&](float m) {                                   // lane q holds the value of query q
+        if (lane < L::NQP) OB[ob_n * L::SROW + lane] = m;
+        if (++ob_n == V2_OBUF_DOCS) flush();
+    };
+
+    int cur_doc = d0 - 1;                                        // last document that has been emitted/opened
+    bool open = false;
+    int cnt = 0;                                                 // rows of the open document seen so far
+    float m = NEG_INF;
+
+    if (c1 > c0) {
+        constexpr int PSTRIDE = TILED ? 64 : 4;
+        constexpr int NBATCH = KSTEPS / LB;
+        const int64_t g0 = c0 >> 4, g1 = (c1 + 15) >> 4;
+        auto row_ptr = [&](int64_t grp) -> const f32x4* {
+            if (TILED) return (const f32x4*)(ix.emb + (size_t)grp * (16 * MSR_DIM)) + lane;
+            int64_t r = grp * 16 + li;
+            if (r > C - 1) r = C - 1;
+            return (const f32x4*)(ix.emb + (size_t)r * MSR_DIM) + lg;
+        };
+        auto meta_row = [&](int64_t grp) -> int64_t {            // row whose chunk_doc / inv_norm this lane fetches
+            int64_t r = grp * 16 + li;
+            return r > C - 1 ? C - 1 : r;
+        };
+        f32x4 buf0[LB], buf1[LB];
+        const f32x4* p = row_ptr(g0);
+#pragma unroll
+        for (int u = 0; u < LB; ++u) buf0[u] = p[(size_t)u * PSTRIDE];
+        int dv = ix.chunk_doc[meta_row(g0)];
+        float iv = ix.inv_norm[meta_row(g0)];
+        __builtin_amdgcn_sched_barrier(0);
+        for (int64_t grp = g0; grp < g1; ++grp) {
+            const f32x4* pn = row_ptr(grp + 1 < g1 ? grp + 1 : grp);
+            const bool has_next = grp + 1 < g1;
+            f32x4 acc[QB];
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) acc[qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            int dv_next = dv;
+            float iv_next = iv;
+#pragma unroll
+            for (int nb = 0; nb < NBATCH; ++nb) {
+                if (nb + 1 < NBATCH) {
+#pragma unroll
+                    for (int u = 0; u < LB; ++u) {
+                        const f32x4 x = p[(size_t)((nb + 1) * LB + u) * PSTRIDE];
+                        if (nb & 1) buf0[u] = x; else buf1[u] = x;
+                    }
+                } else if (has_next) {                           // NBATCH is even: the last batch sits in buf1
+#pragma unroll
+                    for (int u = 0; u < LB; ++u) buf0[u] = pn[(size_t)u * PSTRIDE];
+                    dv_next = ix.chunk_doc[meta_row(grp + 1)];
+                    iv_next = ix.inv_norm[meta_row(grp + 1)];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < LB; ++u) {
+                    const f32x4 a = (nb & 1) ? buf1[u] : buf0[u];
+                    const int t = nb * LB + u;
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) {
+                        const f32x4 bq = Qs[(qb * KSTEPS + t) * 64 + lane];
+                        acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq.x, acc[qb], 0, 0, 0);
+                        acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq.y, acc[qb], 0, 0, 0);
+                        acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq.z, acc[qb], 0, 0, 0);
+                        acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq.w, acc[qb], 0, 0, 0);
+                    }
+                }
+            }
+            // ---- epilogue of this group (wave-private; no barrier: a wave's LDS ops execute in order) ----
+            // D layout: lane (li = query column, lg) holds rows 4 lg + reg.  inv_norm of row r sits in lane r.
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const float inv = __shfl(iv, 4 * lg + reg);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) T[(4 * lg + reg) * L::SROW + 16 * qb + li] = acc[qb][reg] * inv;
+            }
+            const int64_t row0 = grp * 16;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = row0 + r;
+                const int d = __builtin_amdgcn_readlane(dv, r);  // wave-uniform
+                if (row < c0 || row >= c1) continue;             // rows of a neighbouring span
+                if (!open || d != cur_doc) {
+                    if (open) emit(m);
+                    for (int e = cur_doc + 1; e < d; ++e) emit(NEG_INF);     // chunk-less documents in between
+                    cur_doc = d; open = true; cnt = 0; m = NEG_INF;
+                }
+                if (max_chunks == 0 || cnt < max_chunks) {
+                    const float v = lane < L::NQP ? T[r * L::SROW + lane] : NEG_INF;
+                    m = fmaxf(m, v);
+                }
+                ++cnt;
+            }
+            p = pn;
+            dv = dv_next;
+            iv = iv_next;
+        }
+    }
+    if (open) emit(m);
+    for (int e = cur_doc + 1; e < d1; ++e) emit(NEG_INF);        // trailing chunk-less documents
+    if (ob_n) flush();
+}
+
 __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restrict__ q, int nq,
                                                             float* __restrict__ qn, int nq_pad) {
     // one wave per (padded) query row: qn = q / ||q||, zero norm -> divide by 1 (sklearn normalize)
@@ -280,6 +447,29 @@ hipError_t launch_scan(const DenseIndex& ix, const float* qn, int nq, int max_ch
     return hipGetLastError();
 }
 
+template <int QB, bool TILED, int LB>
+hipError_t launch_scan_v2(const DenseIndex& ix, const float* qn, int nq, int max_chunks, float* docscore,
+                          hipStream_t stream) {
+    const size_t lds = ScanLdsV2<QB>::total;
+    hipError_t err = hipFuncSetAttribute((const void*)dense_scan_v2_kernel<QB, TILED, LB>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (err != hipSuccess) return err;
+    const int grid = (ix.n_wspans + V2_WAVES - 1) / V2_WAVES;
+    dense_scan_v2_kernel<QB, TILED, LB><<<grid, V2_THREADS, lds, stream>>>(ix, ix.wspan_doc, ix.n_wspans, qn, nq,
+                                                                           max_chunks, docscore);
+    return hipGetLastError();
+}
+
+template <int QB, bool TILED>
+hipError_t dispatch_variant(const DenseIndex& ix, const float* qn, int nq, int max_chunks, float* docscore,
+                            hipStream_t stream) {
+    switch (ix.variant) {
+        case 1: return launch_scan<QB, TILED>(ix, qn, nq, max_chunks, docscore, stream);
+        case 3: return launch_scan_v2<QB, TILED, 12>(ix, qn, nq, max_chunks, docscore, stream);
+        default: return launch_scan_v2<QB, TILED, 8>(ix, qn, nq, max_chunks, docscore, stream);
+    }
+}
+
 }  // namespace
 
 hipError_t msr_dense_scan(const DenseIndex& ix, const float* qn, int nq, int max_chunks, float* docscore,
@@ -288,10 +478,10 @@ hipError_t msr_dense_scan(const DenseIndex& ix, const float* qn, int nq, int max
     if (nq > 32) return hipErrorInvalidValue;
     const bool tiled = ix.layout == 1;
     if (nq <= 16)
-        return tiled ? launch_scan<1, true>(ix, qn, nq, max_chunks, docscore, stream)
-                     : launch_scan<1, false>(ix, qn, nq, max_chunks, docscore, stream);
-    return tiled ? launch_scan<2, true>(ix, qn, nq, max_chunks, docscore, stream)
-                 : launch_scan<2, false>(ix, qn, nq, max_chunks, docscore, stream);
+        return tiled ? dispatch_variant<1, true>(ix, qn, nq, max_chunks, docscore, stream)
+                     : dispatch_variant<1, false>(ix, qn, nq, max_chunks, docscore, stream);
+    return tiled ? dispatch_variant<2, true>(ix, qn, nq, max_chunks, docscore, stream)
+                 : dispatch_variant<2, false>(ix, qn, nq, max_chunks, docscore, stream);
 }
 
 hipError_t msr_prep_queries(const float* q, int nq, float* qn, int nq_pad, hipStream_t stream) {

@@ -25,6 +25,7 @@ struct msr_engine {
     int32_t* chunk_doc = nullptr;
     float* inv_norm_own = nullptr;
     int32_t* span_doc = nullptr;
+    int32_t* wspan_doc = nullptr;
     float* qn = nullptr;              // [32][768] normalised queries of the current slice
     void* score_rows = nullptr;       // max_queries rows of n_docs float64 (reused as float32 rows)
     size_t score_rows_bytes = 0;
@@ -79,6 +80,8 @@ extern "C" int msr_create(const msr_config* cfg, msr_engine** out) {
         return fail(nullptr, MSR_ERR_INVALID, "msr_create: rerank_max_docs out of range [0, 1024]");
     if (cfg->scan_layout != 0 && cfg->scan_layout != 1)
         return fail(nullptr, MSR_ERR_INVALID, "msr_create: scan_layout must be 0 or 1");
+    if (cfg->scan_variant < 0 || cfg->scan_variant > 3)
+        return fail(nullptr, MSR_ERR_INVALID, "msr_create: scan_variant must be 0..3");
     int ndev = 0;
     hipError_t herr = hipGetDeviceCount(&ndev);
     if (herr != hipSuccess || ndev <= 0)
@@ -127,7 +130,7 @@ extern "C" int msr_create(const msr_config* cfg, msr_engine** out) {
 
 extern "C" int msr_destroy(msr_engine* e) {
     if (!e) return MSR_OK;
-    free_dev(e->chunk_doc); free_dev(e->inv_norm_own); free_dev(e->span_doc); free_dev(e->qn);
+    free_dev(e->chunk_doc); free_dev(e->inv_norm_own); free_dev(e->span_doc); free_dev(e->wspan_doc); free_dev(e->qn);
     free_dev(e->score_rows); free_dev(e->sel.hist); free_dev(e->sel.state); free_dev(e->sel.cand_hi);
     free_dev(e->sel.cand_lo); free_dev(e->sel.cand_n); free_dev(e->rerank_cos); free_dev(e->rerank_meta);
     for (int w = 0; w < 2; ++w)
@@ -195,31 +198,38 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
                     h_off[0], h_off[n_docs], (long long)n_chunks);
     for (int64_t d = 0; d < n_docs; ++d)
         if (h_off[d + 1] < h_off[d]) return fail(e, MSR_ERR_INVALID, "msr_bind_chunks: doc_off not monotone at %lld", (long long)d);
-    // equal-chunk-count spans cut at document boundaries; one persistent workgroup each
-    int target_spans = e->n_cus;
-    const int64_t min_rows = 256;                         // at least one super-tile of work per span
-    if ((int64_t)target_spans * min_rows > n_chunks) target_spans = (int)std::max<int64_t>(1, n_chunks / min_rows);
-    std::vector<int32_t> spans;
-    spans.push_back(0);
-    for (int s = 1; s < target_spans; ++s) {
-        const int64_t want = n_chunks * s / target_spans;
-        // first document whose first chunk is >= want
-        int64_t d = std::lower_bound(h_off.begin(), h_off.end(), (int32_t)want) - h_off.begin();
-        if (d > n_docs) d = n_docs;
-        if (d > spans.back()) spans.push_back((int32_t)d);
-    }
-    if (spans.back() != (int32_t)n_docs) spans.push_back((int32_t)n_docs);
+    // equal-chunk-count spans cut at document boundaries: one per workgroup (variant 1) / per wave (variant 2)
+    auto make_spans = [&](int target, int64_t min_rows) {
+        if ((int64_t)target * min_rows > n_chunks) target = (int)std::max<int64_t>(1, n_chunks / min_rows);
+        std::vector<int32_t> sp;
+        sp.push_back(0);
+        for (int s = 1; s < target; ++s) {
+            const int64_t want = n_chunks * s / target;
+            int64_t d = std::lower_bound(h_off.begin(), h_off.end(), (int32_t)want) - h_off.begin();   // first doc starting at >= want
+            if (d > n_docs) d = n_docs;
+            if (d > sp.back()) sp.push_back((int32_t)d);
+        }
+        if (sp.back() != (int32_t)n_docs) sp.push_back((int32_t)n_docs);
+        return sp;
+    };
+    std::vector<int32_t> spans = make_spans(e->n_cus, 256);
+    std::vector<int32_t> wspans = make_spans(e->n_cus * 8, 64);
     const int n_spans = (int)spans.size() - 1;
+    const int n_wspans = (int)wspans.size() - 1;
 
     free_dev(e->chunk_doc); e->chunk_doc = nullptr;
     free_dev(e->inv_norm_own); e->inv_norm_own = nullptr;
     free_dev(e->span_doc); e->span_doc = nullptr;
+    free_dev(e->wspan_doc); e->wspan_doc = nullptr;
     hipError_t herr;
     if ((herr = hipMalloc((void**)&e->chunk_doc, (size_t)n_chunks * sizeof(int32_t))) != hipSuccess)
         return fail(e, MSR_ERR_NOMEM, "chunk_doc: %s", hipGetErrorString(herr));
     if ((herr = hipMalloc((void**)&e->span_doc, spans.size() * sizeof(int32_t))) != hipSuccess)
         return fail(e, MSR_ERR_NOMEM, "span_doc: %s", hipGetErrorString(herr));
+    if ((herr = hipMalloc((void**)&e->wspan_doc, wspans.size() * sizeof(int32_t))) != hipSuccess)
+        return fail(e, MSR_ERR_NOMEM, "wspan_doc: %s", hipGetErrorString(herr));
     HIP_TRY(e, hipMemcpyAsync(e->span_doc, spans.data(), spans.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(e, hipMemcpyAsync(e->wspan_doc, wspans.data(), wspans.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     HIP_TRY(e, msr_fill_chunk_doc(doc_off, n_docs, e->chunk_doc, st));
     if (!inv_norm) {
         if ((herr = hipMalloc((void**)&e->inv_norm_own, (size_t)n_chunks * sizeof(float))) != hipSuccess)
@@ -229,7 +239,7 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
     }
     HIP_TRY(e, hipStreamSynchronize(st));                 // spans vector goes out of scope
     e->dense = DenseIndex{emb, doc_off, e->chunk_doc, inv_norm, e->span_doc, n_chunks, n_docs, n_spans,
-                          e->cfg.scan_layout};
+                          e->cfg.scan_layout, e->wspan_doc, n_wspans, e->cfg.scan_variant};
     e->have_chunks = true;
     return MSR_OK;
 }

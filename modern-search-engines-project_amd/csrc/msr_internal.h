@@ -58,10 +58,13 @@ struct DenseIndex {
     const int32_t* doc_off;    // [n_docs+1]
     const int32_t* chunk_doc;  // [n_chunks]
     const float* inv_norm;     // [n_chunks]
-    const int32_t* span_doc;   // [n_spans+1] document boundaries of the work spans
+    const int32_t* span_doc;   // [n_spans+1] document boundaries of the workgroup spans (scan variant 1)
     int64_t n_chunks, n_docs;
     int32_t n_spans;
     int32_t layout;            // 0 row-major, 1 interleaved
+    const int32_t* wspan_doc;  // [n_wspans+1] document boundaries of the per-wave spans (scan variants 2, 3)
+    int32_t n_wspans;
+    int32_t variant;           // 0/2: wave-streaming kernel, 8-step load batches; 3: 12-step; 1: super-tile kernel
 };
 // qn: [ceil16(nq)][768] normalised queries (zero rows as padding).
 // docscore[q][n_docs] <- max cosine over the document's chunks (-inf for chunk-less documents).

@@ -5,9 +5,10 @@
 // is what Python's stable sort produces on candidates that arrive in ascending doc_id (:445).
 //
 // Key = (orderable(score), ~index): all keys of a row are distinct, so "the k largest keys" is a unique
-// set.  Passes resolve the key 12 bits at a time with an LDS histogram per workgroup; as soon as the
-// elements at or above the resolved prefix fit MSR_SEL_CAP they are compacted and one workgroup sorts
-// them exactly.  Every pass is a streaming read of the score row: HBM-bound.
+// set.  Two streaming passes resolve the top 24 key bits with LDS histograms (12 bits each); the elements at
+// or above the resolved prefix (<= MSR_SEL_CAP in every non-degenerate case) are compacted and one
+// workgroup sorts them exactly.  Tie groups too large for that are finished digit by digit inside the
+// final kernel.  Every pass is a streaming read of the score row: HBM-bound.
 #include "msr_common.h"
 #include "msr_internal.h"
 
@@ -51,15 +52,64 @@ template <> struct ScoreTraits<double> {
     static __device__ __forceinline__ double neg_inf() { return -__builtin_inf(); }
 };
 
-__global__ void sel_init_kernel(SelState* st, int k) {
-    int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= (int)gridDim.x * (int)blockDim.x) return;
-    SelState s;
-    s.pref_hi = 0; s.mask_hi = 0; s.pref_lo = 0; s.mask_lo = 0;
-    s.k_rem = k; s.n_above = 0; s.done = 0; s.n_sel = 0;
-    st[q] = s;
+// Block-wide step of the radix select on an LDS histogram h[MSR_SEL_BINS] (SCAN_THREADS threads, all of
+// them must call it).  Finds the bin that holds the S.k_rem-th largest element among the elements counted in
+// h, appends that digit to the resolved prefix and updates the counters.  `suf` is LDS scratch of
+// SCAN_THREADS + 1 words, `S_sh` an LDS copy of the state that every thread reads back.
+template <int SB>
+__device__ void select_step(const uint32_t* h, uint32_t* suf, SelState* S_sh, int digit, int k) {
+    const int t = threadIdx.x;
+    uint32_t local = h[4 * t] + h[4 * t + 1] + h[4 * t + 2] + h[4 * t + 3];
+    suf[t] = local;
+    if (t == 0) suf[SCAN_THREADS] = 0;
+    __syncthreads();
+    for (int off = 1; off < SCAN_THREADS; off <<= 1) {           // inclusive suffix sum over threads
+        const uint32_t add = (t + off < SCAN_THREADS) ? suf[t + off] : 0;
+        __syncthreads();
+        suf[t] += add;
+        __syncthreads();
+    }
+    const SelState S = *S_sh;
+    const uint32_t total = suf[0];
+    __syncthreads();
+    if (digit == 0 && total <= (uint32_t)S.k_rem) {              // fewer valid elements than k: take all
+        if (t == 0) { S_sh->done = 1; S_sh->n_sel = (int32_t)total; }
+        __syncthreads();
+        return;
+    }
+    const uint32_t need = (uint32_t)S.k_rem;
+    if (suf[t] >= need && suf[t + 1] < need) {                   // exactly one thread
+        uint32_t above = suf[t + 1];
+        int b = 4 * t + 3;
+        for (; b > 4 * t; --b) {
+            if (above + h[b] >= need) break;
+            above += h[b];
+        }
+        int part, shift, width;
+        digit_pos<SB>(digit, part, shift, width);
+        const uint64_t wmask = ((uint64_t)1 << width) - 1;
+        SelState N = S;
+        if (part == 0) { N.pref_hi |= (uint64_t)b << shift; N.mask_hi |= wmask << shift; }
+        else { N.pref_lo |= (uint32_t)b << shift; N.mask_lo |= (uint32_t)(wmask << shift); }
+        N.n_above += (int32_t)above;
+        N.k_rem -= (int32_t)above;
+        N.n_sel = k;
+        const uint32_t superset = (uint32_t)N.n_above + h[b];
+        if (superset <= MSR_SEL_CAP || digit == KeyCfg<SB>::ND - 1) N.done = 1;
+        *S_sh = N;
+    }
+    __syncthreads();
 }
 
+template <typename T>
+__device__ __forceinline__ bool key_of(const T s, int64_t i, uint64_t& khi, uint32_t& klo) {
+    if (!msr_valid(s)) return false;
+    khi = ScoreTraits<T>::ord(s);
+    klo = ~(uint32_t)i;
+    return true;
+}
+
+// Histogram of digit `digit` over the elements that match the resolved prefix.  digit 0 needs no state.
 template <typename T>
 __global__ __launch_bounds__(SEL_THREADS) void sel_hist_kernel(const T* __restrict__ scores, int64_t n,
                                                                 int64_t stride, int digit,
@@ -67,8 +117,12 @@ __global__ __launch_bounds__(SEL_THREADS) void sel_hist_kernel(const T* __restri
                                                                 uint32_t* __restrict__ hist) {
     constexpr int SB = ScoreTraits<T>::SB;
     const int q = blockIdx.y;
-    const SelState S = st[q];
-    if (S.done) return;
+    SelState S;
+    S.pref_hi = S.mask_hi = 0; S.pref_lo = S.mask_lo = 0; S.done = 0;
+    if (digit > 0) {
+        S = st[q];
+        if (S.done) return;
+    }
     __shared__ uint32_t h[MSR_SEL_BINS];
     for (int b = threadIdx.x; b < MSR_SEL_BINS; b += SEL_THREADS) h[b] = 0;
     __syncthreads();
@@ -80,10 +134,8 @@ __global__ __launch_bounds__(SEL_THREADS) void sel_hist_kernel(const T* __restri
     const int64_t hi = lo + per < n ? lo + per : n;
     const T* row = scores + (int64_t)q * stride;
     for (int64_t i = lo + threadIdx.x; i < hi; i += SEL_THREADS) {
-        const T s = row[i];
-        if (!msr_valid(s)) continue;
-        const uint64_t khi = ScoreTraits<T>::ord(s);
-        const uint32_t klo = ~(uint32_t)i;
+        uint64_t khi; uint32_t klo;
+        if (!key_of(row[i], i, khi, klo)) continue;
         if ((khi & S.mask_hi) != S.pref_hi || (klo & S.mask_lo) != S.pref_lo) continue;
         const uint32_t dg = part == 0 ? (uint32_t)(khi >> shift) & wmask : (klo >> shift) & wmask;
         atomicAdd(&h[dg], 1u);
@@ -94,67 +146,40 @@ __global__ __launch_bounds__(SEL_THREADS) void sel_hist_kernel(const T* __restri
         if (h[b]) atomicAdd(&gh[b], h[b]);
 }
 
+// One workgroup per query: consume the global histogram of `digit` (and leave it zeroed), update the state.
 template <int SB>
 __global__ __launch_bounds__(SCAN_THREADS) void sel_scan_kernel(SelState* __restrict__ st,
                                                                  uint32_t* __restrict__ hist, int digit, int k) {
-    const int q = blockIdx.x;
-    SelState S = st[q];
-    if (S.done) return;                              // nothing was added to hist[q] in this pass
     __shared__ uint32_t h[MSR_SEL_BINS];
     __shared__ uint32_t suf[SCAN_THREADS + 1];
-    uint32_t* gh = hist + (int64_t)q * MSR_SEL_BINS;
-    const int t = threadIdx.x;
-    uint32_t local = 0;
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t v = gh[4 * t + j];
-        h[4 * t + j] = v;
-        gh[4 * t + j] = 0;                           // leave the histogram zeroed for the next pass
-        local += v;
-    }
-    suf[t] = local;
-    if (t == 0) suf[SCAN_THREADS] = 0;
-    __syncthreads();
-    // inclusive suffix sum over threads (Hillis-Steele)
-    for (int off = 1; off < SCAN_THREADS; off <<= 1) {
-        uint32_t add = (t + off < SCAN_THREADS) ? suf[t + off] : 0;
-        __syncthreads();
-        suf[t] += add;
-        __syncthreads();
-    }
-    const uint32_t total = suf[0];
-    if (digit == 0 && total <= (uint32_t)S.k_rem) {
-        // fewer valid elements than k: everything valid is selected
-        if (t == 0) {
-            S.done = 1; S.n_sel = (int32_t)total;
-            st[q] = S;
-        }
-        return;
-    }
-    const uint32_t need = (uint32_t)S.k_rem;
-    if (suf[t] >= need && suf[t + 1] < need) {       // exactly one thread
-        uint32_t above = suf[t + 1];
-        int b = 4 * t + 3;
-        for (; b > 4 * t; --b) {
-            if (above + h[b] >= need) break;
-            above += h[b];
-        }
-        int part, shift, width;
-        digit_pos<SB>(digit, part, shift, width);
-        const uint64_t wmask = ((uint64_t)1 << width) - 1;
-        if (part == 0) {
-            S.pref_hi |= (uint64_t)b << shift; S.mask_hi |= wmask << shift;
+    __shared__ SelState S_sh;
+    const int q = blockIdx.x, t = threadIdx.x;
+    if (t == 0) {
+        if (digit == 0) {
+            SelState S;
+            S.pref_hi = S.mask_hi = 0; S.pref_lo = S.mask_lo = 0;
+            S.k_rem = k; S.n_above = 0; S.done = 0; S.n_sel = 0;
+            S_sh = S;
         } else {
-            S.pref_lo |= (uint32_t)b << shift; S.mask_lo |= (uint32_t)(wmask << shift);
+            S_sh = st[q];
         }
-        S.n_above += (int32_t)above;
-        S.k_rem -= (int32_t)above;
-        S.n_sel = k;
-        const uint32_t superset = (uint32_t)S.n_above + h[b];
-        if (superset <= MSR_SEL_CAP || digit == KeyCfg<SB>::ND - 1) S.done = 1;
-        st[q] = S;
     }
+    __syncthreads();
+    if (S_sh.done) return;                                       // nothing was added to hist[q] in this pass
+    uint32_t* gh = hist + (int64_t)q * MSR_SEL_BINS;
+    for (int j = 0; j < 4; ++j) {
+        h[4 * t + j] = gh[4 * t + j];
+        gh[4 * t + j] = 0;
+    }
+    __syncthreads();
+    select_step<SB>(h, suf, &S_sh, digit, k);
+    if (t == 0) st[q] = S_sh;
 }
 
+// Compaction of the elements at or above the resolved prefix.  Matches are staged in LDS and appended to the
+// query's candidate list with ONE global atomic per workgroup (same-address atomics from every lane made
+// this the slowest kernel of the select in the first profile).  Queries that two passes could not resolve
+// (superset still > MSR_SEL_CAP: huge tie groups) are left to the final kernel's in-kernel loop.
 template <typename T>
 __global__ __launch_bounds__(SEL_THREADS) void sel_compact_kernel(const T* __restrict__ scores, int64_t n,
                                                                    int64_t stride,
@@ -162,29 +187,43 @@ __global__ __launch_bounds__(SEL_THREADS) void sel_compact_kernel(const T* __res
                                                                    uint64_t* __restrict__ cand_hi,
                                                                    uint32_t* __restrict__ cand_lo,
                                                                    int32_t* __restrict__ cand_n) {
+    __shared__ uint64_t s_hi[MSR_SEL_CAP];
+    __shared__ uint32_t s_lo[MSR_SEL_CAP];
+    __shared__ int s_n, s_base;
     const int q = blockIdx.y;
     const SelState S = st[q];
+    if (!S.done) return;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
     const int64_t per = (n + gridDim.x - 1) / gridDim.x;
     const int64_t lo = (int64_t)blockIdx.x * per;
     const int64_t hi = lo + per < n ? lo + per : n;
     const T* row = scores + (int64_t)q * stride;
     for (int64_t i = lo + threadIdx.x; i < hi; i += SEL_THREADS) {
-        const T s = row[i];
-        if (!msr_valid(s)) continue;
-        const uint64_t khi = ScoreTraits<T>::ord(s);
-        const uint32_t klo = ~(uint32_t)i;
+        uint64_t khi; uint32_t klo;
+        if (!key_of(row[i], i, khi, klo)) continue;
         const uint64_t mh = khi & S.mask_hi;
         const bool ge = mh > S.pref_hi || (mh == S.pref_hi && (klo & S.mask_lo) >= S.pref_lo);
         if (!ge) continue;
-        const int pos = atomicAdd(&cand_n[q], 1);
-        if (pos < MSR_SEL_CAP) {
-            cand_hi[(int64_t)q * MSR_SEL_CAP + pos] = khi;
-            cand_lo[(int64_t)q * MSR_SEL_CAP + pos] = klo;
+        const int pos = atomicAdd(&s_n, 1);                      // LDS atomic
+        if (pos < MSR_SEL_CAP) { s_hi[pos] = khi; s_lo[pos] = klo; }
+    }
+    __syncthreads();
+    int cnt = s_n;
+    if (cnt > MSR_SEL_CAP) cnt = MSR_SEL_CAP;
+    if (cnt == 0) return;
+    if (threadIdx.x == 0) s_base = atomicAdd(&cand_n[q], cnt);
+    __syncthreads();
+    const int base = s_base;
+    for (int j = threadIdx.x; j < cnt; j += SEL_THREADS) {
+        if (base + j < MSR_SEL_CAP) {
+            cand_hi[(int64_t)q * MSR_SEL_CAP + base + j] = s_hi[j];
+            cand_lo[(int64_t)q * MSR_SEL_CAP + base + j] = s_lo[j];
         }
     }
 }
 
-// Bitonic sort of (hi, lo) keys, descending, in LDS.  P is a power of two <= MSR_SEL_CAP * 2.
+// Bitonic sort of (hi, lo) keys, descending, in LDS.  P is a power of two.
 __device__ __forceinline__ bool key_less(uint64_t ah, uint32_t al, uint64_t bh, uint32_t bl) {
     return ah < bh || (ah == bh && al < bl);
 }
@@ -200,7 +239,8 @@ __device__ void bitonic_desc(uint64_t* khi, uint32_t* klo, int P) {
                 const uint64_t ah = khi[i], bh = khi[p];
                 const uint32_t al = klo[i], bl = klo[p];
                 const bool a_lt_b = key_less(ah, al, bh, bl);
-                if (desc ? a_lt_b : !a_lt_b && !(ah == bh && al == bl)) {
+                const bool b_lt_a = key_less(bh, bl, ah, al);
+                if (desc ? a_lt_b : b_lt_a) {
                     khi[i] = bh; klo[i] = bl; khi[p] = ah; klo[p] = al;
                 }
             }
@@ -209,37 +249,87 @@ __device__ void bitonic_desc(uint64_t* khi, uint32_t* klo, int P) {
     }
 }
 
+// One workgroup per query: exact sort of the candidates and output.  If the two streaming passes did not
+// resolve the query (state not done), this workgroup finishes the radix select on its own over the score
+// row -- slow (one CU reads the row once per remaining digit) but exact, and only reached with tie groups
+// larger than MSR_SEL_CAP.
 template <typename T>
-__global__ __launch_bounds__(SCAN_THREADS) void sel_final_kernel(const SelState* __restrict__ st,
+__global__ __launch_bounds__(SCAN_THREADS) void sel_final_kernel(const T* __restrict__ scores, int64_t n,
+                                                                  int64_t stride, SelState* __restrict__ st,
                                                                   const uint64_t* __restrict__ cand_hi,
                                                                   const uint32_t* __restrict__ cand_lo,
                                                                   int32_t* __restrict__ cand_n, int k,
                                                                   int32_t* __restrict__ out_doc,
                                                                   T* __restrict__ out_score,
                                                                   int32_t* __restrict__ out_n) {
+    constexpr int SB = ScoreTraits<T>::SB;
     __shared__ uint64_t khi[MSR_SEL_CAP];
     __shared__ uint32_t klo[MSR_SEL_CAP];
-    const int q = blockIdx.x;
-    int n = cand_n[q];
-    if (n > MSR_SEL_CAP) n = MSR_SEL_CAP;
-    int P = 64;
-    while (P < n) P <<= 1;
-    for (int i = threadIdx.x; i < P; i += SCAN_THREADS) {
-        khi[i] = i < n ? cand_hi[(int64_t)q * MSR_SEL_CAP + i] : 0;
-        klo[i] = i < n ? cand_lo[(int64_t)q * MSR_SEL_CAP + i] : 0;
+    __shared__ uint32_t suf[SCAN_THREADS + 1];
+    __shared__ SelState S_sh;
+    __shared__ int s_cnt;
+    const int q = blockIdx.x, t = threadIdx.x;
+    const T* row = scores + (int64_t)q * stride;
+    if (t == 0) S_sh = st[q];
+    __syncthreads();
+    int cnt;
+    if (S_sh.done) {
+        cnt = cand_n[q];
+        if (cnt > MSR_SEL_CAP) cnt = MSR_SEL_CAP;
+        for (int i = t; i < cnt; i += SCAN_THREADS) {
+            khi[i] = cand_hi[(int64_t)q * MSR_SEL_CAP + i];
+            klo[i] = cand_lo[(int64_t)q * MSR_SEL_CAP + i];
+        }
+    } else {
+        uint32_t* h = (uint32_t*)khi;                            // the histogram lives in the (still unused) key array
+        for (int d = 2; d < KeyCfg<SB>::ND; ++d) {
+            for (int b = t; b < MSR_SEL_BINS; b += SCAN_THREADS) h[b] = 0;
+            __syncthreads();
+            const SelState S = S_sh;
+            int part, shift, width;
+            digit_pos<SB>(d, part, shift, width);
+            const uint32_t wmask = (1u << width) - 1u;
+            for (int64_t i = t; i < n; i += SCAN_THREADS) {
+                uint64_t a; uint32_t b;
+                if (!key_of(row[i], i, a, b)) continue;
+                if ((a & S.mask_hi) != S.pref_hi || (b & S.mask_lo) != S.pref_lo) continue;
+                atomicAdd(&h[part == 0 ? (uint32_t)(a >> shift) & wmask : (b >> shift) & wmask], 1u);
+            }
+            __syncthreads();
+            select_step<SB>(h, suf, &S_sh, d, k);
+            if (S_sh.done) break;
+        }
+        if (t == 0) s_cnt = 0;
+        __syncthreads();
+        const SelState S = S_sh;
+        for (int64_t i = t; i < n; i += SCAN_THREADS) {
+            uint64_t a; uint32_t b;
+            if (!key_of(row[i], i, a, b)) continue;
+            const uint64_t mh = a & S.mask_hi;
+            if (mh > S.pref_hi || (mh == S.pref_hi && (b & S.mask_lo) >= S.pref_lo)) {
+                const int pos = atomicAdd(&s_cnt, 1);
+                if (pos < MSR_SEL_CAP) { khi[pos] = a; klo[pos] = b; }   // h is dead: safe to overwrite
+            }
+        }
+        __syncthreads();
+        cnt = s_cnt < MSR_SEL_CAP ? s_cnt : MSR_SEL_CAP;
     }
+    int P = 64;
+    while (P < cnt) P <<= 1;
+    __syncthreads();
+    for (int i = cnt + t; i < P; i += SCAN_THREADS) { khi[i] = 0; klo[i] = 0; }
     __syncthreads();
     bitonic_desc<SCAN_THREADS>(khi, klo, P);
-    int n_sel = st[q].n_sel;
-    if (n_sel > n) n_sel = n;
-    for (int i = threadIdx.x; i < k; i += SCAN_THREADS) {
+    int n_sel = S_sh.n_sel;
+    if (n_sel > cnt) n_sel = cnt;
+    for (int i = t; i < k; i += SCAN_THREADS) {
         const bool ok = i < n_sel;
         out_doc[(int64_t)q * k + i] = ok ? (int32_t)~klo[i] : -1;
         out_score[(int64_t)q * k + i] = ok ? ScoreTraits<T>::unord(khi[i]) : ScoreTraits<T>::neg_inf();
     }
-    if (threadIdx.x == 0) {
+    if (t == 0) {
         out_n[q] = n_sel;
-        cand_n[q] = 0;                               // invariant: zero between calls
+        cand_n[q] = 0;                                           // invariant: zero between calls
     }
 }
 
@@ -248,20 +338,20 @@ hipError_t select_impl(const T* scores, int64_t n, int64_t stride, int nq, int k
                        int32_t* out_doc, T* out_score, int32_t* out_n, hipStream_t stream) {
     constexpr int SB = ScoreTraits<T>::SB;
     if (nq <= 0) return hipSuccess;
-    sel_init_kernel<<<nq, 1, 0, stream>>>(sc.state, k);
     int64_t parts = (n + 8191) / 8192;
-    const int64_t max_parts = 4096 / nq > 0 ? 4096 / nq : 1;
+    const int64_t max_parts = 2048 / nq > 0 ? 2048 / nq : 1;
     if (parts > max_parts) parts = max_parts;
     if (parts < 1) parts = 1;
     dim3 grid((unsigned)parts, (unsigned)nq);
-    for (int d = 0; d < KeyCfg<SB>::ND; ++d) {
+    // two streaming histogram passes (24 key bits), one compaction, one exact sort: 6 launches
+    for (int d = 0; d < 2; ++d) {
         sel_hist_kernel<T><<<grid, SEL_THREADS, 0, stream>>>(scores, n, stride, d, sc.state, sc.hist);
         sel_scan_kernel<SB><<<nq, SCAN_THREADS, 0, stream>>>(sc.state, sc.hist, d, k);
     }
     sel_compact_kernel<T><<<grid, SEL_THREADS, 0, stream>>>(scores, n, stride, sc.state, sc.cand_hi, sc.cand_lo,
                                                              sc.cand_n);
-    sel_final_kernel<T><<<nq, SCAN_THREADS, 0, stream>>>(sc.state, sc.cand_hi, sc.cand_lo, sc.cand_n, k, out_doc,
-                                                          out_score, out_n);
+    sel_final_kernel<T><<<nq, SCAN_THREADS, 0, stream>>>(scores, n, stride, sc.state, sc.cand_hi, sc.cand_lo,
+                                                          sc.cand_n, k, out_doc, out_score, out_n);
     return hipGetLastError();
 }
 

@@ -22,7 +22,7 @@ def _ptr(t):
 
 class DeviceEngine:
     def __init__(self, index: CorpusIndex, device=0, max_queries=32, max_k=1000, rerank_max_docs=1000,
-                 scan_layout=0):
+                 scan_layout=0, scan_variant=0):
         if not torch.cuda.is_available():
             raise _abi.MsrError(-102, "no GPU visible: the retrieval path runs on MI355X only (no CPU fallback)")
         self.lib = _abi.load()
@@ -32,7 +32,7 @@ class DeviceEngine:
         self.scan_layout = int(scan_layout)
         self.rerank_max_docs = int(rerank_max_docs)
         cfg = _abi.MsrConfig(C.sizeof(_abi.MsrConfig), self.device.index or 0, DIM, int(max_queries), int(max_k),
-                             int(rerank_max_docs), int(scan_layout), 0)
+                             int(rerank_max_docs), int(scan_layout), int(scan_variant))
         self.handle = C.c_void_p()
         rc = self.lib.msr_create(C.byref(cfg), C.byref(self.handle))
         if rc != 0:

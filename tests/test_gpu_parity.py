@@ -157,13 +157,13 @@ def _check_dense(mods, eng, doc_off, emb, q, k, mc, got):
             assert abs(cos_c - best[d]) <= 2e-5
 
 
-@pytest.mark.parametrize("layout", [0, 1])
-def test_dense_scan_vs_oracle(mods, layout):
+@pytest.mark.parametrize("layout,variant", [(0, 0), (1, 0), (0, 1), (1, 1), (0, 3), (1, 3)])
+def test_dense_scan_vs_oracle(mods, layout, variant):
     rng = np.random.default_rng(17 + layout)
     doc_off, emb = _rand_chunked(rng, 700, 9, big=((5, 70), (300, 300), (301, 0), (699, 33)))
     ix = mods["CorpusIndex"](doc_ids=np.arange(700, dtype=np.int64) * 2 + 11, doc_off=doc_off.astype(np.int32),
                              chunk_ids=np.arange(doc_off[-1], dtype=np.int64), emb=emb, total_docs=700)
-    eng = mods["DeviceEngine"](ix, max_queries=32, max_k=200, scan_layout=layout)
+    eng = mods["DeviceEngine"](ix, max_queries=32, max_k=200, scan_layout=layout, scan_variant=variant)
     for Q in (1, 5, 16, 17, 32, 40):
         q = (rng.standard_normal((Q, 768)) * rng.uniform(0.5, 9)).astype(np.float32)
         q[0] = emb[123] * 4.0                                  # an exact hit
@@ -173,20 +173,37 @@ def test_dense_scan_vs_oracle(mods, layout):
     eng.close()
 
 
-def test_dense_tiny_and_ragged(mods):
+@pytest.mark.parametrize("variant", [0, 1])
+def test_dense_tiny_and_ragged(mods, variant):
     rng = np.random.default_rng(2)
-    for n_docs, max_ch in ((1, 1), (3, 2), (40, 1), (17, 40)):
+    for n_docs, max_ch in ((1, 1), (3, 2), (40, 1), (17, 40), (5000, 3)):
         doc_off, emb = _rand_chunked(rng, n_docs, max_ch)
         if doc_off[-1] == 0:
             continue
         ix = mods["CorpusIndex"](doc_ids=np.arange(n_docs, dtype=np.int64), doc_off=doc_off.astype(np.int32),
                                  chunk_ids=np.arange(doc_off[-1], dtype=np.int64), emb=emb, total_docs=n_docs)
-        eng = mods["DeviceEngine"](ix, max_queries=4, max_k=64)
+        eng = mods["DeviceEngine"](ix, max_queries=4, max_k=64, scan_variant=variant)
         q = rng.standard_normal((3, 768)).astype(np.float32)
         q[1] = 0.0                                              # zero query: cosine 0 everywhere (sklearn)
         got = eng.dense_topk(q, k=64)
         _check_dense(mods, eng, doc_off, emb, q, 64, 0, got)
         eng.close()
+
+
+def test_dense_massive_ties(mods):
+    """Every chunk identical => every document has the same cosine: the k lowest indices, in order."""
+    n = 9000
+    v = np.random.default_rng(1).standard_normal(768).astype(np.float32)
+    v /= np.linalg.norm(v)
+    E = np.tile(v, (n, 1))
+    ix = mods["CorpusIndex"](doc_ids=np.arange(n, dtype=np.int64), doc_off=np.arange(n + 1, dtype=np.int32),
+                             chunk_ids=np.arange(n, dtype=np.int64), emb=E, total_docs=n)
+    eng = mods["DeviceEngine"](ix, max_queries=4, max_k=1000)
+    doc, score, chunk, cnt = [x.cpu().numpy() for x in eng.dense_topk(np.stack([v * 3, -v]), k=1000)]
+    assert cnt.tolist() == [1000, 1000]
+    assert doc[0].tolist() == list(range(1000)) and doc[1].tolist() == list(range(1000))
+    assert abs(score[0, 0] - 1.0) < 1e-5 and abs(score[1, 0] + 1.0) < 1e-5
+    eng.close()
 
 
 def test_dense_cosine_golden(mods):
