@@ -465,8 +465,9 @@ hipError_t dispatch_variant(const DenseIndex& ix, const float* qn, int nq, int m
                             hipStream_t stream) {
     switch (ix.variant) {
         case 1: return launch_scan<QB, TILED>(ix, qn, nq, max_chunks, docscore, stream);
-        case 3: return launch_scan_v2<QB, TILED, 12>(ix, qn, nq, max_chunks, docscore, stream);
-        default: return launch_scan_v2<QB, TILED, 8>(ix, qn, nq, max_chunks, docscore, stream);
+        case 2: return launch_scan_v2<QB, TILED, 8>(ix, qn, nq, max_chunks, docscore, stream);
+        case 4: return launch_scan_v2<QB, TILED, 24>(ix, qn, nq, max_chunks, docscore, stream);
+        default: return launch_scan_v2<QB, TILED, 12>(ix, qn, nq, max_chunks, docscore, stream);   // 0, 3
     }
 }
 

@@ -64,7 +64,8 @@ struct DenseIndex {
     int32_t layout;            // 0 row-major, 1 interleaved
     const int32_t* wspan_doc;  // [n_wspans+1] document boundaries of the per-wave spans (scan variants 2, 3)
     int32_t n_wspans;
-    int32_t variant;           // 0/2: wave-streaming kernel, 8-step load batches; 3: 12-step; 1: super-tile kernel
+    int32_t variant;           // 0/3: wave-streaming kernel, 12-step load batches (default); 2: 8-step; 4: 24-step;
+                               // 1: super-tile kernel of the first profile
 };
 // qn: [ceil16(nq)][768] normalised queries (zero rows as padding).
 // docscore[q][n_docs] <- max cosine over the document's chunks (-inf for chunk-less documents).

@@ -50,7 +50,7 @@ class ShardedEngine:
 
     @staticmethod
     def _globalise(idx, base):
-        return torch.where(idx >= 0, idx + base, idx)
+        return idx if base == 0 else torch.where(idx >= 0, idx + base, idx)
 
     # ------------------------------------------------------------------ the sharded hot path
     def search(self, term_lists, qvec, k1=1000, k2=100, min_score=0.0, max_chunks_per_doc=0, rerank=True,
