@@ -2,9 +2,9 @@
 //
 // Replaces the per-query SQL fetch + Python grouping + scoring loop of the reference
 // (indexer/bm25_indexer.py:434-481).  The dense doc index is cut into tiles of TILE documents; one
-// workgroup owns one (tile, query) pair and keeps the tile's float64 accumulators in LDS.  For each query
-// term, IN QUERY ORDER, it locates the tile's slice of the term's posting list (wave-wide 64-ary search)
-// and streams it with coalesced loads; a document occurs at most once per posting list
+// workgroup owns one (tile, query) pair and keeps the tile's float64 accumulators in LDS.  It first locates
+// the tile's slice of every query term's posting list (wave-wide 64-ary searches, one term per wave side by
+// side), then, IN QUERY ORDER, streams each slice with coalesced loads; a document occurs at most once per posting list
 // (PRIMARY KEY (doc_id, term), :100-104), so the read-modify-write of acc[doc] needs no atomics, and a
 // barrier between terms makes the float64 summation order equal to the reference's (:466-478).
 // The arithmetic is written operation by operation as Python evaluates it and this file is compiled with
@@ -19,6 +19,7 @@ namespace {
 
 constexpr int BM25_TILE = 4096;
 constexpr int BM25_THREADS = 256;
+constexpr int BM25_MAX_TERMS = 64;                            // MSR_MAX_QUERY_TERMS
 constexpr uint64_t UNTOUCHED = 0x7FF8DEADBEEF0001ull;   // a quiet-NaN payload no computation produces
 
 // First index in [s, e) with a[idx] >= target (e if none).  Executed by one full wave.
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
                                                                   double* __restrict__ scores) {
     __shared__ double acc[BM25_TILE];
     __shared__ int32_t dl[BM25_TILE];
-    __shared__ int64_t slice[2];
+    __shared__ int64_t slice[2 * BM25_MAX_TERMS];                // [term slot][begin, end) of the tile's postings
     const int tid = threadIdx.x;
     const int q = blockIdx.y;                        // row of `scores`
     const int64_t lo = (int64_t)blockIdx.x * BM25_TILE;
@@ -68,20 +69,31 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
     const double k1 = ix.k1, b = ix.b, avgdl = ix.avgdl;
     const double k1p1 = k1 + 1.0;                    // self.k1 + 1
     const double omb = 1.0 - b;                      // 1 - self.b
-    const int t0 = q_term_off[q_first + q], t1 = q_term_off[q_first + q + 1];
-    __syncthreads();
-    for (int j = t0; j < t1; ++j) {
-        const int32_t t = q_terms[j];
-        if (t < 0 || t >= ix.n_terms) continue;      // block-uniform
-        const int64_t s = ix.term_off[t], e = ix.term_off[t + 1];
-        if (e <= s) continue;
-        if (tid < 64) {
-            const int64_t ps = wave_lower_bound(ix.post_doc, s, e, (int32_t)lo);
-            const int64_t pe = wave_lower_bound(ix.post_doc, ps, e, (int32_t)hi);
-            if (tid == 0) { slice[0] = ps; slice[1] = pe; }
+    const int t0 = q_term_off[q_first + q];
+    int t1 = q_term_off[q_first + q + 1];
+    if (t1 - t0 > BM25_MAX_TERMS) t1 = t0 + BM25_MAX_TERMS;      // the host never sends more
+    // Locate the tile's slice of every posting list first, one term per wave at a time: the searches are
+    // chains of dependent loads, so running them for all terms side by side hides most of their latency.
+    {
+        const int wv = tid >> 6;
+        for (int j = t0 + wv; j < t1; j += BM25_THREADS / 64) {
+            const int32_t t = q_terms[j];
+            int64_t ps = 0, pe = 0;
+            if (t >= 0 && t < ix.n_terms) {
+                const int64_t s = ix.term_off[t], e = ix.term_off[t + 1];
+                if (e > s) {
+                    ps = wave_lower_bound(ix.post_doc, s, e, (int32_t)lo);
+                    pe = wave_lower_bound(ix.post_doc, ps, e, (int32_t)hi);
+                }
+            }
+            if ((tid & 63) == 0) { slice[2 * (j - t0)] = ps; slice[2 * (j - t0) + 1] = pe; }
         }
-        __syncthreads();
-        const int64_t ps = slice[0], pe = slice[1];
+    }
+    __syncthreads();
+    for (int j = t0; j < t1; ++j) {                              // query order: the float64 sums must match
+        const int64_t ps = slice[2 * (j - t0)], pe = slice[2 * (j - t0) + 1];
+        if (pe <= ps) continue;                                  // block-uniform
+        const int32_t t = q_terms[j];
         const double idf = (double)ix.idf[t];
         const double qtf = (double)q_qtf[j];
         for (int64_t i = ps + tid; i < pe; i += BM25_THREADS) {

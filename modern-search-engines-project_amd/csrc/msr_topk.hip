@@ -133,12 +133,23 @@ __global__ __launch_bounds__(SEL_THREADS) void sel_hist_kernel(const T* __restri
     const int64_t lo = (int64_t)blockIdx.x * per;
     const int64_t hi = lo + per < n ? lo + per : n;
     const T* row = scores + (int64_t)q * stride;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += SEL_THREADS) {
-        uint64_t khi; uint32_t klo;
-        if (!key_of(row[i], i, khi, klo)) continue;
-        if ((khi & S.mask_hi) != S.pref_hi || (klo & S.mask_lo) != S.pref_lo) continue;
-        const uint32_t dg = part == 0 ? (uint32_t)(khi >> shift) & wmask : (klo >> shift) & wmask;
-        atomicAdd(&h[dg], 1u);
+    // four independent loads in flight per thread (one per iteration left the pass latency-bound)
+    for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += 4 * SEL_THREADS) {
+        T v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + (int64_t)u * SEL_THREADS;
+            v[u] = i < hi ? row[i] : ScoreTraits<T>::neg_inf();
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + (int64_t)u * SEL_THREADS;
+            uint64_t khi; uint32_t klo;
+            if (!key_of(v[u], i, khi, klo)) continue;
+            if ((khi & S.mask_hi) != S.pref_hi || (klo & S.mask_lo) != S.pref_lo) continue;
+            const uint32_t dg = part == 0 ? (uint32_t)(khi >> shift) & wmask : (klo >> shift) & wmask;
+            atomicAdd(&h[dg], 1u);
+        }
     }
     __syncthreads();
     uint32_t* gh = hist + (int64_t)q * MSR_SEL_BINS;
@@ -187,8 +198,9 @@ __global__ __launch_bounds__(SEL_THREADS) void sel_compact_kernel(const T* __res
                                                                    uint64_t* __restrict__ cand_hi,
                                                                    uint32_t* __restrict__ cand_lo,
                                                                    int32_t* __restrict__ cand_n) {
-    __shared__ uint64_t s_hi[MSR_SEL_CAP];
-    __shared__ uint32_t s_lo[MSR_SEL_CAP];
+    constexpr int STAGE = 1024;                                  // staged matches per workgroup (12 KB of LDS)
+    __shared__ uint64_t s_hi[STAGE];
+    __shared__ uint32_t s_lo[STAGE];
     __shared__ int s_n, s_base;
     const int q = blockIdx.y;
     const SelState S = st[q];
@@ -199,18 +211,36 @@ __global__ __launch_bounds__(SEL_THREADS) void sel_compact_kernel(const T* __res
     const int64_t lo = (int64_t)blockIdx.x * per;
     const int64_t hi = lo + per < n ? lo + per : n;
     const T* row = scores + (int64_t)q * stride;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += SEL_THREADS) {
-        uint64_t khi; uint32_t klo;
-        if (!key_of(row[i], i, khi, klo)) continue;
-        const uint64_t mh = khi & S.mask_hi;
-        const bool ge = mh > S.pref_hi || (mh == S.pref_hi && (klo & S.mask_lo) >= S.pref_lo);
-        if (!ge) continue;
-        const int pos = atomicAdd(&s_n, 1);                      // LDS atomic
-        if (pos < MSR_SEL_CAP) { s_hi[pos] = khi; s_lo[pos] = klo; }
+    for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += 4 * SEL_THREADS) {
+        T v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + (int64_t)u * SEL_THREADS;
+            v[u] = i < hi ? row[i] : ScoreTraits<T>::neg_inf();
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + (int64_t)u * SEL_THREADS;
+            uint64_t khi; uint32_t klo;
+            if (!key_of(v[u], i, khi, klo)) continue;
+            const uint64_t mh = khi & S.mask_hi;
+            const bool ge = mh > S.pref_hi || (mh == S.pref_hi && (klo & S.mask_lo) >= S.pref_lo);
+            if (!ge) continue;
+            const int pos = atomicAdd(&s_n, 1);                  // LDS atomic
+            if (pos < STAGE) {
+                s_hi[pos] = khi; s_lo[pos] = klo;
+            } else {                                             // more matches than the stage holds: append directly
+                const int g = atomicAdd(&cand_n[q], 1);
+                if (g < MSR_SEL_CAP) {
+                    cand_hi[(int64_t)q * MSR_SEL_CAP + g] = khi;
+                    cand_lo[(int64_t)q * MSR_SEL_CAP + g] = klo;
+                }
+            }
+        }
     }
     __syncthreads();
     int cnt = s_n;
-    if (cnt > MSR_SEL_CAP) cnt = MSR_SEL_CAP;
+    if (cnt > STAGE) cnt = STAGE;
     if (cnt == 0) return;
     if (threadIdx.x == 0) s_base = atomicAdd(&cand_n[q], cnt);
     __syncthreads();

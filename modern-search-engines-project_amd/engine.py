@@ -109,6 +109,8 @@ class DeviceEngine:
             cnt = {}
             for t in tl:
                 cnt[int(t)] = cnt.get(int(t), 0) + 1
+            if len(cnt) > 64:
+                raise ValueError("a query may hold at most 64 unique terms (MSR_MAX_QUERY_TERMS)")
             for t, c in cnt.items():
                 terms.append(t)
                 qtf.append(c)

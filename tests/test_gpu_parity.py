@@ -86,6 +86,7 @@ def test_bm25_synthetic_vs_oracle(mods):
     terms[3] = [7, 7, 7, 0, 19999, 250000, -1]          # repeats, rare, out-of-range and negative ids
     terms[4] = []                                        # empty query
     terms[5] = [0]                                       # only the negative-idf term
+    terms[6] = [int(t) for t in np.random.default_rng(1).choice(5000, size=41, replace=False)] + [3, 3]   # many terms
     z = {k: (getattr(ix, k).cpu().numpy() if torch.is_tensor(getattr(ix, k)) else getattr(ix, k))
          for k in ("doc_ids", "doc_len", "term_off", "post_doc", "post_tf", "idf")}
     z["avgdl"] = ix.avgdl

@@ -31,7 +31,7 @@ def stats(stats_csv, trace_csv, out):
         lines.append(f"| {short(r['Name'])} | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['MinNs']) / 1e3:.1f} | "
                      f"{float(r['MaxNs']) / 1e3:.1f} | {float(r['TotalDurationNs']) / 1e6:.3f} |")
     tr = sorted(csv.DictReader(open(trace_csv)), key=lambda r: int(r["Start_Timestamp"]))
-    idx = [i for i, r in enumerate(tr) if "dense_scan_kernel<2" in r["Kernel_Name"]]
+    idx = [i for i, r in enumerate(tr) if ("dense_scan_kernel<2" in r["Kernel_Name"] or "dense_scan_v2_kernel<2" in r["Kernel_Name"])]
     step = []
     if len(idx) >= 8:
         def start(j):
