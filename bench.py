@@ -51,6 +51,8 @@ def build_shard(args, rank, world, dev, n_queries):
     if world > 1:
         del full
     C = shard.n_chunks
+    if C == 0:
+        return shard, terms
     g = torch.Generator(device=dev)
     g.manual_seed(SEED + 7919 * (rank + 1))
     emb = torch.empty((C, 768), dtype=torch.float32, device=dev)
@@ -72,6 +74,20 @@ def make_query_vectors(n, dev, seed):
     v = torch.randn((n, 768), generator=g)
     v = v / v.norm(dim=1, keepdim=True) * torch.empty(n, 1).uniform_(5.0, 15.0, generator=g)
     return v.to(dev)
+
+
+def measured_traffic(args, world, kernel):
+    """HBM bytes per launch of the roofline kernel from the rocprofv3 PMC passes committed under profiles/
+    (FETCH_SIZE and WRITE_SIZE are collected in separate runs of this same command and corrected as
+    MI355X_MICROARCH.md prescribes; see tools/summarize_prof.py).  None if no matching measurement exists."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if world != 1 or not os.path.exists(path):
+        return None
+    for e in json.load(open(path)):
+        if (e["kernel"] == kernel and e["n_chunks"] == args.chunks and e["n_docs"] == args.docs and
+                e["queries_per_step"] == args.queries_per_step and e["workload"] == args.workload):
+            return e["hbm_bytes_per_launch"]
+    return None
 
 
 def cpu_baseline(args, shard, terms, qvec):
@@ -127,7 +143,12 @@ def main():
     ap.add_argument("--cpu-sample-frac", type=float, default=0.125)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-queries", type=int, default=20)
+    ap.add_argument("--workload", choices=["hybrid", "bm25", "dense"], default="hybrid",
+                    help="hybrid = the headline (BASELINE configs[2]); bm25 = stage 1 only (configs[1]: use --docs "
+                         "100000 --chunks 0 --terms 200000 --queries-per-step 1024 --k1 100); dense = full scan only")
     args = ap.parse_args()
+    if args.workload == "bm25":
+        args.chunks = 0
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -153,10 +174,24 @@ def main():
     for b in range(n_pool // Q):
         tl = [shard.term_ids(t) for t in terms[b * Q:(b + 1) * Q]]
         batches.append((eng.pack_queries(tl), qvec[b * Q:(b + 1) * Q].contiguous()))
+    out = {}
 
-    def step(i):
-        packed, qv = batches[i % len(batches)]
-        return se.search(None, qv, k1=args.k1, k2=args.k2, packed=packed)
+    def step(i, one=None):
+        packed, qv = one if one is not None else batches[i % len(batches)]
+        if args.workload == "hybrid":
+            return se.search(None, qv, k1=args.k1, k2=args.k2, packed=packed)
+        if args.workload == "bm25":       # stage 1 only; shards merge their lists like the hybrid path does
+            b = eng.bm25_topk(None, k=args.k1, packed=packed)
+            if world > 1:
+                parts = se._allgather_bytes([se._globalise(b[0], se.doc_base), b[1], b[2]])
+                b = eng.merge_topk(*[torch.stack([p[j] for p in parts]) for j in range(3)], args.k1)
+            return {"bm25": b}
+        d = eng.dense_topk(qv, k=args.k2)
+        if world > 1:
+            parts = se._allgather_bytes([se._globalise(d[0], se.doc_base), d[1], d[3]])
+            m = eng.merge_topk(*[torch.stack([p[j] for p in parts]) for j in range(3)], args.k2)
+            d = (m[0], m[1], None, m[2])
+        return {"dense": d}
 
     def fence():
         if world > 1:
@@ -175,8 +210,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    scan_ms, scan_n = eng.kernel_time_ms(0)
-    bm_ms, bm_n = eng.kernel_time_ms(1)
+    scan_ms, scan_n = eng.kernel_time_ms(0) if args.workload != "bm25" else (0.0, 0)
+    bm_ms, bm_n = eng.kernel_time_ms(1) if args.workload != "dense" else (0.0, 0)
     eng.set_timing(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -190,42 +225,60 @@ def main():
         for packed, qv in one:
             fence()
             t1 = time.perf_counter()
-            se.search(None, qv, k1=args.k1, k2=args.k2, packed=packed)
+            step(0, one=(packed, qv))
             torch.cuda.synchronize()
             if rep:
                 lat.append(time.perf_counter() - t1)
     p50_ms = 1e3 * float(np.median(lat)) if lat else None
 
     # sanity of the last step's outputs (cheap, outside the timed region)
-    b_doc, b_score, b_n = out["bm25"]
-    d_doc, d_score, d_chunk, d_n = out["dense"]
-    r_doc, r_score, r_orig, r_chunk, r_n, r_rows = out["rerank"]
-    ok = bool((d_n == args.k2).all().item()) and bool((torch.diff(d_score, dim=1) <= 0).all().item())
-    ok = ok and bool((b_n > 0).all().item()) and bool((r_n > 0).all().item())
+    ok = True
+    if "dense" in out:
+        d_doc, d_score, d_chunk, d_n = out["dense"]
+        ok = ok and bool((d_n == args.k2).all().item()) and bool((torch.diff(d_score, dim=1) <= 0).all().item())
+    if "bm25" in out:
+        ok = ok and bool((out["bm25"][2] > 0).all().item())
+    if "rerank" in out:
+        ok = ok and bool((out["rerank"][4] > 0).all().item())
 
     if rank == 0:
         n_ch = shard.n_chunks
-        alg_bytes = n_ch * 768 * 4 + (shard.n_docs + 1) * 4 + Q * 768 * 4
-        per_launch_ms = scan_ms / max(1, scan_n)
+        if args.workload == "bm25":
+            # 8 B per posting of the query's terms + 4 B doc_len + 8 B score row per document
+            tq = batches[0][0][1].long()
+            tq = tq[(tq >= 0) & (tq < shard.n_terms)]
+            toff = shard.term_off.to(tq.device)
+            post_bytes = 8 * int((toff[tq + 1] - toff[tq]).sum().item())
+            alg_bytes = post_bytes + Q * 12 * shard.n_docs
+            k_ms, k_n, kname = bm_ms, bm_n, "bm25_taat_kernel"
+        else:
+            alg_bytes = n_ch * 768 * 4 + (shard.n_docs + 1) * 4 + Q * 768 * 4
+            k_ms, k_n, kname = scan_ms, scan_n, "dense_scan_v2_kernel"
+        per_launch_ms = k_ms / max(1, k_n)
         achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "dense_scan_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "algorithmic_bytes_per_launch": alg_bytes, "launches": scan_n, "ms_per_launch": per_launch_ms,
-                "bm25_taat_ms_per_launch": bm_ms / max(1, bm_n)}
+        roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, world, kname),
+                "algorithmic_bytes_per_launch": alg_bytes, "launches": k_n, "ms_per_launch": per_launch_ms}
+        if args.workload == "hybrid":
+            roof["bm25_taat_ms_per_launch"] = bm_ms / max(1, bm_n)
+        names = {"hybrid": "two-stage retrieval top-100 (BM25 top-1000 + dense full scan + rerank/fuse)",
+                 "bm25": f"BM25 top-{args.k1}", "dense": f"dense full-scan top-{args.k2}"}
         line = {
-            "metric": "queries/sec, two-stage retrieval top-100 (BM25 top-1000 + dense full scan + rerank/fuse)",
+            "metric": "queries/sec, " + names[args.workload],
             "value": Q * args.steps / elapsed, "unit": "queries/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32 (dense cosine) / f64 (BM25, fuse)",
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": {"hybrid": "f32 (dense cosine) / f64 (BM25, fuse)", "bm25": "f64", "dense": "f32"}[args.workload],
             "data": "synthetic",
-            "config": {"workload": f"hybrid two-stage retrieval, {args.docs} docs / {args.chunks} x 768 f32 chunks, "
+            "config": {"workload": f"{args.workload}: {args.docs} docs / {args.chunks} x 768 f32 chunks / "
+                                   f"{int(shard.post_doc.numel()) if world == 1 else 'sharded'} postings, "
                                    f"{Q} queries per step, doc-sharded x{world}",
                        "n_docs": args.docs, "n_chunks": args.chunks, "n_terms": args.terms,
                        "queries_per_step": Q, "k_stage1": args.k1, "k_final": args.k2,
                        "scan_layout": args.scan_layout, "scan_variant": args.scan_variant},
             "p50_latency_ms_single_query": p50_ms, "outputs_sane": ok, "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "hybrid":
             try:
                 cb, cres = cpu_baseline(args, shard, terms, qvec)
                 line["cpu_baseline"] = cb

@@ -1,0 +1,147 @@
+"""Full-size checks (BASELINE.json shape: 1 M docs / 5 M x 768 f32 chunks / ~2.3e8 postings) on the MI355X.
+The CPU oracle cannot finish these sizes in seconds, so the checks are (a) plain-PyTorch references of the
+same arithmetic evaluated on the GPU (float64 for BM25 -> bitwise, float32 for the cosine -> 1e-5, the
+north_star tolerance) and (b) size-independent properties: sortedness + tie rule, idempotence, scale
+invariance of the cosine, max-pool monotonicity, sharded == unsharded."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+N_DOCS, N_CHUNKS = 1_000_000, 5_000_000
+
+
+@pytest.fixture(scope="module")
+def world():
+    assert torch.cuda.is_available()
+    from msretr.engine import DeviceEngine
+    from msretr.synthetic import synthetic_corpus, synthetic_queries
+    dev = torch.device("cuda", 0)
+    ix = synthetic_corpus(N_DOCS, n_chunks=N_CHUNKS, device=dev)
+    terms, qvec = synthetic_queries(ix, 40, seed=99)
+    eng = DeviceEngine(ix, max_queries=32, max_k=1000, rerank_max_docs=1000)
+    yield dict(ix=ix, eng=eng, terms=terms, qvec=qvec, dev=dev, DeviceEngine=DeviceEngine)
+    eng.close()
+
+
+def _bm25_torch(ix, term_ids, k, min_score):
+    """float64 PyTorch restatement of bm25_indexer.py:458-488 (one elementwise op per Python operation, so no
+    fused multiply-add can sneak in)."""
+    N = ix.n_docs
+    acc = torch.zeros(N, dtype=torch.float64, device=ix.post_doc.device)
+    touched = torch.zeros(N, dtype=torch.bool, device=acc.device)
+    avgdl = float(np.float32(ix.avgdl))
+    cnt = {}
+    for t in term_ids:
+        cnt[t] = cnt.get(t, 0) + 1
+    for t, f in cnt.items():
+        if t < 0 or t >= ix.n_terms:
+            continue
+        lo, hi = int(ix.term_off[t]), int(ix.term_off[t + 1])
+        if hi <= lo:
+            continue
+        d = ix.post_doc[lo:hi].long()
+        tf = ix.post_tf[lo:hi].double()
+        dl = ix.doc_len[d].double()
+        idf = float(ix.idf[t])
+        comp = (tf * (ix.k1 + 1)) / (tf + ix.k1 * ((1 - ix.b) + (ix.b * dl) / avgdl))
+        acc[d] = acc[d] + (idf * comp) * float(f)
+        touched[d] = True
+    s = torch.where(touched & (acc >= min_score), acc, torch.full_like(acc, -float("inf")))
+    key = torch.sort(-s, stable=True)                    # stable: ties keep ascending doc index
+    n = int((s > -float("inf")).sum())
+    return key.indices[:min(k, n)], -key.values[:min(k, n)]
+
+
+def test_bm25_fullsize_bitwise_vs_torch_f64(world):
+    ix, eng = world["ix"], world["eng"]
+    tl = [ix.term_ids(t) for t in world["terms"][:12]]
+    for k, ms in ((1000, 0.0), (100, -3.0)):
+        doc, score, n = eng.bm25_topk(tl, k=k, min_score=ms)
+        for i, t in enumerate(tl):
+            ri, rs = _bm25_torch(ix, t, k, ms)
+            assert int(n[i]) == len(ri)
+            assert torch.equal(doc[i, :len(ri)].long(), ri)
+            assert torch.equal(score[i, :len(ri)], rs)                   # float64, bitwise
+            assert bool((torch.diff(score[i, :len(ri)]) <= 0).all())
+
+
+def _dense_torch(ix, q, k):
+    qn = q / torch.linalg.vector_norm(q)
+    cos = torch.empty(ix.emb.shape[0], dtype=torch.float32, device=q.device)
+    for s in range(0, ix.emb.shape[0], 1 << 20):
+        e = ix.emb[s:s + (1 << 20)]
+        cos[s:s + len(e)] = (e @ qn) / torch.linalg.vector_norm(e, dim=1)
+    seg = torch.repeat_interleave(torch.arange(ix.n_docs, device=q.device), torch.diff(ix.doc_off.long()))
+    best = torch.full((ix.n_docs,), -float("inf"), dtype=torch.float32, device=q.device)
+    best = best.scatter_reduce(0, seg, cos, reduce="amax", include_self=True)
+    top = torch.topk(best, k)
+    return best, top.indices, top.values
+
+
+def test_dense_fullsize_vs_torch_f32(world):
+    ix, eng, qvec = world["ix"], world["eng"], world["qvec"]
+    k = 100
+    doc, score, chunk, n = eng.dense_topk(qvec[:32], k=k)
+    assert bool((n == k).all())
+    for i in (0, 7, 31):
+        best, ti, tv = _dense_torch(ix, qvec[i], k)
+        assert float((score[i] - best[doc[i].long()]).abs().max()) <= 1e-5       # every reported score is right
+        assert float((score[i] - tv).abs().max()) <= 1e-5                          # and the list is the top-k
+        missing = set(ti.tolist()) ^ set(doc[i].tolist())
+        assert all(abs(float(best[d]) - float(tv[-1])) <= 2e-5 for d in missing)  # only boundary near-ties may swap
+        lo = ix.doc_off[doc[i].long()].long(); hi = ix.doc_off[doc[i].long() + 1].long()
+        assert bool(((chunk[i] >= lo) & (chunk[i] < hi)).all())
+    # the planted source chunk of every query (synthetic_queries) is found, with a high cosine
+    assert float(score[:, 0].min()) > 0.8
+
+
+def test_dense_fullsize_properties(world):
+    eng, qvec = world["eng"], world["qvec"]
+    a = eng.dense_topk(qvec[:32], k=100)
+    b = eng.dense_topk(qvec[:32], k=100)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)                                                   # idempotent, bit for bit
+    assert bool((torch.diff(a[1], dim=1) <= 0).all())                              # sorted
+    eq = torch.diff(a[1], dim=1) == 0
+    assert bool((torch.diff(a[0], dim=1)[eq] > 0).all())                           # ties: ascending index
+    c = eng.dense_topk(qvec[:32] * 7.5, k=100)                                     # cosine is scale invariant
+    assert float((c[1] - a[1]).abs().max()) <= 2e-6
+    assert float((c[0] == a[0]).float().mean()) > 0.99
+    d1 = eng.dense_topk(qvec[:8], k=100, max_chunks_per_doc=1)                     # max over fewer chunks is smaller
+    d3 = eng.dense_topk(qvec[:8], k=100, max_chunks_per_doc=3)
+    assert bool((d1[1] <= d3[1] + 1e-7).all()) and bool((d3[1] <= a[1][:8] + 1e-7).all())
+    # a batch of 40 (two internal sweeps) equals the same queries issued as 32 + 8
+    e = eng.dense_topk(world["qvec"][:40], k=100)
+    f = eng.dense_topk(world["qvec"][32:40], k=100)
+    assert torch.equal(e[0][:32], a[0]) and torch.equal(e[0][32:], f[0]) and torch.equal(e[1][32:], f[1])
+
+
+def test_fullsize_two_shards_equal_unsharded(world):
+    ix, eng, qvec = world["ix"], world["eng"], world["qvec"]
+    tl = [ix.term_ids(t) for t in world["terms"][:8]]
+    fb = eng.bm25_topk(tl, k=1000)
+    fd = eng.dense_topk(qvec[:8], k=100)
+    fr = eng.rerank(qvec[:8], fb[0], fb[1], fb[2])
+    shards = [ix.shard(r, 2) for r in range(2)]
+    engs = [world["DeviceEngine"](s, max_queries=8, max_k=1000, rerank_max_docs=1000) for s in shards]
+    glob = lambda t, base: torch.where(t >= 0, t + base, t)
+    pb = [e.bm25_topk(tl, k=1000) for e in engs]
+    pd_ = [e.dense_topk(qvec[:8], k=100) for e in engs]
+    mb = engs[0].merge_topk(torch.stack([glob(p[0], s.doc_base) for p, s in zip(pb, shards)]),
+                            torch.stack([p[1] for p in pb]), torch.stack([p[2] for p in pb]), 1000)
+    md = engs[0].merge_topk(torch.stack([glob(p[0], s.doc_base) for p, s in zip(pd_, shards)]),
+                            torch.stack([p[1] for p in pd_]), torch.stack([p[3] for p in pd_]), 100)
+    for x, y in zip(mb, fb):
+        assert torch.equal(x, y)
+    for x, y in zip(md, (fd[0], fd[1], fd[3])):
+        assert torch.equal(x, y)
+    parts = [e.rerank_gather(qvec[:8], mb[0], mb[2], doc_base=s.doc_base, row_base=s.row_base) for e, s in zip(engs, shards)]
+    cos = parts[0][0].view(torch.int32) | parts[1][0].view(torch.int32)
+    meta = parts[0][1] | parts[1][1]
+    mr = engs[1].rerank_fuse(mb[0], mb[1], mb[2], cos.view(torch.float32), meta)
+    for x, y in zip(mr, fr):
+        assert torch.equal(x, y)
+    for e in engs:
+        e.close()
