@@ -31,7 +31,8 @@ def _bm25_torch(ix, term_ids, k, min_score):
     N = ix.n_docs
     acc = torch.zeros(N, dtype=torch.float64, device=ix.post_doc.device)
     touched = torch.zeros(N, dtype=torch.bool, device=acc.device)
-    avgdl = float(np.float32(ix.avgdl))
+    # a 0-dim DEVICE tensor: dividing by a Python scalar makes torch multiply by the reciprocal instead
+    avgdl = torch.tensor(float(np.float32(ix.avgdl)), dtype=torch.float64, device=acc.device)
     cnt = {}
     for t in term_ids:
         cnt[t] = cnt.get(t, 0) + 1
