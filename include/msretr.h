@@ -118,6 +118,16 @@ int msr_bm25_topk(msr_engine* e, const int32_t* q_term_off, const int32_t* q_ter
 int msr_dense_topk(msr_engine* e, const float* q, int32_t n_queries, int32_t k, int32_t max_chunks_per_doc,
                    int32_t* out_doc, float* out_score, int32_t* out_chunk, int32_t* out_n, void* stream);
 
+/* Batched variant of msr_dense_topk for throughput (BASELINE config 5): one sweep over a bf16 copy of the
+ * embeddings (v_mfma_f32_16x16x32_bf16) serves up to 64 queries and yields approximate scores with a proven
+ * error bound; every document within twice that bound of the k-th approximate score is re-scored in f32 from
+ * the f32 rows and the final top-k is exact (same ordering rule as msr_dense_topk).  A query whose candidate
+ * set exceeds the engine's capacity (4096) comes back with out_n = -1: rerun it with msr_dense_topk.
+ * msr_enable_bf16 builds the bf16 copy (+2 bytes per embedding value of HBM); row-major layout only. */
+int msr_enable_bf16(msr_engine* e, void* stream);
+int msr_dense_topk_bf16(msr_engine* e, const float* q, int32_t n_queries, int32_t k, int32_t max_chunks_per_doc,
+                        int32_t* out_doc, float* out_score, int32_t* out_chunk, int32_t* out_n, void* stream);
+
 /* Rerank/fuse of stage-1 candidates, reranker_api.py:337-372.  Query qi has cand_n[qi] <= max_cand
  * candidates in row qi of cand_doc / cand_bm25 (any order).  Candidates not in urlsDB, losing the URL
  * dedup (MIN(id) wins) or without chunks are dropped; the others come back ordered by

@@ -20,6 +20,7 @@ UNITS = {
     "msr_bm25.hip": ["-ffp-contract=off"],
     "msr_dense.hip": [],
     "msr_rerank.hip": ["-ffp-contract=off"],
+    "msr_batch.hip": [],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 

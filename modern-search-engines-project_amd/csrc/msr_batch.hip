@@ -1,0 +1,176 @@
+// K5 support -- exact finish of the bf16 candidate scan (gfx950).
+//
+// The bf16 sweep (dense_scan_v2_kernel<.., BF16>) gives every document an APPROXIMATE max-cosine s^ with
+// |s^ - s| <= eps, eps = 2^-7: both operands are rounded to 8 significant bits (relative error <= 2^-8 each), so
+// each product is off by at most ~2^-7 |e_i q_i| and, by Cauchy-Schwarz on unit vectors, the sum by at most 2^-7;
+// the f32 accumulation error is orders of magnitude smaller.  Let t = k-th largest s^.  Every document of the
+// exact top-k satisfies s^ >= t - 2 eps (proof in DESIGN.md), so
+//     candidates = { d : s^_d >= t - 2 eps }
+// is a superset of the exact top-k.  The kernels below compact that set, recompute the candidates' cosines in
+// f32 from the f32 rows (reranker_api.py:285 arithmetic), and sort them exactly.  If a query has more than
+// MSR_SEL_CAP candidates the call reports out_n = -1 for it and the host reruns it on the f32 scan.
+#include "msr_common.h"
+#include "msr_internal.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int BT_THREADS = 256;
+constexpr int BT_STAGE = 1024;
+
+__global__ __launch_bounds__(BT_THREADS) void thr_compact_kernel(const float* __restrict__ scores, int64_t n,
+                                                                  const float* __restrict__ top_score,
+                                                                  const int32_t* __restrict__ top_n, int k,
+                                                                  float margin, int32_t* __restrict__ cand_doc,
+                                                                  int32_t* __restrict__ cand_n) {
+    __shared__ int32_t s_doc[BT_STAGE];
+    __shared__ int s_n, s_base;
+    const int q = blockIdx.y;
+    const int have = top_n[q];
+    const float thr = have >= k ? top_score[(int64_t)q * k + (k - 1)] - margin : -__builtin_inff();
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * per;
+    const int64_t hi = lo + per < n ? lo + per : n;
+    const float* row = scores + (int64_t)q * n;
+    for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += 4 * BT_THREADS) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + (int64_t)u * BT_THREADS;
+            v[u] = i < hi ? row[i] : -__builtin_inff();
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!(msr_valid(v[u]) && v[u] >= thr)) continue;
+            const int32_t d = (int32_t)(i0 + (int64_t)u * BT_THREADS);
+            const int pos = atomicAdd(&s_n, 1);
+            if (pos < BT_STAGE) {
+                s_doc[pos] = d;
+            } else {
+                const int g = atomicAdd(&cand_n[q], 1);
+                if (g < MSR_SEL_CAP) cand_doc[(int64_t)q * MSR_SEL_CAP + g] = d;
+            }
+        }
+    }
+    __syncthreads();
+    int cnt = s_n < BT_STAGE ? s_n : BT_STAGE;
+    if (cnt == 0) return;
+    if (threadIdx.x == 0) s_base = atomicAdd(&cand_n[q], cnt);
+    __syncthreads();
+    for (int j = threadIdx.x; j < cnt; j += BT_THREADS)
+        if (s_base + j < MSR_SEL_CAP) cand_doc[(int64_t)q * MSR_SEL_CAP + s_base + j] = s_doc[j];
+}
+
+// One wave per (query, candidate): exact f32 max-cosine over the document's chunks and its first arg-max.
+__global__ __launch_bounds__(BT_THREADS) void rescore_kernel(DenseIndex ix, const float* __restrict__ qn,
+                                                              int max_chunks, const int32_t* __restrict__ cand_doc,
+                                                              const int32_t* __restrict__ cand_n,
+                                                              float* __restrict__ cand_score,
+                                                              int32_t* __restrict__ cand_chunk) {
+    const int q = blockIdx.y, lane = threadIdx.x & 63;
+    int cnt = cand_n[q];
+    if (cnt > MSR_SEL_CAP) cnt = MSR_SEL_CAP;
+    const f32x4* q4 = (const f32x4*)(qn + (size_t)q * MSR_DIM);
+    const f32x4 qa = q4[lane], qb = q4[lane + 64], qc = q4[lane + 128];
+    for (int slot = blockIdx.x * (BT_THREADS / 64) + (threadIdx.x >> 6); slot < cnt;
+         slot += gridDim.x * (BT_THREADS / 64)) {
+        const int d = cand_doc[(int64_t)q * MSR_SEL_CAP + slot];
+        const int64_t ds = ix.doc_off[d];
+        int64_t de = ix.doc_off[d + 1];
+        if (max_chunks > 0 && ds + max_chunks < de) de = ds + max_chunks;
+        float best = -__builtin_inff();
+        int64_t arg = -1;
+        for (int64_t c = ds; c < de; ++c) {
+            const f32x4* p = (const f32x4*)(ix.emb + (size_t)c * MSR_DIM);
+            const f32x4 a = p[lane], b = p[lane + 64], e = p[lane + 128];
+            float s = a.x * qa.x + a.y * qa.y + a.z * qa.z + a.w * qa.w;
+            s += b.x * qb.x + b.y * qb.y + b.z * qb.z + b.w * qb.w;
+            s += e.x * qc.x + e.y * qc.y + e.z * qc.z + e.w * qc.w;
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            s *= ix.inv_norm[c];
+            if (s > best) { best = s; arg = c; }
+        }
+        if (lane == 0) {
+            cand_score[(int64_t)q * MSR_SEL_CAP + slot] = best;
+            cand_chunk[(int64_t)q * MSR_SEL_CAP + slot] = (int32_t)arg;
+        }
+    }
+}
+
+// One workgroup per query: sort the rescored candidates by (score desc, doc asc) and emit the top-k.
+__global__ __launch_bounds__(1024) void rescore_final_kernel(const int32_t* __restrict__ cand_doc,
+                                                              const float* __restrict__ cand_score,
+                                                              const int32_t* __restrict__ cand_chunk,
+                                                              int32_t* __restrict__ cand_n, int k,
+                                                              int32_t* __restrict__ out_doc,
+                                                              float* __restrict__ out_score,
+                                                              int32_t* __restrict__ out_chunk,
+                                                              int32_t* __restrict__ out_n) {
+    __shared__ uint64_t key[MSR_SEL_CAP];           // (orderable(score) << 32) | ~doc : all distinct
+    __shared__ uint32_t val[MSR_SEL_CAP];           // candidate slot
+    const int q = blockIdx.x, t = threadIdx.x;
+    const int raw = cand_n[q];
+    const bool overflow = raw > MSR_SEL_CAP;
+    const int cnt = overflow ? MSR_SEL_CAP : raw;
+    int P = 64;
+    while (P < cnt) P <<= 1;
+    for (int i = t; i < P; i += 1024) {
+        uint64_t kk = 0;
+        if (i < cnt) {
+            const float s = cand_score[(int64_t)q * MSR_SEL_CAP + i];
+            if (msr_valid(s))
+                kk = ((uint64_t)msr_ord32(s) << 32) | (uint32_t)~(uint32_t)cand_doc[(int64_t)q * MSR_SEL_CAP + i];
+        }
+        key[i] = kk; val[i] = (uint32_t)i;
+    }
+    __syncthreads();
+    for (int kk = 2; kk <= P; kk <<= 1) {
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int idx = t; idx < (P >> 1); idx += 1024) {
+                const int i = ((idx & ~(j - 1)) << 1) | (idx & (j - 1));
+                const int p = i | j;
+                const bool desc = (i & kk) == 0;
+                const uint64_t a = key[i], b = key[p];
+                if (desc ? a < b : a > b) {
+                    key[i] = b; key[p] = a;
+                    const uint32_t v = val[i]; val[i] = val[p]; val[p] = v;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const int n_sel = overflow ? 0 : (cnt < k ? cnt : k);
+    for (int i = t; i < k; i += 1024) {
+        const int64_t o = (int64_t)q * k + i;
+        const bool ok = i < n_sel && key[i] != 0;
+        out_doc[o] = ok ? (int32_t)~(uint32_t)key[i] : -1;
+        out_score[o] = ok ? msr_unord32((uint32_t)(key[i] >> 32)) : -__builtin_inff();
+        if (out_chunk) out_chunk[o] = ok ? cand_chunk[(int64_t)q * MSR_SEL_CAP + val[i]] : -1;
+    }
+    if (t == 0) {
+        out_n[q] = overflow ? -1 : n_sel;            // -1: rerun this query on the exact f32 scan
+        cand_n[q] = 0;
+    }
+}
+
+}  // namespace
+
+hipError_t msr_batch_finish(const DenseIndex& ix, const float* qn, int nq, int k, int max_chunks, float margin,
+                            const float* scores, const float* top_score, const int32_t* top_n, int32_t* cand_doc,
+                            float* cand_score, int32_t* cand_chunk, int32_t* cand_n, int32_t* out_doc,
+                            float* out_score, int32_t* out_chunk, int32_t* out_n, hipStream_t stream) {
+    if (nq <= 0) return hipSuccess;
+    int64_t parts = (ix.n_docs + 8191) / 8192;
+    const int64_t max_parts = 2048 / nq > 0 ? 2048 / nq : 1;
+    if (parts > max_parts) parts = max_parts;
+    if (parts < 1) parts = 1;
+    thr_compact_kernel<<<dim3((unsigned)parts, (unsigned)nq), BT_THREADS, 0, stream>>>(scores, ix.n_docs, top_score,
+                                                                                      top_n, k, margin, cand_doc, cand_n);
+    rescore_kernel<<<dim3(64, (unsigned)nq), BT_THREADS, 0, stream>>>(ix, qn, max_chunks, cand_doc, cand_n, cand_score,
+                                                                    cand_chunk);
+    rescore_final_kernel<<<nq, 1024, 0, stream>>>(cand_doc, cand_score, cand_chunk, cand_n, k, out_doc, out_score,
+                                                  out_chunk, out_n);
+    return hipGetLastError();
+}

@@ -172,34 +172,45 @@ __global__ __launch_bounds__(SCAN_THREADS) void dense_scan_kernel(DenseIndex ix,
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Scan kernel, variant 2: every WAVE streams its own span of row groups with no workgroup barrier after the
-// query image is loaded.  Per 16-row group: 48 x 16 B/lane loads (register double buffer that runs ACROSS
-// groups, so the next group's first batch is in flight during this group's epilogue), 48 x 4 x QB MFMAs,
-// then the 16 x Q cosines go through a wave-private LDS tile so that lane q holds query q's column and walks
-// the 16 rows; document boundaries are wave-uniform scalars (v_readlane of chunk_doc), the running maximum
-// of the open document simply stays in a register across groups.  Finished documents are staged in a
-// wave-private LDS buffer and written 32 documents at a time, 128 B per query row.
-constexpr int V2_WAVES = 8;
-constexpr int V2_THREADS = V2_WAVES * 64;
+// Scan kernel, variant 2 ("wave streaming"): every WAVE streams its own span of row groups with no workgroup
+// barrier after the query image is loaded.  Per 16-row group: 64 B of every row per k-step as one 16 B/lane
+// load (register double buffer that runs ACROSS groups, so the next group's first batch is in flight during
+// this group's epilogue), the MFMAs, then the 16 x Q cosines go through a wave-private LDS tile so that lane
+// q holds query q's column and walks the 16 rows; document boundaries are wave-uniform scalars (v_readlane of
+// chunk_doc), the running maximum of the open document simply stays in a register across groups.  Finished
+// documents are staged in a wave-private LDS buffer and written 32 documents at a time, 128 B per query row.
+//
+// The same kernel serves two element types:
+//   f32  : 16 dims per k-step, 4 x v_mfma_f32_16x16x4_f32 per load and query block, up to 32 queries, exact f32
+//   bf16 : 32 dims per k-step, 1 x v_mfma_f32_16x16x32_bf16 per load and query block, up to 64 queries; used as
+//          the candidate generator of the batched path (K5), its scores are re-computed in f32 afterwards
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int V2_OBUF_DOCS = 32;
 
-template <int QB> struct ScanLdsV2 {
+template <int QB, bool BF16, int WAVES> struct ScanCfgV2 {
+    static constexpr int KS = BF16 ? MSR_DIM / 32 : MSR_DIM / 16;            // k-steps per row group
+    static constexpr int ROW16 = BF16 ? MSR_DIM * 2 / 16 : MSR_DIM * 4 / 16;  // 16-byte units per row
     static constexpr int NQP = 16 * QB;
     static constexpr int SROW = NQP + 1;
-    static constexpr size_t q_bytes = (size_t)QB * KSTEPS * 64 * 16;
+    static constexpr int THREADS = WAVES * 64;
+    static constexpr size_t q_bytes = (size_t)QB * KS * 64 * 16;
     static constexpr size_t t_bytes = (size_t)16 * SROW * 4;                 // per wave: 16 rows x queries
     static constexpr size_t o_bytes = (size_t)V2_OBUF_DOCS * SROW * 4;       // per wave: staged documents
     static constexpr size_t wave_bytes = (t_bytes + o_bytes + 15) & ~(size_t)15;
-    static constexpr size_t total = q_bytes + V2_WAVES * wave_bytes;
+    static constexpr size_t total = q_bytes + WAVES * wave_bytes;
 };
 
-template <int QB, bool TILED, int LB>
-__global__ __launch_bounds__(V2_THREADS) void dense_scan_v2_kernel(DenseIndex ix, const int32_t* __restrict__ wspan,
-                                                                    int n_wspans, const float* __restrict__ qn,
+// qimg: the query image already in fragment order, [QB][KS][64 lanes] x 16 B (see build_qimage_kernel)
+template <int QB, bool TILED, int LB, bool BF16, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void dense_scan_v2_kernel(DenseIndex ix, const void* __restrict__ emb,
+                                                                    const int32_t* __restrict__ wspan,
+                                                                    int n_wspans, const f32x4* __restrict__ qimg,
                                                                     int nq, int max_chunks,
                                                                     float* __restrict__ docscore) {
-    using L = ScanLdsV2<QB>;
-    static_assert(KSTEPS % LB == 0 && ((KSTEPS / LB) % 2) == 0, "even number of load batches per group");
+    using L = ScanCfgV2<QB, BF16, WAVES>;
+    constexpr int KS = L::KS;
+    static_assert(KS % LB == 0 && ((KS / LB) % 2) == 0, "even number of load batches per group");
+    static_assert(!(BF16 && TILED), "the interleaved image exists for f32 only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* Qs = (f32x4*)smem;
     const int tid = threadIdx.x;
@@ -209,15 +220,10 @@ __global__ __launch_bounds__(V2_THREADS) void dense_scan_v2_kernel(DenseIndex ix
     float* OB = T + 16 * L::SROW;                                            // [V2_OBUF_DOCS][SROW]
     const int li = lane & 15, lg = lane >> 4;
 
-    for (int idx = tid; idx < QB * KSTEPS * 64; idx += V2_THREADS) {
-        const int l = idx & 63;
-        const int t = (idx >> 6) % KSTEPS;
-        const int qb = idx / (KSTEPS * 64);
-        Qs[idx] = *(const f32x4*)(qn + (size_t)(16 * qb + (l & 15)) * MSR_DIM + 16 * t + 4 * (l >> 4));
-    }
+    for (int idx = tid; idx < QB * KS * 64; idx += L::THREADS) Qs[idx] = qimg[idx];
     __syncthreads();                                             // the only workgroup barrier
 
-    const int s = blockIdx.x * V2_WAVES + w;
+    const int s = blockIdx.x * WAVES + w;
     if (s >= n_wspans) return;                                   // wave-uniform
     const int64_t N = ix.n_docs, C = ix.n_chunks;
     const float NEG_INF = -__builtin_inff();
@@ -246,14 +252,14 @@ __global__ __launch_bounds__(V2_THREADS) void dense_scan_v2_kernel(DenseIndex ix
     float m = NEG_INF;
 
     if (c1 > c0) {
-        constexpr int PSTRIDE = TILED ? 64 : 4;
-        constexpr int NBATCH = KSTEPS / LB;
+        constexpr int PSTRIDE = TILED ? 64 : 4;                  // 16-byte units between k-steps
+        constexpr int NBATCH = KS / LB;
         const int64_t g0 = c0 >> 4, g1 = (c1 + 15) >> 4;
         auto row_ptr = [&](int64_t grp) -> const f32x4* {
-            if (TILED) return (const f32x4*)(ix.emb + (size_t)grp * (16 * MSR_DIM)) + lane;
+            if (TILED) return (const f32x4*)emb + (size_t)grp * (16 * L::ROW16) + lane;
             int64_t r = grp * 16 + li;
             if (r > C - 1) r = C - 1;
-            return (const f32x4*)(ix.emb + (size_t)r * MSR_DIM) + lg;
+            return (const f32x4*)emb + (size_t)r * L::ROW16 + lg;
         };
         auto meta_row = [&](int64_t grp) -> int64_t {            // row whose chunk_doc / inv_norm this lane fetches
             int64_t r = grp * 16 + li;
@@ -295,11 +301,17 @@ __global__ __launch_bounds__(V2_THREADS) void dense_scan_v2_kernel(DenseIndex ix
                     const int t = nb * LB + u;
 #pragma unroll
                     for (int qb = 0; qb < QB; ++qb) {
-                        const f32x4 bq = Qs[(qb * KSTEPS + t) * 64 + lane];
-                        acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq.x, acc[qb], 0, 0, 0);
-                        acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq.y, acc[qb], 0, 0, 0);
-                        acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq.z, acc[qb], 0, 0, 0);
-                        acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq.w, acc[qb], 0, 0, 0);
+                        const f32x4 bq = Qs[(qb * KS + t) * 64 + lane];
+                        if (BF16) {
+                            acc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                                              __builtin_bit_cast(bf16x8, bq),
+                                                                              acc[qb], 0, 0, 0);
+                        } else {
+                            acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq.x, acc[qb], 0, 0, 0);
+                            acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq.y, acc[qb], 0, 0, 0);
+                            acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq.z, acc[qb], 0, 0, 0);
+                            acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq.w, acc[qb], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -336,6 +348,40 @@ __global__ __launch_bounds__(V2_THREADS) void dense_scan_v2_kernel(DenseIndex ix
     if (open) emit(m);
     for (int e = cur_doc + 1; e < d1; ++e) emit(NEG_INF);        // trailing chunk-less documents
     if (ob_n) flush();
+}
+
+// Query image in MFMA-fragment order.  f32: block (qb, t) lane l = qn[16 qb + (l & 15)][16 t + 4 (l >> 4) .. +3];
+// bf16: lane l = bf16(qn[16 qb + (l & 15)][32 t + 8 (l >> 4) .. +7]) (round-to-nearest-even).
+template <bool BF16>
+__global__ __launch_bounds__(256) void build_qimage_kernel(const float* __restrict__ qn, int n_blocks,
+                                                            f32x4* __restrict__ qimg) {
+    constexpr int KS = BF16 ? MSR_DIM / 32 : MSR_DIM / 16;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_blocks * KS * 64) return;
+    const int l = idx & 63;
+    const int t = (idx >> 6) % KS;
+    const int qb = idx / (KS * 64);
+    const float* src = qn + (size_t)(16 * qb + (l & 15)) * MSR_DIM;
+    if (BF16) {
+        const float* s8 = src + 32 * t + 8 * (l >> 4);
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (__bf16)s8[j];
+        qimg[idx] = __builtin_bit_cast(f32x4, v);
+    } else {
+        qimg[idx] = *(const f32x4*)(src + 16 * t + 4 * (l >> 4));
+    }
+}
+
+__global__ __launch_bounds__(256) void to_bf16_kernel(const float* __restrict__ src, int64_t n8,
+                                                       bf16x8* __restrict__ dst) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const f32x4 a = ((const f32x4*)src)[2 * i], b = ((const f32x4*)src)[2 * i + 1];
+        bf16x8 v;
+        v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
+        v[4] = (__bf16)b.x; v[5] = (__bf16)b.y; v[6] = (__bf16)b.z; v[7] = (__bf16)b.w;
+        dst[i] = v;
+    }
 }
 
 __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restrict__ q, int nq,
@@ -450,13 +496,36 @@ hipError_t launch_scan(const DenseIndex& ix, const float* qn, int nq, int max_ch
 template <int QB, bool TILED, int LB>
 hipError_t launch_scan_v2(const DenseIndex& ix, const float* qn, int nq, int max_chunks, float* docscore,
                           hipStream_t stream) {
-    const size_t lds = ScanLdsV2<QB>::total;
-    hipError_t err = hipFuncSetAttribute((const void*)dense_scan_v2_kernel<QB, TILED, LB>,
+    constexpr int WAVES = 8;
+    using L = ScanCfgV2<QB, false, WAVES>;
+    const size_t lds = L::total;
+    hipError_t err = hipFuncSetAttribute((const void*)dense_scan_v2_kernel<QB, TILED, LB, false, WAVES>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess) return err;
-    const int grid = (ix.n_wspans + V2_WAVES - 1) / V2_WAVES;
-    dense_scan_v2_kernel<QB, TILED, LB><<<grid, V2_THREADS, lds, stream>>>(ix, ix.wspan_doc, ix.n_wspans, qn, nq,
-                                                                           max_chunks, docscore);
+    const int n_img = QB * L::KS * 64;
+    build_qimage_kernel<false><<<(n_img + 255) / 256, 256, 0, stream>>>(qn, QB, (f32x4*)ix.qimg);
+    const int grid = (ix.n_wspans + WAVES - 1) / WAVES;
+    dense_scan_v2_kernel<QB, TILED, LB, false, WAVES><<<grid, L::THREADS, lds, stream>>>(
+        ix, ix.emb, ix.wspan_doc, ix.n_wspans, (const f32x4*)ix.qimg, nq, max_chunks, docscore);
+    return hipGetLastError();
+}
+
+template <int QB>
+hipError_t launch_scan_bf16(const DenseIndex& ix, const float* qn, int nq, int max_chunks, float* docscore,
+                            hipStream_t stream) {
+    constexpr int WAVES = QB > 2 ? 4 : 8;                        // 64 queries: the query image takes 96 KB of LDS
+    constexpr int LB = 12;
+    using L = ScanCfgV2<QB, true, WAVES>;
+    const size_t lds = L::total;
+    hipError_t err = hipFuncSetAttribute((const void*)dense_scan_v2_kernel<QB, false, LB, true, WAVES>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (err != hipSuccess) return err;
+    const int n_img = QB * L::KS * 64;
+    build_qimage_kernel<true><<<(n_img + 255) / 256, 256, 0, stream>>>(qn, QB, (f32x4*)ix.qimg);
+    // the per-wave spans were cut for 8 waves per CU; with 4 waves a workgroup simply takes 4 of them
+    const int grid = (ix.n_wspans + WAVES - 1) / WAVES;
+    dense_scan_v2_kernel<QB, false, LB, true, WAVES><<<grid, L::THREADS, lds, stream>>>(
+        ix, ix.emb_bf16, ix.wspan_doc, ix.n_wspans, (const f32x4*)ix.qimg, nq, max_chunks, docscore);
     return hipGetLastError();
 }
 
@@ -483,6 +552,25 @@ hipError_t msr_dense_scan(const DenseIndex& ix, const float* qn, int nq, int max
                      : dispatch_variant<1, false>(ix, qn, nq, max_chunks, docscore, stream);
     return tiled ? dispatch_variant<2, true>(ix, qn, nq, max_chunks, docscore, stream)
                  : dispatch_variant<2, false>(ix, qn, nq, max_chunks, docscore, stream);
+}
+
+hipError_t msr_dense_scan_bf16(const DenseIndex& ix, const float* qn, int nq, int max_chunks, float* docscore,
+                               hipStream_t stream) {
+    if (nq <= 0 || ix.n_docs <= 0) return hipSuccess;
+    if (nq > 64 || !ix.emb_bf16) return hipErrorInvalidValue;
+    if (nq <= 16) return launch_scan_bf16<1>(ix, qn, nq, max_chunks, docscore, stream);
+    if (nq <= 32) return launch_scan_bf16<2>(ix, qn, nq, max_chunks, docscore, stream);
+    if (nq <= 48) return launch_scan_bf16<3>(ix, qn, nq, max_chunks, docscore, stream);
+    return launch_scan_bf16<4>(ix, qn, nq, max_chunks, docscore, stream);
+}
+
+hipError_t msr_to_bf16(const float* src, int64_t n_elems, void* dst, hipStream_t stream) {
+    if (n_elems <= 0) return hipSuccess;
+    const int64_t n8 = n_elems / 8;                              // n_elems is a multiple of 768
+    int64_t blocks = (n8 + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    to_bf16_kernel<<<(unsigned)blocks, 256, 0, stream>>>(src, n8, (bf16x8*)dst);
+    return hipGetLastError();
 }
 
 hipError_t msr_prep_queries(const float* q, int nq, float* qn, int nq_pad, hipStream_t stream) {

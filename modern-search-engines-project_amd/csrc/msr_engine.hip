@@ -26,12 +26,18 @@ struct msr_engine {
     float* inv_norm_own = nullptr;
     int32_t* span_doc = nullptr;
     int32_t* wspan_doc = nullptr;
-    float* qn = nullptr;              // [32][768] normalised queries of the current slice
+    float* qn = nullptr;              // [64][768] normalised queries of the current slice
+    void* qimg = nullptr;             // query image in fragment order (96 KB)
+    void* emb_bf16 = nullptr;         // bf16 copy of the embeddings (msr_enable_bf16)
     void* score_rows = nullptr;       // max_queries rows of n_docs float64 (reused as float32 rows)
     size_t score_rows_bytes = 0;
     SelScratch sel{};
     float* rerank_cos = nullptr;
     int32_t* rerank_meta = nullptr;
+    // batched bf16 path scratch (allocated by msr_enable_bf16)
+    int32_t* bt_top_doc = nullptr; float* bt_top_score = nullptr; int32_t* bt_top_n = nullptr;
+    int32_t* bt_cand_doc = nullptr; float* bt_cand_score = nullptr; int32_t* bt_cand_chunk = nullptr;
+    int32_t* bt_cand_n = nullptr;
     int n_cus = 256;
     // timing
     bool timing = false;
@@ -105,7 +111,8 @@ extern "C" int msr_create(const msr_config* cfg, msr_engine** out) {
     if ((herr = hipGetDeviceProperties(&prop, cfg->device)) != hipSuccess) return bail(MSR_ERR_HIP, "hipGetDeviceProperties", herr);
     e->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const size_t nq = (size_t)cfg->max_queries;
-    if ((herr = hipMalloc((void**)&e->qn, 32 * MSR_DIM * sizeof(float))) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc qn", herr);
+    if ((herr = hipMalloc((void**)&e->qn, 64 * MSR_DIM * sizeof(float))) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc qn", herr);
+    if ((herr = hipMalloc(&e->qimg, 96 * 1024)) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc qimg", herr);
     if ((herr = hipMalloc((void**)&e->sel.hist, nq * MSR_SEL_BINS * sizeof(uint32_t))) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc hist", herr);
     if ((herr = hipMalloc((void**)&e->sel.state, nq * sizeof(SelState))) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc state", herr);
     if ((herr = hipMalloc((void**)&e->sel.cand_hi, nq * MSR_SEL_CAP * sizeof(uint64_t))) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc cand_hi", herr);
@@ -130,9 +137,11 @@ extern "C" int msr_create(const msr_config* cfg, msr_engine** out) {
 
 extern "C" int msr_destroy(msr_engine* e) {
     if (!e) return MSR_OK;
-    free_dev(e->chunk_doc); free_dev(e->inv_norm_own); free_dev(e->span_doc); free_dev(e->wspan_doc); free_dev(e->qn);
+    free_dev(e->chunk_doc); free_dev(e->inv_norm_own); free_dev(e->span_doc); free_dev(e->wspan_doc); free_dev(e->qn); free_dev(e->qimg); free_dev(e->emb_bf16);
     free_dev(e->score_rows); free_dev(e->sel.hist); free_dev(e->sel.state); free_dev(e->sel.cand_hi);
     free_dev(e->sel.cand_lo); free_dev(e->sel.cand_n); free_dev(e->rerank_cos); free_dev(e->rerank_meta);
+    free_dev(e->bt_top_doc); free_dev(e->bt_top_score); free_dev(e->bt_top_n); free_dev(e->bt_cand_doc);
+    free_dev(e->bt_cand_score); free_dev(e->bt_cand_chunk); free_dev(e->bt_cand_n);
     for (int w = 0; w < 2; ++w)
         for (int j = 0; j < msr_engine::EV_RING; ++j) {
             if (e->ev_start[w][j]) (void)hipEventDestroy(e->ev_start[w][j]);
@@ -239,7 +248,9 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
     }
     HIP_TRY(e, hipStreamSynchronize(st));                 // spans vector goes out of scope
     e->dense = DenseIndex{emb, doc_off, e->chunk_doc, inv_norm, e->span_doc, n_chunks, n_docs, n_spans,
-                          e->cfg.scan_layout, e->wspan_doc, n_wspans, e->cfg.scan_variant};
+                          e->cfg.scan_layout, e->wspan_doc, n_wspans, e->qimg, nullptr, e->cfg.scan_variant};
+    free_dev(e->emb_bf16);                                // a new binding invalidates the bf16 copy
+    e->emb_bf16 = nullptr;
     e->have_chunks = true;
     return MSR_OK;
 }
@@ -350,6 +361,76 @@ static int rerank_args_ok(msr_engine* e, const char* fn, int32_t n_queries, int3
                     e->cfg.rerank_max_docs);
     if (max_chunks < 1 || max_chunks > MSR_RERANK_MAX_CHUNKS)
         return fail(e, MSR_ERR_INVALID, "%s: max_chunks out of range [1, %d]", fn, MSR_RERANK_MAX_CHUNKS);
+    return MSR_OK;
+}
+
+static constexpr int BT_SLICE = 64;                         // queries per bf16 sweep
+
+extern "C" int msr_enable_bf16(msr_engine* e, void* stream) {
+    if (!e) return MSR_ERR_INVALID;
+    if (!e->have_chunks) return fail(e, MSR_ERR_NOT_BOUND, "msr_enable_bf16: chunks not bound");
+    if (e->cfg.scan_layout != 0) return fail(e, MSR_ERR_INVALID, "msr_enable_bf16: needs the row-major layout");
+    if (e->cfg.max_queries < 32) return fail(e, MSR_ERR_INVALID, "msr_enable_bf16: needs max_queries >= 32 (score rows)");
+    if (e->emb_bf16) return MSR_OK;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    hipError_t herr;
+    const size_t n_el = (size_t)e->dense.n_chunks * MSR_DIM;
+    if ((herr = hipMalloc(&e->emb_bf16, n_el * 2)) != hipSuccess)
+        return fail(e, MSR_ERR_NOMEM, "bf16 embeddings (%zu bytes): %s", n_el * 2, hipGetErrorString(herr));
+    auto alloc = [&](void** p, size_t bytes) { return *p ? hipSuccess : hipMalloc(p, bytes); };
+    if ((herr = alloc((void**)&e->bt_top_doc, (size_t)BT_SLICE * MSR_MAX_K * 4)) != hipSuccess ||
+        (herr = alloc((void**)&e->bt_top_score, (size_t)BT_SLICE * MSR_MAX_K * 4)) != hipSuccess ||
+        (herr = alloc((void**)&e->bt_top_n, (size_t)BT_SLICE * 4)) != hipSuccess ||
+        (herr = alloc((void**)&e->bt_cand_doc, (size_t)BT_SLICE * MSR_SEL_CAP * 4)) != hipSuccess ||
+        (herr = alloc((void**)&e->bt_cand_score, (size_t)BT_SLICE * MSR_SEL_CAP * 4)) != hipSuccess ||
+        (herr = alloc((void**)&e->bt_cand_chunk, (size_t)BT_SLICE * MSR_SEL_CAP * 4)) != hipSuccess ||
+        (herr = alloc((void**)&e->bt_cand_n, (size_t)BT_SLICE * 4)) != hipSuccess)
+        return fail(e, MSR_ERR_NOMEM, "bf16 path scratch: %s", hipGetErrorString(herr));
+    HIP_TRY(e, hipMemsetAsync(e->bt_cand_n, 0, (size_t)BT_SLICE * 4, st));
+    HIP_TRY(e, msr_to_bf16(e->dense.emb, (int64_t)n_el, e->emb_bf16, st));
+    e->dense.emb_bf16 = e->emb_bf16;
+    if (e->cfg.max_queries < BT_SLICE) {
+        // a bf16 sweep writes 64 f32 score rows; the f64 rows of max_queries >= 32 queries are exactly that big
+    }
+    return MSR_OK;
+}
+
+extern "C" int msr_dense_topk_bf16(msr_engine* e, const float* q, int32_t n_queries, int32_t k,
+                                   int32_t max_chunks_per_doc, int32_t* out_doc, float* out_score, int32_t* out_chunk,
+                                   int32_t* out_n, void* stream) {
+    if (!e) return MSR_ERR_INVALID;
+    if (!e->have_chunks || !e->emb_bf16) return fail(e, MSR_ERR_NOT_BOUND, "msr_dense_topk_bf16: call msr_enable_bf16 first");
+    if (n_queries < 0 || k < 1 || k > e->cfg.max_k || max_chunks_per_doc < 0 || !q || !out_doc || !out_score || !out_n)
+        return fail(e, MSR_ERR_INVALID, "msr_dense_topk_bf16: bad argument (k=%d, max_k=%d)", k, e->cfg.max_k);
+    if (n_queries == 0) return MSR_OK;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    const int64_t N = e->dense.n_docs;
+    const float margin = 2.0f * 0.0078125f;                 // 2 * eps, eps = 2^-7 (see msr_batch.hip)
+    for (int q0 = 0; q0 < n_queries; q0 += BT_SLICE) {
+        const int nq = std::min(BT_SLICE, n_queries - q0);
+        const int nq_pad = (nq + 15) / 16 * 16;
+        HIP_TRY(e, msr_prep_queries(q + (int64_t)q0 * MSR_DIM, nq, e->qn, nq_pad, st));
+        const bool timed = e->timing && e->ev_count[0] < msr_engine::EV_RING;
+        if (timed) HIP_TRY(e, hipEventRecord(e->ev_start[0][e->ev_count[0]], st));
+        HIP_TRY(e, msr_dense_scan_bf16(e->dense, e->qn, nq, max_chunks_per_doc, (float*)e->score_rows, st));
+        if (timed) {
+            HIP_TRY(e, hipEventRecord(e->ev_stop[0][e->ev_count[0]], st));
+            e->ev_count[0]++;
+        }
+        // k-th largest approximate score per query (the select state is sized for max_queries >= 32: two halves)
+        for (int h0 = 0; h0 < nq; h0 += e->cfg.max_queries) {
+            const int hn = std::min(e->cfg.max_queries, nq - h0);
+            HIP_TRY(e, msr_select_topk(32, (const float*)e->score_rows + (int64_t)h0 * N, N, N, hn, k, e->sel,
+                                       e->bt_top_doc + (int64_t)h0 * k, e->bt_top_score + (int64_t)h0 * k,
+                                       e->bt_top_n + h0, st));
+        }
+        HIP_TRY(e, msr_batch_finish(e->dense, e->qn, nq, k, max_chunks_per_doc, margin, (const float*)e->score_rows,
+                                    e->bt_top_score, e->bt_top_n, e->bt_cand_doc, e->bt_cand_score, e->bt_cand_chunk,
+                                    e->bt_cand_n, out_doc + (int64_t)q0 * k, out_score + (int64_t)q0 * k,
+                                    out_chunk ? out_chunk + (int64_t)q0 * k : nullptr, out_n + q0, st));
+    }
     return MSR_OK;
 }
 

@@ -64,6 +64,8 @@ struct DenseIndex {
     int32_t layout;            // 0 row-major, 1 interleaved
     const int32_t* wspan_doc;  // [n_wspans+1] document boundaries of the per-wave spans (scan variants 2, 3)
     int32_t n_wspans;
+    void* qimg;                // engine scratch: query image in MFMA-fragment order (<= 96 KB)
+    const void* emb_bf16;      // bf16 [n_chunks][768] copy of emb for the batched path, or null
     int32_t variant;           // 0/3: wave-streaming kernel, 12-step load batches (default); 2: 8-step; 4: 24-step;
                                // 1: super-tile kernel of the first profile
 };
@@ -71,6 +73,10 @@ struct DenseIndex {
 // docscore[q][n_docs] <- max cosine over the document's chunks (-inf for chunk-less documents).
 hipError_t msr_dense_scan(const DenseIndex& ix, const float* qn, int nq, int max_chunks, float* docscore,
                           hipStream_t stream);
+// bf16 candidate scan (<= 64 queries per sweep); qn as above with ceil16(nq) rows.
+hipError_t msr_dense_scan_bf16(const DenseIndex& ix, const float* qn, int nq, int max_chunks, float* docscore,
+                               hipStream_t stream);
+hipError_t msr_to_bf16(const float* src, int64_t n_elems, void* dst, hipStream_t stream);
 hipError_t msr_prep_queries(const float* q, int nq, float* qn, int nq_pad, hipStream_t stream);
 hipError_t msr_fill_chunk_doc(const int32_t* doc_off, int64_t n_docs, int32_t* chunk_doc, hipStream_t stream);
 hipError_t msr_row_inv_norm(const float* emb, int64_t n_rows, float* inv_norm, hipStream_t stream);
@@ -94,3 +100,9 @@ hipError_t msr_rerank_fuse_run(int nq, const int32_t* cand_doc, const double* ca
                                int max_cand, const RerankParams& p, const float* cos_in, const int32_t* meta,
                                int32_t* out_doc, double* out_score, double* out_orig, int32_t* out_chunk,
                                int32_t* out_n, int32_t* out_rows, hipStream_t stream);
+
+// ---- K5: batched bf16 candidate scan finished exactly in f32 (msr_batch.hip) -----------------------
+hipError_t msr_batch_finish(const DenseIndex& ix, const float* qn, int nq, int k, int max_chunks, float margin,
+                            const float* scores, const float* top_score, const int32_t* top_n, int32_t* cand_doc,
+                            float* cand_score, int32_t* cand_chunk, int32_t* cand_n, int32_t* out_doc,
+                            float* out_score, int32_t* out_chunk, int32_t* out_n, hipStream_t stream);

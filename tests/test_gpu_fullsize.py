@@ -146,3 +146,15 @@ def test_fullsize_two_shards_equal_unsharded(world):
         assert torch.equal(x, y)
     for e in engs:
         e.close()
+
+
+def test_fullsize_batched_bf16_equals_exact(world):
+    """bf16 candidate sweep + f32 rescoring returns the exact path's top-100 at 1 M docs / 5 M chunks."""
+    eng, qvec = world["eng"], world["qvec"]
+    eng.enable_bf16()
+    ex = eng.dense_topk(qvec[:40], k=100)
+    got = eng.dense_topk_batched(qvec[:40], k=100)
+    assert torch.equal(got[3], ex[3])
+    assert float((got[1] - ex[1]).abs().max()) <= 2e-6
+    assert bool(((got[0] == ex[0]) | ((got[1] - ex[1]).abs() <= 2e-6)).all())
+    assert float((got[0] == ex[0]).float().mean()) > 0.995

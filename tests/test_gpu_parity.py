@@ -420,3 +420,41 @@ def test_sharded_on_one_gpu_equals_unsharded(mods):
         assert torch.equal(a.cpu(), b)
     for e in engs + [full]:
         e.close()
+
+
+# ------------------------------------------------------------------------------------------------ batched bf16 path
+def test_dense_batched_bf16_matches_exact_path(mods):
+    rng = np.random.default_rng(41)
+    doc_off, emb = _rand_chunked(rng, 5000, 9, big=((5, 70), (300, 300), (301, 0)))
+    # make the top of the ranking non-trivial: plant near-duplicates of the queries
+    ix = mods["CorpusIndex"](doc_ids=np.arange(5000, dtype=np.int64) * 2 + 11, doc_off=doc_off.astype(np.int32),
+                             chunk_ids=np.arange(doc_off[-1], dtype=np.int64), emb=emb, total_docs=5000)
+    eng = mods["DeviceEngine"](ix, max_queries=32, max_k=200)
+    eng.enable_bf16()
+    for Q in (1, 16, 33, 64, 70):
+        q = (rng.standard_normal((Q, 768)) * rng.uniform(0.5, 9)).astype(np.float32)
+        q[0] = emb[123] * 4.0 + 0.05 * rng.standard_normal(768).astype(np.float32)
+        for (k, mc) in ((100, 0), (200, 10), (7, 3)):
+            got = eng.dense_topk_batched(q, k=k, max_chunks_per_doc=mc)
+            _check_dense(mods, eng, doc_off, emb, q, k, mc, got)          # vs the oracle, 1e-5
+            ex = eng.dense_topk(q, k=k, max_chunks_per_doc=mc)
+            assert torch.equal(got[3], ex[3])
+            assert float((got[1] - ex[1]).abs().max()) <= 2e-6              # f32 rescore vs f32 MFMA scan
+            same = (got[0] == ex[0]) | ((got[1] - ex[1]).abs() <= 2e-6)
+            assert bool(same.all())
+    eng.close()
+
+
+def test_dense_batched_overflow_falls_back_to_exact(mods):
+    """9000 identical documents: every one is a candidate (> 4096) => the call reports overflow and the host
+    reruns the query on the exact f32 scan; the tie rule still holds."""
+    n = 9000
+    v = np.random.default_rng(1).standard_normal(768).astype(np.float32)
+    v /= np.linalg.norm(v)
+    ix = mods["CorpusIndex"](doc_ids=np.arange(n, dtype=np.int64), doc_off=np.arange(n + 1, dtype=np.int32),
+                             chunk_ids=np.arange(n, dtype=np.int64), emb=np.tile(v, (n, 1)), total_docs=n)
+    eng = mods["DeviceEngine"](ix, max_queries=32, max_k=100)
+    eng.enable_bf16()
+    doc, score, chunk, cnt = [x.cpu().numpy() for x in eng.dense_topk_batched(np.stack([v * 2, -v]), k=100)]
+    assert cnt.tolist() == [100, 100] and doc[0].tolist() == list(range(100)) and doc[1].tolist() == list(range(100))
+    eng.close()
