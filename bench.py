@@ -7,7 +7,7 @@ A STEP = one pass of the whole hot path over one batch of `--queries-per-step` q
     stage 2  dense full scan: q x chunk cosine, per-doc max-pool, top-100   (msr_dense_topk; one sweep of E)
     fuse     reference rerank chain on the stage-1 candidates -> top-100     (msr_rerank_gather + _fuse)
 With N > 1 GPUs the corpus is doc-sharded (strong scaling: the corpus is fixed); per step one all-gather of
-the per-shard top-k lists and one bit-OR all-reduce of the candidates' cosines cross xGMI.
+the per-shard top-k lists and one integer-SUM all-reduce of the raw bits of the candidates' cosines cross xGMI.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -146,6 +146,9 @@ def main():
     ap.add_argument("--workload", choices=["hybrid", "bm25", "dense"], default="hybrid",
                     help="hybrid = the headline (BASELINE configs[2]); bm25 = stage 1 only (configs[1]: use --docs "
                          "100000 --chunks 0 --terms 200000 --queries-per-step 1024 --k1 100); dense = full scan only")
+    ap.add_argument("--dense-mode", choices=["f32", "bf16"], default="f32",
+                    help="workload dense only: bf16 = batched candidate sweep (64 queries/sweep) + exact f32 rescoring "
+                         "(BASELINE configs[4] shape: use --queries-per-step 1024)")
     args = ap.parse_args()
     if args.workload == "bm25":
         args.chunks = 0
@@ -170,6 +173,8 @@ def main():
     eng = DeviceEngine(shard, device=local_rank, max_queries=max(Q, 1), max_k=max(args.k1, args.k2),
                        rerank_max_docs=args.k1, scan_layout=args.scan_layout, scan_variant=args.scan_variant)
     se = ShardedEngine(eng, shard.doc_base, shard.row_base)
+    if args.workload == "dense" and args.dense_mode == "bf16":
+        eng.enable_bf16()
     batches = []
     for b in range(n_pool // Q):
         tl = [shard.term_ids(t) for t in terms[b * Q:(b + 1) * Q]]
@@ -186,7 +191,7 @@ def main():
                 parts = se._allgather_bytes([se._globalise(b[0], se.doc_base), b[1], b[2]])
                 b = eng.merge_topk(*[torch.stack([p[j] for p in parts]) for j in range(3)], args.k1)
             return {"bm25": b}
-        d = eng.dense_topk(qv, k=args.k2)
+        d = eng.dense_topk_batched(qv, k=args.k2) if args.dense_mode == "bf16" else eng.dense_topk(qv, k=args.k2)
         if world > 1:
             parts = se._allgather_bytes([se._globalise(d[0], se.doc_base), d[1], d[3]])
             m = eng.merge_topk(*[torch.stack([p[j] for p in parts]) for j in range(3)], args.k2)
@@ -252,8 +257,10 @@ def main():
             alg_bytes = post_bytes + Q * 12 * shard.n_docs
             k_ms, k_n, kname = bm_ms, bm_n, "bm25_taat_kernel"
         else:
-            alg_bytes = n_ch * 768 * 4 + (shard.n_docs + 1) * 4 + Q * 768 * 4
-            k_ms, k_n, kname = scan_ms, scan_n, "dense_scan_v2_kernel"
+            bf = args.workload == "dense" and args.dense_mode == "bf16"
+            q_launch = min(Q, 64 if bf else 32)                 # queries served by one sweep
+            alg_bytes = n_ch * 768 * (2 if bf else 4) + (shard.n_docs + 1) * 4 + q_launch * 768 * 4
+            k_ms, k_n, kname = scan_ms, scan_n, "dense_scan_v2_kernel" + ("<bf16>" if bf else "")
         per_launch_ms = k_ms / max(1, k_n)
         achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -262,13 +269,14 @@ def main():
         if args.workload == "hybrid":
             roof["bm25_taat_ms_per_launch"] = bm_ms / max(1, bm_n)
         names = {"hybrid": "two-stage retrieval top-100 (BM25 top-1000 + dense full scan + rerank/fuse)",
-                 "bm25": f"BM25 top-{args.k1}", "dense": f"dense full-scan top-{args.k2}"}
+                 "bm25": f"BM25 top-{args.k1}", "dense": f"dense full-scan top-{args.k2}" + (" (bf16 candidates + f32 rescore)" if args.dense_mode == "bf16" else "")}
         line = {
             "metric": "queries/sec, " + names[args.workload],
             "value": Q * args.steps / elapsed, "unit": "queries/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
-            "dtype": {"hybrid": "f32 (dense cosine) / f64 (BM25, fuse)", "bm25": "f64", "dense": "f32"}[args.workload],
+            "dtype": {"hybrid": "f32 (dense cosine) / f64 (BM25, fuse)", "bm25": "f64",
+                      "dense": "bf16 candidates, f32 final scores" if args.dense_mode == "bf16" else "f32"}[args.workload],
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {args.docs} docs / {args.chunks} x 768 f32 chunks / "
                                    f"{int(shard.post_doc.numel()) if world == 1 else 'sharded'} postings, "

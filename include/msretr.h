@@ -144,7 +144,7 @@ int msr_rerank(msr_engine* e, const float* q, int32_t n_queries, const int32_t* 
  *   msr_rerank_gather: for the candidates this shard owns (doc_base <= doc < doc_base + n_docs) writes the
  *     cosines of their first <= max_chunks chunks into out_cos[q][m][0..10) and
  *     out_meta[q][m] = (rows, url_group + 2, row_base + first row); everything else is written as 0.
- *     Summing out_cos / out_meta over the shards (one RCCL all-reduce) yields the arrays of the whole
+ *     Summing out_cos / out_meta over the shards (one RCCL all-reduce, integer SUM of the raw bits,) yields the arrays of the whole
  *     candidate list, because exactly one shard contributes a non-zero entry.
  *   msr_rerank_fuse: the float64 chain of reranker_api.py:360-372 on those arrays; touches no index, so
  *     every rank computes the same result.  Outputs as msr_rerank (out_doc are global indices). */

@@ -8,8 +8,8 @@ to the unsharded ones.  Per query batch:
   2. ONE all-gather of the packed per-shard lists (k1*(4+8) + k2*(4+4+4) bytes per query)
   3. every rank: the same deterministic merge (score desc, doc index asc)    (msr_merge_topk)
   4. reference-exact rerank of the GLOBAL stage-1 candidates: each rank computes the cosines of the
-     candidates it owns (msr_rerank_gather), one bit-OR all-reduce combines them (exactly one rank
-     contributes non-zero bits per candidate), and every rank runs the float64 chain (msr_rerank_fuse).
+     candidates it owns (msr_rerank_gather), one all-reduce (integer SUM over the raw bits: exactly one rank
+     contributes non-zero bits per candidate, so the sum is a select), and every rank runs the float64 chain (msr_rerank_fuse).
 
 No embedding or posting ever crosses a link: only k records per query do.  The reference has no counterpart
 (it is a single process talking HTTP to itself).
@@ -79,7 +79,9 @@ class ShardedEngine:
                                         max_chunks=rerank_params.get("max_chunks", 10))
             if self.world > 1:
                 buf = torch.cat([cos.view(torch.int32).reshape(-1), meta.reshape(-1)])
-                dist.all_reduce(buf, op=dist.ReduceOp.BOR, group=self.group)
+                # integer SUM of the raw bits: exactly one rank holds non-zero bits per word, so the sum IS that word
+                # (RCCL/NCCL has no bitwise reduce op; float SUM would also be exact here but -0.0 + 0.0 is not)
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
                 cos = buf[:cos.numel()].view(torch.float32).reshape(cos.shape)
                 meta = buf[cos.numel():].reshape(meta.shape)
             out["rerank"] = e.rerank_fuse(b_doc, b_score, b_n, cos, meta, **rerank_params)

@@ -1,5 +1,5 @@
 """N > 1 path on CPU: two gloo ranks, each with its document shard, must reproduce the unsharded result
-exactly (bm25 + dense lists after the all-gather + merge; rerank after the bit-OR all-reduce).  The compute
+exactly (bm25 + dense lists after the all-gather + merge; rerank after the integer-SUM all-reduce of the raw bits).  The compute
 is the oracle (tests/oracle_engine.py); what is under test is msretr.distributed + CorpusIndex.shard."""
 import os
 import sys
