@@ -108,3 +108,75 @@ def test_index_roundtrip_and_url_groups(tmp_path):
     jx = CorpusIndex.load(p)
     assert jx.post_doc.tolist() == ix.post_doc.tolist() and jx.vocab == ix.vocab and jx.avgdl == ix.avgdl
     assert np.array_equal(jx.emb, ix.emb)
+
+
+def test_bm25_index_build_matches_reference_tables():
+    """Index build from tokens reproduces the tables the goldens' corpora were described with."""
+    from msretr.index_build import bm25_index_from_tokens, normalise_document_text
+    from oracle import bm25_ref
+    case = next(c for c in _load("bm25_kat.json") if c["name"] == "null_idf_lengths")
+    docs = {}
+    for t, pl in case["postings"].items():
+        if t == "nullidf":            # that fixture row is a hand-made NULL-idf case, not a tokenisable term
+            continue
+        for d, tf in pl:
+            docs.setdefault(d, []).extend([t] * tf)
+    doc_len = {int(d): l for d, l in case["doc_len"].items()}
+    for d, l in doc_len.items():                                  # pad with filler terms up to doc_length
+        docs.setdefault(d, [])
+        docs[d] += [f"filler{d}_{i}" for i in range(l - len(docs[d]))]
+    ix = bm25_index_from_tokens(list(docs), list(docs.values()))
+    assert ix.doc_ids.tolist() == sorted(doc_len) and ix.doc_len.tolist() == [doc_len[d] for d in sorted(doc_len)]
+    assert ix.avgdl == case["avgdl_f32"]
+    for t in ("a", "b"):
+        lo, hi = ix.term_off[ix.vocab[t]], ix.term_off[ix.vocab[t] + 1]
+        got = [(int(ix.doc_ids[d]), int(tf)) for d, tf in zip(ix.post_doc[lo:hi], ix.post_tf[lo:hi])]
+        assert got == [tuple(p) for p in case["postings"][t]]
+    # idf follows the stored-REAL formula with N = number of indexed documents
+    import math
+    N = len(doc_len)
+    for t in ("a", "b"):
+        df = len(case["postings"][t])
+        assert float(ix.idf[ix.vocab[t]]) == float(np.float32(math.log10((N - df + 0.5) / (df + 0.5))))
+    assert normalise_document_text("Tuebingen", "TUBINGEN x") == "tübingen tübingen x"
+    assert bm25_index_from_tokens([1, 2], [[], ["x"]]).doc_ids.tolist() == [2]     # empty documents get no row
+
+
+def test_http_facade_shapes_and_status_codes():
+    from fastapi.testclient import TestClient
+    from msretr.reranker import RerankNotFound
+    from msretr.server import create_app
+
+    class FakeReranker:
+        def rerank(self, doc_ids, similarities, query=None, query_embedding=None):
+            if doc_ids == ["404"]:
+                raise RerankNotFound("No documents found for the provided doc_ids")
+            if doc_ids == ["boom"]:
+                raise RuntimeError("x")
+            return {"document_scores": [], "top_windows": [], "total_documents": 0, "total_windows": 100}
+
+    class FakeRetriever:
+        reranker = FakeReranker()
+
+        def search(self, query, top_k=1000, query_embedding=None, terms=None, query_id=None):
+            return [{"query_id": query_id, "rank": 1, "url": "https://a.de", "score": 0.5, "title": "t",
+                     "snippet": "s", "domain": "a", "doc_id": "7"}]
+
+        def batch_search(self, queries):
+            return [{"query_num": n, "rank": 1, "url": "u", "score": "0.500", "formatted_line": f"{n}\t1\tu\t0.500"}
+                    for n, _ in queries]
+
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False, encoding="utf-8") as f:
+        f.write("1\tfood and drinks\n2\tcastle\n")
+    c = TestClient(create_app(FakeRetriever(), llm=lambda q, w: "summary", queries_file=f.name))
+    assert c.post("/rerank", json={"doc_ids": ["1"], "similarities": [1.0], "query": "q"}).status_code == 200
+    assert c.post("/rerank", json={"doc_ids": ["404"], "similarities": [1.0], "query": "q"}).status_code == 401
+    assert c.post("/rerank", json={"doc_ids": ["boom"], "similarities": [1.0], "query": "q"}).status_code == 500
+    r = c.post("/api/search", json={"query": "Food", "query_id": "abc"})
+    assert r.status_code == 200 and r.json()["llm_response"] == "summary"
+    assert set(r.json()["documents"][0]) == {"query_id", "rank", "url", "score", "title", "snippet", "domain", "doc_id"}
+    b = c.post("/api/batch_search").json()
+    assert b["total_queries"] == 2 and b["results"][1]["formatted_line"] == "2\t1\tu\t0.500"
+    assert c.get("/api/health").json()["status"] == "healthy"
+    assert TestClient(create_app(FakeRetriever(), queries_file="/nonexistent")).post("/api/batch_search").status_code == 404
