@@ -147,7 +147,7 @@ def main():
                     help="hybrid = the headline (BASELINE configs[2]); bm25 = stage 1 only (configs[1]: use --docs "
                          "100000 --chunks 0 --terms 200000 --queries-per-step 1024 --k1 100); dense = full scan only")
     ap.add_argument("--dense-mode", choices=["f32", "bf16"], default="f32",
-                    help="workload dense only: bf16 = batched candidate sweep (64 queries/sweep) + exact f32 rescoring "
+                    help="dense / hybrid workloads: bf16 = batched candidate sweep (64 queries/sweep) + exact f32 rescoring "
                          "(BASELINE configs[4] shape: use --queries-per-step 1024)")
     args = ap.parse_args()
     if args.workload == "bm25":
@@ -173,7 +173,7 @@ def main():
     eng = DeviceEngine(shard, device=local_rank, max_queries=max(Q, 1), max_k=max(args.k1, args.k2),
                        rerank_max_docs=args.k1, scan_layout=args.scan_layout, scan_variant=args.scan_variant)
     se = ShardedEngine(eng, shard.doc_base, shard.row_base)
-    if args.workload == "dense" and args.dense_mode == "bf16":
+    if args.workload != "bm25" and args.dense_mode == "bf16":
         eng.enable_bf16()
     batches = []
     for b in range(n_pool // Q):
@@ -184,7 +184,7 @@ def main():
     def step(i, one=None):
         packed, qv = one if one is not None else batches[i % len(batches)]
         if args.workload == "hybrid":
-            return se.search(None, qv, k1=args.k1, k2=args.k2, packed=packed)
+            return se.search(None, qv, k1=args.k1, k2=args.k2, packed=packed, dense_batched=args.dense_mode == "bf16")
         if args.workload == "bm25":       # stage 1 only; shards merge their lists like the hybrid path does
             b = eng.bm25_topk(None, k=args.k1, packed=packed)
             if world > 1:
@@ -257,7 +257,7 @@ def main():
             alg_bytes = post_bytes + Q * 12 * shard.n_docs
             k_ms, k_n, kname = bm_ms, bm_n, "bm25_taat_kernel"
         else:
-            bf = args.workload == "dense" and args.dense_mode == "bf16"
+            bf = args.dense_mode == "bf16"
             q_launch = min(Q, 64 if bf else 32)                 # queries served by one sweep
             alg_bytes = n_ch * 768 * (2 if bf else 4) + (shard.n_docs + 1) * 4 + q_launch * 768 * 4
             k_ms, k_n, kname = scan_ms, scan_n, "dense_scan_v2_kernel" + ("<bf16>" if bf else "")
@@ -268,7 +268,8 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes, "launches": k_n, "ms_per_launch": per_launch_ms}
         if args.workload == "hybrid":
             roof["bm25_taat_ms_per_launch"] = bm_ms / max(1, bm_n)
-        names = {"hybrid": "two-stage retrieval top-100 (BM25 top-1000 + dense full scan + rerank/fuse)",
+        names = {"hybrid": "two-stage retrieval top-100 (BM25 top-1000 + dense full scan + rerank/fuse)" +
+                           (" [dense stage: bf16 candidates + f32 rescore]" if args.dense_mode == "bf16" else ""),
                  "bm25": f"BM25 top-{args.k1}", "dense": f"dense full-scan top-{args.k2}" + (" (bf16 candidates + f32 rescore)" if args.dense_mode == "bf16" else "")}
         line = {
             "metric": "queries/sec, " + names[args.workload],

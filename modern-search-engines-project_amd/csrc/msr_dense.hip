@@ -187,7 +187,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void dense_scan_kernel(DenseIndex ix,
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int V2_OBUF_DOCS = 32;
 
-template <int QB, bool BF16, int WAVES> struct ScanCfgV2 {
+template <int QB, bool BF16, int WAVES, bool DIRECT = false> struct ScanCfgV2 {
     static constexpr int KS = BF16 ? MSR_DIM / 32 : MSR_DIM / 16;            // k-steps per row group
     static constexpr int ROW16 = BF16 ? MSR_DIM * 2 / 16 : MSR_DIM * 4 / 16;  // 16-byte units per row
     static constexpr int NQP = 16 * QB;
@@ -195,19 +195,19 @@ template <int QB, bool BF16, int WAVES> struct ScanCfgV2 {
     static constexpr int THREADS = WAVES * 64;
     static constexpr size_t q_bytes = (size_t)QB * KS * 64 * 16;
     static constexpr size_t t_bytes = (size_t)16 * SROW * 4;                 // per wave: 16 rows x queries
-    static constexpr size_t o_bytes = (size_t)V2_OBUF_DOCS * SROW * 4;       // per wave: staged documents
+    static constexpr size_t o_bytes = DIRECT ? 0 : (size_t)V2_OBUF_DOCS * SROW * 4;   // per wave: staged documents
     static constexpr size_t wave_bytes = (t_bytes + o_bytes + 15) & ~(size_t)15;
     static constexpr size_t total = q_bytes + WAVES * wave_bytes;
 };
 
 // qimg: the query image already in fragment order, [QB][KS][64 lanes] x 16 B (see build_qimage_kernel)
-template <int QB, bool TILED, int LB, bool BF16, int WAVES>
+template <int QB, bool TILED, int LB, bool BF16, int WAVES, bool DIRECT = false>
 __global__ __launch_bounds__(WAVES * 64) void dense_scan_v2_kernel(DenseIndex ix, const void* __restrict__ emb,
                                                                     const int32_t* __restrict__ wspan,
                                                                     int n_wspans, const f32x4* __restrict__ qimg,
                                                                     int nq, int max_chunks,
                                                                     float* __restrict__ docscore) {
-    using L = ScanCfgV2<QB, BF16, WAVES>;
+    using L = ScanCfgV2<QB, BF16, WAVES, DIRECT>;
     constexpr int KS = L::KS;
     static_assert(KS % LB == 0 && ((KS / LB) % 2) == 0, "even number of load batches per group");
     static_assert(!(BF16 && TILED), "the interleaved image exists for f32 only");
@@ -242,6 +242,13 @@ __global__ __launch_bounds__(WAVES * 64) void dense_scan_v2_kernel(DenseIndex ix
         ob_n = 0;
     };
     auto emit = [&](float m) {                                   // lane q holds the value of query q
+        if (DIRECT) {
+            // 64-query sweeps have no LDS left for staging: each lane stores its query's value; the 32 stores that
+            // complete a 128 B line of a score row come from this same wave within ~10 row groups (L2 merges them)
+            if (lane < nq) docscore[(int64_t)lane * N + ob_base] = m;
+            ++ob_base;
+            return;
+        }
         if (lane < L::NQP) OB[ob_n * L::SROW + lane] = m;
         if (++ob_n == V2_OBUF_DOCS) flush();
     };
@@ -513,18 +520,18 @@ hipError_t launch_scan_v2(const DenseIndex& ix, const float* qn, int nq, int max
 template <int QB>
 hipError_t launch_scan_bf16(const DenseIndex& ix, const float* qn, int nq, int max_chunks, float* docscore,
                             hipStream_t stream) {
-    constexpr int WAVES = QB > 2 ? 4 : 8;                        // 64 queries: the query image takes 96 KB of LDS
+    constexpr int WAVES = 8;
     constexpr int LB = 12;
-    using L = ScanCfgV2<QB, true, WAVES>;
+    constexpr bool DIRECT = QB > 2;                              // the 64-query image takes 96 KB of LDS
+    using L = ScanCfgV2<QB, true, WAVES, DIRECT>;
     const size_t lds = L::total;
-    hipError_t err = hipFuncSetAttribute((const void*)dense_scan_v2_kernel<QB, false, LB, true, WAVES>,
+    hipError_t err = hipFuncSetAttribute((const void*)dense_scan_v2_kernel<QB, false, LB, true, WAVES, DIRECT>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess) return err;
     const int n_img = QB * L::KS * 64;
     build_qimage_kernel<true><<<(n_img + 255) / 256, 256, 0, stream>>>(qn, QB, (f32x4*)ix.qimg);
-    // the per-wave spans were cut for 8 waves per CU; with 4 waves a workgroup simply takes 4 of them
     const int grid = (ix.n_wspans + WAVES - 1) / WAVES;
-    dense_scan_v2_kernel<QB, false, LB, true, WAVES><<<grid, L::THREADS, lds, stream>>>(
+    dense_scan_v2_kernel<QB, false, LB, true, WAVES, DIRECT><<<grid, L::THREADS, lds, stream>>>(
         ix, ix.emb_bf16, ix.wspan_doc, ix.n_wspans, (const f32x4*)ix.qimg, nq, max_chunks, docscore);
     return hipGetLastError();
 }

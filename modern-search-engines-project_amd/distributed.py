@@ -54,10 +54,11 @@ class ShardedEngine:
 
     # ------------------------------------------------------------------ the sharded hot path
     def search(self, term_lists, qvec, k1=1000, k2=100, min_score=0.0, max_chunks_per_doc=0, rerank=True,
-               packed=None, **rerank_params):
+               packed=None, dense_batched=False, **rerank_params):
         e = self.engine
         b_doc, b_score, b_n = e.bm25_topk(term_lists, k=k1, min_score=min_score, packed=packed)
-        d_doc, d_score, d_chunk, d_n = e.dense_topk(qvec, k=k2, max_chunks_per_doc=max_chunks_per_doc)
+        dense = e.dense_topk_batched if dense_batched else e.dense_topk
+        d_doc, d_score, d_chunk, d_n = dense(qvec, k=k2, max_chunks_per_doc=max_chunks_per_doc)
         b_doc = self._globalise(b_doc, self.doc_base)
         d_doc = self._globalise(d_doc, self.doc_base)
         d_chunk = self._globalise(d_chunk, self.row_base)
