@@ -16,6 +16,8 @@
 // 16 x Q scores to LDS, and after a barrier the workgroup reduces the chunk scores to per-document maxima
 // (segments are contiguous; a document that crosses a super-tile boundary is carried in LDS).  Documents
 // never cross spans, so no inter-workgroup communication exists.
+#include <stdlib.h>
+
 #include "msr_common.h"
 #include "msr_internal.h"
 
@@ -185,9 +187,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void dense_scan_kernel(DenseIndex ix,
 //   bf16 : 32 dims per k-step, 1 x v_mfma_f32_16x16x32_bf16 per load and query block, up to 64 queries; used as
 //          the candidate generator of the batched path (K5), its scores are re-computed in f32 afterwards
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int V2_OBUF_DOCS = 32;
 
-template <int QB, bool BF16, int WAVES, bool DIRECT = false> struct ScanCfgV2 {
+template <int QB, bool BF16, int WAVES, int OBD = 32> struct ScanCfgV2 {   // OBD: staged documents per wave (0 = none)
     static constexpr int KS = BF16 ? MSR_DIM / 32 : MSR_DIM / 16;            // k-steps per row group
     static constexpr int ROW16 = BF16 ? MSR_DIM * 2 / 16 : MSR_DIM * 4 / 16;  // 16-byte units per row
     static constexpr int NQP = 16 * QB;
@@ -195,20 +196,22 @@ template <int QB, bool BF16, int WAVES, bool DIRECT = false> struct ScanCfgV2 {
     static constexpr int THREADS = WAVES * 64;
     static constexpr size_t q_bytes = (size_t)QB * KS * 64 * 16;
     static constexpr size_t t_bytes = (size_t)16 * SROW * 4;                 // per wave: 16 rows x queries
-    static constexpr size_t o_bytes = DIRECT ? 0 : (size_t)V2_OBUF_DOCS * SROW * 4;   // per wave: staged documents
+    static constexpr size_t o_bytes = (size_t)OBD * SROW * 4;                // per wave: staged documents
     static constexpr size_t wave_bytes = (t_bytes + o_bytes + 15) & ~(size_t)15;
     static constexpr size_t total = q_bytes + WAVES * wave_bytes;
 };
 
 // qimg: the query image already in fragment order, [QB][KS][64 lanes] x 16 B (see build_qimage_kernel)
-template <int QB, bool TILED, int LB, bool BF16, int WAVES, bool DIRECT = false>
+template <int QB, bool TILED, int LB, bool BF16, int WAVES, int OBD = 32>
 __global__ __launch_bounds__(WAVES * 64) void dense_scan_v2_kernel(DenseIndex ix, const void* __restrict__ emb,
                                                                     const int32_t* __restrict__ wspan,
                                                                     int n_wspans, const f32x4* __restrict__ qimg,
                                                                     int nq, int max_chunks,
                                                                     float* __restrict__ docscore) {
-    using L = ScanCfgV2<QB, BF16, WAVES, DIRECT>;
+    using L = ScanCfgV2<QB, BF16, WAVES, OBD>;
     constexpr int KS = L::KS;
+    constexpr bool DIRECT = OBD == 0;
+    static_assert(OBD == 0 || OBD == 8 || OBD == 16 || OBD == 32, "staging depth");
     static_assert(KS % LB == 0 && ((KS / LB) % 2) == 0, "even number of load batches per group");
     static_assert(!(BF16 && TILED), "the interleaved image exists for f32 only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(WAVES * 64) void dense_scan_v2_kernel(DenseIndex ix
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* T = (float*)(smem + L::q_bytes + (size_t)w * L::wave_bytes);      // [16][SROW]
-    float* OB = T + 16 * L::SROW;                                            // [V2_OBUF_DOCS][SROW]
+    float* OB = T + 16 * L::SROW;                                            // [OBD][SROW]
     const int li = lane & 15, lg = lane >> 4;
 
     for (int idx = tid; idx < QB * KS * 64; idx += L::THREADS) Qs[idx] = qimg[idx];
@@ -233,9 +236,11 @@ __global__ __launch_bounds__(WAVES * 64) void dense_scan_v2_kernel(DenseIndex ix
     // staged output: documents ob_base .. ob_base + ob_n - 1 (consecutive) for every query
     int ob_base = d0, ob_n = 0;
     auto flush = [&]() {
-        // lane -> (query sub-index, document): 64 lanes cover 2 queries x 32 documents per instruction
-        for (int qq0 = 0; qq0 < nq; qq0 += 2) {
-            const int qq = qq0 + (lane >> 5), dd = lane & 31;
+        // lane -> (query sub-index, document): 64 lanes cover (64 / OBD) queries x OBD documents per instruction
+        constexpr int OD = OBD > 0 ? OBD : 32;
+        constexpr int QPI = 64 / OD;
+        for (int qq0 = 0; qq0 < nq; qq0 += QPI) {
+            const int qq = qq0 + lane / OD, dd = lane % OD;
             if (qq < nq && dd < ob_n) docscore[(int64_t)qq * N + ob_base + dd] = OB[dd * L::SROW + qq];
         }
         ob_base += ob_n;
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(WAVES * 64) void dense_scan_v2_kernel(DenseIndex ix
             return;
         }
         if (lane < L::NQP) OB[ob_n * L::SROW + lane] = m;
-        if (++ob_n == V2_OBUF_DOCS) flush();
+        if (++ob_n == OBD) flush();
     };
 
     int cur_doc = d0 - 1;                                        // last document that has been emitted/opened
@@ -517,23 +522,35 @@ hipError_t launch_scan_v2(const DenseIndex& ix, const float* qn, int nq, int max
     return hipGetLastError();
 }
 
-template <int QB>
-hipError_t launch_scan_bf16(const DenseIndex& ix, const float* qn, int nq, int max_chunks, float* docscore,
-                            hipStream_t stream) {
-    constexpr int WAVES = 8;
+template <int QB, int WAVES, int OBD>
+hipError_t launch_scan_bf16_cfg(const DenseIndex& ix, const float* qn, int nq, int max_chunks, float* docscore,
+                                hipStream_t stream) {
     constexpr int LB = 12;
-    constexpr bool DIRECT = QB > 2;                              // the 64-query image takes 96 KB of LDS
-    using L = ScanCfgV2<QB, true, WAVES, DIRECT>;
+    using L = ScanCfgV2<QB, true, WAVES, OBD>;
     const size_t lds = L::total;
-    hipError_t err = hipFuncSetAttribute((const void*)dense_scan_v2_kernel<QB, false, LB, true, WAVES, DIRECT>,
+    static_assert(L::total <= 160 * 1024, "LDS budget");
+    hipError_t err = hipFuncSetAttribute((const void*)dense_scan_v2_kernel<QB, false, LB, true, WAVES, OBD>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess) return err;
     const int n_img = QB * L::KS * 64;
     build_qimage_kernel<true><<<(n_img + 255) / 256, 256, 0, stream>>>(qn, QB, (f32x4*)ix.qimg);
+    // the per-wave spans were cut for 8 waves per CU; with fewer waves a workgroup takes fewer of them
     const int grid = (ix.n_wspans + WAVES - 1) / WAVES;
-    dense_scan_v2_kernel<QB, false, LB, true, WAVES, DIRECT><<<grid, L::THREADS, lds, stream>>>(
+    dense_scan_v2_kernel<QB, false, LB, true, WAVES, OBD><<<grid, L::THREADS, lds, stream>>>(
         ix, ix.emb_bf16, ix.wspan_doc, ix.n_wspans, (const f32x4*)ix.qimg, nq, max_chunks, docscore);
     return hipGetLastError();
+}
+
+template <int QB>
+hipError_t launch_scan_bf16(const DenseIndex& ix, const float* qn, int nq, int max_chunks, float* docscore,
+                            hipStream_t stream) {
+    if constexpr (QB <= 2) return launch_scan_bf16_cfg<QB, 8, 32>(ix, qn, nq, max_chunks, docscore, stream);
+    // 48/64 queries: the query image takes 72/96 KB of LDS, which leaves room for either 4 waves with 32 staged
+    // documents or 8 waves with 8 (A/B knob for measurements: MSR_BF16_CFG = 0 | 1 | 2)
+    static const int knob = [] { const char* v = getenv("MSR_BF16_CFG"); return v ? atoi(v) : 0; }();
+    if (knob == 1) return launch_scan_bf16_cfg<QB, 8, 8>(ix, qn, nq, max_chunks, docscore, stream);
+    if (knob == 2) return launch_scan_bf16_cfg<QB, 8, 0>(ix, qn, nq, max_chunks, docscore, stream);
+    return launch_scan_bf16_cfg<QB, 4, 32>(ix, qn, nq, max_chunks, docscore, stream);
 }
 
 template <int QB, bool TILED>
