@@ -18,6 +18,8 @@
 // never cross spans, so no inter-workgroup communication exists.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "msr_common.h"
 #include "msr_internal.h"
 
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(WAVES * 64) void dense_scan_v2_kernel(DenseIndex ix
     constexpr int KS = L::KS;
     constexpr bool DIRECT = OBD == 0;
     static_assert(OBD == 0 || OBD == 8 || OBD == 16 || OBD == 32, "staging depth");
-    static_assert(KS % LB == 0 && ((KS / LB) % 2) == 0, "even number of load batches per group");
+    static_assert(KS % LB == 0, "whole load batches per group");
     static_assert(!(BF16 && TILED), "the interleaved image exists for f32 only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* Qs = (f32x4*)smem;
@@ -284,7 +286,12 @@ __global__ __launch_bounds__(WAVES * 64) void dense_scan_v2_kernel(DenseIndex ix
         int dv = ix.chunk_doc[meta_row(g0)];
         float iv = ix.inv_norm[meta_row(g0)];
         __builtin_amdgcn_sched_barrier(0);
-        for (int64_t grp = g0; grp < g1; ++grp) {
+        // One row group.  Batch b of the group (b = 0 .. NBATCH-1) lives in buf[(b + PH) & 1]; PH is the parity the
+        // group starts with.  With an even NBATCH it is always 0; with an odd one (LB == KS: the whole next group is
+        // prefetched while this one is consumed) the group loop below alternates PH = 0, 1 so that every register
+        // array is indexed statically.
+        auto body = [&](auto ph_c, int64_t grp) {
+            constexpr int PH = decltype(ph_c)::value;
             const f32x4* pn = row_ptr(grp + 1 < g1 ? grp + 1 : grp);
             const bool has_next = grp + 1 < g1;
             f32x4 acc[QB];
@@ -294,22 +301,26 @@ __global__ __launch_bounds__(WAVES * 64) void dense_scan_v2_kernel(DenseIndex ix
             float iv_next = iv;
 #pragma unroll
             for (int nb = 0; nb < NBATCH; ++nb) {
+                const bool into1 = ((nb + 1 + PH) & 1) != 0;     // buffer of the batch being prefetched
                 if (nb + 1 < NBATCH) {
 #pragma unroll
                     for (int u = 0; u < LB; ++u) {
                         const f32x4 x = p[(size_t)((nb + 1) * LB + u) * PSTRIDE];
-                        if (nb & 1) buf0[u] = x; else buf1[u] = x;
+                        if (into1) buf1[u] = x; else buf0[u] = x;
                     }
-                } else if (has_next) {                           // NBATCH is even: the last batch sits in buf1
+                } else if (has_next) {                           // first batch of the next group
 #pragma unroll
-                    for (int u = 0; u < LB; ++u) buf0[u] = pn[(size_t)u * PSTRIDE];
+                    for (int u = 0; u < LB; ++u) {
+                        const f32x4 x = pn[(size_t)u * PSTRIDE];
+                        if (into1) buf1[u] = x; else buf0[u] = x;
+                    }
                     dv_next = ix.chunk_doc[meta_row(grp + 1)];
                     iv_next = ix.inv_norm[meta_row(grp + 1)];
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int u = 0; u < LB; ++u) {
-                    const f32x4 a = (nb & 1) ? buf1[u] : buf0[u];
+                    const f32x4 a = ((nb + PH) & 1) ? buf1[u] : buf0[u];
                     const int t = nb * LB + u;
 #pragma unroll
                     for (int qb = 0; qb < QB; ++qb) {
@@ -355,6 +366,15 @@ __global__ __launch_bounds__(WAVES * 64) void dense_scan_v2_kernel(DenseIndex ix
             p = pn;
             dv = dv_next;
             iv = iv_next;
+        };
+        for (int64_t grp = g0; grp < g1;) {
+            body(std::integral_constant<int, 0>{}, grp);
+            ++grp;
+            if constexpr ((NBATCH & 1) != 0) {
+                if (grp >= g1) break;
+                body(std::integral_constant<int, 1>{}, grp);
+                ++grp;
+            }
         }
     }
     if (open) emit(m);
@@ -522,10 +542,9 @@ hipError_t launch_scan_v2(const DenseIndex& ix, const float* qn, int nq, int max
     return hipGetLastError();
 }
 
-template <int QB, int WAVES, int OBD>
+template <int QB, int WAVES, int OBD, int LB = 12>
 hipError_t launch_scan_bf16_cfg(const DenseIndex& ix, const float* qn, int nq, int max_chunks, float* docscore,
                                 hipStream_t stream) {
-    constexpr int LB = 12;
     using L = ScanCfgV2<QB, true, WAVES, OBD>;
     const size_t lds = L::total;
     static_assert(L::total <= 160 * 1024, "LDS budget");
@@ -550,6 +569,7 @@ hipError_t launch_scan_bf16(const DenseIndex& ix, const float* qn, int nq, int m
     static const int knob = [] { const char* v = getenv("MSR_BF16_CFG"); return v ? atoi(v) : 0; }();
     if (knob == 1) return launch_scan_bf16_cfg<QB, 8, 8>(ix, qn, nq, max_chunks, docscore, stream);
     if (knob == 2) return launch_scan_bf16_cfg<QB, 8, 0>(ix, qn, nq, max_chunks, docscore, stream);
+    if (knob == 3) return launch_scan_bf16_cfg<QB, 4, 32, 24>(ix, qn, nq, max_chunks, docscore, stream);   // whole-group prefetch
     return launch_scan_bf16_cfg<QB, 4, 32>(ix, qn, nq, max_chunks, docscore, stream);
 }
 
