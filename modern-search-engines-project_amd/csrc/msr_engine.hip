@@ -167,7 +167,6 @@ static int ensure_score_rows(msr_engine* e, int64_t n_docs) {
 extern "C" int msr_bind_postings(msr_engine* e, const int64_t* term_off, int64_t n_terms, const int32_t* post_doc,
                                  const int32_t* post_tf, int64_t n_postings, const int32_t* doc_len, int64_t n_docs,
                                  const float* idf, float avgdl, double k1, double b, void* stream) {
-    (void)stream;
     if (!e) return MSR_ERR_INVALID;
     if (!term_off || !doc_len || !idf || n_terms < 0 || n_postings < 0 || n_docs <= 0 || n_docs >= (1ll << 31) ||
         (n_postings > 0 && (!post_doc || !post_tf)))
@@ -178,8 +177,24 @@ extern "C" int msr_bind_postings(msr_engine* e, const int64_t* term_off, int64_t
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     int rc = ensure_score_rows(e, n_docs);
     if (rc) return rc;
-    e->bm25 = Bm25Index{term_off, post_doc, post_tf, doc_len, idf, n_terms, n_postings, n_docs,
-                        (double)avgdl, k1, b};
+    const Bm25Index cand{term_off, post_doc, post_tf, doc_len, idf, n_terms, n_postings, n_docs, (double)avgdl, k1, b};
+    // the scoring kernel indexes LDS with (post_doc - tile start): validate the CSR once, on the device
+    hipStream_t st = (hipStream_t)stream;
+    int32_t h_flag = 0;
+    HIP_TRY(e, msr_bm25_validate(cand, e->sel.cand_n, st));           // cand_n[0] as a scratch word (zero between calls)
+    HIP_TRY(e, hipMemcpyAsync(&h_flag, e->sel.cand_n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(e, hipMemsetAsync(e->sel.cand_n, 0, sizeof(int32_t), st));
+    HIP_TRY(e, hipStreamSynchronize(st));
+    if (h_flag != 0) {
+        static const char* why[] = {"", "term_off is not a monotone offset array ending at n_postings",
+                                    "a posting's document index is outside [0, n_docs)",
+                                    "documents are not strictly ascending inside a posting list",
+                                    "negative doc_len", "non-positive term frequency"};
+        return fail(e, MSR_ERR_INVALID, "msr_bind_postings: malformed index: %s", why[h_flag < 6 ? h_flag : 0]);
+    }
+    if (!(avgdl > 0.0f) || !(k1 >= 0.0) || !(b >= 0.0 && b <= 1.0))
+        return fail(e, MSR_ERR_INVALID, "msr_bind_postings: avgdl must be > 0, k1 >= 0, 0 <= b <= 1");
+    e->bm25 = cand;
     e->have_postings = true;
     return MSR_OK;
 }

@@ -458,3 +458,47 @@ def test_dense_batched_overflow_falls_back_to_exact(mods):
     doc, score, chunk, cnt = [x.cpu().numpy() for x in eng.dense_topk_batched(np.stack([v * 2, -v]), k=100)]
     assert cnt.tolist() == [100, 100] and doc[0].tolist() == list(range(100)) and doc[1].tolist() == list(range(100))
     eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ ABI robustness
+def test_bind_rejects_malformed_index(mods):
+    """The scoring kernel indexes LDS with the posting's document index: a malformed CSR must be refused at bind."""
+    from msretr._abi import MsrError
+    N = 100
+    good = dict(doc_ids=np.arange(N, dtype=np.int64), doc_len=np.full(N, 5, np.int32),
+                term_off=np.array([0, 3, 5], np.int64), post_doc=np.array([1, 4, 9, 0, 7], np.int32),
+                post_tf=np.ones(5, np.int32), idf=np.ones(2, np.float32), avgdl=5.0, total_docs=N)
+    mods["DeviceEngine"](mods["CorpusIndex"](**good), max_queries=2, max_k=4).close()
+    bad = [("post_doc", np.array([1, 4, 4, 0, 7], np.int32), "ascending"),
+           ("post_doc", np.array([1, 4, 100, 0, 7], np.int32), "outside"),
+           ("post_doc", np.array([9, 4, 1, 0, 7], np.int32), "ascending"),
+           ("term_off", np.array([0, 4, 3], np.int64), "offset"),
+           ("post_tf", np.array([1, 0, 1, 1, 1], np.int32), "frequency"),
+           ("doc_len", np.full(N, -1, np.int32), "doc_len")]
+    for key, val, msg in bad:
+        kw = dict(good); kw[key] = val
+        with pytest.raises(MsrError) as ei:
+            mods["DeviceEngine"](mods["CorpusIndex"](**kw), max_queries=2, max_k=4)
+        assert msg in str(ei.value), (key, str(ei.value))
+    # chunk side: non-monotone doc_off / wrong total
+    emb = np.zeros((6, 768), np.float32)
+    for off in ([0, 4, 2, 6], [0, 2, 4, 5], [1, 2, 4, 6]):
+        ix = mods["CorpusIndex"](doc_ids=np.arange(3, dtype=np.int64), doc_off=np.array(off, np.int32),
+                                 chunk_ids=np.arange(6, dtype=np.int64), emb=emb, total_docs=3)
+        with pytest.raises(MsrError):
+            mods["DeviceEngine"](ix, max_queries=2, max_k=4)
+
+
+def test_queries_with_nan_or_zero_vectors(mods):
+    rng = np.random.default_rng(3)
+    doc_off, emb = _rand_chunked(rng, 300, 4)
+    ix = mods["CorpusIndex"](doc_ids=np.arange(300, dtype=np.int64), doc_off=doc_off.astype(np.int32),
+                             chunk_ids=np.arange(doc_off[-1], dtype=np.int64), emb=emb, total_docs=300)
+    eng = mods["DeviceEngine"](ix, max_queries=8, max_k=10)
+    q = rng.standard_normal((3, 768)).astype(np.float32)
+    q[1, 5] = np.nan                                   # a poisoned query must not disturb its neighbours
+    doc, score, chunk, n = [x.cpu().numpy() for x in eng.dense_topk(q, k=10)]
+    assert n[1] == 0 and n[0] == 10 and n[2] == 10
+    oi, os_, _ = mods["dense_ref"].quick_search(emb, doc_off, q[2], 10)
+    assert doc[2].tolist() == oi.tolist()
+    eng.close()
