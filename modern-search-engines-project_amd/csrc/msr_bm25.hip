@@ -119,22 +119,22 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
 
 // Bind-time validation of the CSR the scoring kernel trusts: offsets monotone and complete, document indices
 // in range and strictly ascending inside every posting list (that is what makes the LDS accumulation
-// conflict-free and in-bounds), positive term frequencies, non-negative lengths.  flag: 0 = ok, else first
-// violated rule.
+// conflict-free and in-bounds), positive term frequencies, non-negative lengths.  flag starts at 0x7F7F7F7F and
+// receives the lowest number among the violated rules.
 __global__ __launch_bounds__(256) void validate_postings_kernel(Bm25Index ix, int32_t* __restrict__ flag) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (int64_t t = g; t <= ix.n_terms; t += stride) {
         const int64_t o = ix.term_off[t];
         if ((t == 0 && o != 0) || (t == ix.n_terms && o != ix.n_postings) || (t < ix.n_terms && ix.term_off[t + 1] < o))
-            atomicMax(flag, 1);
+            atomicMin(flag, 1);
     }
     for (int64_t d = g; d < ix.n_docs; d += stride)
-        if (ix.doc_len[d] < 0) atomicMax(flag, 4);
+        if (ix.doc_len[d] < 0) atomicMin(flag, 4);
     for (int64_t i = g; i < ix.n_postings; i += stride) {
         const int32_t d = ix.post_doc[i];
-        if (d < 0 || d >= ix.n_docs) { atomicMax(flag, 2); continue; }
-        if (ix.post_tf[i] <= 0) atomicMax(flag, 5);
+        if (d < 0 || d >= ix.n_docs) { atomicMin(flag, 2); continue; }
+        if (ix.post_tf[i] <= 0) atomicMin(flag, 5);
         if (i > 0 && d <= ix.post_doc[i - 1]) {
             // a descent is only legal at the first posting of a term: i must be one of the offsets
             int64_t lo = 0, hi = ix.n_terms;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void validate_postings_kernel(Bm25Index ix, in
                 const int64_t mid = (lo + hi) >> 1;
                 if (ix.term_off[mid] < i) lo = mid + 1; else hi = mid;
             }
-            if (ix.term_off[lo] != i) atomicMax(flag, 3);
+            if (ix.term_off[lo] != i) atomicMin(flag, 3);
         }
     }
 }
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void validate_postings_kernel(Bm25Index ix, in
 }  // namespace
 
 hipError_t msr_bm25_validate(const Bm25Index& ix, int32_t* flag, hipStream_t stream) {
-    hipError_t err = hipMemsetAsync(flag, 0, sizeof(int32_t), stream);
+    hipError_t err = hipMemsetAsync(flag, 0x7F, sizeof(int32_t), stream);
     if (err != hipSuccess) return err;
     validate_postings_kernel<<<2048, 256, 0, stream>>>(ix, flag);
     return hipGetLastError();

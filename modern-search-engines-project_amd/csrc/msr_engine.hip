@@ -185,12 +185,12 @@ extern "C" int msr_bind_postings(msr_engine* e, const int64_t* term_off, int64_t
     HIP_TRY(e, hipMemcpyAsync(&h_flag, e->sel.cand_n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(e, hipMemsetAsync(e->sel.cand_n, 0, sizeof(int32_t), st));
     HIP_TRY(e, hipStreamSynchronize(st));
-    if (h_flag != 0) {
+    if (h_flag >= 1 && h_flag <= 5) {
         static const char* why[] = {"", "term_off is not a monotone offset array ending at n_postings",
                                     "a posting's document index is outside [0, n_docs)",
                                     "documents are not strictly ascending inside a posting list",
                                     "negative doc_len", "non-positive term frequency"};
-        return fail(e, MSR_ERR_INVALID, "msr_bind_postings: malformed index: %s", why[h_flag < 6 ? h_flag : 0]);
+        return fail(e, MSR_ERR_INVALID, "msr_bind_postings: malformed index: %s", why[h_flag]);
     }
     if (!(avgdl > 0.0f) || !(k1 >= 0.0) || !(b >= 0.0 && b <= 1.0))
         return fail(e, MSR_ERR_INVALID, "msr_bind_postings: avgdl must be > 0, k1 >= 0, 0 <= b <= 1");

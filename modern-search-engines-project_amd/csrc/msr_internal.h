@@ -52,7 +52,7 @@ hipError_t msr_bm25_scores(const Bm25Index& ix, const int32_t* q_term_off, const
                            const int32_t* q_qtf, int q_first, int nq, double min_score, double* scores,
                            hipStream_t stream);
 
-// *flag (device) <- 0 if the CSR is well formed, else the number of the first violated rule (see msr_bm25.hip).
+// *flag (device) <- 0x7F7F7F7F if the CSR is well formed, else the lowest violated rule number (msr_bm25.hip).
 hipError_t msr_bm25_validate(const Bm25Index& ix, int32_t* flag, hipStream_t stream);
 
 // ---- K2/K3: dense scan + per-document max ---------------------------------------------------------
