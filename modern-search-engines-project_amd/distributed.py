@@ -33,18 +33,28 @@ class ShardedEngine:
 
     # ------------------------------------------------------------------ exchange helpers
     def _allgather_bytes(self, parts):
-        """parts: list of tensors -> list (per rank) of lists of tensors with the same shapes/dtypes."""
-        flat = torch.cat([p.contiguous().view(torch.uint8).reshape(-1) for p in parts])
+        """parts: list of tensors -> list (per rank) of lists of tensors with the same shapes/dtypes.
+        One collective: everything is packed into a single byte buffer (8-byte aligned segments, so the
+        float64 scores can be viewed in place on the receiving side)."""
+        segs, sizes = [], []
+        for p in parts:
+            b = p.contiguous().view(torch.uint8).reshape(-1)
+            pad = (-b.numel()) % 8
+            if pad:
+                b = torch.cat([b, torch.zeros(pad, dtype=torch.uint8, device=b.device)])
+            segs.append(b)
+            sizes.append(b.numel())
+        flat = torch.cat(segs)
         out = torch.empty(self.world * flat.numel(), dtype=torch.uint8, device=flat.device)
         dist.all_gather_into_tensor(out, flat, group=self.group)
         out = out.view(self.world, flat.numel())
         res = []
         for g in range(self.world):
             o, lst = 0, []
-            for p in parts:
+            for p, sz in zip(parts, sizes):
                 nb = p.numel() * p.element_size()
                 lst.append(out[g, o:o + nb].view(p.dtype).reshape(p.shape))
-                o += nb
+                o += sz
             res.append(lst)
         return res
 

@@ -84,3 +84,32 @@ def test_shard_partition_is_exact():
         # chunk balance within one document of the ideal cut
         sizes = [ix.shard(r, world).n_chunks for r in range(world)]
         assert max(sizes) - min(sizes) <= 2 * 64
+
+
+def _run_odd(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from msretr.distributed import ShardedEngine
+        se = ShardedEngine(None, 0, 0)
+        # odd element counts: every segment must still be viewable as its dtype on the receiving side
+        parts = [torch.arange(7, dtype=torch.int32) + rank, torch.arange(3, dtype=torch.float64) * (rank + 1),
+                 torch.tensor([rank], dtype=torch.int32), torch.arange(5, dtype=torch.float32) - rank]
+        got = se._allgather_bytes(parts)
+        ret[rank] = [[t.clone().numpy() for t in g] for g in got]
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_packed_allgather_with_odd_sizes():
+    world = 3
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_run_odd, args=(world, 31000 + os.getpid() % 2000, ret), nprocs=world, join=True)
+    for r in range(world):
+        for g in range(world):
+            a = ret[r][g]
+            assert a[0].tolist() == (np.arange(7) + g).tolist() and a[1].tolist() == (np.arange(3) * (g + 1.0)).tolist()
+            assert a[2].tolist() == [g] and a[3].tolist() == (np.arange(5) - g).astype(np.float32).tolist()
