@@ -44,15 +44,17 @@ def build_shard(args, rank, world, dev, n_queries):
     # postings + chunk layout of the WHOLE corpus (same seed on every rank => identical), embeddings only
     # for this rank's rows (they are i.i.d., so a shard-local stream is the same distribution)
     full = synthetic_corpus(args.docs, n_chunks=args.chunks, n_terms=args.terms, seed=SEED, device=dev,
-                            with_embeddings=False)
+                            with_embeddings=args.verify)
     # query terms come from the GLOBAL document frequencies, so every rank draws the same queries
-    terms, _ = synthetic_queries(full, n_queries, seed=777, device="cpu")
+    terms, _ = synthetic_queries(full if not args.verify else _without_emb(full), n_queries, seed=777, device="cpu")
     shard = full.shard(rank, world) if world > 1 else full
+    if args.verify:                                   # rehearsal mode: shards are slices of ONE global matrix
+        return shard, terms, full
     if world > 1:
         del full
     C = shard.n_chunks
     if C == 0:
-        return shard, terms
+        return shard, terms, None
     g = torch.Generator(device=dev)
     g.manual_seed(SEED + 7919 * (rank + 1))
     emb = torch.empty((C, 768), dtype=torch.float32, device=dev)
@@ -64,7 +66,32 @@ def build_shard(args, rank, world, dev, n_queries):
     torch.cuda.synchronize()
     log(f"[rank {rank}] corpus: {shard.n_docs} docs, {C} chunks, {int(shard.post_doc.numel())} postings "
         f"(doc_base {shard.doc_base}) in {time.time() - t0:.1f}s")
-    return shard, terms
+    return shard, terms, None
+
+
+def _without_emb(ix):
+    import copy
+    c = copy.copy(ix)
+    c.emb = None
+    return c
+
+
+def verify_against_unsharded(args, full, terms, qvec, out_sharded, dev):
+    """Rehearsal check (small corpora): the sharded step must reproduce an unsharded engine bit for bit."""
+    from msretr.distributed import ShardedEngine
+    from msretr.engine import DeviceEngine
+    Q = args.queries_per_step
+    eng = DeviceEngine(full, device=dev.index, max_queries=Q, max_k=max(args.k1, args.k2), rerank_max_docs=args.k1)
+    ref = ShardedEngine(eng, 0, 0)
+    ref.world = 1                                     # no collectives: this is the single-engine reference
+    exp = ref.search([full.term_ids(t) for t in terms[:Q]], qvec[:Q], k1=args.k1, k2=args.k2)
+    for key in exp:
+        for a, b in zip(out_sharded[key], exp[key]):
+            if a is None or b is None:
+                continue
+            assert torch.equal(a, b), f"sharded != unsharded for {key}"
+    eng.close()
+    return True
 
 
 def make_query_vectors(n, dev, seed):
@@ -143,6 +170,12 @@ def main():
     ap.add_argument("--cpu-sample-frac", type=float, default=0.125)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-queries", type=int, default=20)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="rehearsal: every rank uses cuda:0 (with --backend gloo), to exercise the N>1 path on one GPU")
+    ap.add_argument("--verify", action="store_true",
+                    help="rehearsal: shards are slices of one global corpus and rank 0 checks the sharded results "
+                         "against an unsharded engine (small --docs/--chunks only)")
     ap.add_argument("--workload", choices=["hybrid", "bm25", "dense"], default="hybrid",
                     help="hybrid = the headline (BASELINE configs[2]); bm25 = stage 1 only (configs[1]: use --docs "
                          "100000 --chunks 0 --terms 200000 --queries-per-step 1024 --k1 100); dense = full scan only")
@@ -158,17 +191,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from msretr.distributed import ShardedEngine
     from msretr.engine import DeviceEngine
 
     Q = args.queries_per_step
     n_pool = Q * 8
-    shard, terms = build_shard(args, rank, world, dev, n_pool)
+    shard, terms, full = build_shard(args, rank, world, dev, n_pool)
     qvec = make_query_vectors(n_pool, dev, seed=778)
     eng = DeviceEngine(shard, device=local_rank, max_queries=max(Q, 1), max_k=max(args.k1, args.k2),
                        rerank_max_docs=args.k1, scan_layout=args.scan_layout, scan_variant=args.scan_variant)
@@ -246,6 +284,12 @@ def main():
     if "rerank" in out:
         ok = ok and bool((out["rerank"][4] > 0).all().item())
 
+    verified = None
+    if args.verify and world > 1:
+        first = step(0)                               # batch 0 again, outside the timed region
+        if rank == 0:
+            verified = verify_against_unsharded(args, full, terms, qvec, first, dev)
+        dist.barrier()
     if rank == 0:
         n_ch = shard.n_chunks
         if args.workload == "bm25":
@@ -287,6 +331,8 @@ def main():
                        "scan_layout": args.scan_layout, "scan_variant": args.scan_variant},
             "p50_latency_ms_single_query": p50_ms, "outputs_sane": ok, "roofline": roof,
         }
+        if verified is not None:
+            line["sharded_equals_unsharded"] = verified
         if world == 1 and not args.no_cpu_baseline and args.workload == "hybrid":
             try:
                 cb, cres = cpu_baseline(args, shard, terms, qvec)
