@@ -255,6 +255,5 @@ class CorpusIndex:
             v = getattr(self, name)
             if v is not None:
                 setattr(sub, name, v[d0:d1])
-        if self._url_group is not None or self.urls is not None:
-            sub._url_group = self.url_group()[d0:d1]        # group ids stay global
+        sub._url_group = self.url_group()[d0:d1]            # group ids stay GLOBAL (dedup works across shards)
         return sub
