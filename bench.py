@@ -2,9 +2,9 @@
 """Headline benchmark: queries/sec (and single-query p50 latency) of the two-stage retriever, top-100 on a
 synthetic 1 M-document / 5 M x 768 f32-chunk corpus resident in HBM (BASELINE.json metric / configs[2]).
 
-A STEP = one pass of the whole hot path over one batch of `--queries-per-step` queries:
+A STEP = one pass of the whole hot path over one batch of `--queries-per-step` (default 128) queries:
     stage 1  BM25 term-at-a-time + top-1000                        (msr_bm25_topk)
-    stage 2  dense full scan: q x chunk cosine, per-doc max-pool, top-100   (msr_dense_topk; one sweep of E)
+    stage 2  dense full scan: q x chunk cosine, per-doc max-pool, top-100   (msr_dense_topk; one sweep of E per 32 queries)
     fuse     reference rerank chain on the stage-1 candidates -> top-100     (msr_rerank_gather + _fuse)
 With N > 1 GPUs the corpus is doc-sharded (strong scaling: the corpus is fixed); per step one all-gather of
 the per-shard top-k lists and one integer-SUM all-reduce of the raw bits of the candidates' cosines cross xGMI.
@@ -161,7 +161,8 @@ def main():
     ap.add_argument("--docs", type=int, default=1_000_000)
     ap.add_argument("--chunks", type=int, default=5_000_000)
     ap.add_argument("--terms", type=int, default=1_000_000)
-    ap.add_argument("--queries-per-step", type=int, default=32)
+    ap.add_argument("--queries-per-step", type=int, default=128,
+                    help="queries per step; the dense stage sweeps E once per 32 of them")
     ap.add_argument("--k1", type=int, default=1000, help="stage-1 candidates (config.py:13)")
     ap.add_argument("--k2", type=int, default=100, help="final top-k (reranker/config.yaml:30)")
     ap.add_argument("--scan-layout", type=int, default=0)
