@@ -121,6 +121,7 @@ def cpu_baseline(args, shard, terms, qvec):
     """C restatement (oracle/) on the host cores: BM25 over the full postings + dense scan over the first
     `frac` of the chunk rows, extrapolated to the full corpus.  Returns the cpu_baseline object."""
     from oracle import bm25_ref, c_oracle
+    c_oracle.set_threads(max(1, min(args.cpu_threads, os.cpu_count() or 1)))
     nq = min(args.cpu_queries, len(terms))
     frac = args.cpu_sample_frac
     n_docs_s = max(1, int(shard.n_docs * frac))
@@ -169,6 +170,8 @@ def main():
     ap.add_argument("--scan-variant", type=int, default=0)
     ap.add_argument("--cpu-queries", type=int, default=16)
     ap.add_argument("--cpu-sample-frac", type=float, default=0.125)
+    ap.add_argument("--cpu-threads", type=int, default=16,
+                    help="OpenMP threads of the CPU baseline (a 1-GPU box is entitled to 16 host cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-queries", type=int, default=20)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")

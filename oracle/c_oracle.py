@@ -53,3 +53,7 @@ def dense_topk(emb, doc_off, q, k, max_chunks=0):
 
 def threads():
     return load().orc_threads()
+
+
+def set_threads(n):
+    load().orc_set_threads(C.c_int(int(n)))

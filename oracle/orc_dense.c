@@ -21,6 +21,14 @@ static int cmp_cand(const void* a, const void* b) {
     return (x->d > y->d) - (x->d < y->d);
 }
 
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int orc_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();
