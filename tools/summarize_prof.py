@@ -31,21 +31,21 @@ def stats(stats_csv, trace_csv, out):
         lines.append(f"| {short(r['Name'])} | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['MinNs']) / 1e3:.1f} | "
                      f"{float(r['MaxNs']) / 1e3:.1f} | {float(r['TotalDurationNs']) / 1e6:.3f} |")
     tr = sorted(csv.DictReader(open(trace_csv)), key=lambda r: int(r["Start_Timestamp"]))
-    idx = [i for i, r in enumerate(tr) if ("dense_scan_kernel<2" in r["Kernel_Name"] or "dense_scan_v2_kernel<2" in r["Kernel_Name"])]
+    dur = lambda r: int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    # a step starts at its BM25 kernel; timed (batched) steps are the ones with the long BM25 launches
+    starts = [i for i, r in enumerate(tr) if "bm25_taat" in r["Kernel_Name"]]
     step = []
-    if len(idx) >= 8:
-        def start(j):
-            i = idx[j]
-            while i > 0 and "bm25_taat" not in tr[i]["Kernel_Name"]:
-                i -= 1
-            return i
-        a, b = start(6), start(7)
+    if len(starts) >= 4:
+        longest = max(dur(tr[i]) for i in starts)
+        big = [j for j, i in enumerate(starts[:-1]) if dur(tr[i]) > 0.5 * longest]
+        j = big[len(big) // 2]
+        a, b = starts[j], starts[j + 1]
         agg = collections.OrderedDict()
         for r in tr[a:b]:
-            n = short(r["Kernel_Name"]); d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            n = short(r["Kernel_Name"]); d = dur(r)
             agg.setdefault(n, [0, 0]); agg[n][0] += 1; agg[n][1] += d
         wall = (int(tr[b]["Start_Timestamp"]) - int(tr[a]["Start_Timestamp"])) / 1e3
-        step = [f"", f"One 32-query step (dispatch {a}..{b}): wall {wall:.1f} us, {b - a} dispatches", "",
+        step = [f"", f"One timed step (dispatch {a}..{b}): wall {wall:.1f} us, {b - a} dispatches", "",
                 "| kernel | dispatches | us |", "|---|---|---|"]
         for n, (c, d) in sorted(agg.items(), key=lambda x: -x[1][1]):
             step.append(f"| {n} | {c} | {d / 1e3:.1f} |")
