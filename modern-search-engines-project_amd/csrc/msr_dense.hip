@@ -525,20 +525,23 @@ hipError_t launch_scan(const DenseIndex& ix, const float* qn, int nq, int max_ch
     return hipGetLastError();
 }
 
-template <int QB, bool TILED, int LB>
+template <int QB, bool TILED, int LB, int WAVES = 8, int OBD = 32>
 hipError_t launch_scan_v2(const DenseIndex& ix, const float* qn, int nq, int max_chunks, float* docscore,
                           hipStream_t stream) {
-    constexpr int WAVES = 8;
-    using L = ScanCfgV2<QB, false, WAVES>;
+    using L = ScanCfgV2<QB, false, WAVES, OBD>;
+    static_assert(L::total <= 160 * 1024, "LDS budget");
     const size_t lds = L::total;
-    hipError_t err = hipFuncSetAttribute((const void*)dense_scan_v2_kernel<QB, TILED, LB, false, WAVES>,
+    hipError_t err = hipFuncSetAttribute((const void*)dense_scan_v2_kernel<QB, TILED, LB, false, WAVES, OBD>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess) return err;
     const int n_img = QB * L::KS * 64;
     build_qimage_kernel<false><<<(n_img + 255) / 256, 256, 0, stream>>>(qn, QB, (f32x4*)ix.qimg);
-    const int grid = (ix.n_wspans + WAVES - 1) / WAVES;
-    dense_scan_v2_kernel<QB, TILED, LB, false, WAVES><<<grid, L::THREADS, lds, stream>>>(
-        ix, ix.emb, ix.wspan_doc, ix.n_wspans, (const f32x4*)ix.qimg, nq, max_chunks, docscore);
+    // per-wave span tables exist for 8 and for 12 waves per CU
+    const int32_t* spans = WAVES == 12 ? ix.wspan12_doc : ix.wspan_doc;
+    const int n_sp = WAVES == 12 ? ix.n_wspans12 : ix.n_wspans;
+    const int grid = (n_sp + WAVES - 1) / WAVES;
+    dense_scan_v2_kernel<QB, TILED, LB, false, WAVES, OBD><<<grid, L::THREADS, lds, stream>>>(
+        ix, ix.emb, spans, n_sp, (const f32x4*)ix.qimg, nq, max_chunks, docscore);
     return hipGetLastError();
 }
 
@@ -580,6 +583,8 @@ hipError_t dispatch_variant(const DenseIndex& ix, const float* qn, int nq, int m
         case 1: return launch_scan<QB, TILED>(ix, qn, nq, max_chunks, docscore, stream);
         case 2: return launch_scan_v2<QB, TILED, 8>(ix, qn, nq, max_chunks, docscore, stream);
         case 4: return launch_scan_v2<QB, TILED, 24>(ix, qn, nq, max_chunks, docscore, stream);
+        case 5: return launch_scan_v2<QB, TILED, 12, 12, 16>(ix, qn, nq, max_chunks, docscore, stream);   // 3 waves/SIMD
+        case 6: return launch_scan_v2<QB, TILED, 8, 12, 16>(ix, qn, nq, max_chunks, docscore, stream);
         default: return launch_scan_v2<QB, TILED, 12>(ix, qn, nq, max_chunks, docscore, stream);   // 0, 3
     }
 }

@@ -26,6 +26,7 @@ struct msr_engine {
     float* inv_norm_own = nullptr;
     int32_t* span_doc = nullptr;
     int32_t* wspan_doc = nullptr;
+    int32_t* wspan12_doc = nullptr;
     float* qn = nullptr;              // [64][768] normalised queries of the current slice
     void* qimg = nullptr;             // query image in fragment order (96 KB)
     void* emb_bf16 = nullptr;         // bf16 copy of the embeddings (msr_enable_bf16)
@@ -86,8 +87,8 @@ extern "C" int msr_create(const msr_config* cfg, msr_engine** out) {
         return fail(nullptr, MSR_ERR_INVALID, "msr_create: rerank_max_docs out of range [0, 1024]");
     if (cfg->scan_layout != 0 && cfg->scan_layout != 1)
         return fail(nullptr, MSR_ERR_INVALID, "msr_create: scan_layout must be 0 or 1");
-    if (cfg->scan_variant < 0 || cfg->scan_variant > 4)
-        return fail(nullptr, MSR_ERR_INVALID, "msr_create: scan_variant must be 0..4");
+    if (cfg->scan_variant < 0 || cfg->scan_variant > 6)
+        return fail(nullptr, MSR_ERR_INVALID, "msr_create: scan_variant must be 0..6");
     int ndev = 0;
     hipError_t herr = hipGetDeviceCount(&ndev);
     if (herr != hipSuccess || ndev <= 0)
@@ -137,7 +138,7 @@ extern "C" int msr_create(const msr_config* cfg, msr_engine** out) {
 
 extern "C" int msr_destroy(msr_engine* e) {
     if (!e) return MSR_OK;
-    free_dev(e->chunk_doc); free_dev(e->inv_norm_own); free_dev(e->span_doc); free_dev(e->wspan_doc); free_dev(e->qn); free_dev(e->qimg); free_dev(e->emb_bf16);
+    free_dev(e->chunk_doc); free_dev(e->inv_norm_own); free_dev(e->span_doc); free_dev(e->wspan_doc); free_dev(e->wspan12_doc); free_dev(e->qn); free_dev(e->qimg); free_dev(e->emb_bf16);
     free_dev(e->score_rows); free_dev(e->sel.hist); free_dev(e->sel.state); free_dev(e->sel.cand_hi);
     free_dev(e->sel.cand_lo); free_dev(e->sel.cand_n); free_dev(e->rerank_cos); free_dev(e->rerank_meta);
     free_dev(e->bt_top_doc); free_dev(e->bt_top_score); free_dev(e->bt_top_n); free_dev(e->bt_cand_doc);
@@ -238,13 +239,16 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
     };
     std::vector<int32_t> spans = make_spans(e->n_cus, 256);
     std::vector<int32_t> wspans = make_spans(e->n_cus * 8, 64);
+    std::vector<int32_t> wspans12 = make_spans(e->n_cus * 12, 64);
     const int n_spans = (int)spans.size() - 1;
     const int n_wspans = (int)wspans.size() - 1;
+    const int n_wspans12 = (int)wspans12.size() - 1;
 
     free_dev(e->chunk_doc); e->chunk_doc = nullptr;
     free_dev(e->inv_norm_own); e->inv_norm_own = nullptr;
     free_dev(e->span_doc); e->span_doc = nullptr;
     free_dev(e->wspan_doc); e->wspan_doc = nullptr;
+    free_dev(e->wspan12_doc); e->wspan12_doc = nullptr;
     hipError_t herr;
     if ((herr = hipMalloc((void**)&e->chunk_doc, (size_t)n_chunks * sizeof(int32_t))) != hipSuccess)
         return fail(e, MSR_ERR_NOMEM, "chunk_doc: %s", hipGetErrorString(herr));
@@ -254,6 +258,9 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
         return fail(e, MSR_ERR_NOMEM, "wspan_doc: %s", hipGetErrorString(herr));
     HIP_TRY(e, hipMemcpyAsync(e->span_doc, spans.data(), spans.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     HIP_TRY(e, hipMemcpyAsync(e->wspan_doc, wspans.data(), wspans.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    if ((herr = hipMalloc((void**)&e->wspan12_doc, wspans12.size() * sizeof(int32_t))) != hipSuccess)
+        return fail(e, MSR_ERR_NOMEM, "wspan12_doc: %s", hipGetErrorString(herr));
+    HIP_TRY(e, hipMemcpyAsync(e->wspan12_doc, wspans12.data(), wspans12.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     HIP_TRY(e, msr_fill_chunk_doc(doc_off, n_docs, e->chunk_doc, st));
     if (!inv_norm) {
         if ((herr = hipMalloc((void**)&e->inv_norm_own, (size_t)n_chunks * sizeof(float))) != hipSuccess)
@@ -263,7 +270,8 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
     }
     HIP_TRY(e, hipStreamSynchronize(st));                 // spans vector goes out of scope
     e->dense = DenseIndex{emb, doc_off, e->chunk_doc, inv_norm, e->span_doc, n_chunks, n_docs, n_spans,
-                          e->cfg.scan_layout, e->wspan_doc, n_wspans, e->qimg, nullptr, e->cfg.scan_variant};
+                          e->cfg.scan_layout, e->wspan_doc, n_wspans, e->wspan12_doc, n_wspans12, e->qimg, nullptr,
+                          e->cfg.scan_variant};
     free_dev(e->emb_bf16);                                // a new binding invalidates the bf16 copy
     e->emb_bf16 = nullptr;
     e->have_chunks = true;

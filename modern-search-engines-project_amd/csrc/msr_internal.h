@@ -67,6 +67,8 @@ struct DenseIndex {
     int32_t layout;            // 0 row-major, 1 interleaved
     const int32_t* wspan_doc;  // [n_wspans+1] document boundaries of the per-wave spans (scan variants 2, 3)
     int32_t n_wspans;
+    const int32_t* wspan12_doc; // the same for 12 waves per CU (scan variants 5, 6)
+    int32_t n_wspans12;
     void* qimg;                // engine scratch: query image in MFMA-fragment order (<= 96 KB)
     const void* emb_bf16;      // bf16 [n_chunks][768] copy of emb for the batched path, or null
     int32_t variant;           // 0/3: wave-streaming kernel, 12-step load batches (default); 2: 8-step; 4: 24-step;
