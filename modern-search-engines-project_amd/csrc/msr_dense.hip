@@ -10,12 +10,15 @@
 // MFMA is only a label: lane (i = lane & 15, g = lane >> 4) loads E[row i][16t + 4g .. +3] and the query
 // image in LDS is stored in the same permuted order, so no data ever moves between lanes.
 //
-// Work decomposition: the document range is cut into `n_spans` spans with equal chunk counts, at
-// document boundaries; one persistent workgroup (16 waves) per span.  Inside a span a super-tile is
-// 16 waves x 16 rows = 256 chunk rows: each wave multiplies its 16 rows against all queries, writes the
-// 16 x Q scores to LDS, and after a barrier the workgroup reduces the chunk scores to per-document maxima
-// (segments are contiguous; a document that crosses a super-tile boundary is carried in LDS).  Documents
-// never cross spans, so no inter-workgroup communication exists.
+// Two decompositions live in this file:
+//   * dense_scan_v2_kernel ("wave streaming", the default; described at its definition): every wave streams
+//     its own span of rows, no workgroup barriers, also instantiated for bf16 rows (batched path);
+//   * dense_scan_kernel (the first version, scan_variant = 1, kept for A/B runs): one persistent 16-wave
+//     workgroup per span; a super-tile is 16 waves x 16 rows = 256 chunk rows: each wave multiplies its 16
+//     rows against all queries, writes the 16 x Q scores to LDS, and after a barrier the workgroup reduces the
+//     chunk scores to per-document maxima (a document that crosses a super-tile boundary is carried in LDS).
+// In both, spans are cut at document boundaries with equal chunk counts, so documents never cross spans and
+// no inter-workgroup communication exists.
 #include <stdlib.h>
 
 #include <type_traits>
