@@ -502,3 +502,47 @@ def test_queries_with_nan_or_zero_vectors(mods):
     oi, os_, _ = mods["dense_ref"].quick_search(emb, doc_off, q[2], 10)
     assert doc[2].tolist() == oi.tolist()
     eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ queries.txt end to end
+def test_queries_txt_end_to_end_matches_oracle(mods, tmp_path):
+    """The reference's batch path (search_api.py:204-367) on a synthetic crawl: preprocess_query -> tokens ->
+    BM25 top-1000 -> rerank -> top-100 -> `qnum<TAB>rank<TAB>url<TAB>score`; every line equals the oracle's."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("demo", os.path.join(os.path.dirname(__file__), "..", "examples", "run_queries_txt.py"))
+    demo = importlib.util.module_from_spec(spec); spec.loader.exec_module(demo)
+    from msretr.retriever import Retriever
+    from msretr.text import preprocess_query, simple_tokenize
+    ix = demo.synthetic_crawl(n_docs=1500)
+    enc = demo.fake_encoder()
+    rt = Retriever(embedder=enc, indexer=ix, tokenizer=simple_tokenize, max_queries=8, max_k=1000)
+    qf = tmp_path / "queries.txt"
+    qf.write_text("".join(f"{i + 1}\t{q}\n" for i, q in enumerate(demo.DEFAULT_QUERIES)), encoding="utf-8")
+    out = tmp_path / "batch_search_results.txt"
+    n = rt.batch_search_to_file(str(qf), str(out))
+    lines = out.read_text(encoding="utf-8").splitlines()
+    assert n == len(lines) and n > 0
+    z = dict(doc_ids=ix.doc_ids, doc_len=ix.doc_len, term_off=ix.term_off, post_doc=ix.post_doc, post_tf=ix.post_tf,
+             idf=ix.idf, avgdl=ix.avgdl)
+    urls_bm = {int(d): (ix.titles[i], ix.texts[i]) for i, d in enumerate(ix.doc_ids)}
+    urls_rr = {int(d): (ix.urls[i], ix.titles[i], ix.texts[i]) for i, d in enumerate(ix.doc_ids)}
+    chunk_doc = np.repeat(ix.doc_ids, np.diff(ix.doc_off))
+    exp = []
+    for qi, q in enumerate(demo.DEFAULT_QUERIES):
+        pq = preprocess_query(q)
+        tids = [ix.vocab.get(t, -1) for t in simple_tokenize(pq)]
+        s1 = mods["bm25_ref"].search(z, tids, 1000, 0.0, urls_bm)
+        if not s1:
+            continue
+        resp = mods["rerank_ref"].rerank(urls_rr, ix.chunk_ids, chunk_doc, ix.emb, enc(pq),
+                                         [str(r["doc_id"]) for r in s1], [r["score"] for r in s1])
+        for rank, d in enumerate(resp["document_scores"], start=1):
+            exp.append((str(qi + 1), rank, d["url"], d["similarity_score"]))
+    assert len(lines) == len(exp)
+    mism = 0
+    for line, (qn, rank, url, score) in zip(lines, exp):
+        a = line.split("\t")
+        assert a[0] == qn and int(a[1]) == rank and abs(float(a[3]) - score) < 1.5e-3       # 3 decimals in the file
+        mism += a[2] != url
+    assert mism <= 2                       # a near-tie may swap two neighbours
+    rt.engine.close()
