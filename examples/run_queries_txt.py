@@ -25,7 +25,8 @@ def synthetic_crawl(n_docs=3000, seed=7, queries=DEFAULT_QUERIES):
     words = sorted({w for q in queries for w in simple_tokenize(preprocess_query(q))})
     filler = [f"wort{i}" for i in range(400)]
     vocab = words + filler
-    p = np.r_[np.full(len(words), 3.0), 1.0 / np.arange(1, len(filler) + 1) ** 0.8]
+    p = 1.0 / np.arange(1, len(filler) + 1) ** 0.8
+    p = np.r_[np.full(len(words), 0.0035), 0.95 * p / p.sum()]      # a query word is in ~1/3 of the documents
     p /= p.sum()
     doc_ids = (np.cumsum(rng.integers(1, 4, size=n_docs)) + 10).tolist()
     tokens, urls, titles, texts = [], [], [], []
