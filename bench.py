@@ -297,12 +297,13 @@ def main():
     if rank == 0:
         n_ch = shard.n_chunks
         if args.workload == "bm25":
-            # 8 B per posting of the query's terms + 4 B doc_len + 8 B score row per document
+            # 8 B per posting of the query's terms + 4 B doc_len per document (+ 12 B per candidate emitted,
+            # not counted here: the count is data dependent, so the reported fraction is a lower bound)
             tq = batches[0][0][1].long()
             tq = tq[(tq >= 0) & (tq < shard.n_terms)]
             toff = shard.term_off.to(tq.device)
             post_bytes = 8 * int((toff[tq + 1] - toff[tq]).sum().item())
-            alg_bytes = post_bytes + Q * 12 * shard.n_docs
+            alg_bytes = post_bytes + Q * 4 * shard.n_docs
             k_ms, k_n, kname = bm_ms, bm_n, "bm25_taat_kernel"
         else:
             bf = args.dense_mode == "bf16"

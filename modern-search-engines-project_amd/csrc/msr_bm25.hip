@@ -10,8 +10,8 @@
 // The arithmetic is written operation by operation as Python evaluates it and this file is compiled with
 // -ffp-contract=off, so scores are bit-identical to the oracle.
 //
-// HBM traffic per query: 8 B per posting of the query's terms + 4 B per document (doc_len) + 8 B per
-// document (dense float64 score row consumed by the top-k select).
+// HBM traffic per query: 8 B per posting of the query's terms + 4 B per document (doc_len) + 12 B per
+// candidate document (the (score, doc) list consumed by the top-k select).
 #include "msr_common.h"
 #include "msr_internal.h"
 
@@ -53,7 +53,9 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
                                                                   const int32_t* __restrict__ q_terms,
                                                                   const int32_t* __restrict__ q_qtf,
                                                                   int q_first, double min_score,
-                                                                  double* __restrict__ scores) {
+                                                                  double* __restrict__ cand_score,
+                                                                  int32_t* __restrict__ cand_doc,
+                                                                  int32_t* __restrict__ cand_n) {
     __shared__ double acc[BM25_TILE];
     __shared__ int32_t dl[BM25_TILE];
     __shared__ int64_t slice[2 * BM25_MAX_TERMS];                // [term slot][begin, end) of the tile's postings
@@ -109,11 +111,32 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
         }
         __syncthreads();
     }
-    double* row = scores + (int64_t)q * ix.n_docs + lo;
+    // Emit the tile's candidates (touched by a posting AND score >= min_score, :461,480) as (score, doc) pairs
+    // appended to the query's list: one reservation per workgroup.  Most documents of a tile are not
+    // candidates, so this replaces an 8 B/document dense row by 12 B per candidate.
+    __shared__ int s_cnt, s_base;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    int mine = 0;
     for (int i = tid; i < n; i += BM25_THREADS) {
         const double a = acc[i];
-        const bool touched = (uint64_t)__double_as_longlong(a) != UNTOUCHED;
-        row[i] = (touched && a >= min_score) ? a : -__builtin_inf();
+        mine += ((uint64_t)__double_as_longlong(a) != UNTOUCHED && a >= min_score) ? 1 : 0;
+    }
+    int pos = mine ? atomicAdd(&s_cnt, mine) : 0;
+    __syncthreads();
+    if (tid == 0 && s_cnt) s_base = atomicAdd(&cand_n[q], s_cnt);
+    __syncthreads();
+    if (mine) {
+        const int64_t o = (int64_t)q * ix.n_docs + s_base + pos;
+        int w = 0;
+        for (int i = tid; i < n; i += BM25_THREADS) {
+            const double a = acc[i];
+            if ((uint64_t)__double_as_longlong(a) != UNTOUCHED && a >= min_score) {
+                cand_score[o + w] = a;
+                cand_doc[o + w] = (int32_t)(lo + i);
+                ++w;
+            }
+        }
     }
 }
 
@@ -157,10 +180,11 @@ hipError_t msr_bm25_validate(const Bm25Index& ix, int32_t* flag, hipStream_t str
 }
 
 hipError_t msr_bm25_scores(const Bm25Index& ix, const int32_t* q_term_off, const int32_t* q_terms,
-                           const int32_t* q_qtf, int q_first, int nq, double min_score, double* scores,
-                           hipStream_t stream) {
+                           const int32_t* q_qtf, int q_first, int nq, double min_score, double* cand_score,
+                           int32_t* cand_doc, int32_t* cand_n, hipStream_t stream) {
     if (nq <= 0 || ix.n_docs <= 0) return hipSuccess;
     dim3 grid((unsigned)((ix.n_docs + BM25_TILE - 1) / BM25_TILE), (unsigned)nq);
-    bm25_taat_kernel<<<grid, BM25_THREADS, 0, stream>>>(ix, q_term_off, q_terms, q_qtf, q_first, min_score, scores);
+    bm25_taat_kernel<<<grid, BM25_THREADS, 0, stream>>>(ix, q_term_off, q_terms, q_qtf, q_first, min_score, cand_score,
+                                                        cand_doc, cand_n);
     return hipGetLastError();
 }

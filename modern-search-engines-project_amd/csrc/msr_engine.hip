@@ -32,6 +32,9 @@ struct msr_engine {
     void* emb_bf16 = nullptr;         // bf16 copy of the embeddings (msr_enable_bf16)
     void* score_rows = nullptr;       // max_queries rows of n_docs float64 (reused as float32 rows)
     size_t score_rows_bytes = 0;
+    int32_t* bm_cand_doc = nullptr;    // max_queries rows of n_docs i32: document of each BM25 candidate
+    int32_t* bm_cand_n = nullptr;      // [max_queries] candidates per query (zero between calls)
+    size_t bm_cand_bytes = 0;
     SelScratch sel{};
     float* rerank_cos = nullptr;
     int32_t* rerank_meta = nullptr;
@@ -139,7 +142,7 @@ extern "C" int msr_create(const msr_config* cfg, msr_engine** out) {
 extern "C" int msr_destroy(msr_engine* e) {
     if (!e) return MSR_OK;
     free_dev(e->chunk_doc); free_dev(e->inv_norm_own); free_dev(e->span_doc); free_dev(e->wspan_doc); free_dev(e->wspan12_doc); free_dev(e->qn); free_dev(e->qimg); free_dev(e->emb_bf16);
-    free_dev(e->score_rows); free_dev(e->sel.hist); free_dev(e->sel.state); free_dev(e->sel.cand_hi);
+    free_dev(e->score_rows); free_dev(e->bm_cand_doc); free_dev(e->bm_cand_n); free_dev(e->sel.hist); free_dev(e->sel.state); free_dev(e->sel.cand_hi);
     free_dev(e->sel.cand_lo); free_dev(e->sel.cand_n); free_dev(e->rerank_cos); free_dev(e->rerank_meta);
     free_dev(e->bt_top_doc); free_dev(e->bt_top_score); free_dev(e->bt_top_n); free_dev(e->bt_cand_doc);
     free_dev(e->bt_cand_score); free_dev(e->bt_cand_chunk); free_dev(e->bt_cand_n);
@@ -178,6 +181,20 @@ extern "C" int msr_bind_postings(msr_engine* e, const int64_t* term_off, int64_t
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     int rc = ensure_score_rows(e, n_docs);
     if (rc) return rc;
+    {   // candidate lists of the BM25 stage: worst case every document of every query
+        const size_t need = (size_t)e->cfg.max_queries * (size_t)n_docs * sizeof(int32_t);
+        hipError_t herr;
+        if (need > e->bm_cand_bytes) {
+            free_dev(e->bm_cand_doc); e->bm_cand_doc = nullptr; e->bm_cand_bytes = 0;
+            if ((herr = hipMalloc((void**)&e->bm_cand_doc, need)) != hipSuccess)
+                return fail(e, MSR_ERR_NOMEM, "BM25 candidate lists (%zu bytes): %s", need, hipGetErrorString(herr));
+            e->bm_cand_bytes = need;
+        }
+        if (!e->bm_cand_n) {
+            if ((herr = hipMalloc((void**)&e->bm_cand_n, (size_t)e->cfg.max_queries * sizeof(int32_t))) != hipSuccess)
+                return fail(e, MSR_ERR_NOMEM, "BM25 candidate counts: %s", hipGetErrorString(herr));
+        }
+    }
     const Bm25Index cand{term_off, post_doc, post_tf, doc_len, idf, n_terms, n_postings, n_docs, (double)avgdl, k1, b};
     // the scoring kernel indexes LDS with (post_doc - tile start): validate the CSR once, on the device
     hipStream_t st = (hipStream_t)stream;
@@ -336,13 +353,15 @@ extern "C" int msr_bm25_topk(msr_engine* e, const int32_t* q_term_off, const int
         // every kernel launch gets its own event pair (ring of EV_RING; later launches are not recorded)
         const bool timed = e->timing && e->ev_count[1] < msr_engine::EV_RING;
         if (timed) HIP_TRY(e, hipEventRecord(e->ev_start[1][e->ev_count[1]], st));
-        HIP_TRY(e, msr_bm25_scores(e->bm25, q_term_off, q_terms, q_qtf, q0, nq, min_score, (double*)e->score_rows, st));
+        HIP_TRY(e, hipMemsetAsync(e->bm_cand_n, 0, (size_t)nq * sizeof(int32_t), st));
+        HIP_TRY(e, msr_bm25_scores(e->bm25, q_term_off, q_terms, q_qtf, q0, nq, min_score, (double*)e->score_rows,
+                                   e->bm_cand_doc, e->bm_cand_n, st));
         if (timed) {
             HIP_TRY(e, hipEventRecord(e->ev_stop[1][e->ev_count[1]], st));
             e->ev_count[1]++;
         }
-        HIP_TRY(e, msr_select_topk(64, e->score_rows, N, N, nq, k, e->sel, out_doc + (int64_t)q0 * k,
-                                   out_score + (int64_t)q0 * k, out_n + q0, st));
+        HIP_TRY(e, msr_select_topk_list((const double*)e->score_rows, e->bm_cand_doc, e->bm_cand_n, N, N, nq, k, e->sel,
+                                        out_doc + (int64_t)q0 * k, out_score + (int64_t)q0 * k, out_n + q0, st));
     }
     return MSR_OK;
 }

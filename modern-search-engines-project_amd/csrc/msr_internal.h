@@ -32,6 +32,11 @@ hipError_t msr_select_topk(int score_bits, const void* scores, int64_t n, int64_
                            const SelScratch& sc, int32_t* out_doc, void* out_score, int32_t* out_n,
                            hipStream_t stream);
 
+// The same over LISTS: row q holds counts[q] (<= n_max) pairs (scores[q][i], idx[q][i]) in any order.
+hipError_t msr_select_topk_list(const double* scores, const int32_t* idx, const int32_t* counts, int64_t n_max,
+                                int64_t stride, int nq, int k, const SelScratch& sc, int32_t* out_doc,
+                                double* out_score, int32_t* out_n, hipStream_t stream);
+
 // Merge lists: in_* [n_parts][nq][k]; see msretr.h msr_merge_topk.
 hipError_t msr_merge_lists(int score_bits, const int32_t* in_doc, const void* in_score, const int32_t* in_n,
                            int n_parts, int nq, int k, int32_t* out_doc, void* out_score, int32_t* out_n,
@@ -47,10 +52,12 @@ struct Bm25Index {
     int64_t n_terms, n_postings, n_docs;
     double avgdl, k1, b;
 };
-// scores[q][n_docs] (row stride n_docs) <- BM25 score, or -inf for documents that are not candidates.
+// Candidate lists: for query q, cand_n[q] pairs (cand_score[q][i], cand_doc[q][i]) -- exactly the documents
+// touched by a posting whose score is >= min_score, in no particular order (row stride n_docs).  cand_n must
+// be zero on entry.
 hipError_t msr_bm25_scores(const Bm25Index& ix, const int32_t* q_term_off, const int32_t* q_terms,
-                           const int32_t* q_qtf, int q_first, int nq, double min_score, double* scores,
-                           hipStream_t stream);
+                           const int32_t* q_qtf, int q_first, int nq, double min_score, double* cand_score,
+                           int32_t* cand_doc, int32_t* cand_n, hipStream_t stream);
 
 // *flag (device) <- 0x7F7F7F7F if the CSR is well formed, else the lowest violated rule number (msr_bm25.hip).
 hipError_t msr_bm25_validate(const Bm25Index& ix, int32_t* flag, hipStream_t stream);

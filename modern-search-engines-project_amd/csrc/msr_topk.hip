@@ -109,10 +109,20 @@ __device__ __forceinline__ bool key_of(const T s, int64_t i, uint64_t& khi, uint
     return true;
 }
 
+// A row is either dense (element i belongs to index i, n elements) or a LIST (element i belongs to index
+// idx[i]; the row holds counts[q] elements in no particular order).  Lists are what the BM25 kernel emits:
+// only the documents that are candidates at all.
+struct RowView {
+    const int32_t* idx;      // null: dense
+    const int32_t* counts;   // null: every row has n elements
+};
+__device__ __forceinline__ int64_t row_len(const RowView& v, int q, int64_t n) { return v.counts ? v.counts[q] : n; }
+__device__ __forceinline__ int64_t row_index(const int32_t* idx_row, int64_t i) { return idx_row ? idx_row[i] : i; }
+
 // Histogram of digit `digit` over the elements that match the resolved prefix.  digit 0 needs no state.
 template <typename T>
-__global__ __launch_bounds__(SEL_THREADS) void sel_hist_kernel(const T* __restrict__ scores, int64_t n,
-                                                                int64_t stride, int digit,
+__global__ __launch_bounds__(SEL_THREADS) void sel_hist_kernel(const T* __restrict__ scores, int64_t n_dense,
+                                                                int64_t stride, RowView view, int digit,
                                                                 const SelState* __restrict__ st,
                                                                 uint32_t* __restrict__ hist) {
     constexpr int SB = ScoreTraits<T>::SB;
@@ -129,23 +139,26 @@ __global__ __launch_bounds__(SEL_THREADS) void sel_hist_kernel(const T* __restri
     int part, shift, width;
     digit_pos<SB>(digit, part, shift, width);
     const uint32_t wmask = (1u << width) - 1u;
+    const int64_t n = row_len(view, q, n_dense);
     const int64_t per = (n + gridDim.x - 1) / gridDim.x;
     const int64_t lo = (int64_t)blockIdx.x * per;
     const int64_t hi = lo + per < n ? lo + per : n;
     const T* row = scores + (int64_t)q * stride;
+    const int32_t* irow = view.idx ? view.idx + (int64_t)q * stride : nullptr;
     // four independent loads in flight per thread (one per iteration left the pass latency-bound)
     for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += 4 * SEL_THREADS) {
         T v[4];
+        int64_t ix[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int64_t i = i0 + (int64_t)u * SEL_THREADS;
             v[u] = i < hi ? row[i] : ScoreTraits<T>::neg_inf();
+            ix[u] = i < hi ? row_index(irow, i) : 0;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int64_t i = i0 + (int64_t)u * SEL_THREADS;
             uint64_t khi; uint32_t klo;
-            if (!key_of(v[u], i, khi, klo)) continue;
+            if (!key_of(v[u], ix[u], khi, klo)) continue;
             if ((khi & S.mask_hi) != S.pref_hi || (klo & S.mask_lo) != S.pref_lo) continue;
             const uint32_t dg = part == 0 ? (uint32_t)(khi >> shift) & wmask : (klo >> shift) & wmask;
             atomicAdd(&h[dg], 1u);
@@ -192,8 +205,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void sel_scan_kernel(SelState* __rest
 // this the slowest kernel of the select in the first profile).  Queries that two passes could not resolve
 // (superset still > MSR_SEL_CAP: huge tie groups) are left to the final kernel's in-kernel loop.
 template <typename T>
-__global__ __launch_bounds__(SEL_THREADS) void sel_compact_kernel(const T* __restrict__ scores, int64_t n,
-                                                                   int64_t stride,
+__global__ __launch_bounds__(SEL_THREADS) void sel_compact_kernel(const T* __restrict__ scores, int64_t n_dense,
+                                                                   int64_t stride, RowView view,
                                                                    const SelState* __restrict__ st,
                                                                    uint64_t* __restrict__ cand_hi,
                                                                    uint32_t* __restrict__ cand_lo,
@@ -207,22 +220,25 @@ __global__ __launch_bounds__(SEL_THREADS) void sel_compact_kernel(const T* __res
     if (!S.done) return;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
+    const int64_t n = row_len(view, q, n_dense);
     const int64_t per = (n + gridDim.x - 1) / gridDim.x;
     const int64_t lo = (int64_t)blockIdx.x * per;
     const int64_t hi = lo + per < n ? lo + per : n;
     const T* row = scores + (int64_t)q * stride;
+    const int32_t* irow = view.idx ? view.idx + (int64_t)q * stride : nullptr;
     for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += 4 * SEL_THREADS) {
         T v[4];
+        int64_t ix[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int64_t i = i0 + (int64_t)u * SEL_THREADS;
             v[u] = i < hi ? row[i] : ScoreTraits<T>::neg_inf();
+            ix[u] = i < hi ? row_index(irow, i) : 0;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int64_t i = i0 + (int64_t)u * SEL_THREADS;
             uint64_t khi; uint32_t klo;
-            if (!key_of(v[u], i, khi, klo)) continue;
+            if (!key_of(v[u], ix[u], khi, klo)) continue;
             const uint64_t mh = khi & S.mask_hi;
             const bool ge = mh > S.pref_hi || (mh == S.pref_hi && (klo & S.mask_lo) >= S.pref_lo);
             if (!ge) continue;
@@ -284,8 +300,9 @@ __device__ void bitonic_desc(uint64_t* khi, uint32_t* klo, int P) {
 // row -- slow (one CU reads the row once per remaining digit) but exact, and only reached with tie groups
 // larger than MSR_SEL_CAP.
 template <typename T>
-__global__ __launch_bounds__(SCAN_THREADS) void sel_final_kernel(const T* __restrict__ scores, int64_t n,
-                                                                  int64_t stride, SelState* __restrict__ st,
+__global__ __launch_bounds__(SCAN_THREADS) void sel_final_kernel(const T* __restrict__ scores, int64_t n_dense,
+                                                                  int64_t stride, RowView view,
+                                                                  SelState* __restrict__ st,
                                                                   const uint64_t* __restrict__ cand_hi,
                                                                   const uint32_t* __restrict__ cand_lo,
                                                                   int32_t* __restrict__ cand_n, int k,
@@ -300,6 +317,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void sel_final_kernel(const T* __rest
     __shared__ int s_cnt;
     const int q = blockIdx.x, t = threadIdx.x;
     const T* row = scores + (int64_t)q * stride;
+    const int32_t* irow = view.idx ? view.idx + (int64_t)q * stride : nullptr;
+    const int64_t n = row_len(view, q, n_dense);
     if (t == 0) S_sh = st[q];
     __syncthreads();
     int cnt;
@@ -321,7 +340,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void sel_final_kernel(const T* __rest
             const uint32_t wmask = (1u << width) - 1u;
             for (int64_t i = t; i < n; i += SCAN_THREADS) {
                 uint64_t a; uint32_t b;
-                if (!key_of(row[i], i, a, b)) continue;
+                if (!key_of(row[i], row_index(irow, i), a, b)) continue;
                 if ((a & S.mask_hi) != S.pref_hi || (b & S.mask_lo) != S.pref_lo) continue;
                 atomicAdd(&h[part == 0 ? (uint32_t)(a >> shift) & wmask : (b >> shift) & wmask], 1u);
             }
@@ -334,7 +353,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void sel_final_kernel(const T* __rest
         const SelState S = S_sh;
         for (int64_t i = t; i < n; i += SCAN_THREADS) {
             uint64_t a; uint32_t b;
-            if (!key_of(row[i], i, a, b)) continue;
+            if (!key_of(row[i], row_index(irow, i), a, b)) continue;
             const uint64_t mh = a & S.mask_hi;
             if (mh > S.pref_hi || (mh == S.pref_hi && (b & S.mask_lo) >= S.pref_lo)) {
                 const int pos = atomicAdd(&s_cnt, 1);
@@ -364,7 +383,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void sel_final_kernel(const T* __rest
 }
 
 template <typename T>
-hipError_t select_impl(const T* scores, int64_t n, int64_t stride, int nq, int k, const SelScratch& sc,
+hipError_t select_impl(const T* scores, int64_t n, int64_t stride, RowView view, int nq, int k, const SelScratch& sc,
                        int32_t* out_doc, T* out_score, int32_t* out_n, hipStream_t stream) {
     constexpr int SB = ScoreTraits<T>::SB;
     if (nq <= 0) return hipSuccess;
@@ -375,12 +394,12 @@ hipError_t select_impl(const T* scores, int64_t n, int64_t stride, int nq, int k
     dim3 grid((unsigned)parts, (unsigned)nq);
     // two streaming histogram passes (24 key bits), one compaction, one exact sort: 6 launches
     for (int d = 0; d < 2; ++d) {
-        sel_hist_kernel<T><<<grid, SEL_THREADS, 0, stream>>>(scores, n, stride, d, sc.state, sc.hist);
+        sel_hist_kernel<T><<<grid, SEL_THREADS, 0, stream>>>(scores, n, stride, view, d, sc.state, sc.hist);
         sel_scan_kernel<SB><<<nq, SCAN_THREADS, 0, stream>>>(sc.state, sc.hist, d, k);
     }
-    sel_compact_kernel<T><<<grid, SEL_THREADS, 0, stream>>>(scores, n, stride, sc.state, sc.cand_hi, sc.cand_lo,
+    sel_compact_kernel<T><<<grid, SEL_THREADS, 0, stream>>>(scores, n, stride, view, sc.state, sc.cand_hi, sc.cand_lo,
                                                              sc.cand_n);
-    sel_final_kernel<T><<<nq, SCAN_THREADS, 0, stream>>>(scores, n, stride, sc.state, sc.cand_hi, sc.cand_lo,
+    sel_final_kernel<T><<<nq, SCAN_THREADS, 0, stream>>>(scores, n, stride, view, sc.state, sc.cand_hi, sc.cand_lo,
                                                           sc.cand_n, k, out_doc, out_score, out_n);
     return hipGetLastError();
 }
@@ -438,9 +457,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void merge_kernel(const int32_t* __re
 hipError_t msr_select_topk(int score_bits, const void* scores, int64_t n, int64_t stride, int nq, int k,
                            const SelScratch& sc, int32_t* out_doc, void* out_score, int32_t* out_n,
                            hipStream_t stream) {
+    const RowView dense{nullptr, nullptr};
     if (score_bits == 32)
-        return select_impl<float>((const float*)scores, n, stride, nq, k, sc, out_doc, (float*)out_score, out_n, stream);
-    return select_impl<double>((const double*)scores, n, stride, nq, k, sc, out_doc, (double*)out_score, out_n, stream);
+        return select_impl<float>((const float*)scores, n, stride, dense, nq, k, sc, out_doc, (float*)out_score, out_n, stream);
+    return select_impl<double>((const double*)scores, n, stride, dense, nq, k, sc, out_doc, (double*)out_score, out_n, stream);
+}
+
+hipError_t msr_select_topk_list(const double* scores, const int32_t* idx, const int32_t* counts, int64_t n_max,
+                                int64_t stride, int nq, int k, const SelScratch& sc, int32_t* out_doc,
+                                double* out_score, int32_t* out_n, hipStream_t stream) {
+    const RowView list{idx, counts};
+    return select_impl<double>(scores, n_max, stride, list, nq, k, sc, out_doc, out_score, out_n, stream);
 }
 
 hipError_t msr_merge_lists(int score_bits, const int32_t* in_doc, const void* in_score, const int32_t* in_n,
