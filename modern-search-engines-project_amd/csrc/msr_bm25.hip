@@ -3,8 +3,8 @@
 // Replaces the per-query SQL fetch + Python grouping + scoring loop of the reference
 // (indexer/bm25_indexer.py:434-481).  The dense doc index is cut into tiles of TILE documents; one
 // workgroup owns one (tile, query) pair and keeps the tile's float64 accumulators in LDS.  It first locates
-// the tile's slice of every query term's posting list (wave-wide 64-ary searches, one term per wave side by
-// side), then, IN QUERY ORDER, streams each slice with coalesced loads; a document occurs at most once per posting list
+// the tile's slice of every query term's posting list (two loads from the skip table for long lists, a
+// wave-wide 64-ary search for short ones; one term per wave side by side), then, IN QUERY ORDER, streams each slice with coalesced loads; a document occurs at most once per posting list
 // (PRIMARY KEY (doc_id, term), :100-104), so the read-modify-write of acc[doc] needs no atomics, and a
 // barrier between terms makes the float64 summation order equal to the reference's (:466-478).
 // The arithmetic is written operation by operation as Python evaluates it and this file is compiled with
@@ -17,7 +17,7 @@
 
 namespace {
 
-constexpr int BM25_TILE = 4096;
+constexpr int BM25_TILE = MSR_BM25_TILE;
 constexpr int BM25_THREADS = 256;
 constexpr int BM25_MAX_TERMS = 64;                            // MSR_MAX_QUERY_TERMS
 constexpr uint64_t UNTOUCHED = 0x7FF8DEADBEEF0001ull;   // a quiet-NaN payload no computation produces
@@ -84,8 +84,15 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
             if (t >= 0 && t < ix.n_terms) {
                 const int64_t s = ix.term_off[t], e = ix.term_off[t + 1];
                 if (e > s) {
-                    ps = wave_lower_bound(ix.post_doc, s, e, (int32_t)lo);
-                    pe = wave_lower_bound(ix.post_doc, ps, e, (int32_t)hi);
+                    const int h = ix.heavy_id ? ix.heavy_id[t] : -1;
+                    if (h >= 0) {                            // long list: the slice comes from the skip table
+                        const uint32_t* row = ix.tile_off + (int64_t)h * (ix.n_tiles + 1) + blockIdx.x;
+                        ps = s + row[0];
+                        pe = s + row[1];
+                    } else {
+                        ps = wave_lower_bound(ix.post_doc, s, e, (int32_t)lo);
+                        pe = wave_lower_bound(ix.post_doc, ps, e, (int32_t)hi);
+                    }
                 }
             }
             if ((tid & 63) == 0) { slice[2 * (j - t0)] = ps; slice[2 * (j - t0) + 1] = pe; }
@@ -170,7 +177,31 @@ __global__ __launch_bounds__(256) void validate_postings_kernel(Bm25Index ix, in
     }
 }
 
+// One workgroup per heavy term: tile_off[h][j] = number of postings of the term with document < j * TILE.
+__global__ __launch_bounds__(256) void build_skip_kernel(Bm25Index ix, const int32_t* __restrict__ heavy_terms,
+                                                          uint32_t* __restrict__ tile_off) {
+    const int h = blockIdx.x;
+    const int32_t t = heavy_terms[h];
+    const int64_t s = ix.term_off[t], e = ix.term_off[t + 1];
+    for (int j = threadIdx.x; j <= ix.n_tiles; j += 256) {
+        const int64_t target = (int64_t)j * BM25_TILE;
+        int64_t lo = s, hi = e;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (ix.post_doc[mid] < target) lo = mid + 1; else hi = mid;
+        }
+        tile_off[(int64_t)h * (ix.n_tiles + 1) + j] = (uint32_t)(lo - s);
+    }
+}
+
 }  // namespace
+
+hipError_t msr_bm25_build_skip(const Bm25Index& ix, const int32_t* heavy_terms, int n_heavy, uint32_t* tile_off,
+                               hipStream_t stream) {
+    if (n_heavy <= 0) return hipSuccess;
+    build_skip_kernel<<<n_heavy, 256, 0, stream>>>(ix, heavy_terms, tile_off);
+    return hipGetLastError();
+}
 
 hipError_t msr_bm25_validate(const Bm25Index& ix, int32_t* flag, hipStream_t stream) {
     hipError_t err = hipMemsetAsync(flag, 0x7F, sizeof(int32_t), stream);

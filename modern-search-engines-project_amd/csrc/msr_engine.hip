@@ -32,6 +32,8 @@ struct msr_engine {
     void* emb_bf16 = nullptr;         // bf16 copy of the embeddings (msr_enable_bf16)
     void* score_rows = nullptr;       // max_queries rows of n_docs float64 (reused as float32 rows)
     size_t score_rows_bytes = 0;
+    int32_t* bm_heavy_id = nullptr;    // skip table of the BM25 stage (see Bm25Index)
+    uint32_t* bm_tile_off = nullptr;
     int32_t* bm_cand_doc = nullptr;    // max_queries rows of n_docs i32: document of each BM25 candidate
     int32_t* bm_cand_n = nullptr;      // [max_queries] candidates per query (zero between calls)
     size_t bm_cand_bytes = 0;
@@ -142,7 +144,7 @@ extern "C" int msr_create(const msr_config* cfg, msr_engine** out) {
 extern "C" int msr_destroy(msr_engine* e) {
     if (!e) return MSR_OK;
     free_dev(e->chunk_doc); free_dev(e->inv_norm_own); free_dev(e->span_doc); free_dev(e->wspan_doc); free_dev(e->wspan12_doc); free_dev(e->qn); free_dev(e->qimg); free_dev(e->emb_bf16);
-    free_dev(e->score_rows); free_dev(e->bm_cand_doc); free_dev(e->bm_cand_n); free_dev(e->sel.hist); free_dev(e->sel.state); free_dev(e->sel.cand_hi);
+    free_dev(e->score_rows); free_dev(e->bm_heavy_id); free_dev(e->bm_tile_off); free_dev(e->bm_cand_doc); free_dev(e->bm_cand_n); free_dev(e->sel.hist); free_dev(e->sel.state); free_dev(e->sel.cand_hi);
     free_dev(e->sel.cand_lo); free_dev(e->sel.cand_n); free_dev(e->rerank_cos); free_dev(e->rerank_meta);
     free_dev(e->bt_top_doc); free_dev(e->bt_top_score); free_dev(e->bt_top_n); free_dev(e->bt_cand_doc);
     free_dev(e->bt_cand_score); free_dev(e->bt_cand_chunk); free_dev(e->bt_cand_n);
@@ -195,7 +197,8 @@ extern "C" int msr_bind_postings(msr_engine* e, const int64_t* term_off, int64_t
                 return fail(e, MSR_ERR_NOMEM, "BM25 candidate counts: %s", hipGetErrorString(herr));
         }
     }
-    const Bm25Index cand{term_off, post_doc, post_tf, doc_len, idf, n_terms, n_postings, n_docs, (double)avgdl, k1, b};
+    Bm25Index cand{term_off, post_doc, post_tf, doc_len, idf, n_terms, n_postings, n_docs, (double)avgdl, k1, b,
+                   nullptr, nullptr, (int32_t)((n_docs + MSR_BM25_TILE - 1) / MSR_BM25_TILE)};
     // the scoring kernel indexes LDS with (post_doc - tile start): validate the CSR once, on the device
     hipStream_t st = (hipStream_t)stream;
     int32_t h_flag = 0;
@@ -212,6 +215,38 @@ extern "C" int msr_bind_postings(msr_engine* e, const int64_t* term_off, int64_t
     }
     if (!(avgdl > 0.0f) || !(k1 >= 0.0) || !(b >= 0.0 && b <= 1.0))
         return fail(e, MSR_ERR_INVALID, "msr_bind_postings: avgdl must be > 0, k1 >= 0, 0 <= b <= 1");
+    // skip table for the long posting lists (one-time; the offsets come to the host once for this)
+    free_dev(e->bm_heavy_id); e->bm_heavy_id = nullptr;
+    free_dev(e->bm_tile_off); e->bm_tile_off = nullptr;
+    if (n_terms > 0) {
+        std::vector<int64_t> h_toff((size_t)n_terms + 1);
+        HIP_TRY(e, hipMemcpyAsync(h_toff.data(), term_off, h_toff.size() * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(e, hipStreamSynchronize(st));
+        std::vector<int32_t> heavy_id((size_t)n_terms, -1), heavy_terms;
+        for (int64_t t = 0; t < n_terms; ++t)
+            if (h_toff[t + 1] - h_toff[t] >= MSR_BM25_HEAVY_DF && h_toff[t + 1] - h_toff[t] < (1ll << 32)) {
+                heavy_id[t] = (int32_t)heavy_terms.size();
+                heavy_terms.push_back((int32_t)t);
+            }
+        if (!heavy_terms.empty()) {
+            hipError_t herr;
+            int32_t* d_terms = nullptr;
+            const size_t rows = heavy_terms.size() * (size_t)(cand.n_tiles + 1);
+            if ((herr = hipMalloc((void**)&e->bm_heavy_id, heavy_id.size() * sizeof(int32_t))) != hipSuccess ||
+                (herr = hipMalloc((void**)&e->bm_tile_off, rows * sizeof(uint32_t))) != hipSuccess ||
+                (herr = hipMalloc((void**)&d_terms, heavy_terms.size() * sizeof(int32_t))) != hipSuccess) {
+                free_dev(d_terms);
+                return fail(e, MSR_ERR_NOMEM, "BM25 skip table: %s", hipGetErrorString(herr));
+            }
+            HIP_TRY(e, hipMemcpyAsync(e->bm_heavy_id, heavy_id.data(), heavy_id.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            HIP_TRY(e, hipMemcpyAsync(d_terms, heavy_terms.data(), heavy_terms.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            HIP_TRY(e, msr_bm25_build_skip(cand, d_terms, (int)heavy_terms.size(), e->bm_tile_off, st));
+            HIP_TRY(e, hipStreamSynchronize(st));
+            free_dev(d_terms);
+            cand.heavy_id = e->bm_heavy_id;
+            cand.tile_off = e->bm_tile_off;
+        }
+    }
     e->bm25 = cand;
     e->have_postings = true;
     return MSR_OK;

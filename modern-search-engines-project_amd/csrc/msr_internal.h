@@ -51,7 +51,16 @@ struct Bm25Index {
     const float* idf;
     int64_t n_terms, n_postings, n_docs;
     double avgdl, k1, b;
+    // skip table (engine-owned, built at bind): for the terms with long posting lists, where each document
+    // tile starts inside the list, so a workgroup finds its slice with two loads instead of a search
+    const int32_t* heavy_id;   // [n_terms]: row of tile_off, or -1
+    const uint32_t* tile_off;  // [n_heavy][n_tiles + 1], relative to term_off[t]
+    int32_t n_tiles;
 };
+constexpr int MSR_BM25_TILE = 4096;          // documents per BM25 tile
+constexpr int MSR_BM25_HEAVY_DF = 2048;      // posting lists at least this long get a skip-table row
+hipError_t msr_bm25_build_skip(const Bm25Index& ix, const int32_t* heavy_terms, int n_heavy, uint32_t* tile_off,
+                               hipStream_t stream);
 // Candidate lists: for query q, cand_n[q] pairs (cand_score[q][i], cand_doc[q][i]) -- exactly the documents
 // touched by a posting whose score is >= min_score, in no particular order (row stride n_docs).  cand_n must
 // be zero on entry.
