@@ -193,13 +193,24 @@ __global__ __launch_bounds__(SCAN_THREADS) void dense_scan_kernel(DenseIndex ix,
 //          the candidate generator of the batched path (K5), its scores are re-computed in f32 afterwards
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int QB, bool BF16, int WAVES, int OBD = 32> struct ScanCfgV2 {   // OBD: staged documents per wave (0 = none)
-    static constexpr int KS = BF16 ? MSR_DIM / 32 : MSR_DIM / 16;            // k-steps per row group
-    static constexpr int ROW16 = BF16 ? MSR_DIM * 2 / 16 : MSR_DIM * 4 / 16;  // 16-byte units per row
+// MODE: how a row group is multiplied
+//   0  f32 rows, v_mfma_f32_16x16x4_f32 (exact f32: bit-for-bit a k-ordered fmaf chain)
+//   1  bf16 rows, v_mfma_f32_16x16x32_bf16 (candidate generator of the batched path)
+//   2  f32 rows split on the fly into two f16 pieces (x = hi + lo, |x - hi - lo| <= 2^-20 |x|); three
+//      v_mfma_f32_16x16x32_f16 (hi*hi + hi*lo + lo*hi) replace eight f32 MFMAs.  Every f16 x f16 product is exact in
+//      f32 and the accumulation is f32, so |error| <= 3 * 2^-20 * sum|e_i q_i| <= 2.9e-6 for unit vectors: inside
+//      the 1e-5 cosine tolerance by construction, at about a third of the matrix-pipe time and far less power.
+constexpr int MODE_F32 = 0, MODE_BF16 = 1, MODE_F16X2 = 2;
+
+template <int QB, int MODE, int WAVES, int OBD = 32> struct ScanCfgV2 {   // OBD: staged documents per wave (0 = none)
+    static constexpr int NL = MODE == MODE_BF16 ? MSR_DIM / 32 : MSR_DIM / 16;      // 16 B loads per lane per row group
+    static constexpr int KS = MODE == MODE_F32 ? MSR_DIM / 16 : MSR_DIM / 32;       // MFMA k-steps per row group
+    static constexpr int QPIECES = MODE == MODE_F16X2 ? 2 : 1;                      // operand pieces per k-step
+    static constexpr int ROW16 = MODE == MODE_BF16 ? MSR_DIM * 2 / 16 : MSR_DIM * 4 / 16;   // 16-byte units per row
     static constexpr int NQP = 16 * QB;
     static constexpr int SROW = NQP + 1;
     static constexpr int THREADS = WAVES * 64;
-    static constexpr size_t q_bytes = (size_t)QB * KS * 64 * 16;
+    static constexpr size_t q_bytes = (size_t)QB * KS * QPIECES * 64 * 16;
     static constexpr size_t t_bytes = (size_t)16 * SROW * 4;                 // per wave: 16 rows x queries
     static constexpr size_t o_bytes = (size_t)OBD * SROW * 4;                // per wave: staged documents
     static constexpr size_t wave_bytes = (t_bytes + o_bytes + 15) & ~(size_t)15;
@@ -207,17 +218,34 @@ template <int QB, bool BF16, int WAVES, int OBD = 32> struct ScanCfgV2 {   // OB
 };
 
 // qimg: the query image already in fragment order, [QB][KS][64 lanes] x 16 B (see build_qimage_kernel)
-template <int QB, bool TILED, int LB, bool BF16, int WAVES, int OBD = 32>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// x (8 floats in two float4) -> hi, lo with x ~= hi + lo.  cvt_pkrtz rounds toward zero, so the residual x - hi is
+// exact in f32 and smaller than 2^-10 |x|; after the second truncation |x - hi - lo| < 2^-20 |x|.
+__device__ __forceinline__ void split_f16(const f32x4& a, const f32x4& b, f16x8& hi, f16x8& lo) {
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x[j], x[j + 1]));
+        const f16x2 l = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x[j] - (float)h[0], x[j + 1] - (float)h[1]));
+        hi[j] = h[0]; hi[j + 1] = h[1];
+        lo[j] = l[0]; lo[j + 1] = l[1];
+    }
+}
+
+template <int QB, bool TILED, int LB, int MODE, int WAVES, int OBD = 32>
 __global__ __launch_bounds__(WAVES * 64) void dense_scan_v2_kernel(DenseIndex ix, const void* __restrict__ emb,
                                                                     const int32_t* __restrict__ wspan,
                                                                     int n_wspans, const f32x4* __restrict__ qimg,
                                                                     int nq, int max_chunks,
                                                                     float* __restrict__ docscore) {
-    using L = ScanCfgV2<QB, BF16, WAVES, OBD>;
-    constexpr int KS = L::KS;
+    using L = ScanCfgV2<QB, MODE, WAVES, OBD>;
+    constexpr int KS = L::KS, NL = L::NL;
+    constexpr bool BF16 = MODE == MODE_BF16;
     constexpr bool DIRECT = OBD == 0;
     static_assert(OBD == 0 || OBD == 8 || OBD == 16 || OBD == 32, "staging depth");
-    static_assert(KS % LB == 0, "whole load batches per group");
+    static_assert(NL % LB == 0 && (MODE != MODE_F16X2 || LB % 2 == 0), "whole load batches per group");
     static_assert(!(BF16 && TILED), "the interleaved image exists for f32 only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* Qs = (f32x4*)smem;
@@ -228,7 +256,7 @@ __global__ __launch_bounds__(WAVES * 64) void dense_scan_v2_kernel(DenseIndex ix
     float* OB = T + 16 * L::SROW;                                            // [OBD][SROW]
     const int li = lane & 15, lg = lane >> 4;
 
-    for (int idx = tid; idx < QB * KS * 64; idx += L::THREADS) Qs[idx] = qimg[idx];
+    for (int idx = tid; idx < QB * KS * L::QPIECES * 64; idx += L::THREADS) Qs[idx] = qimg[idx];
     __syncthreads();                                             // the only workgroup barrier
 
     const int s = blockIdx.x * WAVES + w;
@@ -270,7 +298,7 @@ __global__ __launch_bounds__(WAVES * 64) void dense_scan_v2_kernel(DenseIndex ix
 
     if (c1 > c0) {
         constexpr int PSTRIDE = TILED ? 64 : 4;                  // 16-byte units between k-steps
-        constexpr int NBATCH = KS / LB;
+        constexpr int NBATCH = NL / LB;
         const int64_t g0 = c0 >> 4, g1 = (c1 + 15) >> 4;
         auto row_ptr = [&](int64_t grp) -> const f32x4* {
             if (TILED) return (const f32x4*)emb + (size_t)grp * (16 * L::ROW16) + lane;
@@ -321,22 +349,41 @@ __global__ __launch_bounds__(WAVES * 64) void dense_scan_v2_kernel(DenseIndex ix
                     iv_next = ix.inv_norm[meta_row(grp + 1)];
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (MODE == MODE_F16X2) {
 #pragma unroll
-                for (int u = 0; u < LB; ++u) {
-                    const f32x4 a = ((nb + PH) & 1) ? buf1[u] : buf0[u];
-                    const int t = nb * LB + u;
+                    for (int u = 0; u < LB; u += 2) {
+                        const f32x4 a0 = ((nb + PH) & 1) ? buf1[u] : buf0[u];
+                        const f32x4 a1 = ((nb + PH) & 1) ? buf1[u + 1] : buf0[u + 1];
+                        f16x8 ahi, alo;
+                        split_f16(a0, a1, ahi, alo);
+                        const int t = (nb * LB + u) >> 1;
 #pragma unroll
-                    for (int qb = 0; qb < QB; ++qb) {
-                        const f32x4 bq = Qs[(qb * KS + t) * 64 + lane];
-                        if (BF16) {
-                            acc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
-                                                                              __builtin_bit_cast(bf16x8, bq),
-                                                                              acc[qb], 0, 0, 0);
-                        } else {
-                            acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq.x, acc[qb], 0, 0, 0);
-                            acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq.y, acc[qb], 0, 0, 0);
-                            acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq.z, acc[qb], 0, 0, 0);
-                            acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq.w, acc[qb], 0, 0, 0);
+                        for (int qb = 0; qb < QB; ++qb) {
+                            const f16x8 bhi = __builtin_bit_cast(f16x8, Qs[((qb * KS + t) * 2 + 0) * 64 + lane]);
+                            const f16x8 blo = __builtin_bit_cast(f16x8, Qs[((qb * KS + t) * 2 + 1) * 64 + lane]);
+                            acc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi, acc[qb], 0, 0, 0);
+                            acc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo, acc[qb], 0, 0, 0);
+                            acc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi, acc[qb], 0, 0, 0);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < LB; ++u) {
+                        const f32x4 a = ((nb + PH) & 1) ? buf1[u] : buf0[u];
+                        const int t = nb * LB + u;
+#pragma unroll
+                        for (int qb = 0; qb < QB; ++qb) {
+                            const f32x4 bq = Qs[(qb * KS + t) * 64 + lane];
+                            if (BF16) {
+                                acc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                                                  __builtin_bit_cast(bf16x8, bq),
+                                                                                  acc[qb], 0, 0, 0);
+                            } else {
+                                acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq.x, acc[qb], 0, 0, 0);
+                                acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq.y, acc[qb], 0, 0, 0);
+                                acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq.z, acc[qb], 0, 0, 0);
+                                acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq.w, acc[qb], 0, 0, 0);
+                            }
                         }
                     }
                 }
@@ -387,22 +434,31 @@ __global__ __launch_bounds__(WAVES * 64) void dense_scan_v2_kernel(DenseIndex ix
 
 // Query image in MFMA-fragment order.  f32: block (qb, t) lane l = qn[16 qb + (l & 15)][16 t + 4 (l >> 4) .. +3];
 // bf16: lane l = bf16(qn[16 qb + (l & 15)][32 t + 8 (l >> 4) .. +7]) (round-to-nearest-even).
-template <bool BF16>
+template <int MODE>
 __global__ __launch_bounds__(256) void build_qimage_kernel(const float* __restrict__ qn, int n_blocks,
                                                             f32x4* __restrict__ qimg) {
-    constexpr int KS = BF16 ? MSR_DIM / 32 : MSR_DIM / 16;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    constexpr int KS = MODE == MODE_F32 ? MSR_DIM / 16 : MSR_DIM / 32;
+    const int idx = blockIdx.x * 256 + threadIdx.x;              // one (block, k-step, lane)
     if (idx >= n_blocks * KS * 64) return;
     const int l = idx & 63;
     const int t = (idx >> 6) % KS;
     const int qb = idx / (KS * 64);
     const float* src = qn + (size_t)(16 * qb + (l & 15)) * MSR_DIM;
-    if (BF16) {
+    if (MODE == MODE_BF16) {
         const float* s8 = src + 32 * t + 8 * (l >> 4);
         bf16x8 v;
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (__bf16)s8[j];
         qimg[idx] = __builtin_bit_cast(f32x4, v);
+    } else if (MODE == MODE_F16X2) {
+        // the 8 k-elements of lane (i, g) at k-step t are what the row side loads as two float4:
+        // dims 16 (2t) + 4g .. +3 and 16 (2t + 1) + 4g .. +3
+        const f32x4 a = *(const f32x4*)(src + 16 * (2 * t) + 4 * (l >> 4));
+        const f32x4 b = *(const f32x4*)(src + 16 * (2 * t + 1) + 4 * (l >> 4));
+        f16x8 hi, lo;
+        split_f16(a, b, hi, lo);
+        qimg[(size_t)(idx >> 6) * 128 + l] = __builtin_bit_cast(f32x4, hi);        // [qb][t][piece][lane]
+        qimg[(size_t)(idx >> 6) * 128 + 64 + l] = __builtin_bit_cast(f32x4, lo);
     } else {
         qimg[idx] = *(const f32x4*)(src + 16 * t + 4 * (l >> 4));
     }
@@ -528,22 +584,22 @@ hipError_t launch_scan(const DenseIndex& ix, const float* qn, int nq, int max_ch
     return hipGetLastError();
 }
 
-template <int QB, bool TILED, int LB, int WAVES = 8, int OBD = 32>
+template <int QB, bool TILED, int LB, int WAVES = 8, int OBD = 32, int MODE = MODE_F32>
 hipError_t launch_scan_v2(const DenseIndex& ix, const float* qn, int nq, int max_chunks, float* docscore,
                           hipStream_t stream) {
-    using L = ScanCfgV2<QB, false, WAVES, OBD>;
+    using L = ScanCfgV2<QB, MODE, WAVES, OBD>;
     static_assert(L::total <= 160 * 1024, "LDS budget");
     const size_t lds = L::total;
-    hipError_t err = hipFuncSetAttribute((const void*)dense_scan_v2_kernel<QB, TILED, LB, false, WAVES, OBD>,
+    hipError_t err = hipFuncSetAttribute((const void*)dense_scan_v2_kernel<QB, TILED, LB, MODE, WAVES, OBD>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess) return err;
     const int n_img = QB * L::KS * 64;
-    build_qimage_kernel<false><<<(n_img + 255) / 256, 256, 0, stream>>>(qn, QB, (f32x4*)ix.qimg);
+    build_qimage_kernel<MODE><<<(n_img + 255) / 256, 256, 0, stream>>>(qn, QB, (f32x4*)ix.qimg);
     // per-wave span tables exist for 8 and for 12 waves per CU
     const int32_t* spans = WAVES == 12 ? ix.wspan12_doc : ix.wspan_doc;
     const int n_sp = WAVES == 12 ? ix.n_wspans12 : ix.n_wspans;
     const int grid = (n_sp + WAVES - 1) / WAVES;
-    dense_scan_v2_kernel<QB, TILED, LB, false, WAVES, OBD><<<grid, L::THREADS, lds, stream>>>(
+    dense_scan_v2_kernel<QB, TILED, LB, MODE, WAVES, OBD><<<grid, L::THREADS, lds, stream>>>(
         ix, ix.emb, spans, n_sp, (const f32x4*)ix.qimg, nq, max_chunks, docscore);
     return hipGetLastError();
 }
@@ -551,17 +607,17 @@ hipError_t launch_scan_v2(const DenseIndex& ix, const float* qn, int nq, int max
 template <int QB, int WAVES, int OBD, int LB = 12>
 hipError_t launch_scan_bf16_cfg(const DenseIndex& ix, const float* qn, int nq, int max_chunks, float* docscore,
                                 hipStream_t stream) {
-    using L = ScanCfgV2<QB, true, WAVES, OBD>;
+    using L = ScanCfgV2<QB, MODE_BF16, WAVES, OBD>;
     const size_t lds = L::total;
     static_assert(L::total <= 160 * 1024, "LDS budget");
-    hipError_t err = hipFuncSetAttribute((const void*)dense_scan_v2_kernel<QB, false, LB, true, WAVES, OBD>,
+    hipError_t err = hipFuncSetAttribute((const void*)dense_scan_v2_kernel<QB, false, LB, MODE_BF16, WAVES, OBD>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess) return err;
     const int n_img = QB * L::KS * 64;
-    build_qimage_kernel<true><<<(n_img + 255) / 256, 256, 0, stream>>>(qn, QB, (f32x4*)ix.qimg);
+    build_qimage_kernel<MODE_BF16><<<(n_img + 255) / 256, 256, 0, stream>>>(qn, QB, (f32x4*)ix.qimg);
     // the per-wave spans were cut for 8 waves per CU; with fewer waves a workgroup takes fewer of them
     const int grid = (ix.n_wspans + WAVES - 1) / WAVES;
-    dense_scan_v2_kernel<QB, false, LB, true, WAVES, OBD><<<grid, L::THREADS, lds, stream>>>(
+    dense_scan_v2_kernel<QB, false, LB, MODE_BF16, WAVES, OBD><<<grid, L::THREADS, lds, stream>>>(
         ix, ix.emb_bf16, ix.wspan_doc, ix.n_wspans, (const f32x4*)ix.qimg, nq, max_chunks, docscore);
     return hipGetLastError();
 }
@@ -588,6 +644,8 @@ hipError_t dispatch_variant(const DenseIndex& ix, const float* qn, int nq, int m
         case 4: return launch_scan_v2<QB, TILED, 24>(ix, qn, nq, max_chunks, docscore, stream);
         case 5: return launch_scan_v2<QB, TILED, 12, 12, 16>(ix, qn, nq, max_chunks, docscore, stream);   // 3 waves/SIMD
         case 6: return launch_scan_v2<QB, TILED, 8, 12, 16>(ix, qn, nq, max_chunks, docscore, stream);
+        case 7: return launch_scan_v2<QB, TILED, 12, 8, 32, MODE_F16X2>(ix, qn, nq, max_chunks, docscore, stream);   // f16 split
+        case 8: return launch_scan_v2<QB, TILED, 24, 8, 32, MODE_F16X2>(ix, qn, nq, max_chunks, docscore, stream);
         default: return launch_scan_v2<QB, TILED, 12>(ix, qn, nq, max_chunks, docscore, stream);   // 0, 3
     }
 }
