@@ -325,9 +325,14 @@ __global__ __launch_bounds__(WAVES * 64) void dense_scan_v2_kernel(DenseIndex ix
             constexpr int PH = decltype(ph_c)::value;
             const f32x4* pn = row_ptr(grp + 1 < g1 ? grp + 1 : grp);
             const bool has_next = grp + 1 < g1;
-            f32x4 acc[QB];
+            // Independent accumulation chains: back-to-back MFMAs on ONE accumulator stall on its 40-cycle dependent
+            // latency (the first profile showed waves waiting on instruction issue two thirds of the time), so
+            // consecutive MFMAs alternate between chains; with a single query block the k-slices are dealt to two
+            // chains that are added at the end.
+            constexpr int NCH = QB == 1 ? 2 : QB;
+            f32x4 acc[NCH];
 #pragma unroll
-            for (int qb = 0; qb < QB; ++qb) acc[qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < NCH; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
             int dv_next = dv;
             float iv_next = iv;
 #pragma unroll
@@ -357,13 +362,26 @@ __global__ __launch_bounds__(WAVES * 64) void dense_scan_v2_kernel(DenseIndex ix
                         f16x8 ahi, alo;
                         split_f16(a0, a1, ahi, alo);
                         const int t = (nb * LB + u) >> 1;
+                        f16x8 bhi[QB], blo[QB];
 #pragma unroll
                         for (int qb = 0; qb < QB; ++qb) {
-                            const f16x8 bhi = __builtin_bit_cast(f16x8, Qs[((qb * KS + t) * 2 + 0) * 64 + lane]);
-                            const f16x8 blo = __builtin_bit_cast(f16x8, Qs[((qb * KS + t) * 2 + 1) * 64 + lane]);
-                            acc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi, acc[qb], 0, 0, 0);
-                            acc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo, acc[qb], 0, 0, 0);
-                            acc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi, acc[qb], 0, 0, 0);
+                            bhi[qb] = __builtin_bit_cast(f16x8, Qs[((qb * KS + t) * 2 + 0) * 64 + lane]);
+                            blo[qb] = __builtin_bit_cast(f16x8, Qs[((qb * KS + t) * 2 + 1) * 64 + lane]);
+                        }
+                        if constexpr (QB == 1) {
+                            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi[0], acc[0], 0, 0, 0);
+                            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo[0], acc[1], 0, 0, 0);
+                            acc[t & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi[0], acc[t & 1], 0, 0, 0);
+                        } else {
+#pragma unroll
+                            for (int qb = 0; qb < QB; ++qb)
+                                acc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi[qb], acc[qb], 0, 0, 0);
+#pragma unroll
+                            for (int qb = 0; qb < QB; ++qb)
+                                acc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo[qb], acc[qb], 0, 0, 0);
+#pragma unroll
+                            for (int qb = 0; qb < QB; ++qb)
+                                acc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi[qb], acc[qb], 0, 0, 0);
                         }
                     }
                 } else {
@@ -371,23 +389,33 @@ __global__ __launch_bounds__(WAVES * 64) void dense_scan_v2_kernel(DenseIndex ix
                     for (int u = 0; u < LB; ++u) {
                         const f32x4 a = ((nb + PH) & 1) ? buf1[u] : buf0[u];
                         const int t = nb * LB + u;
+                        f32x4 bq[QB];
 #pragma unroll
-                        for (int qb = 0; qb < QB; ++qb) {
-                            const f32x4 bq = Qs[(qb * KS + t) * 64 + lane];
-                            if (BF16) {
-                                acc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
-                                                                                  __builtin_bit_cast(bf16x8, bq),
-                                                                                  acc[qb], 0, 0, 0);
-                            } else {
-                                acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq.x, acc[qb], 0, 0, 0);
-                                acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq.y, acc[qb], 0, 0, 0);
-                                acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq.z, acc[qb], 0, 0, 0);
-                                acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq.w, acc[qb], 0, 0, 0);
+                        for (int qb = 0; qb < QB; ++qb) bq[qb] = Qs[(qb * KS + t) * 64 + lane];
+                        if constexpr (BF16) {
+#pragma unroll
+                            for (int qb = 0; qb < QB; ++qb) {
+                                const int ch = QB == 1 ? (t & 1) : qb;
+                                acc[ch] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                                                  __builtin_bit_cast(bf16x8, bq[qb]),
+                                                                                  acc[ch], 0, 0, 0);
                             }
+                        } else if constexpr (QB == 1) {
+                            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq[0].x, acc[0], 0, 0, 0);
+                            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq[0].y, acc[1], 0, 0, 0);
+                            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq[0].z, acc[0], 0, 0, 0);
+                            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq[0].w, acc[1], 0, 0, 0);
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                                for (int qb = 0; qb < QB; ++qb)
+                                    acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], bq[qb][c], acc[qb], 0, 0, 0);
                         }
                     }
                 }
             }
+            if constexpr (QB == 1) acc[0] = acc[0] + acc[1];     // join the two chains of the single query block
             // ---- epilogue of this group (wave-private; no barrier: a wave's LDS ops execute in order) ----
             // D layout: lane (li = query column, lg) holds rows 4 lg + reg.  inv_norm of row r sits in lane r.
 #pragma unroll
