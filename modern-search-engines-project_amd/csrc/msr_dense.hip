@@ -234,7 +234,7 @@ __device__ __forceinline__ void split_f16(const f32x4& a, const f32x4& b, f16x8&
     }
 }
 
-template <int QB, bool TILED, int LB, int MODE, int WAVES, int OBD = 32>
+template <int QB, bool TILED, int LB, int MODE, int WAVES, int OBD = 32, int G = 1>
 __global__ __launch_bounds__(WAVES * 64) void dense_scan_v2_kernel(DenseIndex ix, const void* __restrict__ emb,
                                                                     const int32_t* __restrict__ wspan,
                                                                     int n_wspans, const f32x4* __restrict__ qimg,
@@ -310,148 +310,176 @@ __global__ __launch_bounds__(WAVES * 64) void dense_scan_v2_kernel(DenseIndex ix
             int64_t r = grp * 16 + li;
             return r > C - 1 ? C - 1 : r;
         };
-        f32x4 buf0[LB], buf1[LB];
-        const f32x4* p = row_ptr(g0);
+        // A wave works on a UNIT of G consecutive row groups at a time: every query fragment read from LDS is used
+        // for G x 16 rows, which divides the LDS read traffic (the cost that grows with the number of queries) by G.
+        auto clampg = [&](int64_t g) { return g < g1 ? g : g1 - 1; };     // a unit may stick out of the span: masked later
+        f32x4 buf0[G][LB], buf1[G][LB];
+        const f32x4* p[G];
+        int dv[G];
+        float iv[G];
 #pragma unroll
-        for (int u = 0; u < LB; ++u) buf0[u] = p[(size_t)u * PSTRIDE];
-        int dv = ix.chunk_doc[meta_row(g0)];
-        float iv = ix.inv_norm[meta_row(g0)];
+        for (int g = 0; g < G; ++g) {
+            p[g] = row_ptr(clampg(g0 + g));
+#pragma unroll
+            for (int u = 0; u < LB; ++u) buf0[g][u] = p[g][(size_t)u * PSTRIDE];
+            dv[g] = ix.chunk_doc[meta_row(clampg(g0 + g))];
+            iv[g] = ix.inv_norm[meta_row(clampg(g0 + g))];
+        }
         __builtin_amdgcn_sched_barrier(0);
-        // One row group.  Batch b of the group (b = 0 .. NBATCH-1) lives in buf[(b + PH) & 1]; PH is the parity the
-        // group starts with.  With an even NBATCH it is always 0; with an odd one (LB == KS: the whole next group is
-        // prefetched while this one is consumed) the group loop below alternates PH = 0, 1 so that every register
-        // array is indexed statically.
+        // One unit.  Batch b of the unit (b = 0 .. NBATCH-1) lives in buf[(b + PH) & 1]; PH is the parity the unit
+        // starts with.  With an even NBATCH it is always 0; with an odd one (LB == NL: the whole next unit is
+        // prefetched while this one is consumed) the loop below alternates PH = 0, 1 so that every register array is
+        // indexed statically.
         auto body = [&](auto ph_c, int64_t grp) {
             constexpr int PH = decltype(ph_c)::value;
-            const f32x4* pn = row_ptr(grp + 1 < g1 ? grp + 1 : grp);
-            const bool has_next = grp + 1 < g1;
-            // Independent accumulation chains: back-to-back MFMAs on ONE accumulator stall on its 40-cycle dependent
-            // latency (the first profile showed waves waiting on instruction issue two thirds of the time), so
-            // consecutive MFMAs alternate between chains; with a single query block the k-slices are dealt to two
-            // chains that are added at the end.
-            constexpr int NCH = QB == 1 ? 2 : QB;
-            f32x4 acc[NCH];
+            const f32x4* pn[G];
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            int dv_next = dv;
-            float iv_next = iv;
+            for (int g = 0; g < G; ++g) pn[g] = row_ptr(clampg(grp + G + g));
+            const bool has_next = grp + G < g1;
+            // Independent accumulation chains: back-to-back MFMAs on ONE accumulator stall on its 40-cycle dependent
+            // latency, so consecutive MFMAs alternate between chains (query blocks x groups); a lone chain (one query
+            // block, one group) is split in two that are added at the end.
+            constexpr int NCH = (QB == 1 && G == 1) ? 2 : QB;
+            f32x4 acc[G][NCH];
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) acc[g][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            int dv_next[G];
+            float iv_next[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) { dv_next[g] = dv[g]; iv_next[g] = iv[g]; }
 #pragma unroll
             for (int nb = 0; nb < NBATCH; ++nb) {
                 const bool into1 = ((nb + 1 + PH) & 1) != 0;     // buffer of the batch being prefetched
                 if (nb + 1 < NBATCH) {
 #pragma unroll
-                    for (int u = 0; u < LB; ++u) {
-                        const f32x4 x = p[(size_t)((nb + 1) * LB + u) * PSTRIDE];
-                        if (into1) buf1[u] = x; else buf0[u] = x;
-                    }
-                } else if (has_next) {                           // first batch of the next group
+                    for (int g = 0; g < G; ++g)
 #pragma unroll
-                    for (int u = 0; u < LB; ++u) {
-                        const f32x4 x = pn[(size_t)u * PSTRIDE];
-                        if (into1) buf1[u] = x; else buf0[u] = x;
+                        for (int u = 0; u < LB; ++u) {
+                            const f32x4 x = p[g][(size_t)((nb + 1) * LB + u) * PSTRIDE];
+                            if (into1) buf1[g][u] = x; else buf0[g][u] = x;
+                        }
+                } else if (has_next) {                           // first batch of the next unit
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+#pragma unroll
+                        for (int u = 0; u < LB; ++u) {
+                            const f32x4 x = pn[g][(size_t)u * PSTRIDE];
+                            if (into1) buf1[g][u] = x; else buf0[g][u] = x;
+                        }
+                        dv_next[g] = ix.chunk_doc[meta_row(clampg(grp + G + g))];
+                        iv_next[g] = ix.inv_norm[meta_row(clampg(grp + G + g))];
                     }
-                    dv_next = ix.chunk_doc[meta_row(grp + 1)];
-                    iv_next = ix.inv_norm[meta_row(grp + 1)];
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (MODE == MODE_F16X2) {
 #pragma unroll
                     for (int u = 0; u < LB; u += 2) {
-                        const f32x4 a0 = ((nb + PH) & 1) ? buf1[u] : buf0[u];
-                        const f32x4 a1 = ((nb + PH) & 1) ? buf1[u + 1] : buf0[u + 1];
-                        f16x8 ahi, alo;
-                        split_f16(a0, a1, ahi, alo);
                         const int t = (nb * LB + u) >> 1;
+                        f16x8 ahi[G], alo[G];
+#pragma unroll
+                        for (int g = 0; g < G; ++g) {
+                            const f32x4 a0 = ((nb + PH) & 1) ? buf1[g][u] : buf0[g][u];
+                            const f32x4 a1 = ((nb + PH) & 1) ? buf1[g][u + 1] : buf0[g][u + 1];
+                            split_f16(a0, a1, ahi[g], alo[g]);
+                        }
                         f16x8 bhi[QB], blo[QB];
 #pragma unroll
                         for (int qb = 0; qb < QB; ++qb) {
                             bhi[qb] = __builtin_bit_cast(f16x8, Qs[((qb * KS + t) * 2 + 0) * 64 + lane]);
                             blo[qb] = __builtin_bit_cast(f16x8, Qs[((qb * KS + t) * 2 + 1) * 64 + lane]);
                         }
-                        if constexpr (QB == 1) {
-                            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi[0], acc[0], 0, 0, 0);
-                            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo[0], acc[1], 0, 0, 0);
-                            acc[t & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi[0], acc[t & 1], 0, 0, 0);
+                        if constexpr (NCH > QB) {                // one block, one group: two chains
+                            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[0], bhi[0], acc[0][0], 0, 0, 0);
+                            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[0], blo[0], acc[0][1], 0, 0, 0);
+                            acc[0][t & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[0], bhi[0], acc[0][t & 1], 0, 0, 0);
                         } else {
 #pragma unroll
-                            for (int qb = 0; qb < QB; ++qb)
-                                acc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi[qb], acc[qb], 0, 0, 0);
+                            for (int piece = 0; piece < 3; ++piece)
 #pragma unroll
-                            for (int qb = 0; qb < QB; ++qb)
-                                acc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo[qb], acc[qb], 0, 0, 0);
+                                for (int g = 0; g < G; ++g)
 #pragma unroll
-                            for (int qb = 0; qb < QB; ++qb)
-                                acc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi[qb], acc[qb], 0, 0, 0);
+                                    for (int qb = 0; qb < QB; ++qb)
+                                        acc[g][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                                            piece == 0 ? alo[g] : ahi[g], piece == 1 ? blo[qb] : bhi[qb], acc[g][qb], 0, 0, 0);
                         }
                     }
                 } else {
 #pragma unroll
                     for (int u = 0; u < LB; ++u) {
-                        const f32x4 a = ((nb + PH) & 1) ? buf1[u] : buf0[u];
                         const int t = nb * LB + u;
+                        f32x4 a[G];
+#pragma unroll
+                        for (int g = 0; g < G; ++g) a[g] = ((nb + PH) & 1) ? buf1[g][u] : buf0[g][u];
                         f32x4 bq[QB];
 #pragma unroll
                         for (int qb = 0; qb < QB; ++qb) bq[qb] = Qs[(qb * KS + t) * 64 + lane];
                         if constexpr (BF16) {
 #pragma unroll
-                            for (int qb = 0; qb < QB; ++qb) {
-                                const int ch = QB == 1 ? (t & 1) : qb;
-                                acc[ch] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
-                                                                                  __builtin_bit_cast(bf16x8, bq[qb]),
-                                                                                  acc[ch], 0, 0, 0);
-                            }
-                        } else if constexpr (QB == 1) {
-                            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq[0].x, acc[0], 0, 0, 0);
-                            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq[0].y, acc[1], 0, 0, 0);
-                            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq[0].z, acc[0], 0, 0, 0);
-                            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq[0].w, acc[1], 0, 0, 0);
+                            for (int g = 0; g < G; ++g)
+#pragma unroll
+                                for (int qb = 0; qb < QB; ++qb) {
+                                    const int ch = NCH > QB ? (t & 1) : qb;
+                                    acc[g][ch] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                        __builtin_bit_cast(bf16x8, a[g]), __builtin_bit_cast(bf16x8, bq[qb]), acc[g][ch], 0, 0, 0);
+                                }
+                        } else if constexpr (NCH > QB) {
+                            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0].x, bq[0].x, acc[0][0], 0, 0, 0);
+                            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0].y, bq[0].y, acc[0][1], 0, 0, 0);
+                            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0].z, bq[0].z, acc[0][0], 0, 0, 0);
+                            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0].w, bq[0].w, acc[0][1], 0, 0, 0);
                         } else {
 #pragma unroll
                             for (int c = 0; c < 4; ++c)
 #pragma unroll
-                                for (int qb = 0; qb < QB; ++qb)
-                                    acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], bq[qb][c], acc[qb], 0, 0, 0);
+                                for (int g = 0; g < G; ++g)
+#pragma unroll
+                                    for (int qb = 0; qb < QB; ++qb)
+                                        acc[g][qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g][c], bq[qb][c], acc[g][qb], 0, 0, 0);
                         }
                     }
                 }
             }
-            if constexpr (QB == 1) acc[0] = acc[0] + acc[1];     // join the two chains of the single query block
-            // ---- epilogue of this group (wave-private; no barrier: a wave's LDS ops execute in order) ----
+            if constexpr (NCH > QB) acc[0][0] = acc[0][0] + acc[0][1];       // join the two chains
+            // ---- epilogue of the unit's groups (wave-private; no barrier: a wave's LDS ops execute in order) ----
             // D layout: lane (li = query column, lg) holds rows 4 lg + reg.  inv_norm of row r sits in lane r.
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const float inv = __shfl(iv, 4 * lg + reg);
+            for (int g = 0; g < G; ++g) {
 #pragma unroll
-                for (int qb = 0; qb < QB; ++qb) T[(4 * lg + reg) * L::SROW + 16 * qb + li] = acc[qb][reg] * inv;
-            }
-            const int64_t row0 = grp * 16;
+                for (int reg = 0; reg < 4; ++reg) {
+                    const float inv = __shfl(iv[g], 4 * lg + reg);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = row0 + r;
-                const int d = __builtin_amdgcn_readlane(dv, r);  // wave-uniform
-                if (row < c0 || row >= c1) continue;             // rows of a neighbouring span
-                if (!open || d != cur_doc) {
-                    if (open) emit(m);
-                    for (int e = cur_doc + 1; e < d; ++e) emit(NEG_INF);     // chunk-less documents in between
-                    cur_doc = d; open = true; cnt = 0; m = NEG_INF;
+                    for (int qb = 0; qb < QB; ++qb) T[(4 * lg + reg) * L::SROW + 16 * qb + li] = acc[g][qb][reg] * inv;
                 }
-                if (max_chunks == 0 || cnt < max_chunks) {
-                    const float v = lane < L::NQP ? T[r * L::SROW + lane] : NEG_INF;
-                    m = fmaxf(m, v);
+                const int64_t row0 = (grp + g) * 16;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = row0 + r;
+                    const int d = __builtin_amdgcn_readlane(dv[g], r);   // wave-uniform
+                    if (row < c0 || row >= c1) continue;         // rows of a neighbouring span / past the span
+                    if (!open || d != cur_doc) {
+                        if (open) emit(m);
+                        for (int e = cur_doc + 1; e < d; ++e) emit(NEG_INF);     // chunk-less documents in between
+                        cur_doc = d; open = true; cnt = 0; m = NEG_INF;
+                    }
+                    if (max_chunks == 0 || cnt < max_chunks) {
+                        const float v = lane < L::NQP ? T[r * L::SROW + lane] : NEG_INF;
+                        m = fmaxf(m, v);
+                    }
+                    ++cnt;
                 }
-                ++cnt;
             }
-            p = pn;
-            dv = dv_next;
-            iv = iv_next;
+#pragma unroll
+            for (int g = 0; g < G; ++g) { p[g] = pn[g]; dv[g] = dv_next[g]; iv[g] = iv_next[g]; }
         };
         for (int64_t grp = g0; grp < g1;) {
             body(std::integral_constant<int, 0>{}, grp);
-            ++grp;
+            grp += G;
             if constexpr ((NBATCH & 1) != 0) {
                 if (grp >= g1) break;
                 body(std::integral_constant<int, 1>{}, grp);
-                ++grp;
+                grp += G;
             }
         }
     }
@@ -612,13 +640,13 @@ hipError_t launch_scan(const DenseIndex& ix, const float* qn, int nq, int max_ch
     return hipGetLastError();
 }
 
-template <int QB, bool TILED, int LB, int WAVES = 8, int OBD = 32, int MODE = MODE_F32>
+template <int QB, bool TILED, int LB, int WAVES = 8, int OBD = 32, int MODE = MODE_F32, int G = 1>
 hipError_t launch_scan_v2(const DenseIndex& ix, const float* qn, int nq, int max_chunks, float* docscore,
                           hipStream_t stream) {
     using L = ScanCfgV2<QB, MODE, WAVES, OBD>;
     static_assert(L::total <= 160 * 1024, "LDS budget");
     const size_t lds = L::total;
-    hipError_t err = hipFuncSetAttribute((const void*)dense_scan_v2_kernel<QB, TILED, LB, MODE, WAVES, OBD>,
+    hipError_t err = hipFuncSetAttribute((const void*)dense_scan_v2_kernel<QB, TILED, LB, MODE, WAVES, OBD, G>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess) return err;
     const int n_img = QB * L::KS * 64;
@@ -627,7 +655,7 @@ hipError_t launch_scan_v2(const DenseIndex& ix, const float* qn, int nq, int max
     const int32_t* spans = WAVES == 12 ? ix.wspan12_doc : ix.wspan_doc;
     const int n_sp = WAVES == 12 ? ix.n_wspans12 : ix.n_wspans;
     const int grid = (n_sp + WAVES - 1) / WAVES;
-    dense_scan_v2_kernel<QB, TILED, LB, MODE, WAVES, OBD><<<grid, L::THREADS, lds, stream>>>(
+    dense_scan_v2_kernel<QB, TILED, LB, MODE, WAVES, OBD, G><<<grid, L::THREADS, lds, stream>>>(
         ix, ix.emb, spans, n_sp, (const f32x4*)ix.qimg, nq, max_chunks, docscore);
     return hipGetLastError();
 }
@@ -674,6 +702,10 @@ hipError_t dispatch_variant(const DenseIndex& ix, const float* qn, int nq, int m
         case 6: return launch_scan_v2<QB, TILED, 8, 12, 16>(ix, qn, nq, max_chunks, docscore, stream);
         case 7: return launch_scan_v2<QB, TILED, 12, 8, 32, MODE_F16X2>(ix, qn, nq, max_chunks, docscore, stream);   // f16 split
         case 8: return launch_scan_v2<QB, TILED, 24, 8, 32, MODE_F16X2>(ix, qn, nq, max_chunks, docscore, stream);
+        case 9: return launch_scan_v2<QB, TILED, 6, 8, 32, MODE_F32, 2>(ix, qn, nq, max_chunks, docscore, stream);     // 2 groups/unit
+        case 10: return launch_scan_v2<QB, TILED, 12, 8, 32, MODE_F32, 2>(ix, qn, nq, max_chunks, docscore, stream);
+        case 11: return launch_scan_v2<QB, TILED, 6, 8, 32, MODE_F16X2, 2>(ix, qn, nq, max_chunks, docscore, stream);
+        case 12: return launch_scan_v2<QB, TILED, 4, 8, 32, MODE_F32, 4>(ix, qn, nq, max_chunks, docscore, stream);     // 4 groups/unit
         default: return launch_scan_v2<QB, TILED, 12>(ix, qn, nq, max_chunks, docscore, stream);   // 0, 3
     }
 }

@@ -92,8 +92,8 @@ extern "C" int msr_create(const msr_config* cfg, msr_engine** out) {
         return fail(nullptr, MSR_ERR_INVALID, "msr_create: rerank_max_docs out of range [0, 1024]");
     if (cfg->scan_layout != 0 && cfg->scan_layout != 1)
         return fail(nullptr, MSR_ERR_INVALID, "msr_create: scan_layout must be 0 or 1");
-    if (cfg->scan_variant < 0 || cfg->scan_variant > 8)
-        return fail(nullptr, MSR_ERR_INVALID, "msr_create: scan_variant must be 0..8");
+    if (cfg->scan_variant < 0 || cfg->scan_variant > 12)
+        return fail(nullptr, MSR_ERR_INVALID, "msr_create: scan_variant must be 0..12");
     int ndev = 0;
     hipError_t herr = hipGetDeviceCount(&ndev);
     if (herr != hipSuccess || ndev <= 0)
