@@ -19,6 +19,7 @@ constexpr int BT_THREADS = 256;
 constexpr int BT_STAGE = 1024;
 
 __global__ __launch_bounds__(BT_THREADS) void thr_compact_kernel(const float* __restrict__ scores, int64_t n,
+                                                                  int64_t stride,
                                                                   const float* __restrict__ top_score,
                                                                   const int32_t* __restrict__ top_n, int k,
                                                                   float margin, int32_t* __restrict__ cand_doc,
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(BT_THREADS) void thr_compact_kernel(const float* __
     const int64_t per = (n + gridDim.x - 1) / gridDim.x;
     const int64_t lo = (int64_t)blockIdx.x * per;
     const int64_t hi = lo + per < n ? lo + per : n;
-    const float* row = scores + (int64_t)q * n;
+    const float* row = scores + (int64_t)q * stride;
     for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += 4 * BT_THREADS) {
         float v[4];
 #pragma unroll
@@ -166,7 +167,7 @@ hipError_t msr_batch_finish(const DenseIndex& ix, const float* qn, int nq, int k
     const int64_t max_parts = 2048 / nq > 0 ? 2048 / nq : 1;
     if (parts > max_parts) parts = max_parts;
     if (parts < 1) parts = 1;
-    thr_compact_kernel<<<dim3((unsigned)parts, (unsigned)nq), BT_THREADS, 0, stream>>>(scores, ix.n_docs, top_score,
+    thr_compact_kernel<<<dim3((unsigned)parts, (unsigned)nq), BT_THREADS, 0, stream>>>(scores, ix.n_docs, ix.score_stride, top_score,
                                                                                       top_n, k, margin, cand_doc, cand_n);
     rescore_kernel<<<dim3(64, (unsigned)nq), BT_THREADS, 0, stream>>>(ix, qn, max_chunks, cand_doc, cand_n, cand_score,
                                                                     cand_chunk);

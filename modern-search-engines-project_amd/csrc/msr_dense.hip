@@ -69,7 +69,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void dense_scan_kernel(DenseIndex ix,
     }
     __syncthreads();
 
-    const int64_t N = ix.n_docs;
     const int64_t C = ix.n_chunks;
     const float NEG_INF = -__builtin_inff();
 
@@ -79,7 +78,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void dense_scan_kernel(DenseIndex ix,
         // chunk-less documents get -inf for every query
         for (int d = d0 + tid; d < d1; d += SCAN_THREADS)
             if (ix.doc_off[d + 1] == ix.doc_off[d])
-                for (int qq = 0; qq < nq; ++qq) docscore[(int64_t)qq * N + d] = NEG_INF;
+                for (int qq = 0; qq < nq; ++qq) docscore[(int64_t)qq * ix.score_stride + d] = NEG_INF;
         int parity = 0;
         for (int64_t st = c0 & ~(int64_t)15; st < c1; st += ST_ROWS) {
             // ---- phase 1: 16 rows x NQP queries per wave on the f32 matrix cores -------------------
@@ -166,7 +165,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void dense_scan_kernel(DenseIndex ix,
                             float m = continued ? carry[parity * L::NQP + qq] : NEG_INF;
                             for (int64_t rr = r; rr < stop; ++rr)
                                 m = fmaxf(m, sbuf[(int)(rr - st) * L::SROW + qq]);
-                            if (finished) docscore[(int64_t)qq * N + d] = m;
+                            if (finished) docscore[(int64_t)qq * ix.score_stride + d] = m;
                             else carry[(parity ^ 1) * L::NQP + qq] = m;
                         }
                     }
@@ -239,7 +238,7 @@ __global__ __launch_bounds__(WAVES * 64) void dense_scan_v2_kernel(DenseIndex ix
                                                                     const int32_t* __restrict__ wspan,
                                                                     int n_wspans, const f32x4* __restrict__ qimg,
                                                                     int nq, int max_chunks,
-                                                                    float* __restrict__ docscore) {
+                                                                    float* __restrict__ docscore, int dbg) {
     using L = ScanCfgV2<QB, MODE, WAVES, OBD>;
     constexpr int KS = L::KS, NL = L::NL;
     constexpr bool BF16 = MODE == MODE_BF16;
@@ -261,7 +260,7 @@ __global__ __launch_bounds__(WAVES * 64) void dense_scan_v2_kernel(DenseIndex ix
 
     const int s = blockIdx.x * WAVES + w;
     if (s >= n_wspans) return;                                   // wave-uniform
-    const int64_t N = ix.n_docs, C = ix.n_chunks;
+    const int64_t C = ix.n_chunks;
     const float NEG_INF = -__builtin_inff();
     const int d0 = wspan[s], d1 = wspan[s + 1];
     const int64_t c0 = ix.doc_off[d0], c1 = ix.doc_off[d1];
@@ -274,7 +273,7 @@ __global__ __launch_bounds__(WAVES * 64) void dense_scan_v2_kernel(DenseIndex ix
         constexpr int QPI = 64 / OD;
         for (int qq0 = 0; qq0 < nq; qq0 += QPI) {
             const int qq = qq0 + lane / OD, dd = lane % OD;
-            if (qq < nq && dd < ob_n) docscore[(int64_t)qq * N + ob_base + dd] = OB[dd * L::SROW + qq];
+            if (qq < nq && dd < ob_n && !(dbg & 1)) docscore[(int64_t)qq * ix.score_stride + ob_base + dd] = OB[dd * L::SROW + qq];
         }
         ob_base += ob_n;
         ob_n = 0;
@@ -283,12 +282,16 @@ __global__ __launch_bounds__(WAVES * 64) void dense_scan_v2_kernel(DenseIndex ix
         if (DIRECT) {
             // 64-query sweeps have no LDS left for staging: each lane stores its query's value; the 32 stores that
             // complete a 128 B line of a score row come from this same wave within ~10 row groups (L2 merges them)
-            if (lane < nq) docscore[(int64_t)lane * N + ob_base] = m;
+            if (lane < nq) docscore[(int64_t)lane * ix.score_stride + ob_base] = m;
             ++ob_base;
             return;
         }
         if (lane < L::NQP) OB[ob_n * L::SROW + lane] = m;
-        if (++ob_n == OBD) flush();
+        // flush when the staged run reaches a 128 B boundary of the score rows: full aligned lines, no partial-sector
+        // writes (they cost a read-modify-write at the ECC memory: 12 % of the 32-query sweep in profile r01_h)
+        constexpr int OD = OBD > 0 ? OBD : 32;
+        ++ob_n;
+        if (((ob_base + ob_n) & (OD - 1)) == 0) flush();
     };
 
     int cur_doc = d0 - 1;                                        // last document that has been emitted/opened
@@ -628,6 +631,12 @@ __global__ __launch_bounds__(64) void best_chunk_kernel(DenseIndex ix, const flo
     if (lane == 0) out_chunk[(int64_t)q * k + r] = (int32_t)arg;
 }
 
+// Diagnostic knob for timing experiments only (MSR_SCAN_DEBUG: bit 0 = drop the score-row stores).
+static int scan_debug_flags() {
+    static const int v = [] { const char* e = getenv("MSR_SCAN_DEBUG"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 template <int QB, bool TILED>
 hipError_t launch_scan(const DenseIndex& ix, const float* qn, int nq, int max_chunks, float* docscore,
                        hipStream_t stream) {
@@ -656,7 +665,7 @@ hipError_t launch_scan_v2(const DenseIndex& ix, const float* qn, int nq, int max
     const int n_sp = WAVES == 12 ? ix.n_wspans12 : ix.n_wspans;
     const int grid = (n_sp + WAVES - 1) / WAVES;
     dense_scan_v2_kernel<QB, TILED, LB, MODE, WAVES, OBD, G><<<grid, L::THREADS, lds, stream>>>(
-        ix, ix.emb, spans, n_sp, (const f32x4*)ix.qimg, nq, max_chunks, docscore);
+        ix, ix.emb, spans, n_sp, (const f32x4*)ix.qimg, nq, max_chunks, docscore, scan_debug_flags());
     return hipGetLastError();
 }
 
@@ -674,7 +683,7 @@ hipError_t launch_scan_bf16_cfg(const DenseIndex& ix, const float* qn, int nq, i
     // the per-wave spans were cut for 8 waves per CU; with fewer waves a workgroup takes fewer of them
     const int grid = (ix.n_wspans + WAVES - 1) / WAVES;
     dense_scan_v2_kernel<QB, false, LB, MODE_BF16, WAVES, OBD><<<grid, L::THREADS, lds, stream>>>(
-        ix, ix.emb_bf16, ix.wspan_doc, ix.n_wspans, (const f32x4*)ix.qimg, nq, max_chunks, docscore);
+        ix, ix.emb_bf16, ix.wspan_doc, ix.n_wspans, (const f32x4*)ix.qimg, nq, max_chunks, docscore, scan_debug_flags());
     return hipGetLastError();
 }
 

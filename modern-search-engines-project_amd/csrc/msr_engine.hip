@@ -159,7 +159,9 @@ extern "C" int msr_destroy(msr_engine* e) {
 
 // (Re)size the per-slice score rows: max_queries rows of n_docs float64.
 static int ensure_score_rows(msr_engine* e, int64_t n_docs) {
-    const size_t need = (size_t)e->cfg.max_queries * (size_t)n_docs * sizeof(double);
+    // f64 candidate scores of max_queries queries, or f32 score rows (padded to 32 documents) of up to 64 queries
+    const size_t pad = (size_t)(n_docs + 31) / 32 * 32;
+    const size_t need = std::max((size_t)e->cfg.max_queries * pad * sizeof(double), (size_t)64 * pad * sizeof(float));
     if (need <= e->score_rows_bytes) return MSR_OK;
     free_dev(e->score_rows);
     e->score_rows = nullptr;
@@ -321,7 +323,7 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
         inv_norm = e->inv_norm_own;
     }
     HIP_TRY(e, hipStreamSynchronize(st));                 // spans vector goes out of scope
-    e->dense = DenseIndex{emb, doc_off, e->chunk_doc, inv_norm, e->span_doc, n_chunks, n_docs, n_spans,
+    e->dense = DenseIndex{emb, doc_off, e->chunk_doc, inv_norm, e->span_doc, n_chunks, n_docs, (n_docs + 31) / 32 * 32, n_spans,
                           e->cfg.scan_layout, e->wspan_doc, n_wspans, e->wspan12_doc, n_wspans12, e->qimg, nullptr,
                           e->cfg.scan_variant};
     free_dev(e->emb_bf16);                                // a new binding invalidates the bf16 copy
@@ -423,7 +425,7 @@ extern "C" int msr_dense_topk(msr_engine* e, const float* q, int32_t n_queries, 
             HIP_TRY(e, hipEventRecord(e->ev_stop[0][e->ev_count[0]], st));
             e->ev_count[0]++;
         }
-        HIP_TRY(e, msr_select_topk(32, e->score_rows, N, N, nq, k, e->sel, out_doc + (int64_t)q0 * k,
+        HIP_TRY(e, msr_select_topk(32, e->score_rows, N, e->dense.score_stride, nq, k, e->sel, out_doc + (int64_t)q0 * k,
                                    out_score + (int64_t)q0 * k, out_n + q0, st));
         if (out_chunk)
             HIP_TRY(e, msr_best_chunk(e->dense, e->qn, nq, k, max_chunks_per_doc, out_doc + (int64_t)q0 * k,
@@ -499,7 +501,8 @@ extern "C" int msr_dense_topk_bf16(msr_engine* e, const float* q, int32_t n_quer
         // k-th largest approximate score per query (the select state is sized for max_queries >= 32: two halves)
         for (int h0 = 0; h0 < nq; h0 += e->cfg.max_queries) {
             const int hn = std::min(e->cfg.max_queries, nq - h0);
-            HIP_TRY(e, msr_select_topk(32, (const float*)e->score_rows + (int64_t)h0 * N, N, N, hn, k, e->sel,
+            HIP_TRY(e, msr_select_topk(32, (const float*)e->score_rows + (int64_t)h0 * e->dense.score_stride, N,
+                                       e->dense.score_stride, hn, k, e->sel,
                                        e->bt_top_doc + (int64_t)h0 * k, e->bt_top_score + (int64_t)h0 * k,
                                        e->bt_top_n + h0, st));
         }

@@ -79,6 +79,8 @@ struct DenseIndex {
     const float* inv_norm;     // [n_chunks]
     const int32_t* span_doc;   // [n_spans+1] document boundaries of the workgroup spans (scan variant 1)
     int64_t n_chunks, n_docs;
+    int64_t score_stride;      // elements between the score rows of consecutive queries (n_docs rounded up to 32:
+                               // every row starts on a 128 B line)
     int32_t n_spans;
     int32_t layout;            // 0 row-major, 1 interleaved
     const int32_t* wspan_doc;  // [n_wspans+1] document boundaries of the per-wave spans (scan variants 2, 3)
@@ -91,7 +93,7 @@ struct DenseIndex {
                                // 1: super-tile kernel of the first profile
 };
 // qn: [ceil16(nq)][768] normalised queries (zero rows as padding).
-// docscore[q][n_docs] <- max cosine over the document's chunks (-inf for chunk-less documents).
+// docscore[q][ix.score_stride] <- max cosine over the document's chunks (-inf for chunk-less documents).
 hipError_t msr_dense_scan(const DenseIndex& ix, const float* qn, int nq, int max_chunks, float* docscore,
                           hipStream_t stream);
 // bf16 candidate scan (<= 64 queries per sweep); qn as above with ceil16(nq) rows.

@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--configs", default="0:0,0:1,0:3,1:0,1:1,1:3", help="layout:variant list")
     ap.add_argument("--queries", default="1,16,32")
+    ap.add_argument("--nonzero", type=int, default=-1,
+                    help="diagnostic: keep only the first N query rows non-zero (the MFMA count stays, operand data changes)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     ix = synthetic_corpus(args.docs, n_chunks=args.chunks, device=dev, with_postings=False)
@@ -32,6 +34,9 @@ def main():
     engines = {c: DeviceEngine(ix, max_queries=32, max_k=100, rerank_max_docs=0, scan_layout=c[0], scan_variant=c[1]) for c in cfgs}
     g = torch.Generator(device="cpu"); g.manual_seed(5)
     qs = {int(q): torch.randn((int(q), 768), generator=g).to(dev) for q in args.queries.split(",")}
+    if args.nonzero >= 0:
+        for v in qs.values():
+            v[args.nonzero:] = 0
     alg = args.chunks * 768 * 4
     res = {}
     ref = {}
@@ -46,6 +51,8 @@ def main():
                 if rnd:                                   # round 0 = warm-up
                     res.setdefault((c, Q), []).append(ms / n)
                 key = Q
+                if args.nonzero >= 0:
+                    continue                              # diagnostic run: results are degenerate, timing only
                 if key not in ref:
                     ref[key] = [x.cpu() for x in (out[0], out[1])]
                 else:
