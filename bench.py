@@ -317,6 +317,8 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes, "launches": k_n, "ms_per_launch": per_launch_ms}
         if args.workload == "hybrid":
             roof["bm25_taat_ms_per_launch"] = bm_ms / max(1, bm_n)
+        dense_dt = {"f32": "f32", "f16x2": "f32 via f16x2-split products, f32 accumulate (|err| <= 8e-6)",
+                    "none": "-"}[eng.scan_arith()]
         names = {"hybrid": "two-stage retrieval top-100 (BM25 top-1000 + dense full scan + rerank/fuse)" +
                            (" [dense stage: bf16 candidates + f32 rescore]" if args.dense_mode == "bf16" else ""),
                  "bm25": f"BM25 top-{args.k1}", "dense": f"dense full-scan top-{args.k2}" + (" (bf16 candidates + f32 rescore)" if args.dense_mode == "bf16" else "")}
@@ -325,8 +327,8 @@ def main():
             "value": Q * args.steps / elapsed, "unit": "queries/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
-            "dtype": {"hybrid": "f32 (dense cosine) / f64 (BM25, fuse)", "bm25": "f64",
-                      "dense": "bf16 candidates, f32 final scores" if args.dense_mode == "bf16" else "f32"}[args.workload],
+            "dtype": {"hybrid": f"{dense_dt} (dense cosine) / f64 (BM25, fuse)", "bm25": "f64",
+                      "dense": "bf16 candidates, f32 final scores" if args.dense_mode == "bf16" else dense_dt}[args.workload],
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {args.docs} docs / {args.chunks} x 768 f32 chunks / "
                                    f"{int(shard.post_doc.numel()) if world == 1 else 'sharded'} postings, "

@@ -58,7 +58,8 @@ typedef struct msr_config {
     int32_t max_k;            /* largest k any call will ask for, <= MSR_MAX_K */
     int32_t rerank_max_docs;  /* largest candidate list per query for msr_rerank, <= 1024 */
     int32_t scan_layout;      /* 0 = row-major embeddings; 1 = 16-row interleaved */
-    int32_t scan_variant;     /* 0 = default scan kernel; 1..3 select alternatives kept for A/B measurements */
+    int32_t scan_variant;     /* 0 = default: f16-split products when every row norm is in [0.5, 2], else exact f32;
+                                 2 = always the exact-f32 MFMA kernel; other values: A/B variants (msr_dense.hip) */
 } msr_config;
 
 /* BM25 parameters travel with the postings (bm25_indexer.py:57 k1=1.2, b=0.75). */
@@ -97,6 +98,11 @@ int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks, const int
  * the query string removed, or -1 when the document is not in urlsDB.   reranker_api.py:38-47 */
 int msr_bind_doc_meta(msr_engine* e, const int32_t* url_group, int64_t n_docs, void* stream);
 
+/* Arithmetic of the bound dense scan: 0 = exact f32 MFMA (bit-for-bit a k-ordered fmaf chain), 1 = f32 rows
+ * split into two f16 pieces, three f16 MFMAs per k-step with f32 accumulation (|error| <= 8e-6 on the cosine
+ * for row norms in [0.5, 2], proof in DESIGN.md); -1 = no chunks bound. */
+int msr_scan_arith(const msr_engine* e);
+
 /* Re-order row-major rows into the 16-row interleaved scan layout (dst may not alias src).
  * n_rows is padded up to a multiple of 16 in dst (pad rows zero): dst holds ceil16(n_rows)*768 floats. */
 int msr_interleave_rows(msr_engine* e, const float* src, int64_t n_rows, float* dst, void* stream);
@@ -112,7 +118,8 @@ int msr_bm25_topk(msr_engine* e, const int32_t* q_term_off, const int32_t* q_ter
                   int32_t* out_n, void* stream);
 
 /* Dense full scan for Q queries: score(d) = max over the document's first `max_chunks_per_doc` chunks
- * (0 = all) of cosine(q, chunk), cosine as sklearn computes it in float32 (reranker_api.py:285).
+ * (0 = all) of cosine(q, chunk), cosine as sklearn computes it in float32 (reranker_api.py:285), to within the
+ * 1e-5 tolerance of the task (see msr_scan_arith for the arithmetic actually used).
  * q is [n_queries][768] f32, NOT normalised (reranker_api.py:355).  Output rows as for msr_bm25_topk,
  * with float32 scores and out_chunk = row index of the arg-max chunk (first maximum). */
 int msr_dense_topk(msr_engine* e, const float* q, int32_t n_queries, int32_t k, int32_t max_chunks_per_doc,

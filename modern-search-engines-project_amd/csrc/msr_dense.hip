@@ -704,19 +704,35 @@ template <int QB, bool TILED>
 hipError_t dispatch_variant(const DenseIndex& ix, const float* qn, int nq, int max_chunks, float* docscore,
                             hipStream_t stream) {
     switch (ix.variant) {
-        case 1: return launch_scan<QB, TILED>(ix, qn, nq, max_chunks, docscore, stream);
-        case 2: return launch_scan_v2<QB, TILED, 8>(ix, qn, nq, max_chunks, docscore, stream);
+        // 0 is resolved by the engine at bind time to 7 (f16 split) or 2 (exact f32), see msr_bind_chunks
+        case 1: return launch_scan<QB, TILED>(ix, qn, nq, max_chunks, docscore, stream);                      // super-tile kernel
+        case 2: return launch_scan_v2<QB, TILED, 12>(ix, qn, nq, max_chunks, docscore, stream);              // exact f32 MFMA
+        case 3: return launch_scan_v2<QB, TILED, 8>(ix, qn, nq, max_chunks, docscore, stream);
         case 4: return launch_scan_v2<QB, TILED, 24>(ix, qn, nq, max_chunks, docscore, stream);
-        case 5: return launch_scan_v2<QB, TILED, 12, 12, 16>(ix, qn, nq, max_chunks, docscore, stream);   // 3 waves/SIMD
+        case 5: return launch_scan_v2<QB, TILED, 12, 12, 16>(ix, qn, nq, max_chunks, docscore, stream);      // 3 waves/SIMD
         case 6: return launch_scan_v2<QB, TILED, 8, 12, 16>(ix, qn, nq, max_chunks, docscore, stream);
-        case 7: return launch_scan_v2<QB, TILED, 12, 8, 32, MODE_F16X2>(ix, qn, nq, max_chunks, docscore, stream);   // f16 split
         case 8: return launch_scan_v2<QB, TILED, 24, 8, 32, MODE_F16X2>(ix, qn, nq, max_chunks, docscore, stream);
-        case 9: return launch_scan_v2<QB, TILED, 6, 8, 32, MODE_F32, 2>(ix, qn, nq, max_chunks, docscore, stream);     // 2 groups/unit
+        case 9: return launch_scan_v2<QB, TILED, 6, 8, 32, MODE_F32, 2>(ix, qn, nq, max_chunks, docscore, stream);    // 2 groups/unit
         case 10: return launch_scan_v2<QB, TILED, 12, 8, 32, MODE_F32, 2>(ix, qn, nq, max_chunks, docscore, stream);
         case 11: return launch_scan_v2<QB, TILED, 6, 8, 32, MODE_F16X2, 2>(ix, qn, nq, max_chunks, docscore, stream);
-        case 12: return launch_scan_v2<QB, TILED, 4, 8, 32, MODE_F32, 4>(ix, qn, nq, max_chunks, docscore, stream);     // 4 groups/unit
-        default: return launch_scan_v2<QB, TILED, 12>(ix, qn, nq, max_chunks, docscore, stream);   // 0, 3
+        case 12: return launch_scan_v2<QB, TILED, 4, 8, 32, MODE_F32, 4>(ix, qn, nq, max_chunks, docscore, stream);   // 4 groups/unit
+        default: return launch_scan_v2<QB, TILED, 12, 8, 32, MODE_F16X2>(ix, qn, nq, max_chunks, docscore, stream);   // 7: f16 split
     }
+}
+
+// min / max of inv_norm over all rows (positive floats order like their bit patterns)
+__global__ __launch_bounds__(256) void norm_range_kernel(const float* __restrict__ inv_norm, int64_t n,
+                                                          uint32_t* __restrict__ out) {
+    uint32_t lo = 0x7F800000u, hi = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const uint32_t u = __float_as_uint(inv_norm[i]);
+        lo = u < lo ? u : lo; hi = u > hi ? u : hi;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t a = __shfl_xor(lo, o), b = __shfl_xor(hi, o);
+        lo = a < lo ? a : lo; hi = b > hi ? b : hi;
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&out[0], lo); atomicMax(&out[1], hi); }
 }
 
 }  // namespace
@@ -731,6 +747,14 @@ hipError_t msr_dense_scan(const DenseIndex& ix, const float* qn, int nq, int max
                      : dispatch_variant<1, false>(ix, qn, nq, max_chunks, docscore, stream);
     return tiled ? dispatch_variant<2, true>(ix, qn, nq, max_chunks, docscore, stream)
                  : dispatch_variant<2, false>(ix, qn, nq, max_chunks, docscore, stream);
+}
+
+hipError_t msr_inv_norm_range(const float* inv_norm, int64_t n, uint32_t* out2, hipStream_t stream) {
+    const uint32_t init[2] = {0x7F800000u, 0u};
+    hipError_t err = hipMemcpyAsync(out2, init, sizeof(init), hipMemcpyHostToDevice, stream);
+    if (err != hipSuccess) return err;
+    if (n > 0) norm_range_kernel<<<1024, 256, 0, stream>>>(inv_norm, n, out2);
+    return hipGetLastError();
 }
 
 hipError_t msr_dense_scan_bf16(const DenseIndex& ix, const float* qn, int nq, int max_chunks, float* docscore,

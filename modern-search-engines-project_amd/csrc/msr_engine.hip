@@ -322,10 +322,23 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
         HIP_TRY(e, msr_row_inv_norm(emb, n_chunks, e->inv_norm_own, st));
         inv_norm = e->inv_norm_own;
     }
+    // The default scan multiplies f16-split pieces (error bound in msr_dense.hip); the bound needs row norms near 1
+    // (the reference stores unit-norm rows, indexer/indexer.py:165).  Otherwise fall back to the exact f32 MFMA kernel.
+    int variant = e->cfg.scan_variant;
+    if (variant == 0) {
+        uint32_t h_rng[2] = {0, 0};
+        HIP_TRY(e, msr_inv_norm_range(inv_norm, n_chunks, (uint32_t*)e->sel.cand_n, st));   // 2 scratch words
+        HIP_TRY(e, hipMemcpyAsync(h_rng, e->sel.cand_n, sizeof(h_rng), hipMemcpyDeviceToHost, st));
+        HIP_TRY(e, hipMemsetAsync(e->sel.cand_n, 0, 2 * sizeof(int32_t), st));
+        HIP_TRY(e, hipStreamSynchronize(st));
+        float lo, hi;
+        memcpy(&lo, &h_rng[0], 4); memcpy(&hi, &h_rng[1], 4);
+        variant = (lo >= 0.5f && hi <= 2.0f) ? 7 : 2;
+    }
     HIP_TRY(e, hipStreamSynchronize(st));                 // spans vector goes out of scope
     e->dense = DenseIndex{emb, doc_off, e->chunk_doc, inv_norm, e->span_doc, n_chunks, n_docs, (n_docs + 31) / 32 * 32, n_spans,
                           e->cfg.scan_layout, e->wspan_doc, n_wspans, e->wspan12_doc, n_wspans12, e->qimg, nullptr,
-                          e->cfg.scan_variant};
+                          variant};
     free_dev(e->emb_bf16);                                // a new binding invalidates the bf16 copy
     e->emb_bf16 = nullptr;
     e->have_chunks = true;
@@ -348,6 +361,12 @@ extern "C" int msr_interleave_rows(msr_engine* e, const float* src, int64_t n_ro
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     HIP_TRY(e, msr_interleave(src, n_rows, dst, (hipStream_t)stream));
     return MSR_OK;
+}
+
+extern "C" int msr_scan_arith(const msr_engine* e) {
+    if (!e || !e->have_chunks) return -1;
+    const int v = e->dense.variant;
+    return (v == 7 || v == 8 || v == 11) ? 1 : 0;
 }
 
 extern "C" int msr_set_timing(msr_engine* e, int32_t enabled) {

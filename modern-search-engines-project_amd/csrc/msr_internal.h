@@ -89,8 +89,8 @@ struct DenseIndex {
     int32_t n_wspans12;
     void* qimg;                // engine scratch: query image in MFMA-fragment order (<= 96 KB)
     const void* emb_bf16;      // bf16 [n_chunks][768] copy of emb for the batched path, or null
-    int32_t variant;           // 0/3: wave-streaming kernel, 12-step load batches (default); 2: 8-step; 4: 24-step;
-                               // 1: super-tile kernel of the first profile
+    int32_t variant;           // scan kernel: 7 = f16-split products (default when the row norms allow it), 2 = exact f32
+                               // MFMA, 1 = super-tile kernel of the first profile, others: A/B variants (msr_dense.hip)
 };
 // qn: [ceil16(nq)][768] normalised queries (zero rows as padding).
 // docscore[q][ix.score_stride] <- max cosine over the document's chunks (-inf for chunk-less documents).
@@ -100,6 +100,8 @@ hipError_t msr_dense_scan(const DenseIndex& ix, const float* qn, int nq, int max
 hipError_t msr_dense_scan_bf16(const DenseIndex& ix, const float* qn, int nq, int max_chunks, float* docscore,
                                hipStream_t stream);
 hipError_t msr_to_bf16(const float* src, int64_t n_elems, void* dst, hipStream_t stream);
+// out2 (device, 2 words) <- bit patterns of min and max of inv_norm[0..n)
+hipError_t msr_inv_norm_range(const float* inv_norm, int64_t n, uint32_t* out2, hipStream_t stream);
 hipError_t msr_prep_queries(const float* q, int nq, float* qn, int nq_pad, hipStream_t stream);
 hipError_t msr_fill_chunk_doc(const int32_t* doc_off, int64_t n_docs, int32_t* chunk_doc, hipStream_t stream);
 hipError_t msr_row_inv_norm(const float* emb, int64_t n_rows, float* inv_norm, hipStream_t stream);

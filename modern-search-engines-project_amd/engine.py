@@ -100,6 +100,10 @@ class DeviceEngine:
                 self._check(self.lib.msr_bind_doc_meta(self.handle, _ptr(t["url_group"]), ix.n_docs, self._stream()))
             torch.cuda.synchronize(self.device)
 
+    def scan_arith(self):
+        """'f32' (exact f32 MFMA) or 'f16x2' (f32 rows split into two f16 pieces, f32 accumulation)."""
+        return {0: "f32", 1: "f16x2"}.get(self.lib.msr_scan_arith(self.handle), "none")
+
     # ------------------------------------------------------------------ stage 1
     def pack_queries(self, term_lists):
         """list of term-id lists (repeats allowed, any unknown id < 0) -> device CSR of UNIQUE terms in

@@ -98,6 +98,22 @@ def test_dense_fullsize_vs_torch_f32(world):
     assert float(score[:, 0].min()) > 0.8
 
 
+def test_dense_fullsize_f16split_vs_exact(world):
+    """The default (f16-split) scan against the exact f32 MFMA scan on the full corpus: same top-100 up to
+    near-ties, scores within the proven bound."""
+    ix, eng, qvec = world["ix"], world["eng"], world["qvec"]
+    assert eng.scan_arith() == "f16x2"
+    exact = world["DeviceEngine"](ix, max_queries=32, max_k=100, rerank_max_docs=0, scan_variant=2)
+    assert exact.scan_arith() == "f32"
+    a = eng.dense_topk(qvec[:32], k=100)
+    b = exact.dense_topk(qvec[:32], k=100)
+    err = float((a[1] - b[1]).abs().max())
+    print(f"max |f16split - exact f32| over 32 x 100 scores: {err:.3e}")
+    assert err <= 8e-6
+    assert bool(((a[0] == b[0]) | ((a[1] - b[1]).abs() <= 8e-6)).all())
+    exact.close()
+
+
 def test_dense_fullsize_properties(world):
     eng, qvec = world["eng"], world["qvec"]
     a = eng.dense_topk(qvec[:32], k=100)

@@ -158,7 +158,8 @@ def _check_dense(mods, eng, doc_off, emb, q, k, mc, got):
             assert abs(cos_c - best[d]) <= 2e-5
 
 
-@pytest.mark.parametrize("layout,variant", [(0, 0), (1, 0), (0, 1), (1, 1), (0, 2), (1, 2), (0, 4), (0, 5), (1, 6), (0, 7), (1, 7), (0, 8), (0, 9), (1, 9), (0, 10), (0, 11), (0, 12)])
+@pytest.mark.parametrize("layout,variant", [(0, 0), (1, 0), (0, 1), (1, 1), (0, 2), (1, 2), (0, 3), (0, 4), (0, 5), (1, 6), (0, 7),
+                                            (1, 7), (0, 8), (0, 9), (1, 9), (0, 10), (0, 11), (1, 11), (0, 12)])
 def test_dense_scan_vs_oracle(mods, layout, variant):
     rng = np.random.default_rng(17 + layout)
     doc_off, emb = _rand_chunked(rng, 700, 9, big=((5, 70), (300, 300), (301, 0), (699, 33)))
@@ -189,6 +190,29 @@ def test_dense_tiny_and_ragged(mods, variant):
         got = eng.dense_topk(q, k=64)
         _check_dense(mods, eng, doc_off, emb, q, 64, 0, got)
         eng.close()
+
+
+def test_scan_arithmetic_is_chosen_from_the_row_norms(mods):
+    """Default engine: f16-split products for (near) unit-norm rows, the exact f32 MFMA kernel as soon as one row
+    norm leaves [0.5, 2]; scan_variant = 2 forces the exact kernel."""
+    rng = np.random.default_rng(8)
+    doc_off, emb = _rand_chunked(rng, 400, 5)
+    mk = lambda e, **kw: mods["DeviceEngine"](mods["CorpusIndex"](
+        doc_ids=np.arange(400, dtype=np.int64), doc_off=doc_off.astype(np.int32),
+        chunk_ids=np.arange(doc_off[-1], dtype=np.int64), emb=e, total_docs=400), max_queries=4, max_k=10, **kw)
+    a = mk(emb); assert a.scan_arith() == "f16x2"
+    b = mk(emb, scan_variant=2); assert b.scan_arith() == "f32"
+    big = emb.copy(); big[7] *= 2.5
+    c = mk(big); assert c.scan_arith() == "f32"
+    small = emb.copy(); small[9] *= 0.3
+    d = mk(small); assert d.scan_arith() == "f32"
+    zero = emb.copy(); zero[3] = 0.0                       # a zero row has "norm 1" (sklearn) and stays eligible
+    z = mk(zero); assert z.scan_arith() == "f16x2"
+    q = rng.standard_normal((2, 768)).astype(np.float32)
+    sa, sb = a.dense_topk(q, k=10)[1].cpu().numpy(), b.dense_topk(q, k=10)[1].cpu().numpy()
+    assert np.abs(sa - sb).max() <= 8e-6                    # the proven bound; typically ~1e-7
+    for e in (a, b, c, d, z):
+        e.close()
 
 
 def test_dense_massive_ties(mods):
