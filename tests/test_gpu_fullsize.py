@@ -128,7 +128,8 @@ def test_dense_fullsize_properties(world):
     assert float((c[0] == a[0]).float().mean()) > 0.99
     d1 = eng.dense_topk(qvec[:8], k=100, max_chunks_per_doc=1)                     # max over fewer chunks is smaller
     d3 = eng.dense_topk(qvec[:8], k=100, max_chunks_per_doc=3)
-    assert bool((d1[1] <= d3[1] + 1e-7).all()) and bool((d3[1] <= a[1][:8] + 1e-7).all())
+    # (8-query and 32-query launches sum in a different order: allow the rounding of two f32 sums)
+    assert bool((d1[1] <= d3[1] + 2e-6).all()) and bool((d3[1] <= a[1][:8] + 2e-6).all())
     # a batch of 40 (two internal sweeps) equals the same queries issued as 32 + 8
     e = eng.dense_topk(world["qvec"][:40], k=100)
     f = eng.dense_topk(world["qvec"][32:40], k=100)
