@@ -158,8 +158,7 @@ def _check_dense(mods, eng, doc_off, emb, q, k, mc, got):
             assert abs(cos_c - best[d]) <= 2e-5
 
 
-@pytest.mark.parametrize("layout,variant", [(0, 0), (1, 0), (0, 1), (1, 1), (0, 2), (1, 2), (0, 3), (0, 4), (0, 5), (1, 6), (0, 7),
-                                            (1, 7), (0, 8), (0, 9), (1, 9), (0, 10), (0, 11), (1, 11), (0, 12)])
+@pytest.mark.parametrize("layout,variant", [(0, 0), (1, 0), (0, 1), (0, 2), (1, 2), (0, 4), (0, 5), (0, 8), (0, 9), (1, 11), (0, 12)])
 def test_dense_scan_vs_oracle(mods, layout, variant):
     rng = np.random.default_rng(17 + layout)
     doc_off, emb = _rand_chunked(rng, 700, 9, big=((5, 70), (300, 300), (301, 0), (699, 33)))
