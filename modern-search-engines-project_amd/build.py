@@ -19,6 +19,7 @@ UNITS = {
     "msr_topk.hip": [],
     "msr_bm25.hip": ["-ffp-contract=off"],
     "msr_dense.hip": [],
+    "msr_dense_ks.hip": [],
     "msr_rerank.hip": ["-ffp-contract=off"],
     "msr_batch.hip": [],
 }

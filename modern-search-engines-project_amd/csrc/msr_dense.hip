@@ -25,10 +25,9 @@
 
 #include "msr_common.h"
 #include "msr_internal.h"
+#include "msr_frag.h"
 
 namespace {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SCAN_WAVES = 16;
 constexpr int SCAN_THREADS = SCAN_WAVES * 64;
@@ -190,7 +189,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void dense_scan_kernel(DenseIndex ix,
 //   f32  : 16 dims per k-step, 4 x v_mfma_f32_16x16x4_f32 per load and query block, up to 32 queries, exact f32
 //   bf16 : 32 dims per k-step, 1 x v_mfma_f32_16x16x32_bf16 per load and query block, up to 64 queries; used as
 //          the candidate generator of the batched path (K5), its scores are re-computed in f32 afterwards
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // MODE: how a row group is multiplied
 //   0  f32 rows, v_mfma_f32_16x16x4_f32 (exact f32: bit-for-bit a k-ordered fmaf chain)
@@ -199,7 +197,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 //      v_mfma_f32_16x16x32_f16 (hi*hi + hi*lo + lo*hi) replace eight f32 MFMAs.  Every f16 x f16 product is exact in
 //      f32 and the accumulation is f32, so |error| <= 3 * 2^-20 * sum|e_i q_i| <= 2.9e-6 for unit vectors: inside
 //      the 1e-5 cosine tolerance by construction, at about a third of the matrix-pipe time and far less power.
-constexpr int MODE_F32 = 0, MODE_BF16 = 1, MODE_F16X2 = 2;
 
 template <int QB, int MODE, int WAVES, int OBD = 32> struct ScanCfgV2 {   // OBD: staged documents per wave (0 = none)
     static constexpr int NL = MODE == MODE_BF16 ? MSR_DIM / 32 : MSR_DIM / 16;      // 16 B loads per lane per row group
@@ -217,22 +214,6 @@ template <int QB, int MODE, int WAVES, int OBD = 32> struct ScanCfgV2 {   // OBD
 };
 
 // qimg: the query image already in fragment order, [QB][KS][64 lanes] x 16 B (see build_qimage_kernel)
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-
-// x (8 floats in two float4) -> hi, lo with x ~= hi + lo.  cvt_pkrtz rounds toward zero, so the residual x - hi is
-// exact in f32 and smaller than 2^-10 |x|; after the second truncation |x - hi - lo| < 2^-20 |x|.
-__device__ __forceinline__ void split_f16(const f32x4& a, const f32x4& b, f16x8& hi, f16x8& lo) {
-    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-        const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x[j], x[j + 1]));
-        const f16x2 l = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x[j] - (float)h[0], x[j + 1] - (float)h[1]));
-        hi[j] = h[0]; hi[j + 1] = h[1];
-        lo[j] = l[0]; lo[j + 1] = l[1];
-    }
-}
-
 template <int QB, bool TILED, int LB, int MODE, int WAVES, int OBD = 32, int G = 1>
 __global__ __launch_bounds__(WAVES * 64) void dense_scan_v2_kernel(DenseIndex ix, const void* __restrict__ emb,
                                                                     const int32_t* __restrict__ wspan,
@@ -740,6 +721,9 @@ __global__ __launch_bounds__(256) void norm_range_kernel(const float* __restrict
 hipError_t msr_dense_scan(const DenseIndex& ix, const float* qn, int nq, int max_chunks, float* docscore,
                           hipStream_t stream) {
     if (nq <= 0 || ix.n_docs <= 0) return hipSuccess;
+    // variants 13 / 14: K-split kernel (msr_dense_ks.hip) for 33..64 queries / for any count
+    if (((ix.variant == 13 && nq > 32) || ix.variant == 14) && ix.wide_ok && ix.layout == 0 && max_chunks == 0)
+        return msr_dense_scan_wide(ix, qn, nq, docscore, stream);
     if (nq > 32) return hipErrorInvalidValue;
     const bool tiled = ix.layout == 1;
     if (nq <= 16)
@@ -747,6 +731,16 @@ hipError_t msr_dense_scan(const DenseIndex& ix, const float* qn, int nq, int max
                      : dispatch_variant<1, false>(ix, qn, nq, max_chunks, docscore, stream);
     return tiled ? dispatch_variant<2, true>(ix, qn, nq, max_chunks, docscore, stream)
                  : dispatch_variant<2, false>(ix, qn, nq, max_chunks, docscore, stream);
+}
+
+hipError_t msr_build_qimage(int mode, const float* qn, int n_blocks, void* qimg, hipStream_t stream) {
+    const int ks = mode == MODE_F32 ? MSR_DIM / 16 : MSR_DIM / 32;
+    const int n_img = n_blocks * ks * 64;
+    const int grid = (n_img + 255) / 256;
+    if (mode == MODE_F32) build_qimage_kernel<MODE_F32><<<grid, 256, 0, stream>>>(qn, n_blocks, (f32x4*)qimg);
+    else if (mode == MODE_BF16) build_qimage_kernel<MODE_BF16><<<grid, 256, 0, stream>>>(qn, n_blocks, (f32x4*)qimg);
+    else build_qimage_kernel<MODE_F16X2><<<grid, 256, 0, stream>>>(qn, n_blocks, (f32x4*)qimg);
+    return hipGetLastError();
 }
 
 hipError_t msr_inv_norm_range(const float* inv_norm, int64_t n, uint32_t* out2, hipStream_t stream) {

@@ -1,0 +1,275 @@
+// K2 + K3, wide sweeps -- one pass over the embedding matrix for up to 64 queries (f32 or bf16 rows).
+//
+// Same job as dense_scan_v2_kernel (msr_dense.hip; reference: reranker/reranker_api.py:273-287 cosines and the
+// per-document arg-max :370 at full-corpus scale), but decomposed so that the query side needs NO LDS: the wave
+// streaming kernel keeps the whole query image in LDS (96 KB at 32 queries), which caps a sweep at 32 queries
+// and makes every extra query cost another full read of E.  Here the K dimension is split over the 8 waves of
+// a workgroup: wave w owns the 96 dimensions [96 w, 96 w + 96) of every row and holds the matching slice of ALL
+// queries' fragments in registers for the whole kernel (the B operand of every MFMA is a loop-invariant VGPR).
+//
+//   per 16-row group ("unit") and wave:
+//     6 x 16 B loads per lane (its 384 B slice of 16 rows; 64 B of a row per instruction; prefetched NBUF-1 units
+//     ahead in a register ring), f32 -> f16 hi/lo split, 3 k-steps x 3 products x QB query blocks MFMAs into QB
+//     accumulators, the 16 x Q partial sums go to LDS (one of two buffers), ONE workgroup barrier;
+//     then every wave adds the 8 partial tiles for its eighth of the (row, query) pairs in a fixed order, scales
+//     by the row's inverse norm and folds the value into the document's slot of a ring of per-document maxima in
+//     LDS with ds_max_f32 -- no wave carries sequential per-document state, so this work is spread evenly.
+//   Documents are finished in order: when the first row of document b + 32 has been passed, the 32 maxima of the
+//   aligned block [b, b + 32) are written (whole 128 B lines of the score rows, all waves share the block) and
+//   their ring slots reset to -inf, which is also what a chunk-less document reports.
+//
+// The ring holds 128 documents; it never wraps onto live slots if any 32 consecutive rows (on 16-row group
+// boundaries) span fewer than 96 documents, which the engine checks when the chunks are bound (DenseIndex.wide_ok;
+// otherwise the narrow kernel runs).  max_chunks > 0 (a per-document row limit) also stays on the narrow kernel.
+//
+// The workgroups are persistent, one per CU, each with its own span of rows cut at a document boundary, so there
+// is no traffic between workgroups.  Bytes per launch are those of the narrow kernel (E once, 15.36 GB at 5 M
+// rows) for twice the queries; the LDS traffic is the partial tiles only (64 KB per 48 KB of rows).
+#include <stdlib.h>
+
+#include "msr_common.h"
+#include "msr_internal.h"
+#include "msr_frag.h"
+
+namespace {
+
+template <int QB, int MODE> struct KsCfg {
+    static constexpr int WAVES = 8;
+    static constexpr int THREADS = WAVES * 64;
+    static constexpr int KS = MSR_DIM / 32;                          // MFMA k-steps per row
+    static constexpr int KT = KS / WAVES;                            // k-steps per wave (3)
+    static constexpr int PIECES = MODE == MODE_F16X2 ? 2 : 1;        // operand pieces per k-step (hi, lo)
+    static constexpr int NLU = MODE == MODE_BF16 ? KT : 2 * KT;      // 16 B loads per lane and unit
+    static constexpr int ROW16 = MODE == MODE_BF16 ? MSR_DIM * 2 / 16 : MSR_DIM * 4 / 16;
+    static constexpr int NQ = 16 * QB;                               // padded query count
+    static constexpr int RING = MSR_WIDE_RING;                       // documents in the ring of maxima
+    static constexpr int SWZ = (NQ < 64 ? NQ : 64) - 1;              // column swizzle mask of the ring
+    static constexpr int TILE = QB * 64 * 4;                         // floats of one 16-row x NQ tile
+    static constexpr int PER = QB / 2;                               // tile floats per lane in the reduction
+    static constexpr size_t p_bytes = (size_t)2 * WAVES * TILE * 4;  // partial tiles of the 8 waves, two buffers
+    static constexpr size_t r_bytes = (size_t)RING * NQ * 4;
+    static constexpr size_t total = p_bytes + r_bytes;
+    static_assert(QB == 2 || QB == 4 || QB == 8, "the reduction hands QB / 2 floats (one tile column piece) to a lane");
+    static_assert(KS % WAVES == 0, "k-steps split evenly over the waves");
+    static_assert(MODE == MODE_BF16 || MODE == MODE_F16X2, "f16-split or bf16 products");
+};
+
+template <int QB, int MODE, int NBUF>
+__global__ __launch_bounds__(512) void dense_ksplit_kernel(DenseIndex ix, const void* __restrict__ emb,
+                                                           const f32x4* __restrict__ qimg, int nq,
+                                                           float* __restrict__ docscore, int dbg) {
+    using L = KsCfg<QB, MODE>;
+    constexpr int KT = L::KT, NLU = L::NLU, PIECES = L::PIECES, NQ = L::NQ, RING = L::RING, PER = L::PER;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* P = (f32x4*)smem;                                     // [2][8 waves][QB][64 lanes]
+    float* R = (float*)(smem + L::p_bytes);                      // [RING][NQ], column q of slot s at q ^ (s & SWZ)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int s = blockIdx.x;
+    if (s >= ix.n_spans) return;                                 // workgroup-uniform
+    const int64_t C = ix.n_chunks;
+    const float NEG_INF = -__builtin_inff();
+    const int d0 = ix.span_doc[s], d1 = ix.span_doc[s + 1];
+    const int64_t c0 = ix.doc_off[d0], c1 = ix.doc_off[d1];
+    const int dbase = d0 & ~31;                                  // ring slot of document d: (d - dbase) & (RING - 1)
+
+    // this wave's slice of every query fragment: loop-invariant registers
+    f32x4 B[QB][KT][PIECES];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int tt = 0; tt < KT; ++tt)
+#pragma unroll
+            for (int pc = 0; pc < PIECES; ++pc)
+                B[qb][tt][pc] = qimg[((size_t)(qb * L::KS + KT * w + tt) * PIECES + pc) * 64 + lane];
+
+    for (int i = tid; i < RING * NQ; i += L::THREADS) R[i] = NEG_INF;
+
+    // ---- finished documents: blocks of 32, in order; every wave runs the same scalar bookkeeping ----
+    int next_b = dbase;                                          // first document of the next block to write
+    auto block_end_row = [&](int b) -> int64_t { return ix.doc_off[b + 32 < d1 ? b + 32 : d1]; };
+    int64_t next_end = block_end_row(next_b);                    // once rows below this index are in, the block is complete
+    auto flush_block = [&](int b) {
+        // wave w writes queries [2 QB w, 2 QB (w + 1)): 2 queries x 32 documents per instruction, 128 B per query
+        const int dd = lane & 31, qq = lane >> 5;
+        const int slot = ((b - dbase) & (RING - 1)) + dd;
+        const int d = b + dd;
+#pragma unroll
+        for (int i = 0; i < QB; ++i) {
+            const int q = 2 * QB * w + 2 * i + qq;
+            float* cell = &R[slot * NQ + (q ^ (slot & L::SWZ))];
+            const float v = *cell;
+            *cell = NEG_INF;
+            if (q < nq && d >= d0 && d < d1 && !(dbg & 1)) docscore[(int64_t)q * ix.score_stride + d] = v;
+        }
+    };
+    auto flush_done = [&](int64_t rows_done) {                   // rows [c0, rows_done) have been folded in
+        while (next_b < d1 && next_end <= rows_done) {
+            flush_block(next_b);
+            next_b += 32;
+            if (next_b < d1) next_end = block_end_row(next_b);
+        }
+    };
+
+    const int64_t g0 = c0 >> 4, g1 = c1 > c0 ? (c1 + 15) >> 4 : g0;
+    auto clampg = [&](int64_t g) { return g < g1 ? g : g1 - 1; };
+    auto row_ptr = [&](int64_t grp) -> const f32x4* {
+        int64_t r = clampg(grp) * 16 + li;
+        if (r > C - 1) r = C - 1;
+        return (const f32x4*)emb + (size_t)r * L::ROW16 + NLU * 4 * w + lg;
+    };
+    auto meta_row = [&](int64_t grp) -> int64_t {
+        int64_t r = clampg(grp) * 16 + li;
+        return r > C - 1 ? C - 1 : r;
+    };
+    // Tile float f = ((qb * 4 + g) * 16 + n) * 4 + rr is row 4 g + rr of query 16 qb + n (D layout of the 16x16 MFMA:
+    // lane (n, g) holds rows 4 g .. 4 g + 3).  Lane l of wave w reduces floats f0 .. f0 + PER - 1.
+    const int f0 = (w * 64 + lane) * PER;
+    const int red_q = 16 * (f0 >> 8) + ((f0 >> 2) & 15);
+    const int red_r0 = 4 * ((f0 >> 6) & 3) + (f0 & 3);
+    auto reduce = [&](int buf, int64_t grp, int dv, float iv) {
+        float sum[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) sum[j] = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) {                         // fixed order: the result does not depend on timing
+            const float* src = (const float*)P + (size_t)(buf * 8 + w8) * L::TILE + f0;
+            if constexpr (PER == 4) {
+                const f32x4 x = *(const f32x4*)src;
+                sum[0] += x.x; sum[1] += x.y; sum[2] += x.z; sum[3] += x.w;
+            } else if constexpr (PER == 2) {
+                const float2 x = *(const float2*)src;
+                sum[0] += x.x; sum[1] += x.y;
+            } else {
+                sum[0] += src[0];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int r = red_r0 + j;
+            const int d = __shfl(dv, r);
+            const float inv = __shfl(iv, r);
+            const int64_t row = grp * 16 + r;
+            if (row >= c0 && row < c1) {                         // not a row of a neighbouring span / past the end
+                const int slot = (d - dbase) & (RING - 1);
+                __hip_atomic_fetch_max(&R[slot * NQ + (red_q ^ (slot & L::SWZ))], sum[j] * inv, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    };
+
+    __syncthreads();                                             // ring initialised
+    if (g1 > g0) {
+        f32x4 A[NBUF][NLU];
+        int dvr[NBUF];
+        float ivr[NBUF];
+#pragma unroll
+        for (int b = 0; b < NBUF - 1; ++b) {
+            const f32x4* p = row_ptr(g0 + b);
+#pragma unroll
+            for (int j = 0; j < NLU; ++j) A[b][j] = p[j * 4];
+            dvr[b] = ix.chunk_doc[meta_row(g0 + b)];
+            ivr[b] = ix.inv_norm[meta_row(g0 + b)];
+        }
+        dvr[NBUF - 1] = 0; ivr[NBUF - 1] = 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+
+        for (int64_t base = g0; base < g1; base += NBUF) {
+#pragma unroll
+            for (int ph = 0; ph < NBUF; ++ph) {
+                const int64_t grp = base + ph;
+                if (grp >= g1) break;                            // workgroup-uniform
+                const int nx = (ph + NBUF - 1) % NBUF;           // ring slot of the unit being prefetched
+                {
+                    const f32x4* pn = row_ptr(grp + NBUF - 1);
+#pragma unroll
+                    for (int j = 0; j < NLU; ++j) A[nx][j] = pn[j * 4];
+                    dvr[nx] = ix.chunk_doc[meta_row(grp + NBUF - 1)];
+                    ivr[nx] = ix.inv_norm[meta_row(grp + NBUF - 1)];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                f32x4 acc[QB];
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) acc[qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if constexpr (MODE == MODE_F16X2) {
+#pragma unroll
+                    for (int tt = 0; tt < KT; ++tt) {
+                        f16x8 ahi, alo;
+                        split_f16(A[ph][2 * tt], A[ph][2 * tt + 1], ahi, alo);
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+                            for (int qb = 0; qb < QB; ++qb)
+                                acc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                                    pc == 0 ? alo : ahi, __builtin_bit_cast(f16x8, pc == 1 ? B[qb][tt][PIECES - 1] : B[qb][tt][0]),
+                                    acc[qb], 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int tt = 0; tt < KT; ++tt)
+#pragma unroll
+                        for (int qb = 0; qb < QB; ++qb)
+                            acc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[ph][tt]),
+                                                                              __builtin_bit_cast(bf16x8, B[qb][tt][0]),
+                                                                              acc[qb], 0, 0, 0);
+                }
+                const int buf = (int)((grp - g0) & 1);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) P[((buf * 8 + w) * QB + qb) * 64 + lane] = acc[qb];
+                // Barrier u: unit u's eight partial tiles are complete, and so are the ring updates of unit u - 1.
+                // P[u & 1] is written again for unit u + 2, i.e. after barrier u + 1, which a wave only reaches once
+                // it has read its part of unit u.  The blocks written below are complete through unit u - 1; the ring
+                // updates of unit u that other waves issue meanwhile belong to later documents, i.e. other slots.
+                __syncthreads();
+                reduce(buf, grp, dvr[ph], ivr[ph]);
+                flush_done(grp * 16);
+            }
+        }
+        __syncthreads();                                         // the last unit's ring updates
+    }
+    flush_done((int64_t)1 << 62);                                // what is left, chunk-less tail included
+}
+
+int scan_debug_flags() {
+    static const int v = [] { const char* e = getenv("MSR_SCAN_DEBUG"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
+template <int QB, int MODE, int NBUF>
+hipError_t launch_ksplit(const DenseIndex& ix, const void* emb, const float* qn, int nq, float* docscore,
+                         hipStream_t stream) {
+    using L = KsCfg<QB, MODE>;
+    static_assert(L::total <= 160 * 1024, "LDS budget");
+    hipError_t err = hipFuncSetAttribute((const void*)dense_ksplit_kernel<QB, MODE, NBUF>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::total);
+    if (err != hipSuccess) return err;
+    err = msr_build_qimage(MODE, qn, QB, ix.qimg, stream);
+    if (err != hipSuccess) return err;
+    dense_ksplit_kernel<QB, MODE, NBUF><<<ix.n_spans, L::THREADS, L::total, stream>>>(
+        ix, emb, (const f32x4*)ix.qimg, nq, docscore, scan_debug_flags());
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// f32 rows, f16-split products, up to 64 queries per sweep (row-major layout, ix.wide_ok).
+hipError_t msr_dense_scan_wide(const DenseIndex& ix, const float* qn, int nq, float* docscore, hipStream_t stream) {
+    if (nq <= 0 || ix.n_docs <= 0) return hipSuccess;
+    if (nq > 64 || ix.layout != 0 || !ix.wide_ok) return hipErrorInvalidValue;
+    static const int nbuf = [] { const char* v = getenv("MSR_KS_NBUF"); return v ? atoi(v) : 3; }();
+    if (nq <= 32) return launch_ksplit<2, MODE_F16X2, 3>(ix, ix.emb, qn, nq, docscore, stream);
+    if (nbuf == 2) return launch_ksplit<4, MODE_F16X2, 2>(ix, ix.emb, qn, nq, docscore, stream);
+    return launch_ksplit<4, MODE_F16X2, 3>(ix, ix.emb, qn, nq, docscore, stream);
+}
+
+// bf16 rows, up to 64 queries per sweep (candidate generator of the batched path).
+hipError_t msr_dense_scan_bf16_wide(const DenseIndex& ix, const float* qn, int nq, float* docscore,
+                                    hipStream_t stream) {
+    if (nq <= 0 || ix.n_docs <= 0) return hipSuccess;
+    if (nq > 64 || !ix.emb_bf16 || !ix.wide_ok) return hipErrorInvalidValue;
+    static const int nbuf = [] { const char* v = getenv("MSR_KS_NBUF"); return v ? atoi(v) : 4; }();
+    if (nbuf == 6) return launch_ksplit<4, MODE_BF16, 6>(ix, ix.emb_bf16, qn, nq, docscore, stream);
+    return launch_ksplit<4, MODE_BF16, 4>(ix, ix.emb_bf16, qn, nq, docscore, stream);
+}

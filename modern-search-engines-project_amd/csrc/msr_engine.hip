@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -28,7 +29,7 @@ struct msr_engine {
     int32_t* wspan_doc = nullptr;
     int32_t* wspan12_doc = nullptr;
     float* qn = nullptr;              // [64][768] normalised queries of the current slice
-    void* qimg = nullptr;             // query image in fragment order (96 KB)
+    void* qimg = nullptr;             // query image in fragment order (<= 256 KB)
     void* emb_bf16 = nullptr;         // bf16 copy of the embeddings (msr_enable_bf16)
     void* score_rows = nullptr;       // max_queries rows of n_docs float64 (reused as float32 rows)
     size_t score_rows_bytes = 0;
@@ -92,8 +93,8 @@ extern "C" int msr_create(const msr_config* cfg, msr_engine** out) {
         return fail(nullptr, MSR_ERR_INVALID, "msr_create: rerank_max_docs out of range [0, 1024]");
     if (cfg->scan_layout != 0 && cfg->scan_layout != 1)
         return fail(nullptr, MSR_ERR_INVALID, "msr_create: scan_layout must be 0 or 1");
-    if (cfg->scan_variant < 0 || cfg->scan_variant > 12)
-        return fail(nullptr, MSR_ERR_INVALID, "msr_create: scan_variant must be 0..12");
+    if (cfg->scan_variant < 0 || cfg->scan_variant > 14)
+        return fail(nullptr, MSR_ERR_INVALID, "msr_create: scan_variant must be 0..14");
     int ndev = 0;
     hipError_t herr = hipGetDeviceCount(&ndev);
     if (herr != hipSuccess || ndev <= 0)
@@ -116,9 +117,10 @@ extern "C" int msr_create(const msr_config* cfg, msr_engine** out) {
     hipDeviceProp_t prop;
     if ((herr = hipGetDeviceProperties(&prop, cfg->device)) != hipSuccess) return bail(MSR_ERR_HIP, "hipGetDeviceProperties", herr);
     e->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    const size_t nq = (size_t)cfg->max_queries;
-    if ((herr = hipMalloc((void**)&e->qn, 64 * MSR_DIM * sizeof(float))) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc qn", herr);
-    if ((herr = hipMalloc(&e->qimg, 96 * 1024)) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc qimg", herr);
+    // select scratch and query buffers cover the widest sweep (128 queries) whatever max_queries says
+    const size_t nq = (size_t)std::max(cfg->max_queries, 128);
+    if ((herr = hipMalloc((void**)&e->qn, 128 * MSR_DIM * sizeof(float))) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc qn", herr);
+    if ((herr = hipMalloc(&e->qimg, 256 * 1024)) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc qimg", herr);
     if ((herr = hipMalloc((void**)&e->sel.hist, nq * MSR_SEL_BINS * sizeof(uint32_t))) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc hist", herr);
     if ((herr = hipMalloc((void**)&e->sel.state, nq * sizeof(SelState))) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc state", herr);
     if ((herr = hipMalloc((void**)&e->sel.cand_hi, nq * MSR_SEL_CAP * sizeof(uint64_t))) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc cand_hi", herr);
@@ -159,9 +161,9 @@ extern "C" int msr_destroy(msr_engine* e) {
 
 // (Re)size the per-slice score rows: max_queries rows of n_docs float64.
 static int ensure_score_rows(msr_engine* e, int64_t n_docs) {
-    // f64 candidate scores of max_queries queries, or f32 score rows (padded to 32 documents) of up to 64 queries
+    // f64 candidate scores of max_queries queries, or f32 score rows (padded to 32 documents) of up to 128 queries
     const size_t pad = (size_t)(n_docs + 31) / 32 * 32;
-    const size_t need = std::max((size_t)e->cfg.max_queries * pad * sizeof(double), (size_t)64 * pad * sizeof(float));
+    const size_t need = std::max((size_t)e->cfg.max_queries * pad * sizeof(double), (size_t)128 * pad * sizeof(float));
     if (need <= e->score_rows_bytes) return MSR_OK;
     free_dev(e->score_rows);
     e->score_rows = nullptr;
@@ -294,6 +296,19 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
     std::vector<int32_t> spans = make_spans(e->n_cus, 256);
     std::vector<int32_t> wspans = make_spans(e->n_cus * 8, 64);
     std::vector<int32_t> wspans12 = make_spans(e->n_cus * 12, 64);
+    // K-split kernels: documents spanned by any two consecutive 16-row groups must fit the LDS ring with a block to spare
+    int wide_ok = 1;
+    {
+        const int64_t n_groups = (n_chunks + 15) / 16;
+        int64_t dl = 0, dr = 0;                              // document of the window's first / last row
+        for (int64_t u = 0; u < n_groups && wide_ok; ++u) {
+            const int64_t first = 16 * u, last = std::min<int64_t>(16 * (u + 2), n_chunks) - 1;
+            while (h_off[dl + 1] <= first) ++dl;
+            if (dr < dl) dr = dl;
+            while (h_off[dr + 1] <= last) ++dr;
+            if (dr - dl + 32 > MSR_WIDE_RING) wide_ok = 0;
+        }
+    }
     const int n_spans = (int)spans.size() - 1;
     const int n_wspans = (int)wspans.size() - 1;
     const int n_wspans12 = (int)wspans12.size() - 1;
@@ -334,11 +349,12 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
         float lo, hi;
         memcpy(&lo, &h_rng[0], 4); memcpy(&hi, &h_rng[1], 4);
         variant = (lo >= 0.5f && hi <= 2.0f) ? 7 : 2;
+        if (variant == 7 && e->cfg.scan_layout == 0) variant = 13;   // + the K-split kernel for 33..64 queries per sweep
     }
     HIP_TRY(e, hipStreamSynchronize(st));                 // spans vector goes out of scope
     e->dense = DenseIndex{emb, doc_off, e->chunk_doc, inv_norm, e->span_doc, n_chunks, n_docs, (n_docs + 31) / 32 * 32, n_spans,
                           e->cfg.scan_layout, e->wspan_doc, n_wspans, e->wspan12_doc, n_wspans12, e->qimg, nullptr,
-                          variant};
+                          wide_ok, variant};
     free_dev(e->emb_bf16);                                // a new binding invalidates the bf16 copy
     e->emb_bf16 = nullptr;
     e->have_chunks = true;
@@ -366,7 +382,7 @@ extern "C" int msr_interleave_rows(msr_engine* e, const float* src, int64_t n_ro
 extern "C" int msr_scan_arith(const msr_engine* e) {
     if (!e || !e->have_chunks) return -1;
     const int v = e->dense.variant;
-    return (v == 7 || v == 8 || v == 11) ? 1 : 0;
+    return (v == 7 || v == 8 || v == 11 || v == 13 || v == 14) ? 1 : 0;
 }
 
 extern "C" int msr_set_timing(msr_engine* e, int32_t enabled) {
@@ -431,11 +447,15 @@ extern "C" int msr_dense_topk(msr_engine* e, const float* q, int32_t n_queries, 
     if (n_queries == 0) return MSR_OK;
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(e, hipSetDevice(e->cfg.device));
-    const int slice = std::min(32, e->cfg.max_queries);   // one sweep of E serves up to 32 queries
+    // one sweep of E serves up to 32 queries (wave-streaming kernel) or 64 (K-split kernel, variants 13 / 14)
+    const bool wide = (e->dense.variant == 13 || e->dense.variant == 14) && e->dense.layout == 0 && e->dense.wide_ok &&
+                      max_chunks_per_doc == 0;
+    const int slice = wide ? 64 : 32;
     const int64_t N = e->dense.n_docs;
     for (int q0 = 0; q0 < n_queries; q0 += slice) {
         const int nq = std::min(slice, n_queries - q0);
-        const int nq_pad = nq <= 16 ? 16 : 32;
+        // zero rows up to the query-block count of the kernel that runs (1, 2 or 4 blocks of 16)
+        const int nq_pad = nq > 32 ? 64 : (nq > 16 || (wide && e->dense.variant == 14)) ? 32 : 16;
         const bool timed = e->timing && e->ev_count[0] < msr_engine::EV_RING;
         HIP_TRY(e, msr_prep_queries(q + (int64_t)q0 * MSR_DIM, nq, e->qn, nq_pad, st));
         if (timed) HIP_TRY(e, hipEventRecord(e->ev_start[0][e->ev_count[0]], st));
@@ -468,7 +488,6 @@ extern "C" int msr_enable_bf16(msr_engine* e, void* stream) {
     if (!e) return MSR_ERR_INVALID;
     if (!e->have_chunks) return fail(e, MSR_ERR_NOT_BOUND, "msr_enable_bf16: chunks not bound");
     if (e->cfg.scan_layout != 0) return fail(e, MSR_ERR_INVALID, "msr_enable_bf16: needs the row-major layout");
-    if (e->cfg.max_queries < 32) return fail(e, MSR_ERR_INVALID, "msr_enable_bf16: needs max_queries >= 32 (score rows)");
     if (e->emb_bf16) return MSR_OK;
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(e, hipSetDevice(e->cfg.device));
@@ -488,9 +507,6 @@ extern "C" int msr_enable_bf16(msr_engine* e, void* stream) {
     HIP_TRY(e, hipMemsetAsync(e->bt_cand_n, 0, (size_t)BT_SLICE * 4, st));
     HIP_TRY(e, msr_to_bf16(e->dense.emb, (int64_t)n_el, e->emb_bf16, st));
     e->dense.emb_bf16 = e->emb_bf16;
-    if (e->cfg.max_queries < BT_SLICE) {
-        // a bf16 sweep writes 64 f32 score rows; the f64 rows of max_queries >= 32 queries are exactly that big
-    }
     return MSR_OK;
 }
 
@@ -506,25 +522,27 @@ extern "C" int msr_dense_topk_bf16(msr_engine* e, const float* q, int32_t n_quer
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     const int64_t N = e->dense.n_docs;
     const float margin = 2.0f * 0.0078125f;                 // 2 * eps, eps = 2^-7 (see msr_batch.hip)
+    // 33..64 queries: K-split kernel (msr_dense_ks.hip).  A/B knob for measurements: MSR_BF16_WIDE=0 keeps the
+    // wave-streaming kernel everywhere.
+    static const bool wide_knob = [] { const char* v = getenv("MSR_BF16_WIDE"); return !v || atoi(v) != 0; }();
+    const bool wide_able = wide_knob && e->dense.wide_ok && max_chunks_per_doc == 0;
     for (int q0 = 0; q0 < n_queries; q0 += BT_SLICE) {
         const int nq = std::min(BT_SLICE, n_queries - q0);
-        const int nq_pad = (nq + 15) / 16 * 16;
+        const bool wide = wide_able && nq > 32;
+        // zero rows up to the query-block count of the kernel that runs
+        const int nq_pad = wide ? 64 : (nq + 15) / 16 * 16;
         HIP_TRY(e, msr_prep_queries(q + (int64_t)q0 * MSR_DIM, nq, e->qn, nq_pad, st));
         const bool timed = e->timing && e->ev_count[0] < msr_engine::EV_RING;
         if (timed) HIP_TRY(e, hipEventRecord(e->ev_start[0][e->ev_count[0]], st));
-        HIP_TRY(e, msr_dense_scan_bf16(e->dense, e->qn, nq, max_chunks_per_doc, (float*)e->score_rows, st));
+        if (wide) HIP_TRY(e, msr_dense_scan_bf16_wide(e->dense, e->qn, nq, (float*)e->score_rows, st));
+        else HIP_TRY(e, msr_dense_scan_bf16(e->dense, e->qn, nq, max_chunks_per_doc, (float*)e->score_rows, st));
         if (timed) {
             HIP_TRY(e, hipEventRecord(e->ev_stop[0][e->ev_count[0]], st));
             e->ev_count[0]++;
         }
-        // k-th largest approximate score per query (the select state is sized for max_queries >= 32: two halves)
-        for (int h0 = 0; h0 < nq; h0 += e->cfg.max_queries) {
-            const int hn = std::min(e->cfg.max_queries, nq - h0);
-            HIP_TRY(e, msr_select_topk(32, (const float*)e->score_rows + (int64_t)h0 * e->dense.score_stride, N,
-                                       e->dense.score_stride, hn, k, e->sel,
-                                       e->bt_top_doc + (int64_t)h0 * k, e->bt_top_score + (int64_t)h0 * k,
-                                       e->bt_top_n + h0, st));
-        }
+        // k-th largest approximate score per query
+        HIP_TRY(e, msr_select_topk(32, (const float*)e->score_rows, N, e->dense.score_stride, nq, k, e->sel, e->bt_top_doc,
+                                   e->bt_top_score, e->bt_top_n, st));
         HIP_TRY(e, msr_batch_finish(e->dense, e->qn, nq, k, max_chunks_per_doc, margin, (const float*)e->score_rows,
                                     e->bt_top_score, e->bt_top_n, e->bt_cand_doc, e->bt_cand_score, e->bt_cand_chunk,
                                     e->bt_cand_n, out_doc + (int64_t)q0 * k, out_score + (int64_t)q0 * k,

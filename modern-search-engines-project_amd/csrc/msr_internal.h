@@ -72,6 +72,7 @@ hipError_t msr_bm25_scores(const Bm25Index& ix, const int32_t* q_term_off, const
 hipError_t msr_bm25_validate(const Bm25Index& ix, int32_t* flag, hipStream_t stream);
 
 // ---- K2/K3: dense scan + per-document max ---------------------------------------------------------
+constexpr int MSR_WIDE_RING = 128;           // documents in the K-split kernels' LDS ring of maxima
 struct DenseIndex {
     const float* emb;          // row-major [n_chunks][768] or interleaved image
     const int32_t* doc_off;    // [n_docs+1]
@@ -87,8 +88,10 @@ struct DenseIndex {
     int32_t n_wspans;
     const int32_t* wspan12_doc; // the same for 12 waves per CU (scan variants 5, 6)
     int32_t n_wspans12;
-    void* qimg;                // engine scratch: query image in MFMA-fragment order (<= 96 KB)
+    void* qimg;                // engine scratch: query image in MFMA-fragment order (<= 256 KB)
     const void* emb_bf16;      // bf16 [n_chunks][768] copy of emb for the batched path, or null
+    int32_t wide_ok;           // any 32 consecutive rows (on 16-row group boundaries) span <= MSR_WIDE_RING - 32 documents:
+                               // the K-split kernels' ring of per-document maxima cannot wrap onto live slots
     int32_t variant;           // scan kernel: 7 = f16-split products (default when the row norms allow it), 2 = exact f32
                                // MFMA, 1 = super-tile kernel of the first profile, others: A/B variants (msr_dense.hip)
 };
@@ -99,6 +102,13 @@ hipError_t msr_dense_scan(const DenseIndex& ix, const float* qn, int nq, int max
 // bf16 candidate scan (<= 64 queries per sweep); qn as above with ceil16(nq) rows.
 hipError_t msr_dense_scan_bf16(const DenseIndex& ix, const float* qn, int nq, int max_chunks, float* docscore,
                                hipStream_t stream);
+// Wide sweeps (msr_dense_ks.hip): up to 64 queries per pass; f16-split products over f32 rows, or bf16 rows.
+// Both need ix.wide_ok and have no per-document row limit (max_chunks = 0).
+hipError_t msr_dense_scan_wide(const DenseIndex& ix, const float* qn, int nq, float* docscore, hipStream_t stream);
+hipError_t msr_dense_scan_bf16_wide(const DenseIndex& ix, const float* qn, int nq, float* docscore,
+                                    hipStream_t stream);
+// Query image in MFMA-fragment order for n_blocks x 16 queries (mode: 0 f32, 1 bf16, 2 f16 hi/lo pieces).
+hipError_t msr_build_qimage(int mode, const float* qn, int n_blocks, void* qimg, hipStream_t stream);
 hipError_t msr_to_bf16(const float* src, int64_t n_elems, void* dst, hipStream_t stream);
 // out2 (device, 2 words) <- bit patterns of min and max of inv_norm[0..n)
 hipError_t msr_inv_norm_range(const float* inv_norm, int64_t n, uint32_t* out2, hipStream_t stream);

@@ -158,23 +158,24 @@ def _check_dense(mods, eng, doc_off, emb, q, k, mc, got):
             assert abs(cos_c - best[d]) <= 2e-5
 
 
-@pytest.mark.parametrize("layout,variant", [(0, 0), (1, 0), (0, 1), (0, 2), (1, 2), (0, 4), (0, 5), (0, 8), (0, 9), (1, 11), (0, 12)])
+@pytest.mark.parametrize("layout,variant", [(0, 0), (1, 0), (0, 1), (0, 2), (1, 2), (0, 5), (0, 7), (0, 8), (1, 11), (0, 12), (0, 14)])
 def test_dense_scan_vs_oracle(mods, layout, variant):
     rng = np.random.default_rng(17 + layout)
     doc_off, emb = _rand_chunked(rng, 700, 9, big=((5, 70), (300, 300), (301, 0), (699, 33)))
     ix = mods["CorpusIndex"](doc_ids=np.arange(700, dtype=np.int64) * 2 + 11, doc_off=doc_off.astype(np.int32),
                              chunk_ids=np.arange(doc_off[-1], dtype=np.int64), emb=emb, total_docs=700)
     eng = mods["DeviceEngine"](ix, max_queries=32, max_k=200, scan_layout=layout, scan_variant=variant)
-    for Q in (1, 5, 16, 17, 32, 40):
+    # variants 0 (default), 13, 14 use the K-split kernel for 33..64 queries per sweep (14: for any count)
+    for Q in (1, 5, 16, 17, 32, 40) + ((50, 64, 70) if variant in (0, 13, 14) else ()):
         q = (rng.standard_normal((Q, 768)) * rng.uniform(0.5, 9)).astype(np.float32)
         q[0] = emb[123] * 4.0                                  # an exact hit
-        for (k, mc) in ((100, 0), (200, 10), (7, 3)):
+        for (k, mc) in ((100, 0), (200, 10), (7, 3)) if Q <= 40 else ((100, 0), (9, 2)):
             got = eng.dense_topk(q, k=k, max_chunks_per_doc=mc)
             _check_dense(mods, eng, doc_off, emb, q, k, mc, got)
     eng.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 14])
 def test_dense_tiny_and_ragged(mods, variant):
     rng = np.random.default_rng(2)
     for n_docs, max_ch in ((1, 1), (3, 2), (40, 1), (17, 40), (5000, 3)):

