@@ -4,7 +4,7 @@ synthetic 1 M-document / 5 M x 768 f32-chunk corpus resident in HBM (BASELINE.js
 
 A STEP = one pass of the whole hot path over one batch of `--queries-per-step` (default 128) queries:
     stage 1  BM25 term-at-a-time + top-1000                        (msr_bm25_topk)
-    stage 2  dense full scan: q x chunk cosine, per-doc max-pool, top-100   (msr_dense_topk; one sweep of E per 32 queries)
+    stage 2  dense full scan: q x chunk cosine, per-doc max-pool, top-100   (msr_dense_topk; one sweep of E per 64 queries)
     fuse     reference rerank chain on the stage-1 candidates -> top-100     (msr_rerank_gather + _fuse)
 With N > 1 GPUs the corpus is doc-sharded (strong scaling: the corpus is fixed); per step one all-gather of
 the per-shard top-k lists and one integer-SUM all-reduce of the raw bits of the candidates' cosines cross xGMI.
@@ -307,9 +307,12 @@ def main():
             k_ms, k_n, kname = bm_ms, bm_n, "bm25_taat_kernel"
         else:
             bf = args.dense_mode == "bf16"
-            q_launch = min(Q, 64 if bf else 32)                 # queries served by one sweep
+            width = 64 if bf else eng.scan_width()              # queries served by one sweep
+            q_launch = min(Q, width)
             alg_bytes = n_ch * 768 * (2 if bf else 4) + (shard.n_docs + 1) * 4 + q_launch * 768 * 4
-            k_ms, k_n, kname = scan_ms, scan_n, "dense_scan_v2_kernel" + ("<bf16>" if bf else "")
+            wide_kernel = q_launch > 32                         # 33..64 queries per sweep run on the K-split kernel
+            k_ms, k_n = scan_ms, scan_n
+            kname = ("dense_ksplit_kernel" if wide_kernel else "dense_scan_v2_kernel") + ("<bf16>" if bf else "")
         per_launch_ms = k_ms / max(1, k_n)
         achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,

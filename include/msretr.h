@@ -103,6 +103,10 @@ int msr_bind_doc_meta(msr_engine* e, const int32_t* url_group, int64_t n_docs, v
  * for row norms in [0.5, 2], proof in DESIGN.md); -1 = no chunks bound. */
 int msr_scan_arith(const msr_engine* e);
 
+/* Most queries one sweep of the embedding matrix serves in msr_dense_topk: 64 when the K-split kernel is in use
+ * (f16-split arithmetic, row-major layout, no per-document row limit), else 32; -1 = no chunks bound. */
+int msr_scan_width(const msr_engine* e);
+
 /* Re-order row-major rows into the 16-row interleaved scan layout (dst may not alias src).
  * n_rows is padded up to a multiple of 16 in dst (pad rows zero): dst holds ceil16(n_rows)*768 floats. */
 int msr_interleave_rows(msr_engine* e, const float* src, int64_t n_rows, float* dst, void* stream);

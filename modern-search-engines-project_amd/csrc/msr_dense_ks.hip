@@ -54,7 +54,7 @@ template <int QB, int MODE> struct KsCfg {
     static_assert(MODE == MODE_BF16 || MODE == MODE_F16X2, "f16-split or bf16 products");
 };
 
-template <int QB, int MODE, int NBUF>
+template <int QB, int MODE, int NBUF, bool PIPE>
 __global__ __launch_bounds__(512) void dense_ksplit_kernel(DenseIndex ix, const void* __restrict__ emb,
                                                            const f32x4* __restrict__ qimg, int nq,
                                                            float* __restrict__ docscore, int dbg) {
@@ -129,23 +129,19 @@ __global__ __launch_bounds__(512) void dense_ksplit_kernel(DenseIndex ix, const 
     const int f0 = (w * 64 + lane) * PER;
     const int red_q = 16 * (f0 >> 8) + ((f0 >> 2) & 15);
     const int red_r0 = 4 * ((f0 >> 6) & 3) + (f0 & 3);
-    auto reduce = [&](int buf, int64_t grp, int dv, float iv) {
-        float sum[PER];
+    // The reduction of a unit comes in two halves so that (PIPE) the LDS reads can be in flight during the next
+    // unit's MFMAs: red_load issues them, red_finish adds in a fixed order (wave 0 .. 7: the result does not depend
+    // on timing) and folds the cosines into the ring.
+    typedef float redvec __attribute__((ext_vector_type(PER == 1 ? 1 : PER)));
+    redvec raw[8];
+    auto red_load = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < PER; ++j) sum[j] = 0.f;
+        for (int w8 = 0; w8 < 8; ++w8) raw[w8] = *(const redvec*)((const float*)P + (size_t)(buf * 8 + w8) * L::TILE + f0);
+    };
+    auto red_finish = [&](int64_t grp, int dv, float iv) {
+        redvec sum = raw[0];
 #pragma unroll
-        for (int w8 = 0; w8 < 8; ++w8) {                         // fixed order: the result does not depend on timing
-            const float* src = (const float*)P + (size_t)(buf * 8 + w8) * L::TILE + f0;
-            if constexpr (PER == 4) {
-                const f32x4 x = *(const f32x4*)src;
-                sum[0] += x.x; sum[1] += x.y; sum[2] += x.z; sum[3] += x.w;
-            } else if constexpr (PER == 2) {
-                const float2 x = *(const float2*)src;
-                sum[0] += x.x; sum[1] += x.y;
-            } else {
-                sum[0] += src[0];
-            }
-        }
+        for (int w8 = 1; w8 < 8; ++w8) sum += raw[w8];
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
             const int r = red_r0 + j;
@@ -160,6 +156,8 @@ __global__ __launch_bounds__(512) void dense_ksplit_kernel(DenseIndex ix, const 
         }
     };
 
+    int dv_prev = 0;
+    float iv_prev = 0.f;
     __syncthreads();                                             // ring initialised
     if (g1 > g0) {
         f32x4 A[NBUF][NLU];
@@ -189,15 +187,24 @@ __global__ __launch_bounds__(512) void dense_ksplit_kernel(DenseIndex ix, const 
                     dvr[nx] = ix.chunk_doc[meta_row(grp + NBUF - 1)];
                     ivr[nx] = ix.inv_norm[meta_row(grp + NBUF - 1)];
                 }
+                if (PIPE && grp > g0 && !(dbg & 4)) red_load((int)((grp - 1 - g0) & 1));   // unit u - 1: complete since barrier u - 1
                 __builtin_amdgcn_sched_barrier(0);
                 f32x4 acc[QB];
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) acc[qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if constexpr (MODE == MODE_F16X2) {
+                if (dbg & 2) {                                   // diagnostic: no split, no MFMAs (loads stay live)
+#pragma unroll
+                    for (int j = 0; j < NLU; ++j) acc[j % QB] += A[ph][j];
+                } else if constexpr (MODE == MODE_F16X2) {
 #pragma unroll
                     for (int tt = 0; tt < KT; ++tt) {
                         f16x8 ahi, alo;
-                        split_f16(A[ph][2 * tt], A[ph][2 * tt + 1], ahi, alo);
+                        if (dbg & 8) {                           // diagnostic: no split
+                            ahi = __builtin_bit_cast(f16x8, A[ph][2 * tt]);
+                            alo = __builtin_bit_cast(f16x8, A[ph][2 * tt + 1]);
+                        } else {
+                            split_f16(A[ph][2 * tt], A[ph][2 * tt + 1], ahi, alo);
+                        }
 #pragma unroll
                         for (int pc = 0; pc < 3; ++pc)
 #pragma unroll
@@ -216,16 +223,33 @@ __global__ __launch_bounds__(512) void dense_ksplit_kernel(DenseIndex ix, const 
                                                                               acc[qb], 0, 0, 0);
                 }
                 const int buf = (int)((grp - g0) & 1);
+                if constexpr (PIPE) {
+                    // finish unit u - 1 (its partial tiles were read before the MFMAs above), then publish unit u
+                    if (grp > g0 && !(dbg & 4)) {                // (dbg 4: diagnostic, no reduction)
+                        red_finish(grp - 1, dv_prev, iv_prev);
+                        flush_done((grp - 1) * 16);
+                    }
+                    dv_prev = dvr[ph]; iv_prev = ivr[ph];
 #pragma unroll
-                for (int qb = 0; qb < QB; ++qb) P[((buf * 8 + w) * QB + qb) * 64 + lane] = acc[qb];
-                // Barrier u: unit u's eight partial tiles are complete, and so are the ring updates of unit u - 1.
-                // P[u & 1] is written again for unit u + 2, i.e. after barrier u + 1, which a wave only reaches once
-                // it has read its part of unit u.  The blocks written below are complete through unit u - 1; the ring
-                // updates of unit u that other waves issue meanwhile belong to later documents, i.e. other slots.
-                __syncthreads();
-                reduce(buf, grp, dvr[ph], ivr[ph]);
-                flush_done(grp * 16);
+                    for (int qb = 0; qb < QB; ++qb) P[((buf * 8 + w) * QB + qb) * 64 + lane] = acc[qb];
+                    // Barrier u: unit u's partial tiles are complete and so are the ring updates of unit u - 1.  P[u & 1]
+                    // is written again for unit u + 2, after barrier u + 1, which a wave only reaches once it has read
+                    // its part of unit u.  Blocks written after barrier u are complete through unit u - 1; the ring
+                    // updates of unit u that other waves issue meanwhile belong to later documents, i.e. other slots.
+                    __syncthreads();
+                } else {
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) P[((buf * 8 + w) * QB + qb) * 64 + lane] = acc[qb];
+                    __syncthreads();                             // as above, with the reduction right behind the barrier
+                    red_load(buf);
+                    red_finish(grp, dvr[ph], ivr[ph]);
+                    flush_done(grp * 16);
+                }
             }
+        }
+        if constexpr (PIPE) {
+            red_load((int)((g1 - 1 - g0) & 1));
+            red_finish(g1 - 1, dv_prev, iv_prev);
         }
         __syncthreads();                                         // the last unit's ring updates
     }
@@ -237,17 +261,17 @@ int scan_debug_flags() {
     return v;
 }
 
-template <int QB, int MODE, int NBUF>
+template <int QB, int MODE, int NBUF, bool PIPE = true>
 hipError_t launch_ksplit(const DenseIndex& ix, const void* emb, const float* qn, int nq, float* docscore,
                          hipStream_t stream) {
     using L = KsCfg<QB, MODE>;
     static_assert(L::total <= 160 * 1024, "LDS budget");
-    hipError_t err = hipFuncSetAttribute((const void*)dense_ksplit_kernel<QB, MODE, NBUF>,
+    hipError_t err = hipFuncSetAttribute((const void*)dense_ksplit_kernel<QB, MODE, NBUF, PIPE>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::total);
     if (err != hipSuccess) return err;
     err = msr_build_qimage(MODE, qn, QB, ix.qimg, stream);
     if (err != hipSuccess) return err;
-    dense_ksplit_kernel<QB, MODE, NBUF><<<ix.n_spans, L::THREADS, L::total, stream>>>(
+    dense_ksplit_kernel<QB, MODE, NBUF, PIPE><<<ix.n_spans, L::THREADS, L::total, stream>>>(
         ix, emb, (const f32x4*)ix.qimg, nq, docscore, scan_debug_flags());
     return hipGetLastError();
 }
@@ -260,7 +284,9 @@ hipError_t msr_dense_scan_wide(const DenseIndex& ix, const float* qn, int nq, fl
     if (nq > 64 || ix.layout != 0 || !ix.wide_ok) return hipErrorInvalidValue;
     static const int nbuf = [] { const char* v = getenv("MSR_KS_NBUF"); return v ? atoi(v) : 3; }();
     if (nq <= 32) return launch_ksplit<2, MODE_F16X2, 3>(ix, ix.emb, qn, nq, docscore, stream);
+    static const int pipe = [] { const char* v = getenv("MSR_KS_PIPE"); return v ? atoi(v) : 1; }();
     if (nbuf == 2) return launch_ksplit<4, MODE_F16X2, 2>(ix, ix.emb, qn, nq, docscore, stream);
+    if (!pipe) return launch_ksplit<4, MODE_F16X2, 3, false>(ix, ix.emb, qn, nq, docscore, stream);
     return launch_ksplit<4, MODE_F16X2, 3>(ix, ix.emb, qn, nq, docscore, stream);
 }
 
@@ -270,6 +296,8 @@ hipError_t msr_dense_scan_bf16_wide(const DenseIndex& ix, const float* qn, int n
     if (nq <= 0 || ix.n_docs <= 0) return hipSuccess;
     if (nq > 64 || !ix.emb_bf16 || !ix.wide_ok) return hipErrorInvalidValue;
     static const int nbuf = [] { const char* v = getenv("MSR_KS_NBUF"); return v ? atoi(v) : 4; }();
+    static const int pipe = [] { const char* v = getenv("MSR_KS_PIPE"); return v ? atoi(v) : 1; }();
     if (nbuf == 6) return launch_ksplit<4, MODE_BF16, 6>(ix, ix.emb_bf16, qn, nq, docscore, stream);
+    if (!pipe) return launch_ksplit<4, MODE_BF16, 4, false>(ix, ix.emb_bf16, qn, nq, docscore, stream);
     return launch_ksplit<4, MODE_BF16, 4>(ix, ix.emb_bf16, qn, nq, docscore, stream);
 }

@@ -385,6 +385,12 @@ extern "C" int msr_scan_arith(const msr_engine* e) {
     return (v == 7 || v == 8 || v == 11 || v == 13 || v == 14) ? 1 : 0;
 }
 
+extern "C" int msr_scan_width(const msr_engine* e) {
+    if (!e || !e->have_chunks) return -1;
+    const bool wide = (e->dense.variant == 13 || e->dense.variant == 14) && e->dense.layout == 0 && e->dense.wide_ok;
+    return wide ? 64 : 32;
+}
+
 extern "C" int msr_set_timing(msr_engine* e, int32_t enabled) {
     if (!e) return MSR_ERR_INVALID;
     e->timing = enabled != 0;

@@ -105,6 +105,10 @@ class DeviceEngine:
         return {0: "f32", 1: "f16x2"}.get(self.lib.msr_scan_arith(self.handle), "none")
 
     # ------------------------------------------------------------------ stage 1
+    def scan_width(self):
+        """Queries served by one sweep of the embedding matrix in dense_topk (64 with the K-split kernel, else 32)."""
+        return int(self.lib.msr_scan_width(self.handle))
+
     def pack_queries(self, term_lists):
         """list of term-id lists (repeats allowed, any unknown id < 0) -> device CSR of UNIQUE terms in
         first-occurrence order with their query frequencies (bm25_indexer.py:405-409)."""

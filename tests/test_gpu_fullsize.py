@@ -130,10 +130,16 @@ def test_dense_fullsize_properties(world):
     d3 = eng.dense_topk(qvec[:8], k=100, max_chunks_per_doc=3)
     # (8-query and 32-query launches sum in a different order: allow the rounding of two f32 sums)
     assert bool((d1[1] <= d3[1] + 2e-6).all()) and bool((d3[1] <= a[1][:8] + 2e-6).all())
-    # a batch of 40 (two internal sweeps) equals the same queries issued as 32 + 8
+    # a batch of 40 (one 64-wide sweep of the K-split kernel) against the same queries issued as 32 + 8 (narrow kernel):
+    # another summation order, so equal up to f32 rounding and near-tie swaps
     e = eng.dense_topk(world["qvec"][:40], k=100)
     f = eng.dense_topk(world["qvec"][32:40], k=100)
-    assert torch.equal(e[0][:32], a[0]) and torch.equal(e[0][32:], f[0]) and torch.equal(e[1][32:], f[1])
+    ref_doc, ref_score = torch.cat([a[0], f[0]]), torch.cat([a[1], f[1]])
+    assert float((e[1] - ref_score).abs().max()) <= 2e-6
+    assert bool(((e[0] == ref_doc) | ((e[1] - ref_score).abs() <= 2e-6)).all())
+    # and the wide sweep is itself idempotent, bit for bit
+    e2 = eng.dense_topk(world["qvec"][:40], k=100)
+    assert torch.equal(e[0], e2[0]) and torch.equal(e[1], e2[1])
 
 
 def test_fullsize_two_shards_equal_unsharded(world):

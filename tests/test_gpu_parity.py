@@ -192,6 +192,27 @@ def test_dense_tiny_and_ragged(mods, variant):
         eng.close()
 
 
+def test_wide_sweep_needs_a_bounded_document_span(mods):
+    """The 64-query K-split kernel keeps per-document maxima in an LDS ring of 128 documents; a corpus where 32
+    consecutive rows span more documents than that (a long run of chunk-less documents) stays on the 32-query kernel.
+    Both give the oracle's answer for a batch of 40."""
+    rng = np.random.default_rng(31)
+    for gap, width in ((0, 64), (300, 32)):
+        n = rng.integers(1, 7, size=900)
+        if gap:
+            n[400:400 + gap] = 0
+        doc_off = np.zeros(901, np.int64); doc_off[1:] = np.cumsum(n)
+        emb = rng.standard_normal((int(doc_off[-1]), 768)).astype(np.float32)
+        emb /= np.linalg.norm(emb, axis=1, keepdims=True)
+        ix = mods["CorpusIndex"](doc_ids=np.arange(900, dtype=np.int64), doc_off=doc_off.astype(np.int32),
+                                 chunk_ids=np.arange(doc_off[-1], dtype=np.int64), emb=emb, total_docs=900)
+        eng = mods["DeviceEngine"](ix, max_queries=8, max_k=100)
+        assert eng.scan_arith() == "f16x2" and eng.scan_width() == width
+        q = rng.standard_normal((40, 768)).astype(np.float32)
+        _check_dense(mods, eng, doc_off, emb, q, 100, 0, eng.dense_topk(q, k=100))
+        eng.close()
+
+
 def test_scan_arithmetic_is_chosen_from_the_row_norms(mods):
     """Default engine: f16-split products for (near) unit-norm rows, the exact f32 MFMA kernel as soon as one row
     norm leaves [0.5, 2]; scan_variant = 2 forces the exact kernel."""
