@@ -307,7 +307,7 @@ def main():
             k_ms, k_n, kname = bm_ms, bm_n, "bm25_taat_kernel"
         else:
             bf = args.dense_mode == "bf16"
-            width = 64 if bf else eng.scan_width()              # queries served by one sweep
+            width = eng.batch_width() if bf else eng.scan_width()   # queries served by one sweep
             q_launch = min(Q, width)
             alg_bytes = n_ch * 768 * (2 if bf else 4) + (shard.n_docs + 1) * 4 + q_launch * 768 * 4
             wide_kernel = q_launch > 32                         # 33..64 queries per sweep run on the K-split kernel

@@ -106,6 +106,8 @@ int msr_scan_arith(const msr_engine* e);
 /* Most queries one sweep of the embedding matrix serves in msr_dense_topk: 64 when the K-split kernel is in use
  * (f16-split arithmetic, row-major layout, no per-document row limit), else 32; -1 = no chunks bound. */
 int msr_scan_width(const msr_engine* e);
+/* The same for msr_dense_topk_bf16 (after msr_enable_bf16): 128, 64, or -1. */
+int msr_batch_width(const msr_engine* e);
 
 /* Re-order row-major rows into the 16-row interleaved scan layout (dst may not alias src).
  * n_rows is padded up to a multiple of 16 in dst (pad rows zero): dst holds ceil16(n_rows)*768 floats. */

@@ -1,4 +1,4 @@
-// K2 + K3, wide sweeps -- one pass over the embedding matrix for up to 64 queries (f32 or bf16 rows).
+// K2 + K3, wide sweeps -- one pass over the embedding matrix for up to 64 queries (f32 rows) or 128 (bf16 rows).
 //
 // Same job as dense_scan_v2_kernel (msr_dense.hip; reference: reranker/reranker_api.py:273-287 cosines and the
 // per-document arg-max :370 at full-corpus scale), but decomposed so that the query side needs NO LDS: the wave
@@ -33,7 +33,7 @@
 
 namespace {
 
-template <int QB, int MODE> struct KsCfg {
+template <int QB, int MODE, int RING_DOCS = MSR_WIDE_RING> struct KsCfg {
     static constexpr int WAVES = 8;
     static constexpr int THREADS = WAVES * 64;
     static constexpr int KS = MSR_DIM / 32;                          // MFMA k-steps per row
@@ -42,7 +42,7 @@ template <int QB, int MODE> struct KsCfg {
     static constexpr int NLU = MODE == MODE_BF16 ? KT : 2 * KT;      // 16 B loads per lane and unit
     static constexpr int ROW16 = MODE == MODE_BF16 ? MSR_DIM * 2 / 16 : MSR_DIM * 4 / 16;
     static constexpr int NQ = 16 * QB;                               // padded query count
-    static constexpr int RING = MSR_WIDE_RING;                       // documents in the ring of maxima
+    static constexpr int RING = RING_DOCS;                           // documents in the ring of maxima
     static constexpr int SWZ = (NQ < 64 ? NQ : 64) - 1;              // column swizzle mask of the ring
     static constexpr int TILE = QB * 64 * 4;                         // floats of one 16-row x NQ tile
     static constexpr int PER = QB / 2;                               // tile floats per lane in the reduction
@@ -54,11 +54,11 @@ template <int QB, int MODE> struct KsCfg {
     static_assert(MODE == MODE_BF16 || MODE == MODE_F16X2, "f16-split or bf16 products");
 };
 
-template <int QB, int MODE, int NBUF, bool PIPE>
+template <int QB, int MODE, int NBUF, bool PIPE, int RING_DOCS>
 __global__ __launch_bounds__(512) void dense_ksplit_kernel(DenseIndex ix, const void* __restrict__ emb,
                                                            const f32x4* __restrict__ qimg, int nq,
                                                            float* __restrict__ docscore, int dbg) {
-    using L = KsCfg<QB, MODE>;
+    using L = KsCfg<QB, MODE, RING_DOCS>;
     constexpr int KT = L::KT, NLU = L::NLU, PIECES = L::PIECES, NQ = L::NQ, RING = L::RING, PER = L::PER;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* P = (f32x4*)smem;                                     // [2][8 waves][QB][64 lanes]
@@ -105,6 +105,18 @@ __global__ __launch_bounds__(512) void dense_ksplit_kernel(DenseIndex ix, const 
             if (q < nq && d >= d0 && d < d1 && !(dbg & 1)) docscore[(int64_t)q * ix.score_stride + d] = v;
         }
     };
+    // Inside the loop at most two blocks become complete per unit (the engine admits the kernel only if a 16-row group
+    // spans <= 32 documents), so two plain ifs do: a loop with stores in it would make the compiler wait for ALL
+    // outstanding loads, prefetches included, at the next use of a row register.
+    auto flush_step = [&](int64_t rows_done) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (next_b < d1 && next_end <= rows_done) {
+                flush_block(next_b);
+                next_b += 32;
+                if (next_b < d1) next_end = block_end_row(next_b);
+            }
+    };
     auto flush_done = [&](int64_t rows_done) {                   // rows [c0, rows_done) have been folded in
         while (next_b < d1 && next_end <= rows_done) {
             flush_block(next_b);
@@ -113,6 +125,11 @@ __global__ __launch_bounds__(512) void dense_ksplit_kernel(DenseIndex ix, const 
         }
     };
 
+    // Tile float f = ((qb * 4 + g) * 16 + n) * 4 + rr is row 4 g + rr of query 16 qb + n (D layout of the 16x16 MFMA:
+    // lane (n, g) holds rows 4 g .. 4 g + 3).  Lane l of wave w reduces floats f0 .. f0 + PER - 1.
+    const int f0 = (w * 64 + lane) * PER;
+    const int red_q = 16 * (f0 >> 8) + ((f0 >> 2) & 15);
+    const int red_r0 = 4 * ((f0 >> 6) & 3) + (f0 & 3);
     const int64_t g0 = c0 >> 4, g1 = c1 > c0 ? (c1 + 15) >> 4 : g0;
     auto clampg = [&](int64_t g) { return g < g1 ? g : g1 - 1; };
     auto row_ptr = [&](int64_t grp) -> const f32x4* {
@@ -120,15 +137,21 @@ __global__ __launch_bounds__(512) void dense_ksplit_kernel(DenseIndex ix, const 
         if (r > C - 1) r = C - 1;
         return (const f32x4*)emb + (size_t)r * L::ROW16 + NLU * 4 * w + lg;
     };
-    auto meta_row = [&](int64_t grp) -> int64_t {
-        int64_t r = clampg(grp) * 16 + li;
-        return r > C - 1 ? C - 1 : r;
+    struct Meta { int d[PER]; float inv[PER]; };                 // document and inverse norm of the lane's reduce rows
+    auto load_meta = [&](int64_t grp, Meta& mt) {                // PER consecutive {doc, inv} pairs: 8 PER bytes, aligned
+        const int2* src = (const int2*)ix.row_meta + clampg(grp) * 16 + red_r0;   // (padded: no clamp at the last row)
+        if constexpr (PER == 1) {
+            const int2 x = src[0];
+            mt.d[0] = x.x; mt.inv[0] = __int_as_float(x.y);
+        } else {
+#pragma unroll
+            for (int j = 0; j < PER; j += 2) {
+                const int4 x = *(const int4*)(src + j);
+                mt.d[j] = x.x; mt.inv[j] = __int_as_float(x.y);
+                mt.d[j + 1] = x.z; mt.inv[j + 1] = __int_as_float(x.w);
+            }
+        }
     };
-    // Tile float f = ((qb * 4 + g) * 16 + n) * 4 + rr is row 4 g + rr of query 16 qb + n (D layout of the 16x16 MFMA:
-    // lane (n, g) holds rows 4 g .. 4 g + 3).  Lane l of wave w reduces floats f0 .. f0 + PER - 1.
-    const int f0 = (w * 64 + lane) * PER;
-    const int red_q = 16 * (f0 >> 8) + ((f0 >> 2) & 15);
-    const int red_r0 = 4 * ((f0 >> 6) & 3) + (f0 & 3);
     // The reduction of a unit comes in two halves so that (PIPE) the LDS reads can be in flight during the next
     // unit's MFMAs: red_load issues them, red_finish adds in a fixed order (wave 0 .. 7: the result does not depend
     // on timing) and folds the cosines into the ring.
@@ -138,40 +161,33 @@ __global__ __launch_bounds__(512) void dense_ksplit_kernel(DenseIndex ix, const 
 #pragma unroll
         for (int w8 = 0; w8 < 8; ++w8) raw[w8] = *(const redvec*)((const float*)P + (size_t)(buf * 8 + w8) * L::TILE + f0);
     };
-    auto red_finish = [&](int64_t grp, int dv, float iv) {
+    auto red_finish = [&](int64_t grp, const Meta& mt) {
         redvec sum = raw[0];
 #pragma unroll
         for (int w8 = 1; w8 < 8; ++w8) sum += raw[w8];
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
-            const int r = red_r0 + j;
-            const int d = __shfl(dv, r);
-            const float inv = __shfl(iv, r);
-            const int64_t row = grp * 16 + r;
+            const int64_t row = grp * 16 + red_r0 + j;
             if (row >= c0 && row < c1) {                         // not a row of a neighbouring span / past the end
-                const int slot = (d - dbase) & (RING - 1);
-                __hip_atomic_fetch_max(&R[slot * NQ + (red_q ^ (slot & L::SWZ))], sum[j] * inv, __ATOMIC_RELAXED,
+                const int slot = (mt.d[j] - dbase) & (RING - 1);
+                __hip_atomic_fetch_max(&R[slot * NQ + (red_q ^ (slot & L::SWZ))], sum[j] * mt.inv[j], __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
     };
 
-    int dv_prev = 0;
-    float iv_prev = 0.f;
+    Meta mt_prev = {};
     __syncthreads();                                             // ring initialised
     if (g1 > g0) {
         f32x4 A[NBUF][NLU];
-        int dvr[NBUF];
-        float ivr[NBUF];
+        Meta mtr[NBUF] = {};
 #pragma unroll
         for (int b = 0; b < NBUF - 1; ++b) {
             const f32x4* p = row_ptr(g0 + b);
 #pragma unroll
             for (int j = 0; j < NLU; ++j) A[b][j] = p[j * 4];
-            dvr[b] = ix.chunk_doc[meta_row(g0 + b)];
-            ivr[b] = ix.inv_norm[meta_row(g0 + b)];
+            load_meta(g0 + b, mtr[b]);
         }
-        dvr[NBUF - 1] = 0; ivr[NBUF - 1] = 0.f;
         __builtin_amdgcn_sched_barrier(0);
 
         for (int64_t base = g0; base < g1; base += NBUF) {
@@ -184,27 +200,18 @@ __global__ __launch_bounds__(512) void dense_ksplit_kernel(DenseIndex ix, const 
                     const f32x4* pn = row_ptr(grp + NBUF - 1);
 #pragma unroll
                     for (int j = 0; j < NLU; ++j) A[nx][j] = pn[j * 4];
-                    dvr[nx] = ix.chunk_doc[meta_row(grp + NBUF - 1)];
-                    ivr[nx] = ix.inv_norm[meta_row(grp + NBUF - 1)];
+                    load_meta(grp + NBUF - 1, mtr[nx]);
                 }
-                if (PIPE && grp > g0 && !(dbg & 4)) red_load((int)((grp - 1 - g0) & 1));   // unit u - 1: complete since barrier u - 1
+                if (PIPE && grp > g0) red_load((int)((grp - 1 - g0) & 1));      // unit u - 1: complete since barrier u - 1
                 __builtin_amdgcn_sched_barrier(0);
                 f32x4 acc[QB];
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) acc[qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (dbg & 2) {                                   // diagnostic: no split, no MFMAs (loads stay live)
-#pragma unroll
-                    for (int j = 0; j < NLU; ++j) acc[j % QB] += A[ph][j];
-                } else if constexpr (MODE == MODE_F16X2) {
+                if constexpr (MODE == MODE_F16X2) {
 #pragma unroll
                     for (int tt = 0; tt < KT; ++tt) {
                         f16x8 ahi, alo;
-                        if (dbg & 8) {                           // diagnostic: no split
-                            ahi = __builtin_bit_cast(f16x8, A[ph][2 * tt]);
-                            alo = __builtin_bit_cast(f16x8, A[ph][2 * tt + 1]);
-                        } else {
-                            split_f16(A[ph][2 * tt], A[ph][2 * tt + 1], ahi, alo);
-                        }
+                        split_f16(A[ph][2 * tt], A[ph][2 * tt + 1], ahi, alo);
 #pragma unroll
                         for (int pc = 0; pc < 3; ++pc)
 #pragma unroll
@@ -225,11 +232,11 @@ __global__ __launch_bounds__(512) void dense_ksplit_kernel(DenseIndex ix, const 
                 const int buf = (int)((grp - g0) & 1);
                 if constexpr (PIPE) {
                     // finish unit u - 1 (its partial tiles were read before the MFMAs above), then publish unit u
-                    if (grp > g0 && !(dbg & 4)) {                // (dbg 4: diagnostic, no reduction)
-                        red_finish(grp - 1, dv_prev, iv_prev);
-                        flush_done((grp - 1) * 16);
+                    if (grp > g0) {
+                        red_finish(grp - 1, mt_prev);
+                        flush_step((grp - 1) * 16);
                     }
-                    dv_prev = dvr[ph]; iv_prev = ivr[ph];
+                    mt_prev = mtr[ph];
 #pragma unroll
                     for (int qb = 0; qb < QB; ++qb) P[((buf * 8 + w) * QB + qb) * 64 + lane] = acc[qb];
                     // Barrier u: unit u's partial tiles are complete and so are the ring updates of unit u - 1.  P[u & 1]
@@ -242,18 +249,27 @@ __global__ __launch_bounds__(512) void dense_ksplit_kernel(DenseIndex ix, const 
                     for (int qb = 0; qb < QB; ++qb) P[((buf * 8 + w) * QB + qb) * 64 + lane] = acc[qb];
                     __syncthreads();                             // as above, with the reduction right behind the barrier
                     red_load(buf);
-                    red_finish(grp, dvr[ph], ivr[ph]);
-                    flush_done(grp * 16);
+                    red_finish(grp, mtr[ph]);
+                    flush_step(grp * 16);
                 }
             }
         }
         if constexpr (PIPE) {
             red_load((int)((g1 - 1 - g0) & 1));
-            red_finish(g1 - 1, dv_prev, iv_prev);
+            red_finish(g1 - 1, mt_prev);
         }
         __syncthreads();                                         // the last unit's ring updates
     }
     flush_done((int64_t)1 << 62);                                // what is left, chunk-less tail included
+}
+
+__global__ __launch_bounds__(256) void pack_row_meta_kernel(const int32_t* __restrict__ chunk_doc,
+                                                            const float* __restrict__ inv_norm, int64_t n,
+                                                            int2* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n + 16) return;
+    const int64_t r = i < n ? i : n - 1;
+    out[i] = make_int2(chunk_doc[r], __float_as_int(inv_norm[r]));
 }
 
 int scan_debug_flags() {
@@ -261,43 +277,53 @@ int scan_debug_flags() {
     return v;
 }
 
-template <int QB, int MODE, int NBUF, bool PIPE = true>
+template <int QB, int MODE, int NBUF, bool PIPE = true, int RING_DOCS = MSR_WIDE_RING>
 hipError_t launch_ksplit(const DenseIndex& ix, const void* emb, const float* qn, int nq, float* docscore,
                          hipStream_t stream) {
-    using L = KsCfg<QB, MODE>;
+    using L = KsCfg<QB, MODE, RING_DOCS>;
     static_assert(L::total <= 160 * 1024, "LDS budget");
-    hipError_t err = hipFuncSetAttribute((const void*)dense_ksplit_kernel<QB, MODE, NBUF, PIPE>,
+    hipError_t err = hipFuncSetAttribute((const void*)dense_ksplit_kernel<QB, MODE, NBUF, PIPE, RING_DOCS>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::total);
     if (err != hipSuccess) return err;
     err = msr_build_qimage(MODE, qn, QB, ix.qimg, stream);
     if (err != hipSuccess) return err;
-    dense_ksplit_kernel<QB, MODE, NBUF, PIPE><<<ix.n_spans, L::THREADS, L::total, stream>>>(
+    dense_ksplit_kernel<QB, MODE, NBUF, PIPE, RING_DOCS><<<ix.n_spans, L::THREADS, L::total, stream>>>(
         ix, emb, (const f32x4*)ix.qimg, nq, docscore, scan_debug_flags());
     return hipGetLastError();
 }
 
 }  // namespace
 
+hipError_t msr_pack_row_meta(const int32_t* chunk_doc, const float* inv_norm, int64_t n, void* row_meta,
+                             hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    pack_row_meta_kernel<<<(unsigned)((n + 16 + 255) / 256), 256, 0, stream>>>(chunk_doc, inv_norm, n, (int2*)row_meta);
+    return hipGetLastError();
+}
+
 // f32 rows, f16-split products, up to 64 queries per sweep (row-major layout, ix.wide_ok).
 hipError_t msr_dense_scan_wide(const DenseIndex& ix, const float* qn, int nq, float* docscore, hipStream_t stream) {
     if (nq <= 0 || ix.n_docs <= 0) return hipSuccess;
-    if (nq > 64 || ix.layout != 0 || !ix.wide_ok) return hipErrorInvalidValue;
-    static const int nbuf = [] { const char* v = getenv("MSR_KS_NBUF"); return v ? atoi(v) : 3; }();
-    if (nq <= 32) return launch_ksplit<2, MODE_F16X2, 3>(ix, ix.emb, qn, nq, docscore, stream);
-    static const int pipe = [] { const char* v = getenv("MSR_KS_PIPE"); return v ? atoi(v) : 1; }();
-    if (nbuf == 2) return launch_ksplit<4, MODE_F16X2, 2>(ix, ix.emb, qn, nq, docscore, stream);
-    if (!pipe) return launch_ksplit<4, MODE_F16X2, 3, false>(ix, ix.emb, qn, nq, docscore, stream);
-    return launch_ksplit<4, MODE_F16X2, 3>(ix, ix.emb, qn, nq, docscore, stream);
+    if (nq > 64 || ix.layout != 0 || !ix.wide_ok || !ix.row_meta) return hipErrorInvalidValue;
+    // A/B knob for measurements: MSR_KS_PIPE=1 issues the reduction's LDS reads before the next unit's MFMAs (the
+    // default for bf16 rows; with f32 rows it costs the registers of a third prefetch slot and gains nothing)
+    static const int pipe = [] { const char* v = getenv("MSR_KS_PIPE"); return v ? atoi(v) : 0; }();
+    if (nq <= 32) return launch_ksplit<2, MODE_F16X2, 3, false>(ix, ix.emb, qn, nq, docscore, stream);
+    if (pipe) return launch_ksplit<4, MODE_F16X2, 2, true>(ix, ix.emb, qn, nq, docscore, stream);
+    return launch_ksplit<4, MODE_F16X2, 3, false>(ix, ix.emb, qn, nq, docscore, stream);
 }
 
-// bf16 rows, up to 64 queries per sweep (candidate generator of the batched path).
+// bf16 rows (candidate generator of the batched path): up to 64 queries per sweep, or up to 128 with a ring of 64
+// documents when the corpus allows it (ix.wide_ok64; 128 queries' partial tiles leave 32 KB of LDS for the ring).
 hipError_t msr_dense_scan_bf16_wide(const DenseIndex& ix, const float* qn, int nq, float* docscore,
                                     hipStream_t stream) {
     if (nq <= 0 || ix.n_docs <= 0) return hipSuccess;
-    if (nq > 64 || !ix.emb_bf16 || !ix.wide_ok) return hipErrorInvalidValue;
-    static const int nbuf = [] { const char* v = getenv("MSR_KS_NBUF"); return v ? atoi(v) : 4; }();
+    if (nq > 128 || !ix.emb_bf16 || !ix.wide_ok || !ix.row_meta || (nq > 64 && !ix.wide_ok64)) return hipErrorInvalidValue;
     static const int pipe = [] { const char* v = getenv("MSR_KS_PIPE"); return v ? atoi(v) : 1; }();
-    if (nbuf == 6) return launch_ksplit<4, MODE_BF16, 6>(ix, ix.emb_bf16, qn, nq, docscore, stream);
+    if (nq > 64) {
+        // (PIPE would need 32 more registers than a wave has here)
+        return launch_ksplit<8, MODE_BF16, 3, false, 64>(ix, ix.emb_bf16, qn, nq, docscore, stream);
+    }
     if (!pipe) return launch_ksplit<4, MODE_BF16, 4, false>(ix, ix.emb_bf16, qn, nq, docscore, stream);
-    return launch_ksplit<4, MODE_BF16, 4>(ix, ix.emb_bf16, qn, nq, docscore, stream);
+    return launch_ksplit<4, MODE_BF16, 4, true>(ix, ix.emb_bf16, qn, nq, docscore, stream);
 }

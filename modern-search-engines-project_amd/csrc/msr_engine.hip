@@ -24,6 +24,7 @@ struct msr_engine {
     int64_t url_group_n = 0;
     // engine-owned device memory
     int32_t* chunk_doc = nullptr;
+    void* row_meta = nullptr;         // packed {document, inverse norm} per row for the K-split kernels
     float* inv_norm_own = nullptr;
     int32_t* span_doc = nullptr;
     int32_t* wspan_doc = nullptr;
@@ -145,7 +146,7 @@ extern "C" int msr_create(const msr_config* cfg, msr_engine** out) {
 
 extern "C" int msr_destroy(msr_engine* e) {
     if (!e) return MSR_OK;
-    free_dev(e->chunk_doc); free_dev(e->inv_norm_own); free_dev(e->span_doc); free_dev(e->wspan_doc); free_dev(e->wspan12_doc); free_dev(e->qn); free_dev(e->qimg); free_dev(e->emb_bf16);
+    free_dev(e->chunk_doc); free_dev(e->row_meta); free_dev(e->inv_norm_own); free_dev(e->span_doc); free_dev(e->wspan_doc); free_dev(e->wspan12_doc); free_dev(e->qn); free_dev(e->qimg); free_dev(e->emb_bf16);
     free_dev(e->score_rows); free_dev(e->bm_heavy_id); free_dev(e->bm_tile_off); free_dev(e->bm_cand_doc); free_dev(e->bm_cand_n); free_dev(e->sel.hist); free_dev(e->sel.state); free_dev(e->sel.cand_hi);
     free_dev(e->sel.cand_lo); free_dev(e->sel.cand_n); free_dev(e->rerank_cos); free_dev(e->rerank_meta);
     free_dev(e->bt_top_doc); free_dev(e->bt_top_score); free_dev(e->bt_top_n); free_dev(e->bt_cand_doc);
@@ -297,16 +298,22 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
     std::vector<int32_t> wspans = make_spans(e->n_cus * 8, 64);
     std::vector<int32_t> wspans12 = make_spans(e->n_cus * 12, 64);
     // K-split kernels: documents spanned by any two consecutive 16-row groups must fit the LDS ring with a block to spare
-    int wide_ok = 1;
+    int wide_ok = 1, wide_ok64 = 1;
     {
         const int64_t n_groups = (n_chunks + 15) / 16;
         int64_t dl = 0, dr = 0;                              // document of the window's first / last row
-        for (int64_t u = 0; u < n_groups && wide_ok; ++u) {
+        for (int64_t u = 0; u < n_groups && (wide_ok || wide_ok64); ++u) {
             const int64_t first = 16 * u, last = std::min<int64_t>(16 * (u + 2), n_chunks) - 1;
             while (h_off[dl + 1] <= first) ++dl;
             if (dr < dl) dr = dl;
             while (h_off[dr + 1] <= last) ++dr;
             if (dr - dl + 32 > MSR_WIDE_RING) wide_ok = 0;
+            if (dr - dl + 32 > 64) wide_ok64 = 0;
+            // ... and one group at most 32 documents: the kernel writes at most two finished blocks per unit
+            int64_t dm = dl;
+            const int64_t glast = std::min<int64_t>(16 * (u + 1), n_chunks) - 1;
+            while (h_off[dm + 1] <= glast) ++dm;
+            if (dm - dl > 32) wide_ok = wide_ok64 = 0;
         }
     }
     const int n_spans = (int)spans.size() - 1;
@@ -314,6 +321,7 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
     const int n_wspans12 = (int)wspans12.size() - 1;
 
     free_dev(e->chunk_doc); e->chunk_doc = nullptr;
+    free_dev(e->row_meta); e->row_meta = nullptr;
     free_dev(e->inv_norm_own); e->inv_norm_own = nullptr;
     free_dev(e->span_doc); e->span_doc = nullptr;
     free_dev(e->wspan_doc); e->wspan_doc = nullptr;
@@ -337,6 +345,11 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
         HIP_TRY(e, msr_row_inv_norm(emb, n_chunks, e->inv_norm_own, st));
         inv_norm = e->inv_norm_own;
     }
+    if (wide_ok) {
+        if ((herr = hipMalloc(&e->row_meta, (size_t)(n_chunks + 16) * 8)) != hipSuccess)
+            return fail(e, MSR_ERR_NOMEM, "row_meta: %s", hipGetErrorString(herr));
+        HIP_TRY(e, msr_pack_row_meta(e->chunk_doc, inv_norm, n_chunks, e->row_meta, st));
+    }
     // The default scan multiplies f16-split pieces (error bound in msr_dense.hip); the bound needs row norms near 1
     // (the reference stores unit-norm rows, indexer/indexer.py:165).  Otherwise fall back to the exact f32 MFMA kernel.
     int variant = e->cfg.scan_variant;
@@ -349,12 +362,12 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
         float lo, hi;
         memcpy(&lo, &h_rng[0], 4); memcpy(&hi, &h_rng[1], 4);
         variant = (lo >= 0.5f && hi <= 2.0f) ? 7 : 2;
-        if (variant == 7 && e->cfg.scan_layout == 0) variant = 13;   // + the K-split kernel for 33..64 queries per sweep
+        if (variant == 7 && e->cfg.scan_layout == 0 && wide_ok) variant = 14;   // K-split kernel: up to 64 queries per sweep
     }
     HIP_TRY(e, hipStreamSynchronize(st));                 // spans vector goes out of scope
     e->dense = DenseIndex{emb, doc_off, e->chunk_doc, inv_norm, e->span_doc, n_chunks, n_docs, (n_docs + 31) / 32 * 32, n_spans,
                           e->cfg.scan_layout, e->wspan_doc, n_wspans, e->wspan12_doc, n_wspans12, e->qimg, nullptr,
-                          wide_ok, variant};
+                          e->row_meta, wide_ok, wide_ok && wide_ok64, variant};
     free_dev(e->emb_bf16);                                // a new binding invalidates the bf16 copy
     e->emb_bf16 = nullptr;
     e->have_chunks = true;
@@ -389,6 +402,11 @@ extern "C" int msr_scan_width(const msr_engine* e) {
     if (!e || !e->have_chunks) return -1;
     const bool wide = (e->dense.variant == 13 || e->dense.variant == 14) && e->dense.layout == 0 && e->dense.wide_ok;
     return wide ? 64 : 32;
+}
+
+extern "C" int msr_batch_width(const msr_engine* e) {
+    if (!e || !e->have_chunks || !e->emb_bf16) return -1;
+    return e->dense.wide_ok && e->dense.wide_ok64 ? 128 : 64;
 }
 
 extern "C" int msr_set_timing(msr_engine* e, int32_t enabled) {
@@ -488,7 +506,7 @@ static int rerank_args_ok(msr_engine* e, const char* fn, int32_t n_queries, int3
     return MSR_OK;
 }
 
-static constexpr int BT_SLICE = 64;                         // queries per bf16 sweep
+static constexpr int BT_SLICE = 128;                        // most queries per bf16 sweep
 
 extern "C" int msr_enable_bf16(msr_engine* e, void* stream) {
     if (!e) return MSR_ERR_INVALID;
@@ -532,11 +550,12 @@ extern "C" int msr_dense_topk_bf16(msr_engine* e, const float* q, int32_t n_quer
     // wave-streaming kernel everywhere.
     static const bool wide_knob = [] { const char* v = getenv("MSR_BF16_WIDE"); return !v || atoi(v) != 0; }();
     const bool wide_able = wide_knob && e->dense.wide_ok && max_chunks_per_doc == 0;
-    for (int q0 = 0; q0 < n_queries; q0 += BT_SLICE) {
-        const int nq = std::min(BT_SLICE, n_queries - q0);
+    const int slice = wide_able && e->dense.wide_ok64 ? 128 : 64;
+    for (int q0 = 0; q0 < n_queries; q0 += slice) {
+        const int nq = std::min(slice, n_queries - q0);
         const bool wide = wide_able && nq > 32;
         // zero rows up to the query-block count of the kernel that runs
-        const int nq_pad = wide ? 64 : (nq + 15) / 16 * 16;
+        const int nq_pad = wide ? (nq > 64 ? 128 : 64) : (nq + 15) / 16 * 16;
         HIP_TRY(e, msr_prep_queries(q + (int64_t)q0 * MSR_DIM, nq, e->qn, nq_pad, st));
         const bool timed = e->timing && e->ev_count[0] < msr_engine::EV_RING;
         if (timed) HIP_TRY(e, hipEventRecord(e->ev_start[0][e->ev_count[0]], st));

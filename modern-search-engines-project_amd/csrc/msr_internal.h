@@ -90,10 +90,16 @@ struct DenseIndex {
     int32_t n_wspans12;
     void* qimg;                // engine scratch: query image in MFMA-fragment order (<= 256 KB)
     const void* emb_bf16;      // bf16 [n_chunks][768] copy of emb for the batched path, or null
-    int32_t wide_ok;           // any 32 consecutive rows (on 16-row group boundaries) span <= MSR_WIDE_RING - 32 documents:
-                               // the K-split kernels' ring of per-document maxima cannot wrap onto live slots
-    int32_t variant;           // scan kernel: 7 = f16-split products (default when the row norms allow it), 2 = exact f32
-                               // MFMA, 1 = super-tile kernel of the first profile, others: A/B variants (msr_dense.hip)
+    const void* row_meta;      // [n_chunks + 16] x {int32 document, float inverse norm} (last row repeated as padding: a row group may stick out by 15 rows),
+                               // one load per unit for the K-split kernels; null when !wide_ok
+    int32_t wide_ok;           // any 32 consecutive rows (on 16-row group boundaries) span <= MSR_WIDE_RING - 32 documents
+                               // (the K-split kernels' ring of per-document maxima cannot wrap onto live slots) and any
+                               // 16-row group <= 32 documents (at most two finished blocks per unit)
+    int32_t wide_ok64;         // the same with a ring of 64 documents (128-query bf16 sweeps)
+    int32_t variant;           // scan kernel: 14 = K-split kernel, f16-split products, <= 64 queries per sweep (default when
+                               // the row norms and wide_ok allow it; 13 = the same for 17..64 queries only), 7 = wave
+                               // streaming with f16-split products, 2 = wave streaming, exact f32 MFMA (default otherwise),
+                               // 1 = super-tile kernel of the first profile, others: A/B variants (msr_dense.hip)
 };
 // qn: [ceil16(nq)][768] normalised queries (zero rows as padding).
 // docscore[q][ix.score_stride] <- max cosine over the document's chunks (-inf for chunk-less documents).
@@ -102,13 +108,16 @@ hipError_t msr_dense_scan(const DenseIndex& ix, const float* qn, int nq, int max
 // bf16 candidate scan (<= 64 queries per sweep); qn as above with ceil16(nq) rows.
 hipError_t msr_dense_scan_bf16(const DenseIndex& ix, const float* qn, int nq, int max_chunks, float* docscore,
                                hipStream_t stream);
-// Wide sweeps (msr_dense_ks.hip): up to 64 queries per pass; f16-split products over f32 rows, or bf16 rows.
+// Wide sweeps (msr_dense_ks.hip): f16-split products over f32 rows for <= 64 queries per pass; bf16 rows for <= 64,
+// or <= 128 with ix.wide_ok64.
 // Both need ix.wide_ok and have no per-document row limit (max_chunks = 0).
 hipError_t msr_dense_scan_wide(const DenseIndex& ix, const float* qn, int nq, float* docscore, hipStream_t stream);
 hipError_t msr_dense_scan_bf16_wide(const DenseIndex& ix, const float* qn, int nq, float* docscore,
                                     hipStream_t stream);
 // Query image in MFMA-fragment order for n_blocks x 16 queries (mode: 0 f32, 1 bf16, 2 f16 hi/lo pieces).
 hipError_t msr_build_qimage(int mode, const float* qn, int n_blocks, void* qimg, hipStream_t stream);
+// row_meta[i] = {chunk_doc[min(i, n-1)], inv_norm[min(i, n-1)]} for i in [0, n + 16)
+hipError_t msr_pack_row_meta(const int32_t* chunk_doc, const float* inv_norm, int64_t n, void* row_meta, hipStream_t stream);
 hipError_t msr_to_bf16(const float* src, int64_t n_elems, void* dst, hipStream_t stream);
 // out2 (device, 2 words) <- bit patterns of min and max of inv_norm[0..n)
 hipError_t msr_inv_norm_range(const float* inv_norm, int64_t n, uint32_t* out2, hipStream_t stream);

@@ -105,6 +105,10 @@ class DeviceEngine:
         return {0: "f32", 1: "f16x2"}.get(self.lib.msr_scan_arith(self.handle), "none")
 
     # ------------------------------------------------------------------ stage 1
+    def batch_width(self):
+        """Queries served by one bf16 sweep in dense_topk_batched (128 or 64; -1 before enable_bf16)."""
+        return int(self.lib.msr_batch_width(self.handle))
+
     def scan_width(self):
         """Queries served by one sweep of the embedding matrix in dense_topk (64 with the K-split kernel, else 32)."""
         return int(self.lib.msr_scan_width(self.handle))
@@ -156,7 +160,7 @@ class DeviceEngine:
         torch.cuda.synchronize(self.device)
 
     def dense_topk_batched(self, qvec, k=100, max_chunks_per_doc=0, want_chunk=True):
-        """Throughput variant of dense_topk: bf16 candidate sweep (64 queries per sweep) + exact f32 rescoring.
+        """Throughput variant of dense_topk: bf16 candidate sweep (up to 128 queries per sweep) + exact f32 rescoring.
         Same outputs; queries whose candidate set overflowed are rerun on the exact f32 scan."""
         q = self._dev(qvec, torch.float32).reshape(-1, DIM)
         Q = int(q.shape[0])

@@ -476,10 +476,11 @@ def test_dense_batched_bf16_matches_exact_path(mods):
                              chunk_ids=np.arange(doc_off[-1], dtype=np.int64), emb=emb, total_docs=5000)
     eng = mods["DeviceEngine"](ix, max_queries=32, max_k=200)
     eng.enable_bf16()
-    for Q in (1, 16, 33, 64, 70):
+    assert eng.batch_width() == 128                             # this corpus admits the 128-query sweep (64-document ring)
+    for Q in (1, 16, 33, 64, 70, 128, 150):
         q = (rng.standard_normal((Q, 768)) * rng.uniform(0.5, 9)).astype(np.float32)
         q[0] = emb[123] * 4.0 + 0.05 * rng.standard_normal(768).astype(np.float32)
-        for (k, mc) in ((100, 0), (200, 10), (7, 3)):
+        for (k, mc) in ((100, 0), (200, 10), (7, 3)) if Q <= 70 else ((100, 0),):
             got = eng.dense_topk_batched(q, k=k, max_chunks_per_doc=mc)
             _check_dense(mods, eng, doc_off, emb, q, k, mc, got)          # vs the oracle, 1e-5
             ex = eng.dense_topk(q, k=k, max_chunks_per_doc=mc)

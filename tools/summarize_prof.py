@@ -23,7 +23,7 @@ def short(name):
 
 def stats(stats_csv, trace_csv, out):
     rows = list(csv.DictReader(open(stats_csv)))
-    ours = [r for r in rows if any(k in r["Name"] for k in ("dense_scan", "bm25_taat", "sel_", "rerank_", "best_chunk",
+    ours = [r for r in rows if any(k in r["Name"] for k in ("dense_scan", "dense_ksplit", "build_qimage", "thr_compact", "rescore", "bm25_taat", "sel_", "rerank_", "best_chunk",
                                                              "prep_queries", "merge_kernel", "interleave", "row_inv_norm",
                                                              "fill_chunk_doc"))]
     lines = ["| kernel | calls | avg us | min us | max us | total ms |", "|---|---|---|---|---|---|"]
@@ -59,10 +59,10 @@ def pmc(fetch_csv, write_csv, out):
         for r in csv.DictReader(open(f)):
             agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
         for n, v in agg.items():
-            if any(k in n for k in ("dense_scan", "bm25_taat", "sel_", "rerank_")):
+            if any(k in n for k in ("dense_scan", "dense_ksplit", "bm25_taat", "sel_", "rerank_")):
                 res[n][key] = {"per_launch_max": max(v), "per_launch_mean": sum(v) / len(v), "launches": len(v)}
     for n, d in res.items():
-        if "dense_scan" in n and "FETCH_SIZE_KiB" in d and "WRITE_SIZE_KiB" in d:
+        if ("dense_scan" in n or "dense_ksplit" in n) and "FETCH_SIZE_KiB" in d and "WRITE_SIZE_KiB" in d:
             d["hbm_bytes_per_launch"] = 2 * d["FETCH_SIZE_KiB"]["per_launch_max"] * 1024 + d["WRITE_SIZE_KiB"]["per_launch_max"] * 1024
             d["note"] = "read bytes = 2 x FETCH_SIZE (gfx950 wide-load correction), write bytes = WRITE_SIZE"
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
