@@ -59,7 +59,8 @@ typedef struct msr_config {
     int32_t rerank_max_docs;  /* largest candidate list per query for msr_rerank, <= 1024 */
     int32_t scan_layout;      /* 0 = row-major embeddings; 1 = 16-row interleaved */
     int32_t scan_variant;     /* 0 = default: f16-split products when every row norm is in [0.5, 2], else exact f32;
-                                 2 = always the exact-f32 MFMA kernel; other values: A/B variants (msr_dense.hip) */
+                                 2 = always the exact-f32 MFMA kernel; 7 = f16-split on the 32-query kernel; other values (<= 14):
+                                 A/B variants (msr_dense.hip, msr_dense_ks.hip) */
 } msr_config;
 
 /* BM25 parameters travel with the postings (bm25_indexer.py:57 k1=1.2, b=0.75). */
@@ -132,7 +133,7 @@ int msr_dense_topk(msr_engine* e, const float* q, int32_t n_queries, int32_t k, 
                    int32_t* out_doc, float* out_score, int32_t* out_chunk, int32_t* out_n, void* stream);
 
 /* Batched variant of msr_dense_topk for throughput (BASELINE config 5): one sweep over a bf16 copy of the
- * embeddings (v_mfma_f32_16x16x32_bf16) serves up to 64 queries and yields approximate scores with a proven
+ * embeddings (v_mfma_f32_16x16x32_bf16) serves up to 128 queries (msr_batch_width) and yields approximate scores with a proven
  * error bound; every document within twice that bound of the k-th approximate score is re-scored in f32 from
  * the f32 rows and the final top-k is exact (same ordering rule as msr_dense_topk).  A query whose candidate
  * set exceeds the engine's capacity (4096) comes back with out_n = -1: rerun it with msr_dense_topk.
