@@ -162,8 +162,10 @@ def main():
     ap.add_argument("--docs", type=int, default=1_000_000)
     ap.add_argument("--chunks", type=int, default=5_000_000)
     ap.add_argument("--terms", type=int, default=1_000_000)
-    ap.add_argument("--queries-per-step", type=int, default=128,
-                    help="queries per step; the dense stage sweeps E once per 32 of them")
+    ap.add_argument("--queries-per-step", type=int, default=0,
+                    help="queries per step (the dense stage sweeps E once per 64 of them); 0 = 128 per GPU: with the "
+                         "corpus sharded N ways and the batch N times larger, every GPU does the same work per step "
+                         "at every N (weak scaling); an explicit value keeps the batch fixed (strong scaling)")
     ap.add_argument("--k1", type=int, default=1000, help="stage-1 candidates (config.py:13)")
     ap.add_argument("--k2", type=int, default=100, help="final top-k (reranker/config.yaml:30)")
     ap.add_argument("--scan-layout", type=int, default=0)
@@ -191,6 +193,9 @@ def main():
         args.chunks = 0
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    auto_batch = args.queries_per_step <= 0
+    if auto_batch:
+        args.queries_per_step = 128 * world
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
@@ -329,7 +334,7 @@ def main():
             "metric": "queries/sec, " + names[args.workload],
             "value": Q * args.steps / elapsed, "unit": "queries/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None,
+            "scaling": "weak" if auto_batch else "strong", "vs_baseline": None,
             "dtype": {"hybrid": f"{dense_dt} (dense cosine) / f64 (BM25, fuse)", "bm25": "f64",
                       "dense": "bf16 candidates, f32 final scores" if args.dense_mode == "bf16" else dense_dt}[args.workload],
             "data": "synthetic",

@@ -12,18 +12,20 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("nproc", [2, 3])
-def test_bench_two_ranks_on_one_gpu(nproc):
+@pytest.mark.parametrize("nproc,batch", [(2, 8), (3, 8), (2, 0)])
+def test_bench_two_ranks_on_one_gpu(nproc, batch):
     torch = pytest.importorskip("torch")
     assert torch.cuda.is_available()
     port = 29600 + os.getpid() % 300 + nproc
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
            "--gpus", str(nproc), "--backend", "gloo", "--same-device", "--verify", "--docs", "60000", "--chunks", "250000",
-           "--terms", "50000", "--queries-per-step", "8", "--steps", "2", "--warmup", "1", "--latency-queries", "2",
+           "--terms", "50000", "--queries-per-step", str(batch), "--steps", "2", "--warmup", "1", "--latency-queries", "2",
            "--no-cpu-baseline"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == nproc and line["outputs_sane"] and line["sharded_equals_unsharded"] is True
-    assert line["scaling"] == "strong" and line["value"] > 0
+    # an explicit batch is strong scaling; the default (0) is 128 queries per GPU: weak scaling
+    assert line["scaling"] == ("strong" if batch else "weak") and line["value"] > 0
+    assert line["config"]["queries_per_step"] == (batch or 128 * nproc)
