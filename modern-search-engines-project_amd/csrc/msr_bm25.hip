@@ -64,9 +64,13 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
     const int64_t lo = (int64_t)blockIdx.x * BM25_TILE;
     const int64_t hi = lo + BM25_TILE < ix.n_docs ? lo + BM25_TILE : ix.n_docs;
     const int n = (int)(hi - lo);
-    for (int i = tid; i < BM25_TILE; i += BM25_THREADS) {
-        acc[i] = __longlong_as_double((long long)UNTOUCHED);
-        dl[i] = i < n ? ix.doc_len[lo + i] : 0;
+    // the tile's document lengths: issued now, parked in registers while the posting slices are located (both are
+    // chains of dependent loads; side by side their latencies overlap), written to LDS afterwards
+    int32_t dl_reg[BM25_TILE / BM25_THREADS];
+#pragma unroll
+    for (int u = 0; u < BM25_TILE / BM25_THREADS; ++u) {
+        const int i = tid + u * BM25_THREADS;
+        dl_reg[u] = i < n ? ix.doc_len[lo + i] : 0;
     }
     const double k1 = ix.k1, b = ix.b, avgdl = ix.avgdl;
     const double k1p1 = k1 + 1.0;                    // self.k1 + 1
@@ -98,6 +102,12 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
             if ((tid & 63) == 0) { slice[2 * (j - t0)] = ps; slice[2 * (j - t0) + 1] = pe; }
         }
     }
+#pragma unroll
+    for (int u = 0; u < BM25_TILE / BM25_THREADS; ++u) {
+        const int i = tid + u * BM25_THREADS;
+        acc[i] = __longlong_as_double((long long)UNTOUCHED);
+        dl[i] = dl_reg[u];
+    }
     __syncthreads();
     for (int j = t0; j < t1; ++j) {                              // query order: the float64 sums must match
         const int64_t ps = slice[2 * (j - t0)], pe = slice[2 * (j - t0) + 1];
@@ -105,16 +115,29 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
         const int32_t t = q_terms[j];
         const double idf = (double)ix.idf[t];
         const double qtf = (double)q_qtf[j];
-        for (int64_t i = ps + tid; i < pe; i += BM25_THREADS) {
-            const int d = ix.post_doc[i] - (int32_t)lo;
-            const double tf = (double)ix.post_tf[i];
-            const double dlen = (double)dl[d];
-            // tf_component = (tf * (k1 + 1)) / (tf + k1 * (1 - b + b * doc_length / avg_doc_length))
-            const double comp = (tf * k1p1) / (tf + k1 * (omb + (b * dlen) / avgdl));
-            // term_score = idf * tf_component * query_term_freq[term]; bm25_score += term_score
-            const double c = (idf * comp) * qtf;
-            const double a = acc[d];
-            acc[d] = ((uint64_t)__double_as_longlong(a) == UNTOUCHED ? 0.0 : a) + c;
+        // U postings per thread and round: all loads of a round are issued before the first is used
+        constexpr int U = 4;
+        for (int64_t i0 = ps + tid; i0 < pe; i0 += (int64_t)U * BM25_THREADS) {
+            int32_t pd[U], ptf[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t i = i0 + (int64_t)u * BM25_THREADS;
+                pd[u] = i < pe ? ix.post_doc[i] : -1;
+                ptf[u] = i < pe ? ix.post_tf[i] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (pd[u] < 0) continue;
+                const int d = pd[u] - (int32_t)lo;
+                const double tf = (double)ptf[u];
+                const double dlen = (double)dl[d];
+                // tf_component = (tf * (k1 + 1)) / (tf + k1 * (1 - b + b * doc_length / avg_doc_length))
+                const double comp = (tf * k1p1) / (tf + k1 * (omb + (b * dlen) / avgdl));
+                // term_score = idf * tf_component * query_term_freq[term]; bm25_score += term_score
+                const double c = (idf * comp) * qtf;
+                const double a = acc[d];
+                acc[d] = ((uint64_t)__double_as_longlong(a) == UNTOUCHED ? 0.0 : a) + c;
+            }
         }
         __syncthreads();
     }

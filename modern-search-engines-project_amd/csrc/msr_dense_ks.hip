@@ -54,7 +54,7 @@ template <int QB, int MODE, int RING_DOCS = MSR_WIDE_RING> struct KsCfg {
     static_assert(MODE == MODE_BF16 || MODE == MODE_F16X2, "f16-split or bf16 products");
 };
 
-template <int QB, int MODE, int NBUF, bool PIPE, int RING_DOCS>
+template <int QB, int MODE, int NBUF, int PIPE, int RING_DOCS>
 __global__ __launch_bounds__(512) void dense_ksplit_kernel(DenseIndex ix, const void* __restrict__ emb,
                                                            const f32x4* __restrict__ qimg, int nq,
                                                            float* __restrict__ docscore, int dbg) {
@@ -67,6 +67,10 @@ __global__ __launch_bounds__(512) void dense_ksplit_kernel(DenseIndex ix, const 
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
+    // PIPE: 0 = every wave reduces a unit right behind its barrier; 1 = every wave reduces it after the NEXT unit's
+    // MFMAs (LDS reads in flight meanwhile); 2 = waves 4..7 do, waves 0..3 do not: the two waves of a SIMD then run their
+    // MFMA phase and their LDS/VALU phase in opposite order and overlap each other
+    const bool pw = PIPE == 1 || (PIPE == 2 && w >= 4);
     const int s = blockIdx.x;
     if (s >= ix.n_spans) return;                                 // workgroup-uniform
     const int64_t C = ix.n_chunks;
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(512) void dense_ksplit_kernel(DenseIndex ix, const 
                     for (int j = 0; j < NLU; ++j) A[nx][j] = pn[j * 4];
                     load_meta(grp + NBUF - 1, mtr[nx]);
                 }
-                if (PIPE && grp > g0) red_load((int)((grp - 1 - g0) & 1));      // unit u - 1: complete since barrier u - 1
+                if (pw && grp > g0) red_load((int)((grp - 1 - g0) & 1));        // unit u - 1: complete since barrier u - 1
                 __builtin_amdgcn_sched_barrier(0);
                 f32x4 acc[QB];
 #pragma unroll
@@ -230,31 +234,30 @@ __global__ __launch_bounds__(512) void dense_ksplit_kernel(DenseIndex ix, const 
                                                                               acc[qb], 0, 0, 0);
                 }
                 const int buf = (int)((grp - g0) & 1);
-                if constexpr (PIPE) {
-                    // finish unit u - 1 (its partial tiles were read before the MFMAs above), then publish unit u
+                if (pw) {
+                    // finish unit u - 1 (its partial tiles were read before the MFMAs above)
                     if (grp > g0) {
                         red_finish(grp - 1, mt_prev);
                         flush_step((grp - 1) * 16);
                     }
                     mt_prev = mtr[ph];
+                }
 #pragma unroll
-                    for (int qb = 0; qb < QB; ++qb) P[((buf * 8 + w) * QB + qb) * 64 + lane] = acc[qb];
-                    // Barrier u: unit u's partial tiles are complete and so are the ring updates of unit u - 1.  P[u & 1]
-                    // is written again for unit u + 2, after barrier u + 1, which a wave only reaches once it has read
-                    // its part of unit u.  Blocks written after barrier u are complete through unit u - 1; the ring
-                    // updates of unit u that other waves issue meanwhile belong to later documents, i.e. other slots.
-                    __syncthreads();
-                } else {
-#pragma unroll
-                    for (int qb = 0; qb < QB; ++qb) P[((buf * 8 + w) * QB + qb) * 64 + lane] = acc[qb];
-                    __syncthreads();                             // as above, with the reduction right behind the barrier
+                for (int qb = 0; qb < QB; ++qb) P[((buf * 8 + w) * QB + qb) * 64 + lane] = acc[qb];
+                // Barrier u: unit u's partial tiles are complete and so are the ring updates of unit u - 2.  P[u & 1] is
+                // written again for unit u + 2, after barrier u + 1, which a wave only reaches once it has read its part
+                // of unit u.  Between barriers u and u + 1 every wave folds unit u into the ring -- right here, or
+                // (pipelined waves) after the next unit's MFMAs -- and writes the blocks that are complete through
+                // unit u - 1; the ring updates other waves issue meanwhile belong to later documents, i.e. other slots.
+                __syncthreads();
+                if (!pw) {
                     red_load(buf);
                     red_finish(grp, mtr[ph]);
                     flush_step(grp * 16);
                 }
             }
         }
-        if constexpr (PIPE) {
+        if (pw) {
             red_load((int)((g1 - 1 - g0) & 1));
             red_finish(g1 - 1, mt_prev);
         }
@@ -277,7 +280,7 @@ int scan_debug_flags() {
     return v;
 }
 
-template <int QB, int MODE, int NBUF, bool PIPE = true, int RING_DOCS = MSR_WIDE_RING>
+template <int QB, int MODE, int NBUF, int PIPE = 1, int RING_DOCS = MSR_WIDE_RING>
 hipError_t launch_ksplit(const DenseIndex& ix, const void* emb, const float* qn, int nq, float* docscore,
                          hipStream_t stream) {
     using L = KsCfg<QB, MODE, RING_DOCS>;
@@ -305,12 +308,12 @@ hipError_t msr_pack_row_meta(const int32_t* chunk_doc, const float* inv_norm, in
 hipError_t msr_dense_scan_wide(const DenseIndex& ix, const float* qn, int nq, float* docscore, hipStream_t stream) {
     if (nq <= 0 || ix.n_docs <= 0) return hipSuccess;
     if (nq > 64 || ix.layout != 0 || !ix.wide_ok || !ix.row_meta) return hipErrorInvalidValue;
-    // A/B knob for measurements: MSR_KS_PIPE=1 issues the reduction's LDS reads before the next unit's MFMAs (the
-    // default for bf16 rows; with f32 rows it costs the registers of a third prefetch slot and gains nothing)
+    // A/B knob for measurements: MSR_KS_PIPE=2 pipelines the reduction in waves 4..7 only (see PIPE in the kernel); no
+    // gain measured (profile r01_m), so the plain order stays the default for f32 rows
     static const int pipe = [] { const char* v = getenv("MSR_KS_PIPE"); return v ? atoi(v) : 0; }();
-    if (nq <= 32) return launch_ksplit<2, MODE_F16X2, 3, false>(ix, ix.emb, qn, nq, docscore, stream);
-    if (pipe) return launch_ksplit<4, MODE_F16X2, 2, true>(ix, ix.emb, qn, nq, docscore, stream);
-    return launch_ksplit<4, MODE_F16X2, 3, false>(ix, ix.emb, qn, nq, docscore, stream);
+    if (nq <= 32) return launch_ksplit<2, MODE_F16X2, 3, 0>(ix, ix.emb, qn, nq, docscore, stream);
+    if (pipe == 2) return launch_ksplit<4, MODE_F16X2, 3, 2>(ix, ix.emb, qn, nq, docscore, stream);
+    return launch_ksplit<4, MODE_F16X2, 3, 0>(ix, ix.emb, qn, nq, docscore, stream);
 }
 
 // bf16 rows (candidate generator of the batched path): up to 64 queries per sweep, or up to 128 with a ring of 64
@@ -322,8 +325,8 @@ hipError_t msr_dense_scan_bf16_wide(const DenseIndex& ix, const float* qn, int n
     static const int pipe = [] { const char* v = getenv("MSR_KS_PIPE"); return v ? atoi(v) : 1; }();
     if (nq > 64) {
         // (PIPE would need 32 more registers than a wave has here)
-        return launch_ksplit<8, MODE_BF16, 3, false, 64>(ix, ix.emb_bf16, qn, nq, docscore, stream);
+        return launch_ksplit<8, MODE_BF16, 3, 0, 64>(ix, ix.emb_bf16, qn, nq, docscore, stream);
     }
-    if (!pipe) return launch_ksplit<4, MODE_BF16, 4, false>(ix, ix.emb_bf16, qn, nq, docscore, stream);
-    return launch_ksplit<4, MODE_BF16, 4, true>(ix, ix.emb_bf16, qn, nq, docscore, stream);
+    if (!pipe) return launch_ksplit<4, MODE_BF16, 4, 0>(ix, ix.emb_bf16, qn, nq, docscore, stream);
+    return launch_ksplit<4, MODE_BF16, 4, 1>(ix, ix.emb_bf16, qn, nq, docscore, stream);
 }

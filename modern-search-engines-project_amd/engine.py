@@ -20,6 +20,40 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+STREAM_MIN_BYTES = 64 << 20
+_NP_OF = {torch.float32: np.float32, torch.float64: np.float64, torch.int32: np.int32, torch.int64: np.int64}
+
+
+def stream_to_device(arr, device, block_bytes=128 << 20):
+    """numpy array (typically a read-only memory map of a snapshot file, index.CorpusIndex.load_dir) -> device tensor,
+    block by block through two pinned staging buffers: while block i travels to HBM (async copy on the current
+    stream) block i + 1 is read from the file into the other buffer.  The host never holds more than two blocks."""
+    dev = torch.device(device)
+    out = torch.empty(arr.shape, dtype=torch.from_numpy(np.empty(0, arr.dtype)).dtype, device=dev)
+    if arr.size == 0:
+        return out
+    flat_out = out.view(-1)
+    row = int(np.prod(arr.shape[1:], dtype=np.int64)) if arr.ndim > 1 else 1
+    rows_per_block = max(1, block_bytes // max(1, row * arr.itemsize))
+    pinned = dev.type == "cuda"
+    stage = [torch.empty(rows_per_block * row, dtype=out.dtype, pin_memory=pinned) for _ in range(2)]
+    done = [None, None]
+    for b, r0 in enumerate(range(0, arr.shape[0], rows_per_block)):
+        r1 = min(arr.shape[0], r0 + rows_per_block)
+        buf = stage[b & 1]
+        if done[b & 1] is not None:
+            done[b & 1].synchronize()                    # the copy that last used this buffer has finished
+        n = (r1 - r0) * row
+        np.copyto(buf.numpy()[:n].reshape((r1 - r0,) + tuple(arr.shape[1:])), arr[r0:r1])
+        flat_out[r0 * row:r0 * row + n].copy_(buf[:n], non_blocking=pinned)
+        if pinned:
+            done[b & 1] = torch.cuda.Event()
+            done[b & 1].record(torch.cuda.current_stream(dev))
+    if pinned:
+        torch.cuda.current_stream(dev).synchronize()
+    return out
+
+
 class DeviceEngine:
     def __init__(self, index: CorpusIndex, device=0, max_queries=32, max_k=1000, rerank_max_docs=1000,
                  scan_layout=0, scan_variant=0):
@@ -49,6 +83,8 @@ class DeviceEngine:
             return None
         if torch.is_tensor(x):
             return x.to(device=self.device, dtype=dtype).contiguous()
+        if isinstance(x, np.ndarray) and x.nbytes >= STREAM_MIN_BYTES and x.dtype == _NP_OF[dtype]:
+            return stream_to_device(x, self.device)      # large (memory-mapped) arrays: pinned double buffer
         return torch.as_tensor(np.ascontiguousarray(x)).to(device=self.device, dtype=dtype)
 
     def _check(self, rc):

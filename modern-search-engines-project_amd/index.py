@@ -160,6 +160,70 @@ class CorpusIndex:
             ix.vocab = {str(t): i for i, t in enumerate(z["vocab_terms"])}
         return ix
 
+    # ------------------------------------------------------------------ snapshot directory (memory-mappable)
+    _ARRAYS = ("doc_ids", "doc_len", "term_off", "post_doc", "post_tf", "idf", "doc_off", "chunk_ids", "emb")
+
+    def save_dir(self, path, block_rows=1 << 18):
+        """Export format for the reference's tables: one little-endian `.npy` per array + `meta.json`
+        (+ `docs.jsonl` with url / title / text per document when present).  Every array is written through a
+        memory map in blocks, so a 15 GB embedding matrix that lives on the GPU is never held twice on the host.
+        `load_dir(..., mmap=True)` maps the files back without reading them; DeviceEngine then streams them to HBM
+        through pinned staging buffers (engine.stream_to_device)."""
+        import json
+        import os
+        os.makedirs(path, exist_ok=True)
+        present = []
+        for name in self._ARRAYS:
+            a = getattr(self, name)
+            if a is None:
+                continue
+            present.append(name)
+            shape = tuple(int(x) for x in a.shape)
+            dt = np.dtype(str(a.dtype).replace("torch.", "")) if hasattr(a, "detach") else np.asarray(a[:0]).dtype
+            out = np.lib.format.open_memmap(os.path.join(path, name + ".npy"), mode="w+", dtype=dt, shape=shape)
+            step = max(1, block_rows if len(shape) > 1 else block_rows * DIM)
+            for s0 in range(0, shape[0], step):
+                out[s0:s0 + step] = _np(a[s0:s0 + step])
+            out.flush()
+            del out
+        meta = dict(format="msretr-snapshot-1", arrays=present, avgdl=float(self.avgdl), total_docs=int(self.total_docs),
+                    k1=float(self.k1), b=float(self.b), doc_base=int(self.doc_base), row_base=int(self.row_base),
+                    n_docs_global=int(self.n_docs_global), vocab=list(self.vocab.keys()) if self.vocab is not None else None,
+                    has_docs=self.urls is not None)
+        with open(os.path.join(path, "meta.json"), "w", encoding="utf-8") as f:
+            json.dump(meta, f, ensure_ascii=False)
+        if self.urls is not None:
+            with open(os.path.join(path, "docs.jsonl"), "w", encoding="utf-8") as f:
+                for i in range(self.n_docs):
+                    f.write(json.dumps([self.urls[i], self.titles[i] if self.titles else None,
+                                        self.texts[i] if self.texts else None], ensure_ascii=False) + "\n")
+
+    @staticmethod
+    def load_dir(path, mmap=True):
+        import json
+        import os
+        with open(os.path.join(path, "meta.json"), encoding="utf-8") as f:
+            meta = json.load(f)
+        if meta.get("format") != "msretr-snapshot-1":
+            raise ValueError(f"{path}: not an msretr snapshot directory")
+        arrs = {n: np.load(os.path.join(path, n + ".npy"), mmap_mode="r" if mmap else None, allow_pickle=False)
+                for n in meta["arrays"]}
+        ix = CorpusIndex(doc_ids=arrs["doc_ids"], avgdl=meta["avgdl"], total_docs=meta["total_docs"], k1=meta["k1"],
+                         b=meta["b"], doc_base=meta["doc_base"], row_base=meta["row_base"],
+                         n_docs_global=meta["n_docs_global"])
+        for n in CorpusIndex._ARRAYS[1:]:
+            if n in arrs:
+                setattr(ix, n, arrs[n])
+        if meta.get("vocab") is not None:
+            ix.vocab = {t: i for i, t in enumerate(meta["vocab"])}
+        if meta.get("has_docs"):
+            ix.urls, ix.titles, ix.texts = [], [], []
+            with open(os.path.join(path, "docs.jsonl"), encoding="utf-8") as f:
+                for line in f:
+                    u, t, x = json.loads(line)
+                    ix.urls.append(u); ix.titles.append(t); ix.texts.append(x)
+        return ix
+
     # ------------------------------------------------------------------ DuckDB (the reference's store)
     @staticmethod
     def from_duckdb(db_path, with_text=True):

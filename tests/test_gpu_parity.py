@@ -506,6 +506,32 @@ def test_dense_batched_overflow_falls_back_to_exact(mods):
     eng.close()
 
 
+def test_engine_from_mapped_snapshot_streams_to_hbm(mods, tmp_path, monkeypatch):
+    """snapshot directory -> memory map -> pinned double buffer -> HBM gives the same engine as the
+    in-memory index (BM25 bitwise, dense scores bitwise: same arrays, same kernels)."""
+    import msretr.engine as me
+    from msretr.synthetic import synthetic_corpus, synthetic_queries
+    ix = synthetic_corpus(3000, n_chunks=12000, n_terms=2000, device="cpu")
+    d = str(tmp_path / "snap")
+    ix.save_dir(d)
+    back = mods["CorpusIndex"].load_dir(d, mmap=True)
+    monkeypatch.setattr(me, "STREAM_MIN_BYTES", 1 << 16)        # stream everything larger than 64 KB ...
+    calls = []
+    real = me.stream_to_device
+    monkeypatch.setattr(me, "stream_to_device", lambda a, dev, block_bytes=1 << 20: calls.append(a.shape) or real(a, dev, block_bytes))
+    a = mods["DeviceEngine"](ix, max_queries=8, max_k=100)
+    b = mods["DeviceEngine"](back, max_queries=8, max_k=100)
+    assert (12000, 768) in calls                                 # ... in 1 MB blocks: the embeddings took 36 of them
+    terms, qv = synthetic_queries(ix, 6, seed=3)
+    ra, rb = a.bm25_topk([ix.term_ids(t) for t in terms], k=100), b.bm25_topk([back.term_ids(t) for t in terms], k=100)
+    for x, y in zip(ra, rb):
+        assert torch.equal(x, y)
+    da, db = a.dense_topk(qv, k=50), b.dense_topk(qv, k=50)
+    for x, y in zip(da, db):
+        assert torch.equal(x, y)
+    a.close(); b.close()
+
+
 # ------------------------------------------------------------------------------------------------ ABI robustness
 def test_bind_rejects_malformed_index(mods):
     """The scoring kernel indexes LDS with the posting's document index: a malformed CSR must be refused at bind."""

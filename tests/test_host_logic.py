@@ -110,6 +110,38 @@ def test_index_roundtrip_and_url_groups(tmp_path):
     assert np.array_equal(jx.emb, ix.emb)
 
 
+def test_snapshot_directory_roundtrip_and_streaming_upload(tmp_path):
+    """the export format (one .npy per array + meta.json + docs.jsonl) maps back without reading the files,
+    and stream_to_device moves a mapped array block by block (here to the CPU device: same code, unpinned buffers)."""
+    import torch
+    from msretr.engine import stream_to_device
+    from msretr.index import CorpusIndex
+    from msretr.synthetic import synthetic_corpus
+    ix = synthetic_corpus(300, n_chunks=1100, n_terms=500, device="cpu")
+    ix.urls = [f"https://example.org/{i}?x=1" if i % 7 else None for i in range(ix.n_docs)]
+    ix.titles = [f"t{i}" if i % 5 else None for i in range(ix.n_docs)]
+    ix.texts = [("Tübingen " * (i % 3)) or None for i in range(ix.n_docs)]
+    ix.vocab = {f"w{i}": i for i in range(ix.n_terms)}
+    d = str(tmp_path / "snap")
+    ix.save_dir(d, block_rows=128)                             # several blocks per array
+    back = CorpusIndex.load_dir(d, mmap=True)
+    assert isinstance(back.emb, np.memmap) and back.emb.dtype == np.float32 and back.emb.shape == (1100, 768)
+    for name in CorpusIndex._ARRAYS:
+        a, b = getattr(ix, name), getattr(back, name)
+        assert np.array_equal(np.asarray(a.cpu() if hasattr(a, "cpu") else a), np.asarray(b)), name
+    assert (back.avgdl, back.total_docs, back.k1, back.b) == (ix.avgdl, ix.total_docs, ix.k1, ix.b)
+    assert back.urls == ix.urls and back.titles == ix.titles and back.texts == ix.texts and back.vocab == ix.vocab
+    assert np.array_equal(back.url_group(), ix.url_group())
+    for arr in (back.emb, back.post_doc, back.term_off):
+        t = stream_to_device(arr, "cpu", block_bytes=100_000)  # forces many blocks, ragged last one
+        assert t.shape == arr.shape and np.array_equal(t.numpy(), np.asarray(arr))
+    assert stream_to_device(np.zeros((0, 768), np.float32), "cpu").shape == (0, 768)
+    with pytest.raises(ValueError):
+        (tmp_path / "bad").mkdir()
+        (tmp_path / "bad" / "meta.json").write_text("{}")
+        CorpusIndex.load_dir(str(tmp_path / "bad"))
+
+
 def test_bm25_index_build_matches_reference_tables():
     """Index build from tokens reproduces the tables the goldens' corpora were described with."""
     from msretr.index_build import bm25_index_from_tokens, normalise_document_text
