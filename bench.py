@@ -175,6 +175,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="OpenMP threads of the CPU baseline (a 1-GPU box is entitled to 16 host cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the extra timed loop with the bf16 candidate sweep")
     ap.add_argument("--latency-queries", type=int, default=20)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--same-device", action="store_true",
@@ -283,6 +284,37 @@ def main():
                 lat.append(time.perf_counter() - t1)
     p50_ms = 1e3 * float(np.median(lat)) if lat else None
 
+    # The same steps with the dense stage on the batched path (bf16 candidate sweep, 128 queries per pass, + exact f32
+    # rescoring; final scores and top-100 are those of the default path up to f32 rounding).  Reported NEXT TO the
+    # headline, never as `value`.
+    variant = None
+    if args.workload == "hybrid" and args.dense_mode == "f32" and not args.no_variants:
+        try:
+            eng.enable_bf16()
+            vstep = lambda i: se.search(None, batches[i % len(batches)][1], k1=args.k1, k2=args.k2,
+                                        packed=batches[i % len(batches)][0], dense_batched=True)
+            for i in range(2):
+                vstep(i)
+            fence()
+            tv = time.perf_counter()
+            for i in range(args.steps):
+                vout = vstep(args.warmup + i)
+            fence()
+            v_el = time.perf_counter() - tv
+            if world > 1:
+                t = torch.tensor([v_el], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                v_el = float(t.item())
+            a_doc, a_score = out["dense"][0], out["dense"][1]
+            b_doc, b_score = vout["dense"][0], vout["dense"][1]
+            same = bool((((a_doc == b_doc) | ((a_score - b_score).abs() <= 2e-6)).all()
+                         & ((a_score - b_score).abs() <= 2e-6).all()).item())
+            variant = {"dense_stage": "bf16 candidate sweep + exact f32 rescore (msr_dense_topk_bf16)",
+                       "value": Q * args.steps / v_el, "unit": "queries/sec", "ms_per_step": 1e3 * v_el / args.steps,
+                       "top100_equals_default_path_within_2e-6": same}
+        except Exception as ex:
+            variant = {"error": repr(ex)}
+
     # sanity of the last step's outputs (cheap, outside the timed region)
     ok = True
     if "dense" in out:
@@ -348,6 +380,8 @@ def main():
         }
         if verified is not None:
             line["sharded_equals_unsharded"] = verified
+        if variant is not None:
+            line["variant_bf16_candidates"] = variant
         if world == 1 and not args.no_cpu_baseline and args.workload == "hybrid":
             try:
                 cb, cres = cpu_baseline(args, shard, terms, qvec)

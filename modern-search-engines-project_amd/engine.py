@@ -85,7 +85,10 @@ class DeviceEngine:
             return x.to(device=self.device, dtype=dtype).contiguous()
         if isinstance(x, np.ndarray) and x.nbytes >= STREAM_MIN_BYTES and x.dtype == _NP_OF[dtype]:
             return stream_to_device(x, self.device)      # large (memory-mapped) arrays: pinned double buffer
-        return torch.as_tensor(np.ascontiguousarray(x)).to(device=self.device, dtype=dtype)
+        x = np.ascontiguousarray(x)
+        if not x.flags.writeable:                            # small read-only memory maps: torch wants a writable source
+            x = x.copy()
+        return torch.as_tensor(x).to(device=self.device, dtype=dtype)
 
     def _check(self, rc):
         _abi.check(self.handle, rc)
