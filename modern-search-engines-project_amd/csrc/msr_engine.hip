@@ -29,7 +29,7 @@ struct msr_engine {
     int32_t* span_doc = nullptr;
     int32_t* wspan_doc = nullptr;
     int32_t* wspan12_doc = nullptr;
-    float* qn = nullptr;              // [64][768] normalised queries of the current slice
+    float* qn = nullptr;              // [128][768] normalised queries of the current slice
     void* qimg = nullptr;             // query image in fragment order (<= 256 KB)
     void* emb_bf16 = nullptr;         // bf16 copy of the embeddings (msr_enable_bf16)
     void* score_rows = nullptr;       // max_queries rows of n_docs float64 (reused as float32 rows)
@@ -590,8 +590,8 @@ extern "C" int msr_rerank_gather(msr_engine* e, const float* q, int32_t n_querie
     if (n_queries == 0) return MSR_OK;
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(e, hipSetDevice(e->cfg.device));
-    for (int q0 = 0; q0 < n_queries; q0 += 32) {            // qn holds 32 normalised queries
-        const int nq = std::min(32, n_queries - q0);
+    for (int q0 = 0; q0 < n_queries; q0 += 128) {           // qn holds 128 normalised queries
+        const int nq = std::min(128, n_queries - q0);
         HIP_TRY(e, msr_prep_queries(q + (int64_t)q0 * MSR_DIM, nq, e->qn, nq, st));
         const int64_t o = (int64_t)q0 * max_cand;
         HIP_TRY(e, msr_rerank_gather(e->dense, e->url_group, e->qn, nq, cand_doc + o, cand_n + q0, max_cand, doc_base,
@@ -625,7 +625,7 @@ extern "C" int msr_rerank(msr_engine* e, const float* q, int32_t n_queries, cons
     if (!e) return MSR_ERR_INVALID;
     if (!params) return fail(e, MSR_ERR_INVALID, "msr_rerank: null params");
     // unsharded convenience: gather (this engine owns every document) + fuse, slice by slice
-    const int slice = std::min(32, e->cfg.max_queries);
+    const int slice = 128;                                  // the gather scratch holds max(max_queries, 128) queries
     for (int q0 = 0; q0 < n_queries; q0 += slice) {
         const int nq = std::min(slice, n_queries - q0);
         const int64_t o = (int64_t)q0 * max_cand;
