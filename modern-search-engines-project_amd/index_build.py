@@ -51,3 +51,47 @@ def bm25_index_from_tokens(doc_ids, token_lists, k1=1.2, b=0.75):
                      avgdl=avgdl, total_docs=N, k1=k1, b=b, vocab=vocab)
     ix.n_docs_global = N
     return ix
+
+
+def bm25_index_from_token_ids(doc_ids, tok_off, tok_ids, n_terms, device="cpu", k1=1.2, b=0.75, vocab=None):
+    """The same tables from token-id streams, built on `device` (the build given pre-tokenised
+    documents, at corpus scale: one radix sort of (term, document) keys + run lengths instead of Python dicts).
+
+    doc_ids int64 [N]; tok_off int64 [N+1]; tok_ids int32 [T] with document i's tokens at tok_off[i]:tok_off[i+1], term
+    ids in [0, n_terms).  Documents without tokens get no row (bm25_indexer.py:224); documents are numbered by
+    ascending doc_id; inside a term the postings ascend by document.  This is an offline step and uses torch's device
+    primitives (sort / unique_consecutive / bincount), not hand-written kernels; idf is evaluated on the host with the
+    same float64 log10 -> float32 rounding as bm25_index_from_tokens so that the two builders agree bit for bit."""
+    import torch
+    dev = torch.device(device)
+    ids = torch.as_tensor(np.asarray(doc_ids, np.int64))
+    off = torch.as_tensor(np.asarray(tok_off, np.int64)).to(dev)
+    tok = (tok_ids if torch.is_tensor(tok_ids) else torch.as_tensor(np.asarray(tok_ids, np.int32))).to(dev)
+    if len(set(ids.tolist())) != len(ids):
+        raise ValueError("duplicate doc_id")
+    lens = (off[1:] - off[:-1])
+    if tok.numel() and (int(tok.min()) < 0 or int(tok.max()) >= n_terms):
+        raise ValueError("token id outside [0, n_terms)")
+    order = torch.argsort(ids).to(dev)                                      # ascending doc_id
+    keep = order[lens[order] > 0]                                           # documents with tokens, in id order
+    N = int(keep.numel())
+    rank = torch.full((len(ids),), -1, dtype=torch.int64, device=dev)
+    rank[keep] = torch.arange(N, device=dev)
+    tok_doc = torch.repeat_interleave(rank, lens)                           # dense document index of every token
+    key = tok.to(torch.int64) * max(N, 1) + tok_doc                         # (term, document): tokens of dropped docs have none
+    key = torch.sort(key).values
+    uniq, tf = torch.unique_consecutive(key, return_counts=True)
+    p_term, p_doc = uniq // max(N, 1), uniq % max(N, 1)
+    df = torch.bincount(p_term, minlength=n_terms)
+    term_off = torch.zeros(n_terms + 1, dtype=torch.int64, device=dev)
+    term_off[1:] = torch.cumsum(df, 0)
+    doc_len = lens[keep].to(torch.int32)
+    n_real = float(np.float32(N))
+    df_h = df.cpu().numpy()
+    idf = np.array([np.float32(math.log10((n_real - int(c) + 0.5) / (int(c) + 0.5))) for c in df_h], np.float32)
+    avgdl = float(np.float32(doc_len.to(torch.float64).mean().item())) if N else 0.0
+    ix = CorpusIndex(doc_ids=ids[keep.cpu()].numpy(), doc_len=doc_len, term_off=term_off, post_doc=p_doc.to(torch.int32),
+                     post_tf=tf.to(torch.int32), idf=torch.as_tensor(idf).to(dev), avgdl=avgdl, total_docs=N, k1=k1, b=b,
+                     vocab=vocab)
+    ix.n_docs_global = N
+    return ix

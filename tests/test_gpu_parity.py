@@ -532,6 +532,35 @@ def test_engine_from_mapped_snapshot_streams_to_hbm(mods, tmp_path, monkeypatch)
     a.close(); b.close()
 
 
+def test_index_built_on_the_gpu_serves_the_same_results(mods):
+    """token-id streams -> BM25 tables on the GPU (sort-based builder) == the same builder on the CPU
+    device, and the engine bound to the GPU-built tables answers like the oracle on the CPU-built ones."""
+    import time
+    from msretr.index_build import bm25_index_from_token_ids
+    rng = np.random.default_rng(77)
+    n, V = 20000, 5000
+    lens = rng.integers(0, 120, size=n)
+    tok_off = np.zeros(n + 1, np.int64); tok_off[1:] = np.cumsum(lens)
+    tok = (rng.zipf(1.2, size=int(tok_off[-1])) % V).astype(np.int32)
+    doc_ids = np.arange(n, dtype=np.int64) * 3 + 7
+    t0 = time.time(); host = bm25_index_from_token_ids(doc_ids, tok_off, tok, V, device="cpu"); t_cpu = time.time() - t0
+    t0 = time.time(); dev = bm25_index_from_token_ids(doc_ids, tok_off, tok, V, device="cuda"); torch.cuda.synchronize()
+    t_gpu = time.time() - t0
+    print(f"index build, {int(tok_off[-1])} tokens: cpu device {t_cpu:.2f} s, gpu {t_gpu:.2f} s")
+    for name in ("doc_len", "term_off", "post_doc", "post_tf", "idf"):
+        assert np.array_equal(getattr(dev, name).cpu().numpy(), np.asarray(getattr(host, name))), name
+    assert dev.avgdl == host.avgdl and dev.total_docs == host.total_docs
+    eng = mods["DeviceEngine"](dev, max_queries=4, max_k=50)
+    ref = {k: np.asarray(getattr(host, k)) for k in ("doc_ids", "doc_len", "term_off", "post_doc", "post_tf", "idf")}
+    ref.update(avgdl=host.avgdl)
+    qs = [[17, 300, 17], [4999, 2], [1234]]
+    got = [x.cpu().numpy() for x in eng.bm25_topk(qs, k=50)]
+    for i, q in enumerate(qs):
+        d, s_ = mods["bm25_ref"].topk(ref, q, 50, 0.0)
+        assert got[0][i, :got[2][i]].tolist() == d.tolist() and got[1][i, :got[2][i]].tolist() == s_.tolist()
+    eng.close()
+
+
 # ------------------------------------------------------------------------------------------------ ABI robustness
 def test_bind_rejects_malformed_index(mods):
     """The scoring kernel indexes LDS with the posting's document index: a malformed CSR must be refused at bind."""

@@ -174,6 +174,30 @@ def test_bm25_index_build_matches_reference_tables():
     assert bm25_index_from_tokens([1, 2], [[], ["x"]]).doc_ids.tolist() == [2]     # empty documents get no row
 
 
+def test_bm25_index_build_from_token_ids_equals_the_token_list_builder():
+    """the sort-based builder (runs on the GPU at corpus scale; here on the CPU device) against the
+    dict-based one that is pinned to the reference's tables: same postings, lengths, idf bits, avgdl."""
+    from msretr.index_build import bm25_index_from_token_ids, bm25_index_from_tokens
+    rng = np.random.default_rng(9)
+    n = 400
+    doc_ids = rng.permutation(np.arange(1000, 1000 + 3 * n, 3))[:n]      # unsorted, with gaps
+    lens = rng.integers(0, 60, size=n); lens[[3, 77]] = 0                 # two token-less documents: no row
+    toks = [rng.zipf(1.3, size=l).clip(1, 300).tolist() for l in lens]
+    ref = bm25_index_from_tokens(doc_ids, [[f"w{t}" for t in tl] for tl in toks])
+    ids_of = {f"w{t}": i for t, i in ((int(k[1:]), v) for k, v in ref.vocab.items())}    # the dict builder's numbering
+    tok_off = np.zeros(n + 1, np.int64); tok_off[1:] = np.cumsum(lens)
+    tok_ids = np.array([ids_of[f"w{t}"] for tl in toks for t in tl], np.int32)
+    got = bm25_index_from_token_ids(doc_ids, tok_off, tok_ids, len(ref.vocab), device="cpu")
+    assert got.total_docs == ref.total_docs == int((lens > 0).sum()) < n - 1 and got.avgdl == ref.avgdl
+    for name in ("doc_ids", "doc_len", "term_off", "post_doc", "post_tf"):
+        assert np.array_equal(np.asarray(getattr(got, name)), np.asarray(getattr(ref, name))), name
+    assert np.array_equal(np.asarray(got.idf).view(np.uint32), ref.idf.view(np.uint32))
+    with pytest.raises(ValueError):
+        bm25_index_from_token_ids([1, 1], [0, 1, 2], [0, 0], 1)
+    with pytest.raises(ValueError):
+        bm25_index_from_token_ids([1, 2], [0, 1, 2], [0, 5], 2)
+
+
 def test_http_facade_shapes_and_status_codes():
     from fastapi.testclient import TestClient
     from msretr.reranker import RerankNotFound
