@@ -33,11 +33,11 @@
 
 namespace {
 
-template <int QB, int MODE, int RING_DOCS = MSR_WIDE_RING> struct KsCfg {
-    static constexpr int WAVES = 8;
+template <int QB, int MODE, int RING_DOCS = MSR_WIDE_RING, int NWAVES = 8> struct KsCfg {
+    static constexpr int WAVES = NWAVES;                             // K-split ways; waves 0..7 also reduce and write
     static constexpr int THREADS = WAVES * 64;
     static constexpr int KS = MSR_DIM / 32;                          // MFMA k-steps per row
-    static constexpr int KT = KS / WAVES;                            // k-steps per wave (3)
+    static constexpr int KT = KS / WAVES;                            // k-steps per wave (3, or 2 with 12 waves)
     static constexpr int PIECES = MODE == MODE_F16X2 ? 2 : 1;        // operand pieces per k-step (hi, lo)
     static constexpr int NLU = MODE == MODE_BF16 ? KT : 2 * KT;      // 16 B loads per lane and unit
     static constexpr int ROW16 = MODE == MODE_BF16 ? MSR_DIM * 2 / 16 : MSR_DIM * 4 / 16;
@@ -46,7 +46,7 @@ template <int QB, int MODE, int RING_DOCS = MSR_WIDE_RING> struct KsCfg {
     static constexpr int SWZ = (NQ < 64 ? NQ : 64) - 1;              // column swizzle mask of the ring
     static constexpr int TILE = QB * 64 * 4;                         // floats of one 16-row x NQ tile
     static constexpr int PER = QB / 2;                               // tile floats per lane in the reduction
-    static constexpr size_t p_bytes = (size_t)2 * WAVES * TILE * 4;  // partial tiles of the 8 waves, two buffers
+    static constexpr size_t p_bytes = (size_t)2 * WAVES * TILE * 4;  // partial tiles of the waves, two buffers
     static constexpr size_t r_bytes = (size_t)RING * NQ * 4;
     static constexpr size_t total = p_bytes + r_bytes;
     static_assert(QB == 2 || QB == 4 || QB == 8, "the reduction hands QB / 2 floats (one tile column piece) to a lane");
@@ -54,11 +54,11 @@ template <int QB, int MODE, int RING_DOCS = MSR_WIDE_RING> struct KsCfg {
     static_assert(MODE == MODE_BF16 || MODE == MODE_F16X2, "f16-split or bf16 products");
 };
 
-template <int QB, int MODE, int NBUF, int PIPE, int RING_DOCS>
-__global__ __launch_bounds__(512) void dense_ksplit_kernel(DenseIndex ix, const void* __restrict__ emb,
+template <int QB, int MODE, int NBUF, int PIPE, int RING_DOCS, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void dense_ksplit_kernel(DenseIndex ix, const void* __restrict__ emb,
                                                            const f32x4* __restrict__ qimg, int nq,
                                                            float* __restrict__ docscore, int dbg) {
-    using L = KsCfg<QB, MODE, RING_DOCS>;
+    using L = KsCfg<QB, MODE, RING_DOCS, NWAVES>;
     constexpr int KT = L::KT, NLU = L::NLU, PIECES = L::PIECES, NQ = L::NQ, RING = L::RING, PER = L::PER;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* P = (f32x4*)smem;                                     // [2][8 waves][QB][64 lanes]
@@ -70,7 +70,8 @@ __global__ __launch_bounds__(512) void dense_ksplit_kernel(DenseIndex ix, const 
     // PIPE: 0 = every wave reduces a unit right behind its barrier; 1 = every wave reduces it after the NEXT unit's
     // MFMAs (LDS reads in flight meanwhile); 2 = waves 4..7 do, waves 0..3 do not: the two waves of a SIMD then run their
     // MFMA phase and their LDS/VALU phase in opposite order and overlap each other
-    const bool pw = PIPE == 1 || (PIPE == 2 && w >= 4);
+    const bool red = w < 8;                                      // waves 0..7 reduce and write; 12-wave instances: 8..11 only multiply
+    const bool pw = red && (PIPE == 1 || (PIPE == 2 && w >= 4));
     const int s = blockIdx.x;
     if (s >= ix.n_spans) return;                                 // workgroup-uniform
     const int64_t C = ix.n_chunks;
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(512) void dense_ksplit_kernel(DenseIndex ix, const 
     auto block_end_row = [&](int b) -> int64_t { return ix.doc_off[b + 32 < d1 ? b + 32 : d1]; };
     int64_t next_end = block_end_row(next_b);                    // once rows below this index are in, the block is complete
     auto flush_block = [&](int b) {
+        if (w >= 8) return;                                      // (12-wave instances: waves 8..11 only multiply)
         // wave w writes queries [2 QB w, 2 QB (w + 1)): 2 queries x 32 documents per instruction, 128 B per query
         const int dd = lane & 31, qq = lane >> 5;
         const int slot = ((b - dbase) & (RING - 1)) + dd;
@@ -160,15 +162,16 @@ __global__ __launch_bounds__(512) void dense_ksplit_kernel(DenseIndex ix, const 
     // unit's MFMAs: red_load issues them, red_finish adds in a fixed order (wave 0 .. 7: the result does not depend
     // on timing) and folds the cosines into the ring.
     typedef float redvec __attribute__((ext_vector_type(PER == 1 ? 1 : PER)));
-    redvec raw[8];
+    redvec raw[NWAVES];
     auto red_load = [&](int buf) {
 #pragma unroll
-        for (int w8 = 0; w8 < 8; ++w8) raw[w8] = *(const redvec*)((const float*)P + (size_t)(buf * 8 + w8) * L::TILE + f0);
+        for (int w8 = 0; w8 < NWAVES; ++w8)
+            raw[w8] = *(const redvec*)((const float*)P + (size_t)(buf * NWAVES + w8) * L::TILE + f0);
     };
     auto red_finish = [&](int64_t grp, const Meta& mt) {
         redvec sum = raw[0];
 #pragma unroll
-        for (int w8 = 1; w8 < 8; ++w8) sum += raw[w8];
+        for (int w8 = 1; w8 < NWAVES; ++w8) sum += raw[w8];
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
             const int64_t row = grp * 16 + red_r0 + j;
@@ -243,14 +246,14 @@ __global__ __launch_bounds__(512) void dense_ksplit_kernel(DenseIndex ix, const 
                     mt_prev = mtr[ph];
                 }
 #pragma unroll
-                for (int qb = 0; qb < QB; ++qb) P[((buf * 8 + w) * QB + qb) * 64 + lane] = acc[qb];
+                for (int qb = 0; qb < QB; ++qb) P[((buf * NWAVES + w) * QB + qb) * 64 + lane] = acc[qb];
                 // Barrier u: unit u's partial tiles are complete and so are the ring updates of unit u - 2.  P[u & 1] is
                 // written again for unit u + 2, after barrier u + 1, which a wave only reaches once it has read its part
                 // of unit u.  Between barriers u and u + 1 every wave folds unit u into the ring -- right here, or
                 // (pipelined waves) after the next unit's MFMAs -- and writes the blocks that are complete through
                 // unit u - 1; the ring updates other waves issue meanwhile belong to later documents, i.e. other slots.
                 __syncthreads();
-                if (!pw) {
+                if (!pw && red) {
                     red_load(buf);
                     red_finish(grp, mtr[ph]);
                     flush_step(grp * 16);
@@ -280,17 +283,17 @@ int scan_debug_flags() {
     return v;
 }
 
-template <int QB, int MODE, int NBUF, int PIPE = 1, int RING_DOCS = MSR_WIDE_RING>
+template <int QB, int MODE, int NBUF, int PIPE = 1, int RING_DOCS = MSR_WIDE_RING, int NWAVES = 8>
 hipError_t launch_ksplit(const DenseIndex& ix, const void* emb, const float* qn, int nq, float* docscore,
                          hipStream_t stream) {
-    using L = KsCfg<QB, MODE, RING_DOCS>;
+    using L = KsCfg<QB, MODE, RING_DOCS, NWAVES>;
     static_assert(L::total <= 160 * 1024, "LDS budget");
-    hipError_t err = hipFuncSetAttribute((const void*)dense_ksplit_kernel<QB, MODE, NBUF, PIPE, RING_DOCS>,
+    hipError_t err = hipFuncSetAttribute((const void*)dense_ksplit_kernel<QB, MODE, NBUF, PIPE, RING_DOCS, NWAVES>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::total);
     if (err != hipSuccess) return err;
     err = msr_build_qimage(MODE, qn, QB, ix.qimg, stream);
     if (err != hipSuccess) return err;
-    dense_ksplit_kernel<QB, MODE, NBUF, PIPE, RING_DOCS><<<ix.n_spans, L::THREADS, L::total, stream>>>(
+    dense_ksplit_kernel<QB, MODE, NBUF, PIPE, RING_DOCS, NWAVES><<<ix.n_spans, L::THREADS, L::total, stream>>>(
         ix, emb, (const f32x4*)ix.qimg, nq, docscore, scan_debug_flags());
     return hipGetLastError();
 }
@@ -308,12 +311,14 @@ hipError_t msr_pack_row_meta(const int32_t* chunk_doc, const float* inv_norm, in
 hipError_t msr_dense_scan_wide(const DenseIndex& ix, const float* qn, int nq, float* docscore, hipStream_t stream) {
     if (nq <= 0 || ix.n_docs <= 0) return hipSuccess;
     if (nq > 64 || ix.layout != 0 || !ix.wide_ok || !ix.row_meta) return hipErrorInvalidValue;
-    // A/B knob for measurements: MSR_KS_PIPE=2 pipelines the reduction in waves 4..7 only (see PIPE in the kernel); no
-    // gain measured (profile r01_m), so the plain order stays the default for f32 rows
+    // 64 queries: 12-way K split (2 k-steps per wave, 167 VGPRs: three waves per SIMD), 2-3 % faster than the 8-way split
+    // (profile r01_m); 32 queries: 8-way.  A/B knobs for measurements: MSR_KS_PIPE=8 -> 8 waves; 2 -> 8 waves with the
+    // reduction pipelined in waves 4..7 only (see PIPE in the kernel; no gain measured).
     static const int pipe = [] { const char* v = getenv("MSR_KS_PIPE"); return v ? atoi(v) : 0; }();
-    if (nq <= 32) return launch_ksplit<2, MODE_F16X2, 3, 0>(ix, ix.emb, qn, nq, docscore, stream);
+    if (nq <= 32) return launch_ksplit<2, MODE_F16X2, 3, 0>(ix, ix.emb, qn, nq, docscore, stream);   // (8 waves: 12 gain nothing here)
     if (pipe == 2) return launch_ksplit<4, MODE_F16X2, 3, 2>(ix, ix.emb, qn, nq, docscore, stream);
-    return launch_ksplit<4, MODE_F16X2, 3, 0>(ix, ix.emb, qn, nq, docscore, stream);
+    if (pipe == 8) return launch_ksplit<4, MODE_F16X2, 3, 0>(ix, ix.emb, qn, nq, docscore, stream);
+    return launch_ksplit<4, MODE_F16X2, 2, 0, MSR_WIDE_RING, 12>(ix, ix.emb, qn, nq, docscore, stream);
 }
 
 // bf16 rows (candidate generator of the batched path): up to 64 queries per sweep, or up to 128 with a ring of 64
