@@ -60,8 +60,12 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
     __shared__ int32_t dl[BM25_TILE];
     __shared__ int64_t slice[2 * BM25_MAX_TERMS];                // [term slot][begin, end) of the tile's postings
     const int tid = threadIdx.x;
-    const int q = blockIdx.y;                        // row of `scores`
-    const int64_t lo = (int64_t)blockIdx.x * BM25_TILE;
+    // grid = (queries, tiles): consecutive workgroups score the SAME tile for different queries, so the tile's document
+    // lengths and the slices of the terms the queries share (the city term is in every query, search_api.py:155-166)
+    // are served by the L2 after the first of them
+    const int q = blockIdx.x;                        // row of `scores`
+    const int tile = blockIdx.y;
+    const int64_t lo = (int64_t)tile * BM25_TILE;
     const int64_t hi = lo + BM25_TILE < ix.n_docs ? lo + BM25_TILE : ix.n_docs;
     const int n = (int)(hi - lo);
     // the tile's document lengths: issued now, parked in registers while the posting slices are located (both are
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
                 if (e > s) {
                     const int h = ix.heavy_id ? ix.heavy_id[t] : -1;
                     if (h >= 0) {                            // long list: the slice comes from the skip table
-                        const uint32_t* row = ix.tile_off + (int64_t)h * (ix.n_tiles + 1) + blockIdx.x;
+                        const uint32_t* row = ix.tile_off + (int64_t)h * (ix.n_tiles + 1) + tile;
                         ps = s + row[0];
                         pe = s + row[1];
                     } else {
@@ -237,7 +241,7 @@ hipError_t msr_bm25_scores(const Bm25Index& ix, const int32_t* q_term_off, const
                            const int32_t* q_qtf, int q_first, int nq, double min_score, double* cand_score,
                            int32_t* cand_doc, int32_t* cand_n, hipStream_t stream) {
     if (nq <= 0 || ix.n_docs <= 0) return hipSuccess;
-    dim3 grid((unsigned)((ix.n_docs + BM25_TILE - 1) / BM25_TILE), (unsigned)nq);
+    dim3 grid((unsigned)nq, (unsigned)((ix.n_docs + BM25_TILE - 1) / BM25_TILE));
     bm25_taat_kernel<<<grid, BM25_THREADS, 0, stream>>>(ix, q_term_off, q_terms, q_qtf, q_first, min_score, cand_score,
                                                         cand_doc, cand_n);
     return hipGetLastError();

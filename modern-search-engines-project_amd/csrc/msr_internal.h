@@ -57,7 +57,7 @@ struct Bm25Index {
     const uint32_t* tile_off;  // [n_heavy][n_tiles + 1], relative to term_off[t]
     int32_t n_tiles;
 };
-constexpr int MSR_BM25_TILE = 4096;          // documents per BM25 tile
+constexpr int MSR_BM25_TILE = 2048;          // documents per BM25 tile
 constexpr int MSR_BM25_HEAVY_DF = 2048;      // posting lists at least this long get a skip-table row
 hipError_t msr_bm25_build_skip(const Bm25Index& ix, const int32_t* heavy_terms, int n_heavy, uint32_t* tile_off,
                                hipStream_t stream);
