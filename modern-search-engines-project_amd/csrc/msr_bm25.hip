@@ -113,15 +113,22 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
         dl[i] = dl_reg[u];
     }
     __syncthreads();
-    for (int j = t0; j < t1; ++j) {                              // query order: the float64 sums must match
-        const int64_t ps = slice[2 * (j - t0)], pe = slice[2 * (j - t0) + 1];
-        if (pe <= ps) continue;                                  // block-uniform
-        const int32_t t = q_terms[j];
-        const double idf = (double)ix.idf[t];
-        const double qtf = (double)q_qtf[j];
-        // U postings per thread and round: all loads of a round are issued before the first is used
+    // One posting: the reference's arithmetic, operation by operation (:472-478).
+    auto apply = [&](int32_t pdoc, int32_t ptf, double idf, double qtf) {
+        const int d = pdoc - (int32_t)lo;
+        const double tf = (double)ptf;
+        const double dlen = (double)dl[d];
+        // tf_component = (tf * (k1 + 1)) / (tf + k1 * (1 - b + b * doc_length / avg_doc_length))
+        const double comp = (tf * k1p1) / (tf + k1 * (omb + (b * dlen) / avgdl));
+        // term_score = idf * tf_component * query_term_freq[term]; bm25_score += term_score
+        const double c = (idf * comp) * qtf;
+        const double a = acc[d];
+        acc[d] = ((uint64_t)__double_as_longlong(a) == UNTOUCHED ? 0.0 : a) + c;
+    };
+    // The rest of a slice, U postings per thread and round: all loads of a round are issued before the first is used.
+    auto stream = [&](int64_t from, int64_t pe, double idf, double qtf) {
         constexpr int U = 4;
-        for (int64_t i0 = ps + tid; i0 < pe; i0 += (int64_t)U * BM25_THREADS) {
+        for (int64_t i0 = from + tid; i0 < pe; i0 += (int64_t)U * BM25_THREADS) {
             int32_t pd[U], ptf[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -130,19 +137,45 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
                 ptf[u] = i < pe ? ix.post_tf[i] : 0;
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (pd[u] < 0) continue;
-                const int d = pd[u] - (int32_t)lo;
-                const double tf = (double)ptf[u];
-                const double dlen = (double)dl[d];
-                // tf_component = (tf * (k1 + 1)) / (tf + k1 * (1 - b + b * doc_length / avg_doc_length))
-                const double comp = (tf * k1p1) / (tf + k1 * (omb + (b * dlen) / avgdl));
-                // term_score = idf * tf_component * query_term_freq[term]; bm25_score += term_score
-                const double c = (idf * comp) * qtf;
-                const double a = acc[d];
-                acc[d] = ((uint64_t)__double_as_longlong(a) == UNTOUCHED ? 0.0 : a) + c;
+            for (int u = 0; u < U; ++u)
+                if (pd[u] >= 0) apply(pd[u], ptf[u], idf, qtf);
+        }
+    };
+    // The first 256 postings of the first TPRE terms' slices (for most terms: the whole slice) are fetched side by
+    // side BEFORE the ordered accumulation starts, together with the terms' idf and query frequency: otherwise every
+    // term costs a round trip to memory between two barriers.  The accumulation itself stays IN QUERY ORDER with a
+    // barrier between terms: the float64 sums must match the reference's (:466-478).
+    constexpr int TPRE = 6;
+    int32_t pd0[TPRE], ptf0[TPRE];
+    double idf0[TPRE], qtf0[TPRE];
+#pragma unroll
+    for (int jj = 0; jj < TPRE; ++jj) {
+        pd0[jj] = -1; ptf0[jj] = 0; idf0[jj] = 0.0; qtf0[jj] = 0.0;
+        if (t0 + jj < t1) {
+            const int64_t ps = slice[2 * jj], pe = slice[2 * jj + 1];
+            if (pe > ps) {
+                const int32_t t = q_terms[t0 + jj];
+                idf0[jj] = (double)ix.idf[t];
+                qtf0[jj] = (double)q_qtf[t0 + jj];
+                const int64_t i = ps + tid;
+                if (i < pe) { pd0[jj] = ix.post_doc[i]; ptf0[jj] = ix.post_tf[i]; }
             }
         }
+    }
+#pragma unroll
+    for (int jj = 0; jj < TPRE; ++jj) {
+        if (t0 + jj >= t1) break;                                // block-uniform
+        const int64_t ps = slice[2 * jj], pe = slice[2 * jj + 1];
+        if (pe <= ps) continue;                                  // block-uniform
+        if (pd0[jj] >= 0) apply(pd0[jj], ptf0[jj], idf0[jj], qtf0[jj]);
+        stream(ps + BM25_THREADS, pe, idf0[jj], qtf0[jj]);
+        __syncthreads();
+    }
+    for (int j = t0 + TPRE; j < t1; ++j) {
+        const int64_t ps = slice[2 * (j - t0)], pe = slice[2 * (j - t0) + 1];
+        if (pe <= ps) continue;                                  // block-uniform
+        const int32_t t = q_terms[j];
+        stream(ps, pe, (double)ix.idf[t], (double)q_qtf[j]);
         __syncthreads();
     }
     // Emit the tile's candidates (touched by a posting AND score >= min_score, :461,480) as (score, doc) pairs
