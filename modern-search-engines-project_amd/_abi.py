@@ -42,6 +42,11 @@ _SIGNATURES = {
     "msr_bind_doc_meta": (C.c_int, [_P, _P, C.c_int64, _P]),
     "msr_scan_arith": (C.c_int, [_P]),
     "msr_scan_width": (C.c_int, [_P]),
+    # include/msretr_encoder.h
+    "msr_enc_layernorm": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
+    "msr_enc_attention": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P]),
+    "msr_enc_geglu": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
+    "msr_enc_mean_pool": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "msr_batch_width": (C.c_int, [_P]),
     "msr_interleave_rows": (C.c_int, [_P, _P, C.c_int64, _P, _P]),
     "msr_bm25_topk": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_double, _P, _P, _P, _P]),

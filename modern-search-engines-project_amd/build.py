@@ -22,6 +22,7 @@ UNITS = {
     "msr_dense_ks.hip": [],
     "msr_rerank.hip": ["-ffp-contract=off"],
     "msr_batch.hip": [],
+    "msr_encoder.hip": ["-ffp-contract=off"],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
@@ -44,6 +45,7 @@ def build_library(force=False, verbose=False, save_temps=False):
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "msretr.h"))
+    headers.append(os.path.join(HERE, "..", "include", "msretr_encoder.h"))
     objs = []
     for src, extra in UNITS.items():
         s = os.path.join(CSRC, src)

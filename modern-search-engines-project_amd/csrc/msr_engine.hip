@@ -80,6 +80,15 @@ extern "C" int msr_abi_version(void) { return MSR_ABI_VERSION; }
 
 extern "C" const char* msr_last_error(const msr_engine* e) { return e ? e->err : g_create_err; }
 
+// error text of the handle-less entry points (msr_encoder.hip): read back with msr_last_error(NULL)
+int msr_fail_global(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_create_err, sizeof(g_create_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
 extern "C" int msr_create(const msr_config* cfg, msr_engine** out) {
     if (!cfg || !out) return fail(nullptr, MSR_ERR_INVALID, "msr_create: null argument");
     *out = nullptr;

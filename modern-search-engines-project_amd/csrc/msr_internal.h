@@ -42,6 +42,9 @@ hipError_t msr_merge_lists(int score_bits, const int32_t* in_doc, const void* in
                            int n_parts, int nq, int k, int32_t* out_doc, void* out_score, int32_t* out_n,
                            hipStream_t stream);
 
+// error text of handle-less entry points, read back with msr_last_error(NULL) (msr_engine.hip)
+int msr_fail_global(int code, const char* fmt, ...);
+
 // ---- K1: BM25 term-at-a-time ----------------------------------------------------------------------
 struct Bm25Index {
     const int64_t* term_off;

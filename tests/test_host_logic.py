@@ -53,7 +53,7 @@ def test_diversify_matches_reference_outputs():
 
 def test_library_exports_every_declared_symbol():
     from msretr import _abi
-    hdr = open(os.path.join(ROOT, "include", "msretr.h"), encoding="utf-8").read()
+    hdr = "".join(open(os.path.join(ROOT, "include", h), encoding="utf-8").read() for h in ("msretr.h", "msretr_encoder.h"))
     declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(msr_\w+)\s*\(", hdr, flags=re.M))
     assert declared, "no prototypes found in msretr.h"
     lib = _abi.load()
