@@ -98,3 +98,42 @@ def test_encoder_rejects_what_it_cannot_do(enc_world):
     with pytest.raises(ValueError):
         enc.encode(["a query string"])                       # no tokenizer.json was loaded
     assert enc.encode([]).shape == (0, 768) and float(enc.encode([[]]).abs().max()) == 0.0
+
+
+def test_encoder_from_local_directory_and_in_the_retriever(tmp_path):
+    """from_dir: model.safetensors + tokenizer.json + modules.json of a local sentence-transformers directory (a 2-layer
+    model and a word-level tokenizer written by this test), then the query STRING path of the host classes
+    (reranker_api.py:355 -> Retriever.quick_search) with the encoder as the embedder."""
+    from safetensors.torch import save_file
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from msretr.encoder import QueryEncoder, random_weights
+    from msretr.retriever import Retriever
+    from msretr.synthetic import synthetic_corpus
+    d = tmp_path / "model"
+    d.mkdir()
+    w = random_weights(seed=4, layers=2)
+    save_file({("model." + k): v.contiguous() for k, v in w.items()}, str(d / "model.safetensors"))
+    vocab = {"[UNK]": 0, "tübingen": 1, "castle": 2, "food": 3, "and": 4, "drinks": 5}
+    tok = Tokenizer(models.WordLevel(vocab, unk_token="[UNK]"))
+    tok.pre_tokenizer = pre_tokenizers.Whitespace()
+    tok.save(str(d / "tokenizer.json"))
+    (d / "modules.json").write_text('[{"idx": 0, "type": "sentence_transformers.models.Transformer"}, '
+                                    '{"idx": 1, "type": "sentence_transformers.models.Pooling"}, '
+                                    '{"idx": 2, "type": "sentence_transformers.models.Normalize"}]')
+    enc = QueryEncoder.from_dir(str(d), device=0)
+    assert enc.layers == 2 and enc.normalize is True
+    v = enc.encode("food and drinks")
+    assert isinstance(v, np.ndarray) and v.shape == (768,) and abs(float(np.linalg.norm(v)) - 1.0) < 1e-5
+    same = enc.encode([[3, 4, 5]], convert_to_numpy=True)[0]
+    assert np.array_equal(v, same)                              # the string went through tokenizer.json
+    assert not np.allclose(v, enc.encode("tübingen castle"))
+    ix = synthetic_corpus(2000, n_chunks=8000, n_terms=1000, device="cuda")
+    ix.urls = [f"https://example.org/{i}" for i in range(ix.n_docs)]
+    ix.titles = [f"title {i}" for i in range(ix.n_docs)]
+    ix.texts = [f"text {i}" for i in range(ix.n_docs)]
+    r = Retriever(embedder=enc, indexer=ix)
+    hits = r.quick_search("food and drinks", top_k=5, return_unique_docs=True)
+    again = r.quick_search(None, top_k=5, query_embedding=v)
+    assert len(hits) == 5 and [h["doc_id"] for h in hits] == [h["doc_id"] for h in again]
+    with pytest.raises(FileNotFoundError):
+        QueryEncoder.from_dir(str(tmp_path))
