@@ -46,7 +46,7 @@ def build_library(force=False, verbose=False, save_temps=False):
     headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "msretr.h"))
     headers.append(os.path.join(HERE, "..", "include", "msretr_encoder.h"))
-    objs = []
+    objs, jobs = [], []
     for src, extra in UNITS.items():
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
@@ -55,9 +55,17 @@ def build_library(force=False, verbose=False, save_temps=False):
             cmd = [hipcc] + COMMON + extra + ["-c", s, "-o", o]
             if save_temps:
                 cmd.insert(1, "-save-temps=obj")
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            subprocess.run(cmd, check=True, cwd=CSRC)
+            jobs.append(cmd)
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+
+    if jobs:                                                # translation units are independent: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) // 2))) as pool:
+            list(pool.map(run, jobs))
     if force or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
