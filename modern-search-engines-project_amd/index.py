@@ -226,11 +226,17 @@ class CorpusIndex:
 
     # ------------------------------------------------------------------ DuckDB (the reference's store)
     @staticmethod
-    def from_duckdb(db_path, with_text=True):
-        """Read the reference's tables once.  `duckdb` is not installable in the build container, so this
-        loader is written against the DDL cited in the module docstring and has not been executed there."""
-        import duckdb  # noqa: deliberately unguarded: fails loudly where duckdb is absent
-        con = duckdb.connect(db_path, read_only=True)
+    def from_duckdb(db_path, with_text=True, connect=None):
+        """Read the reference's tables once.  `duckdb` is not installable in the build container: the loader is written
+        against the DDL cited in the module docstring and is exercised there through `connect`, a callable that returns
+        a DuckDB-style connection (`.execute(sql).fetchall()` / `.fetchnumpy()`); tests/test_host_logic.py passes a
+        sqlite3 adapter over tables created with the reference's own column names.  Default: duckdb, read-only
+        (search_api.py:32,48)."""
+        if connect is None:
+            import duckdb  # noqa: deliberately unguarded: fails loudly where duckdb is absent
+            con = duckdb.connect(db_path, read_only=True)
+        else:
+            con = connect(db_path)
         docs = con.execute("SELECT doc_id, doc_length FROM bm25_doc_stats ORDER BY doc_id").fetchnumpy()
         stats = dict(con.execute("SELECT stat_name, stat_value FROM bm25_corpus_stats").fetchall())
         terms = con.execute("SELECT term, idf_score FROM bm25_term_stats ORDER BY term").fetchall()

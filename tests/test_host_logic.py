@@ -142,6 +142,86 @@ def test_snapshot_directory_roundtrip_and_streaming_upload(tmp_path):
         CorpusIndex.load_dir(str(tmp_path / "bad"))
 
 
+def test_duckdb_loader_runs_against_the_reference_schema(tmp_path):
+    """CorpusIndex.from_duckdb executes its SQL (duckdb itself is not installable here): a sqlite3 database with the
+    reference's tables and column names (bm25_indexer.py:86-126, embedder.py:31-52, databaseManagement.py:18-51; the
+    FLOAT[768] column held as a float32 blob) behind a DuckDB-shaped adapter must load into the same index as
+    from_tables on the same rows."""
+    import sqlite3
+    from msretr.index import CorpusIndex
+    rng = np.random.default_rng(12)
+    postings = {"castle": [(7, 2), (3, 1)], "tübingen": [(3, 4), (7, 1), (11, 2), (40, 1)], "garden": [(40, 3)]}
+    doc_len = {3: 10, 7: 12, 11: 5, 40: 9}
+    idf = {"castle": 0.25, "tübingen": -0.56, "garden": None}
+    chunks = [(100, 7), (101, 7), (55, 3), (300, 40), (301, 40), (302, 40)]
+    emb = {c: rng.standard_normal(768).astype(np.float32) for c, _ in chunks}
+    urls = {3: ("http://a.de/x?p=1", "t3", "text three"), 7: ("http://a.de/x", None, "text seven"), 40: ("http://b.de/", "t40", None)}
+    db = str(tmp_path / "crawlerDb.sqlite")
+    con = sqlite3.connect(db)
+    con.executescript("""
+        CREATE TABLE bm25_doc_stats (doc_id INTEGER PRIMARY KEY, doc_length INTEGER, processed_at TIMESTAMP DEFAULT CURRENT_TIMESTAMP);
+        CREATE TABLE bm25_term_freq (doc_id INTEGER, term TEXT, freq INTEGER, PRIMARY KEY (doc_id, term));
+        CREATE TABLE bm25_term_stats (term TEXT PRIMARY KEY, doc_freq INTEGER, total_freq INTEGER, idf_score REAL, last_updated TIMESTAMP DEFAULT CURRENT_TIMESTAMP);
+        CREATE TABLE bm25_corpus_stats (stat_name TEXT PRIMARY KEY, stat_value REAL, last_updated TIMESTAMP DEFAULT CURRENT_TIMESTAMP);
+        CREATE TABLE chunks_optimized (chunk_id BIGINT PRIMARY KEY, doc_id BIGINT, chunk_text TEXT);
+        CREATE TABLE embeddings (chunk_id BIGINT PRIMARY KEY, embedding BLOB);
+        CREATE TABLE urlsDB (id BIGINT PRIMARY KEY, url TEXT UNIQUE, title TEXT, text TEXT, lastFetch DOUBLE, incoming TEXT,
+                             domainLinkingDepth TINYINT, linkingDepth TINYINT, tueEngScore DOUBLE);
+    """)
+    con.executemany("INSERT INTO bm25_doc_stats (doc_id, doc_length) VALUES (?, ?)", list(doc_len.items()))
+    con.executemany("INSERT INTO bm25_term_freq VALUES (?, ?, ?)", [(d, t, f) for t, pl in postings.items() for d, f in pl])
+    con.executemany("INSERT INTO bm25_term_stats (term, doc_freq, total_freq, idf_score) VALUES (?, ?, ?, ?)",
+                    [(t, len(pl), sum(f for _, f in pl), idf[t]) for t, pl in postings.items()])
+    con.executemany("INSERT INTO bm25_corpus_stats (stat_name, stat_value) VALUES (?, ?)",
+                    [("avg_doc_length", 9.0), ("total_docs", 4.0)])
+    con.executemany("INSERT INTO chunks_optimized VALUES (?, ?, ?)", [(c, d, f"chunk {c}") for c, d in chunks])
+    con.executemany("INSERT INTO embeddings VALUES (?, ?)", [(c, emb[c].tobytes()) for c, _ in chunks])
+    con.executemany("INSERT INTO urlsDB (id, url, title, text) VALUES (?, ?, ?, ?)", [(i, *u) for i, u in urls.items()])
+    con.commit(); con.close()
+
+    class Cur:
+        def __init__(self, cur):
+            self.cur = cur
+
+        def fetchall(self):
+            return self.cur.fetchall()
+
+        def fetchnumpy(self):                                  # DuckDB: dict column name -> numpy array
+            rows = self.cur.fetchall()
+            out = {}
+            for i, d in enumerate(self.cur.description):
+                col = [r[i] for r in rows]
+                if d[0] == "embedding":                        # FLOAT[768] comes back as one array per row
+                    arr = np.empty(len(col), dtype=object)
+                    arr[:] = [np.frombuffer(b, np.float32) for b in col]
+                    out[d[0]] = arr
+                else:
+                    out[d[0]] = np.array(col)
+            return out
+
+    class Conn:
+        def __init__(self, path):
+            self.con = sqlite3.connect(path)
+
+        def execute(self, sql, params=()):
+            return Cur(self.con.execute(sql, params))
+
+    got = CorpusIndex.from_duckdb(db, connect=Conn)
+    ref = CorpusIndex.from_tables(postings, doc_len, idf, 9.0, chunks=chunks, emb=emb, urls_db=urls)
+    assert got.doc_ids.tolist() == ref.doc_ids.tolist() == [3, 7, 11, 40]
+    assert got.doc_len.tolist() == ref.doc_len.tolist() and got.avgdl == ref.avgdl == 9.0 and got.total_docs == 4
+    assert set(got.vocab) == set(ref.vocab)
+    for t in postings:                                          # same posting list and idf per term (term ids differ: ORDER BY term)
+        a, b = got.vocab[t], ref.vocab[t]
+        sl = lambda ix, i: (np.asarray(ix.post_doc)[ix.term_off[i]:ix.term_off[i + 1]].tolist(),
+                            np.asarray(ix.post_tf)[ix.term_off[i]:ix.term_off[i + 1]].tolist())
+        assert sl(got, a) == sl(ref, b) and np.float32(got.idf[a]) == np.float32(ref.idf[b])
+    assert got.doc_off.tolist() == ref.doc_off.tolist() and got.chunk_ids.tolist() == ref.chunk_ids.tolist()
+    assert np.array_equal(got.emb, ref.emb)
+    assert got.urls == ref.urls and got.titles == ref.titles and got.texts == ref.texts
+    assert got.url_group().tolist() == ref.url_group().tolist()
+
+
 def test_bm25_index_build_matches_reference_tables():
     """Index build from tokens reproduces the tables the goldens' corpora were described with."""
     from msretr.index_build import bm25_index_from_tokens, normalise_document_text
