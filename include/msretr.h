@@ -59,7 +59,8 @@ typedef struct msr_config {
     int32_t rerank_max_docs;  /* largest candidate list per query for msr_rerank, <= 1024 */
     int32_t scan_layout;      /* 0 = row-major embeddings; 1 = 16-row interleaved */
     int32_t scan_variant;     /* 0 = default: f16-split products when every row norm is in [0.5, 2], else exact f32;
-                                 2 = always the exact-f32 MFMA kernel; 7 = f16-split on the 32-query kernel; other values (<= 14):
+                                 2 = always the exact-f32 MFMA kernel; 7 = f16-split on the 32-query kernel; 15 = the default kernel over a
+                                 pre-split f16 hi/lo copy of the rows (+4 bytes per value of HBM, ~4 % faster); other values (<= 15):
                                  A/B variants (msr_dense.hip, msr_dense_ks.hip) */
 } msr_config;
 

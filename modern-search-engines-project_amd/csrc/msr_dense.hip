@@ -722,7 +722,7 @@ hipError_t msr_dense_scan(const DenseIndex& ix, const float* qn, int nq, int max
                           hipStream_t stream) {
     if (nq <= 0 || ix.n_docs <= 0) return hipSuccess;
     // variants 13 / 14: K-split kernel (msr_dense_ks.hip) for 17..64 queries / for any count
-    if (((ix.variant == 13 && nq > 16) || ix.variant == 14) && ix.wide_ok && ix.layout == 0 && max_chunks == 0)
+    if (((ix.variant == 13 && nq > 16) || ix.variant == 14 || ix.variant == 15) && ix.wide_ok && ix.layout == 0 && max_chunks == 0)
         return msr_dense_scan_wide(ix, qn, nq, docscore, stream);
     if (nq > 32) return hipErrorInvalidValue;
     const bool tiled = ix.layout == 1;

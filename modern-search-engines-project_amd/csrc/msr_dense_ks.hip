@@ -38,7 +38,7 @@ template <int QB, int MODE, int RING_DOCS = MSR_WIDE_RING, int NWAVES = 8> struc
     static constexpr int THREADS = WAVES * 64;
     static constexpr int KS = MSR_DIM / 32;                          // MFMA k-steps per row
     static constexpr int KT = KS / WAVES;                            // k-steps per wave (3, or 2 with 12 waves)
-    static constexpr int PIECES = MODE == MODE_F16X2 ? 2 : 1;        // operand pieces per k-step (hi, lo)
+    static constexpr int PIECES = MODE == MODE_BF16 ? 1 : 2;         // operand pieces per k-step (hi, lo)
     static constexpr int NLU = MODE == MODE_BF16 ? KT : 2 * KT;      // 16 B loads per lane and unit
     static constexpr int ROW16 = MODE == MODE_BF16 ? MSR_DIM * 2 / 16 : MSR_DIM * 4 / 16;
     static constexpr int NQ = 16 * QB;                               // padded query count
@@ -51,7 +51,7 @@ template <int QB, int MODE, int RING_DOCS = MSR_WIDE_RING, int NWAVES = 8> struc
     static constexpr size_t total = p_bytes + r_bytes;
     static_assert(QB == 2 || QB == 4 || QB == 8, "the reduction hands QB / 2 floats (one tile column piece) to a lane");
     static_assert(KS % WAVES == 0, "k-steps split evenly over the waves");
-    static_assert(MODE == MODE_BF16 || MODE == MODE_F16X2, "f16-split or bf16 products");
+    static_assert(MODE == MODE_BF16 || MODE == MODE_F16X2 || MODE == MODE_PRE, "f16-split or bf16 products");
 };
 
 template <int QB, int MODE, int NBUF, int PIPE, int RING_DOCS, int NWAVES>
@@ -214,11 +214,16 @@ __global__ __launch_bounds__(NWAVES * 64) void dense_ksplit_kernel(DenseIndex ix
                 f32x4 acc[QB];
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) acc[qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if constexpr (MODE == MODE_F16X2) {
+                if constexpr (MODE == MODE_F16X2 || MODE == MODE_PRE) {
 #pragma unroll
                     for (int tt = 0; tt < KT; ++tt) {
                         f16x8 ahi, alo;
-                        split_f16(A[ph][2 * tt], A[ph][2 * tt + 1], ahi, alo);
+                        if constexpr (MODE == MODE_PRE) {       // the image holds the pieces where the floats would be
+                            ahi = __builtin_bit_cast(f16x8, A[ph][2 * tt]);
+                            alo = __builtin_bit_cast(f16x8, A[ph][2 * tt + 1]);
+                        } else {
+                            split_f16(A[ph][2 * tt], A[ph][2 * tt + 1], ahi, alo);
+                        }
 #pragma unroll
                         for (int pc = 0; pc < 3; ++pc)
 #pragma unroll
@@ -278,6 +283,24 @@ __global__ __launch_bounds__(256) void pack_row_meta_kernel(const int32_t* __res
     out[i] = make_int2(chunk_doc[r], __float_as_int(inv_norm[r]));
 }
 
+// dst f32x4 slot (row, 2T, g) <- f16 hi pieces, slot (row, 2T + 1, g) <- lo pieces of the 8 floats mode 2 takes from those
+// two slots (T = k-step of 32 dimensions, g = lane >> 4)
+__global__ __launch_bounds__(256) void presplit_kernel(const float* __restrict__ src, int64_t n_rows,
+                                                       f32x4* __restrict__ dst) {
+    const int64_t n = n_rows * (MSR_DIM / 32) * 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int g = (int)(i & 3);
+        const int T = (int)((i >> 2) % (MSR_DIM / 32));
+        const int64_t r = i / (4 * (MSR_DIM / 32));
+        const f32x4* row = (const f32x4*)(src + r * MSR_DIM);
+        f16x8 hi, lo;
+        split_f16(row[4 * (2 * T) + g], row[4 * (2 * T + 1) + g], hi, lo);
+        f32x4* out = dst + r * (MSR_DIM / 4);
+        out[4 * (2 * T) + g] = __builtin_bit_cast(f32x4, hi);
+        out[4 * (2 * T + 1) + g] = __builtin_bit_cast(f32x4, lo);
+    }
+}
+
 int scan_debug_flags() {
     static const int v = [] { const char* e = getenv("MSR_SCAN_DEBUG"); return e ? atoi(e) : 0; }();
     return v;
@@ -291,7 +314,7 @@ hipError_t launch_ksplit(const DenseIndex& ix, const void* emb, const float* qn,
     hipError_t err = hipFuncSetAttribute((const void*)dense_ksplit_kernel<QB, MODE, NBUF, PIPE, RING_DOCS, NWAVES>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::total);
     if (err != hipSuccess) return err;
-    err = msr_build_qimage(MODE, qn, QB, ix.qimg, stream);
+    err = msr_build_qimage(MODE == MODE_PRE ? MODE_F16X2 : MODE, qn, QB, ix.qimg, stream);
     if (err != hipSuccess) return err;
     dense_ksplit_kernel<QB, MODE, NBUF, PIPE, RING_DOCS, NWAVES><<<ix.n_spans, L::THREADS, L::total, stream>>>(
         ix, emb, (const f32x4*)ix.qimg, nq, docscore, scan_debug_flags());
@@ -307,6 +330,12 @@ hipError_t msr_pack_row_meta(const int32_t* chunk_doc, const float* inv_norm, in
     return hipGetLastError();
 }
 
+hipError_t msr_presplit_rows(const float* src, int64_t n_rows, void* dst, hipStream_t stream) {
+    if (n_rows <= 0) return hipSuccess;
+    presplit_kernel<<<16384, 256, 0, stream>>>(src, n_rows, (f32x4*)dst);
+    return hipGetLastError();
+}
+
 // f32 rows, f16-split products, up to 64 queries per sweep (row-major layout, ix.wide_ok).
 hipError_t msr_dense_scan_wide(const DenseIndex& ix, const float* qn, int nq, float* docscore, hipStream_t stream) {
     if (nq <= 0 || ix.n_docs <= 0) return hipSuccess;
@@ -315,6 +344,10 @@ hipError_t msr_dense_scan_wide(const DenseIndex& ix, const float* qn, int nq, fl
     // (profile r01_m); 32 queries: 8-way.  A/B knobs for measurements: MSR_KS_PIPE=8 -> 8 waves; 2 -> 8 waves with the
     // reduction pipelined in waves 4..7 only (see PIPE in the kernel; no gain measured).
     static const int pipe = [] { const char* v = getenv("MSR_KS_PIPE"); return v ? atoi(v) : 0; }();
+    if (ix.variant == 15 && ix.emb_presplit) {              // A/B variant: pre-split copy of the rows (+4 bytes per value of HBM)
+        if (nq <= 32) return launch_ksplit<2, MODE_PRE, 3, 0>(ix, ix.emb_presplit, qn, nq, docscore, stream);
+        return launch_ksplit<4, MODE_PRE, 2, 0, MSR_WIDE_RING, 12>(ix, ix.emb_presplit, qn, nq, docscore, stream);
+    }
     if (nq <= 32) return launch_ksplit<2, MODE_F16X2, 3, 0>(ix, ix.emb, qn, nq, docscore, stream);   // (8 waves: 12 gain nothing here)
     if (pipe == 2) return launch_ksplit<4, MODE_F16X2, 3, 2>(ix, ix.emb, qn, nq, docscore, stream);
     if (pipe == 8) return launch_ksplit<4, MODE_F16X2, 3, 0>(ix, ix.emb, qn, nq, docscore, stream);

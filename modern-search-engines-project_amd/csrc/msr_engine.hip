@@ -24,6 +24,7 @@ struct msr_engine {
     int64_t url_group_n = 0;
     // engine-owned device memory
     int32_t* chunk_doc = nullptr;
+    void* emb_presplit = nullptr;     // scan_variant 15: f16 hi/lo image of the rows
     void* row_meta = nullptr;         // packed {document, inverse norm} per row for the K-split kernels
     float* inv_norm_own = nullptr;
     int32_t* span_doc = nullptr;
@@ -103,8 +104,8 @@ extern "C" int msr_create(const msr_config* cfg, msr_engine** out) {
         return fail(nullptr, MSR_ERR_INVALID, "msr_create: rerank_max_docs out of range [0, 1024]");
     if (cfg->scan_layout != 0 && cfg->scan_layout != 1)
         return fail(nullptr, MSR_ERR_INVALID, "msr_create: scan_layout must be 0 or 1");
-    if (cfg->scan_variant < 0 || cfg->scan_variant > 14)
-        return fail(nullptr, MSR_ERR_INVALID, "msr_create: scan_variant must be 0..14");
+    if (cfg->scan_variant < 0 || cfg->scan_variant > 15)
+        return fail(nullptr, MSR_ERR_INVALID, "msr_create: scan_variant must be 0..15");
     int ndev = 0;
     hipError_t herr = hipGetDeviceCount(&ndev);
     if (herr != hipSuccess || ndev <= 0)
@@ -155,7 +156,7 @@ extern "C" int msr_create(const msr_config* cfg, msr_engine** out) {
 
 extern "C" int msr_destroy(msr_engine* e) {
     if (!e) return MSR_OK;
-    free_dev(e->chunk_doc); free_dev(e->row_meta); free_dev(e->inv_norm_own); free_dev(e->span_doc); free_dev(e->wspan_doc); free_dev(e->wspan12_doc); free_dev(e->qn); free_dev(e->qimg); free_dev(e->emb_bf16);
+    free_dev(e->chunk_doc); free_dev(e->emb_presplit); free_dev(e->row_meta); free_dev(e->inv_norm_own); free_dev(e->span_doc); free_dev(e->wspan_doc); free_dev(e->wspan12_doc); free_dev(e->qn); free_dev(e->qimg); free_dev(e->emb_bf16);
     free_dev(e->score_rows); free_dev(e->bm_heavy_id); free_dev(e->bm_tile_off); free_dev(e->bm_cand_doc); free_dev(e->bm_cand_n); free_dev(e->sel.hist); free_dev(e->sel.state); free_dev(e->sel.cand_hi);
     free_dev(e->sel.cand_lo); free_dev(e->sel.cand_n); free_dev(e->rerank_cos); free_dev(e->rerank_meta);
     free_dev(e->bt_top_doc); free_dev(e->bt_top_score); free_dev(e->bt_top_n); free_dev(e->bt_cand_doc);
@@ -331,6 +332,7 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
 
     free_dev(e->chunk_doc); e->chunk_doc = nullptr;
     free_dev(e->row_meta); e->row_meta = nullptr;
+    free_dev(e->emb_presplit); e->emb_presplit = nullptr;
     free_dev(e->inv_norm_own); e->inv_norm_own = nullptr;
     free_dev(e->span_doc); e->span_doc = nullptr;
     free_dev(e->wspan_doc); e->wspan_doc = nullptr;
@@ -373,10 +375,20 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
         variant = (lo >= 0.5f && hi <= 2.0f) ? 7 : 2;
         if (variant == 7 && e->cfg.scan_layout == 0 && wide_ok) variant = 14;   // K-split kernel: up to 64 queries per sweep
     }
+    if (variant == 15) {                                  // A/B variant: K-split scan over a pre-split copy of the rows
+        if (e->cfg.scan_layout != 0 || !wide_ok) {
+            variant = 7;                                  // preconditions of the K-split kernel not met
+        } else {
+            if ((herr = hipMalloc(&e->emb_presplit, (size_t)n_chunks * MSR_DIM * sizeof(float))) != hipSuccess)
+                return fail(e, MSR_ERR_NOMEM, "pre-split rows (%zu bytes): %s", (size_t)n_chunks * MSR_DIM * sizeof(float),
+                            hipGetErrorString(herr));
+            HIP_TRY(e, msr_presplit_rows(emb, n_chunks, e->emb_presplit, st));
+        }
+    }
     HIP_TRY(e, hipStreamSynchronize(st));                 // spans vector goes out of scope
     e->dense = DenseIndex{emb, doc_off, e->chunk_doc, inv_norm, e->span_doc, n_chunks, n_docs, (n_docs + 31) / 32 * 32, n_spans,
                           e->cfg.scan_layout, e->wspan_doc, n_wspans, e->wspan12_doc, n_wspans12, e->qimg, nullptr,
-                          e->row_meta, wide_ok, wide_ok && wide_ok64, variant};
+                          e->emb_presplit, e->row_meta, wide_ok, wide_ok && wide_ok64, variant};
     free_dev(e->emb_bf16);                                // a new binding invalidates the bf16 copy
     e->emb_bf16 = nullptr;
     e->have_chunks = true;
@@ -404,12 +416,13 @@ extern "C" int msr_interleave_rows(msr_engine* e, const float* src, int64_t n_ro
 extern "C" int msr_scan_arith(const msr_engine* e) {
     if (!e || !e->have_chunks) return -1;
     const int v = e->dense.variant;
-    return (v == 7 || v == 8 || v == 11 || v == 13 || v == 14) ? 1 : 0;
+    return (v == 7 || v == 8 || v == 11 || v == 13 || v == 14 || v == 15) ? 1 : 0;
 }
 
 extern "C" int msr_scan_width(const msr_engine* e) {
     if (!e || !e->have_chunks) return -1;
-    const bool wide = (e->dense.variant == 13 || e->dense.variant == 14) && e->dense.layout == 0 && e->dense.wide_ok;
+    const int v = e->dense.variant;
+    const bool wide = (v == 13 || v == 14 || v == 15) && e->dense.layout == 0 && e->dense.wide_ok;
     return wide ? 64 : 32;
 }
 
@@ -481,14 +494,14 @@ extern "C" int msr_dense_topk(msr_engine* e, const float* q, int32_t n_queries, 
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     // one sweep of E serves up to 32 queries (wave-streaming kernel) or 64 (K-split kernel, variants 13 / 14)
-    const bool wide = (e->dense.variant == 13 || e->dense.variant == 14) && e->dense.layout == 0 && e->dense.wide_ok &&
-                      max_chunks_per_doc == 0;
+    const bool wide = (e->dense.variant == 13 || e->dense.variant == 14 || e->dense.variant == 15) && e->dense.layout == 0 &&
+                      e->dense.wide_ok && max_chunks_per_doc == 0;
     const int slice = wide ? 64 : 32;
     const int64_t N = e->dense.n_docs;
     for (int q0 = 0; q0 < n_queries; q0 += slice) {
         const int nq = std::min(slice, n_queries - q0);
         // zero rows up to the query-block count of the kernel that runs (1, 2 or 4 blocks of 16)
-        const int nq_pad = nq > 32 ? 64 : (nq > 16 || (wide && e->dense.variant == 14)) ? 32 : 16;
+        const int nq_pad = nq > 32 ? 64 : (nq > 16 || (wide && e->dense.variant >= 14)) ? 32 : 16;
         const bool timed = e->timing && e->ev_count[0] < msr_engine::EV_RING;
         HIP_TRY(e, msr_prep_queries(q + (int64_t)q0 * MSR_DIM, nq, e->qn, nq_pad, st));
         if (timed) HIP_TRY(e, hipEventRecord(e->ev_start[0][e->ev_count[0]], st));

@@ -12,7 +12,9 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 //   1  bf16 rows, v_mfma_f32_16x16x32_bf16 (candidate generator of the batched path)
 //   2  f32 rows split on the fly into two f16 pieces (x = hi + lo); three v_mfma_f32_16x16x32_f16
 //      (hi*hi + hi*lo + lo*hi) replace eight f32 MFMAs; error bound in DESIGN.md section 3
-constexpr int MODE_F32 = 0, MODE_BF16 = 1, MODE_F16X2 = 2;
+//   3  rows already stored as f16 hi/lo pieces in the positions mode 2 loads them from (msr_presplit_rows): mode 2
+//      without the split instructions, at the price of a second copy of the matrix
+constexpr int MODE_F32 = 0, MODE_BF16 = 1, MODE_F16X2 = 2, MODE_PRE = 3;
 
 // x (8 floats in two float4) -> hi, lo with x ~= hi + lo.  cvt_pkrtz rounds toward zero, so the residual x - hi is
 // exact in f32 and smaller than 2^-10 |x|; after the second truncation |x - hi - lo| < 2^-20 |x|.

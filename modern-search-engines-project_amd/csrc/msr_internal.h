@@ -93,6 +93,7 @@ struct DenseIndex {
     int32_t n_wspans12;
     void* qimg;                // engine scratch: query image in MFMA-fragment order (<= 256 KB)
     const void* emb_bf16;      // bf16 [n_chunks][768] copy of emb for the batched path, or null
+    const void* emb_presplit;  // scan_variant 15 only: the rows as f16 hi/lo pieces (msr_presplit_rows), same size as emb
     const void* row_meta;      // [n_chunks + 16] x {int32 document, float inverse norm} (last row repeated as padding: a row group may stick out by 15 rows),
                                // one load per unit for the K-split kernels; null when !wide_ok
     int32_t wide_ok;           // any 32 consecutive rows (on 16-row group boundaries) span <= MSR_WIDE_RING - 32 documents
@@ -119,6 +120,8 @@ hipError_t msr_dense_scan_bf16_wide(const DenseIndex& ix, const float* qn, int n
                                     hipStream_t stream);
 // Query image in MFMA-fragment order for n_blocks x 16 queries (mode: 0 f32, 1 bf16, 2 f16 hi/lo pieces).
 hipError_t msr_build_qimage(int mode, const float* qn, int n_blocks, void* qimg, hipStream_t stream);
+// dst (n_rows x 768 x 4 bytes) <- the rows as f16 hi/lo pieces in the slots the f16-split scan loads them from
+hipError_t msr_presplit_rows(const float* src, int64_t n_rows, void* dst, hipStream_t stream);
 // row_meta[i] = {chunk_doc[min(i, n-1)], inv_norm[min(i, n-1)]} for i in [0, n + 16)
 hipError_t msr_pack_row_meta(const int32_t* chunk_doc, const float* inv_norm, int64_t n, void* row_meta, hipStream_t stream);
 hipError_t msr_to_bf16(const float* src, int64_t n_elems, void* dst, hipStream_t stream);
