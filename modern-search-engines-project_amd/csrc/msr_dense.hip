@@ -688,13 +688,8 @@ hipError_t dispatch_variant(const DenseIndex& ix, const float* qn, int nq, int m
         // 0 is resolved by the engine at bind time to 7 (f16 split) or 2 (exact f32), see msr_bind_chunks
         case 1: return launch_scan<QB, TILED>(ix, qn, nq, max_chunks, docscore, stream);                      // super-tile kernel
         case 2: return launch_scan_v2<QB, TILED, 12>(ix, qn, nq, max_chunks, docscore, stream);              // exact f32 MFMA
-        case 3: return launch_scan_v2<QB, TILED, 8>(ix, qn, nq, max_chunks, docscore, stream);
-        case 4: return launch_scan_v2<QB, TILED, 24>(ix, qn, nq, max_chunks, docscore, stream);
         case 5: return launch_scan_v2<QB, TILED, 12, 12, 16>(ix, qn, nq, max_chunks, docscore, stream);      // 3 waves/SIMD
-        case 6: return launch_scan_v2<QB, TILED, 8, 12, 16>(ix, qn, nq, max_chunks, docscore, stream);
         case 8: return launch_scan_v2<QB, TILED, 24, 8, 32, MODE_F16X2>(ix, qn, nq, max_chunks, docscore, stream);
-        case 9: return launch_scan_v2<QB, TILED, 6, 8, 32, MODE_F32, 2>(ix, qn, nq, max_chunks, docscore, stream);    // 2 groups/unit
-        case 10: return launch_scan_v2<QB, TILED, 12, 8, 32, MODE_F32, 2>(ix, qn, nq, max_chunks, docscore, stream);
         case 11: return launch_scan_v2<QB, TILED, 6, 8, 32, MODE_F16X2, 2>(ix, qn, nq, max_chunks, docscore, stream);
         case 12: return launch_scan_v2<QB, TILED, 4, 8, 32, MODE_F32, 4>(ix, qn, nq, max_chunks, docscore, stream);   // 4 groups/unit
         default: return launch_scan_v2<QB, TILED, 12, 8, 32, MODE_F16X2>(ix, qn, nq, max_chunks, docscore, stream);   // 7: f16 split

@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--docs", type=int, default=1_000_000)
     ap.add_argument("--chunks", type=int, default=5_000_000)
     ap.add_argument("--rounds", type=int, default=7)
-    ap.add_argument("--configs", default="0:0,0:1,0:3,1:0,1:1,1:3", help="layout:variant list")
+    ap.add_argument("--configs", default="0:14,0:7,0:2,0:1", help="layout:variant list")
     ap.add_argument("--queries", default="1,16,32")
     ap.add_argument("--nonzero", type=int, default=-1,
                     help="diagnostic: keep only the first N query rows non-zero (the MFMA count stays, operand data changes)")
