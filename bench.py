@@ -357,6 +357,15 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes, "launches": k_n, "ms_per_launch": per_launch_ms}
         if args.workload == "hybrid":
             roof["bm25_taat_ms_per_launch"] = bm_ms / max(1, bm_n)
+            # the stage-1 kernel against the same roofline (SURVEY 8d bytes: 8 B per posting of the query's terms + 4 B
+            # doc_len per document and query; emitted candidates not counted, so this is a lower bound)
+            tq = batches[0][0][1].long()
+            tq = tq[(tq >= 0) & (tq < shard.n_terms)]
+            toff = shard.term_off.to(tq.device)
+            bm_bytes = 8 * int((toff[tq + 1] - toff[tq]).sum().item()) + Q * 4 * shard.n_docs
+            bm_gbs = bm_bytes / (roof["bm25_taat_ms_per_launch"] * 1e-3) / 1e9 if bm_n else 0.0
+            roof["bm25_taat"] = {"achieved": bm_gbs, "unit": "GB/s", "frac": bm_gbs / HBM_PEAK_GBS,
+                                 "algorithmic_bytes_per_launch": bm_bytes, "launches": bm_n}
         dense_dt = {"f32": "f32", "f16x2": "f32 via f16x2-split products, f32 accumulate (|err| <= 8e-6)",
                     "none": "-"}[eng.scan_arith()]
         names = {"hybrid": "two-stage retrieval top-100 (BM25 top-1000 + dense full scan + rerank/fuse)" +
