@@ -31,6 +31,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+F32_MFMA_PEAK_TFLOPS = 157.3    # v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -355,6 +356,14 @@ def main():
         roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, world, kname),
                 "algorithmic_bytes_per_launch": alg_bytes, "launches": k_n, "ms_per_launch": per_launch_ms}
+        if args.workload != "bm25" and args.dense_mode == "f32" and eng.scan_arith() == "f32" and q_launch > 32:
+            # exact-f32 products at 64 queries per sweep: v_mfma_f32_16x16x4_f32 runs at the f32 vector rate
+            # (157.3 TFLOP/s, MI355X_MICROARCH.md), which binds before HBM does (2 * 768 flop per row and query)
+            flops = 2.0 * 768 * n_ch * q_launch
+            tf = flops / (per_launch_ms * 1e-3) / 1e12
+            roof.update({"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tf / F32_MFMA_PEAK_TFLOPS, "algorithmic_flops_per_launch": flops,
+                         "hbm_GBps": achieved})
         if args.workload == "hybrid":
             roof["bm25_taat_ms_per_launch"] = bm_ms / max(1, bm_n)
             # the stage-1 kernel against the same roofline (SURVEY 8d bytes: 8 B per posting of the query's terms + 4 B

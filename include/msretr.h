@@ -106,7 +106,8 @@ int msr_bind_doc_meta(msr_engine* e, const int32_t* url_group, int64_t n_docs, v
 int msr_scan_arith(const msr_engine* e);
 
 /* Most queries one sweep of the embedding matrix serves in msr_dense_topk: 64 when the K-split kernel is in use
- * (f16-split arithmetic, row-major layout, no per-document row limit), else 32; -1 = no chunks bound. */
+ * (row-major layout, no per-document row limit, a corpus that meets its preconditions; both arithmetics), else 32;
+ * -1 = no chunks bound. */
 int msr_scan_width(const msr_engine* e);
 /* The same for msr_dense_topk_bf16 (after msr_enable_bf16): 128, 64, or -1. */
 int msr_batch_width(const msr_engine* e);

@@ -687,7 +687,7 @@ hipError_t dispatch_variant(const DenseIndex& ix, const float* qn, int nq, int m
     switch (ix.variant) {
         // 0 is resolved by the engine at bind time to 7 (f16 split) or 2 (exact f32), see msr_bind_chunks
         case 1: return launch_scan<QB, TILED>(ix, qn, nq, max_chunks, docscore, stream);                      // super-tile kernel
-        case 2: return launch_scan_v2<QB, TILED, 12>(ix, qn, nq, max_chunks, docscore, stream);              // exact f32 MFMA
+        case 2: case 16: return launch_scan_v2<QB, TILED, 12>(ix, qn, nq, max_chunks, docscore, stream);     // exact f32 MFMA
         case 5: return launch_scan_v2<QB, TILED, 12, 12, 16>(ix, qn, nq, max_chunks, docscore, stream);      // 3 waves/SIMD
         case 8: return launch_scan_v2<QB, TILED, 24, 8, 32, MODE_F16X2>(ix, qn, nq, max_chunks, docscore, stream);
         case 11: return launch_scan_v2<QB, TILED, 6, 8, 32, MODE_F16X2, 2>(ix, qn, nq, max_chunks, docscore, stream);
@@ -719,6 +719,10 @@ hipError_t msr_dense_scan(const DenseIndex& ix, const float* qn, int nq, int max
     // variants 13 / 14: K-split kernel (msr_dense_ks.hip) for 17..64 queries / for any count
     if (((ix.variant == 13 && nq > 16) || ix.variant == 14 || ix.variant == 15) && ix.wide_ok && ix.layout == 0 && max_chunks == 0)
         return msr_dense_scan_wide(ix, qn, nq, docscore, stream);
+    // exact f32 products: the K-split kernel pays off above 32 queries (matrix-core bound: 4.5 ms per 64 queries against
+    // 2 x 2.8 ms on the narrow kernel; at <= 32 queries the narrow kernel is faster); 16 = K-split for every count (A/B)
+    if (((ix.variant == 2 && nq > 32) || ix.variant == 16) && ix.wide_ok && ix.layout == 0 && max_chunks == 0)
+        return msr_dense_scan_wide_exact(ix, qn, nq, docscore, stream);
     if (nq > 32) return hipErrorInvalidValue;
     const bool tiled = ix.layout == 1;
     if (nq <= 16)

@@ -38,7 +38,8 @@ template <int QB, int MODE, int RING_DOCS = MSR_WIDE_RING, int NWAVES = 8> struc
     static constexpr int THREADS = WAVES * 64;
     static constexpr int KS = MSR_DIM / 32;                          // MFMA k-steps per row
     static constexpr int KT = KS / WAVES;                            // k-steps per wave (3, or 2 with 12 waves)
-    static constexpr int PIECES = MODE == MODE_BF16 ? 1 : 2;         // operand pieces per k-step (hi, lo)
+    static constexpr int PIECES = MODE == MODE_BF16 ? 1 : 2;         // 16 B fragment pieces per 32 dimensions (f16 modes: hi, lo;
+                                                                     // exact f32: two blocks of 16 dimensions)
     static constexpr int NLU = MODE == MODE_BF16 ? KT : 2 * KT;      // 16 B loads per lane and unit
     static constexpr int ROW16 = MODE == MODE_BF16 ? MSR_DIM * 2 / 16 : MSR_DIM * 4 / 16;
     static constexpr int NQ = 16 * QB;                               // padded query count
@@ -51,7 +52,7 @@ template <int QB, int MODE, int RING_DOCS = MSR_WIDE_RING, int NWAVES = 8> struc
     static constexpr size_t total = p_bytes + r_bytes;
     static_assert(QB == 2 || QB == 4 || QB == 8, "the reduction hands QB / 2 floats (one tile column piece) to a lane");
     static_assert(KS % WAVES == 0, "k-steps split evenly over the waves");
-    static_assert(MODE == MODE_BF16 || MODE == MODE_F16X2 || MODE == MODE_PRE, "f16-split or bf16 products");
+    static_assert(MODE == MODE_BF16 || MODE == MODE_F16X2 || MODE == MODE_PRE || MODE == MODE_F32, "supported products");
 };
 
 template <int QB, int MODE, int NBUF, int PIPE, int RING_DOCS, int NWAVES>
@@ -88,7 +89,8 @@ __global__ __launch_bounds__(NWAVES * 64) void dense_ksplit_kernel(DenseIndex ix
         for (int tt = 0; tt < KT; ++tt)
 #pragma unroll
             for (int pc = 0; pc < PIECES; ++pc)
-                B[qb][tt][pc] = qimg[((size_t)(qb * L::KS + KT * w + tt) * PIECES + pc) * 64 + lane];
+                B[qb][tt][pc] = qimg[((size_t)(qb * L::KS + KT * w + tt) * PIECES + pc) * 64 + lane];   // (same index
+                    // arithmetic for the f32 image: its 16-dimension block 2 (KT w + tt) + pc)
 
     for (int i = tid; i < RING * NQ; i += L::THREADS) R[i] = NEG_INF;
 
@@ -214,7 +216,17 @@ __global__ __launch_bounds__(NWAVES * 64) void dense_ksplit_kernel(DenseIndex ix
                 f32x4 acc[QB];
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) acc[qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if constexpr (MODE == MODE_F16X2 || MODE == MODE_PRE) {
+                if constexpr (MODE == MODE_F32) {
+                    // exact f32: four v_mfma_f32_16x16x4_f32 per 16 B load and query block (the k index is only a label,
+                    // see msr_dense.hip); bit-for-bit a k-ordered fmaf chain per K slice, slices added in wave order
+#pragma unroll
+                    for (int j = 0; j < NLU; ++j)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+#pragma unroll
+                            for (int qb = 0; qb < QB; ++qb)
+                                acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[ph][j][c], B[qb][j / 2][j % 2][c], acc[qb], 0, 0, 0);
+                } else if constexpr (MODE == MODE_F16X2 || MODE == MODE_PRE) {
 #pragma unroll
                     for (int tt = 0; tt < KT; ++tt) {
                         f16x8 ahi, alo;
@@ -352,6 +364,14 @@ hipError_t msr_dense_scan_wide(const DenseIndex& ix, const float* qn, int nq, fl
     if (pipe == 2) return launch_ksplit<4, MODE_F16X2, 3, 2>(ix, ix.emb, qn, nq, docscore, stream);
     if (pipe == 8) return launch_ksplit<4, MODE_F16X2, 3, 0>(ix, ix.emb, qn, nq, docscore, stream);
     return launch_ksplit<4, MODE_F16X2, 2, 0, MSR_WIDE_RING, 12>(ix, ix.emb, qn, nq, docscore, stream);
+}
+
+// f32 rows, exact f32 products (v_mfma_f32_16x16x4_f32), up to 64 queries per sweep: matrix-core bound above 32 queries.
+hipError_t msr_dense_scan_wide_exact(const DenseIndex& ix, const float* qn, int nq, float* docscore, hipStream_t stream) {
+    if (nq <= 0 || ix.n_docs <= 0) return hipSuccess;
+    if (nq > 64 || ix.layout != 0 || !ix.wide_ok || !ix.row_meta) return hipErrorInvalidValue;
+    if (nq <= 32) return launch_ksplit<2, MODE_F32, 3, 0>(ix, ix.emb, qn, nq, docscore, stream);
+    return launch_ksplit<4, MODE_F32, 2, 0, MSR_WIDE_RING, 12>(ix, ix.emb, qn, nq, docscore, stream);
 }
 
 // bf16 rows (candidate generator of the batched path): up to 64 queries per sweep, or up to 128 with a ring of 64

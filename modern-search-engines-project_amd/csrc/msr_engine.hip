@@ -104,8 +104,8 @@ extern "C" int msr_create(const msr_config* cfg, msr_engine** out) {
         return fail(nullptr, MSR_ERR_INVALID, "msr_create: rerank_max_docs out of range [0, 1024]");
     if (cfg->scan_layout != 0 && cfg->scan_layout != 1)
         return fail(nullptr, MSR_ERR_INVALID, "msr_create: scan_layout must be 0 or 1");
-    if (cfg->scan_variant < 0 || cfg->scan_variant > 15)
-        return fail(nullptr, MSR_ERR_INVALID, "msr_create: scan_variant must be 0..15");
+    if (cfg->scan_variant < 0 || cfg->scan_variant > 16)
+        return fail(nullptr, MSR_ERR_INVALID, "msr_create: scan_variant must be 0..16");
     int ndev = 0;
     hipError_t herr = hipGetDeviceCount(&ndev);
     if (herr != hipSuccess || ndev <= 0)
@@ -422,7 +422,7 @@ extern "C" int msr_scan_arith(const msr_engine* e) {
 extern "C" int msr_scan_width(const msr_engine* e) {
     if (!e || !e->have_chunks) return -1;
     const int v = e->dense.variant;
-    const bool wide = (v == 13 || v == 14 || v == 15) && e->dense.layout == 0 && e->dense.wide_ok;
+    const bool wide = (v == 2 || (v >= 13 && v <= 16)) && e->dense.layout == 0 && e->dense.wide_ok;
     return wide ? 64 : 32;
 }
 
@@ -494,7 +494,7 @@ extern "C" int msr_dense_topk(msr_engine* e, const float* q, int32_t n_queries, 
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     // one sweep of E serves up to 32 queries (wave-streaming kernel) or 64 (K-split kernel, variants 13 / 14)
-    const bool wide = (e->dense.variant == 13 || e->dense.variant == 14 || e->dense.variant == 15) && e->dense.layout == 0 &&
+    const bool wide = (e->dense.variant == 2 || (e->dense.variant >= 13 && e->dense.variant <= 16)) && e->dense.layout == 0 &&
                       e->dense.wide_ok && max_chunks_per_doc == 0;
     const int slice = wide ? 64 : 32;
     const int64_t N = e->dense.n_docs;

@@ -116,6 +116,7 @@ hipError_t msr_dense_scan_bf16(const DenseIndex& ix, const float* qn, int nq, in
 // or <= 128 with ix.wide_ok64.
 // Both need ix.wide_ok and have no per-document row limit (max_chunks = 0).
 hipError_t msr_dense_scan_wide(const DenseIndex& ix, const float* qn, int nq, float* docscore, hipStream_t stream);
+hipError_t msr_dense_scan_wide_exact(const DenseIndex& ix, const float* qn, int nq, float* docscore, hipStream_t stream);
 hipError_t msr_dense_scan_bf16_wide(const DenseIndex& ix, const float* qn, int nq, float* docscore,
                                     hipStream_t stream);
 // Query image in MFMA-fragment order for n_blocks x 16 queries (mode: 0 f32, 1 bf16, 2 f16 hi/lo pieces).

@@ -158,7 +158,7 @@ def _check_dense(mods, eng, doc_off, emb, q, k, mc, got):
             assert abs(cos_c - best[d]) <= 2e-5
 
 
-@pytest.mark.parametrize("layout,variant", [(0, 0), (1, 0), (0, 1), (0, 2), (1, 2), (0, 5), (0, 7), (0, 8), (1, 11), (0, 12), (0, 14), (0, 15)])
+@pytest.mark.parametrize("layout,variant", [(0, 0), (1, 0), (0, 1), (0, 2), (1, 2), (0, 5), (0, 7), (0, 8), (1, 11), (0, 12), (0, 14), (0, 15), (0, 16)])
 def test_dense_scan_vs_oracle(mods, layout, variant):
     rng = np.random.default_rng(17 + layout)
     doc_off, emb = _rand_chunked(rng, 700, 9, big=((5, 70), (300, 300), (301, 0), (699, 33)))
@@ -166,7 +166,7 @@ def test_dense_scan_vs_oracle(mods, layout, variant):
                              chunk_ids=np.arange(doc_off[-1], dtype=np.int64), emb=emb, total_docs=700)
     eng = mods["DeviceEngine"](ix, max_queries=32, max_k=200, scan_layout=layout, scan_variant=variant)
     # variants 0 (default), 13, 14 use the K-split kernel for 33..64 queries per sweep (14: for any count)
-    for Q in (1, 5, 16, 17, 32, 40) + ((50, 64, 70) if variant in (0, 13, 14, 15) else ()):
+    for Q in (1, 5, 16, 17, 32, 40) + ((50, 64, 70) if variant in (0, 13, 14, 15, 16) else ()):
         q = (rng.standard_normal((Q, 768)) * rng.uniform(0.5, 9)).astype(np.float32)
         q[0] = emb[123] * 4.0                                  # an exact hit
         for (k, mc) in ((100, 0), (200, 10), (7, 3)) if Q <= 40 else ((100, 0), (9, 2)):
