@@ -310,8 +310,18 @@ def main():
             b_doc, b_score = vout["dense"][0], vout["dense"][1]
             same = bool((((a_doc == b_doc) | ((a_score - b_score).abs() <= 2e-6)).all()
                          & ((a_score - b_score).abs() <= 2e-6).all()).item())
+            vlat = []                                         # single-query latency on the same path
+            for rep in range(2):
+                for packed1, qv1 in one[:10]:
+                    fence()
+                    t1 = time.perf_counter()
+                    se.search(None, qv1, k1=args.k1, k2=args.k2, packed=packed1, dense_batched=True)
+                    torch.cuda.synchronize()
+                    if rep:
+                        vlat.append(time.perf_counter() - t1)
             variant = {"dense_stage": "bf16 candidate sweep + exact f32 rescore (msr_dense_topk_bf16)",
                        "value": Q * args.steps / v_el, "unit": "queries/sec", "ms_per_step": 1e3 * v_el / args.steps,
+                       "p50_latency_ms_single_query": 1e3 * float(np.median(vlat)) if vlat else None,
                        "top100_equals_default_path_within_2e-6": same}
         except Exception as ex:
             variant = {"error": repr(ex)}
