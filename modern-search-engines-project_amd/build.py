@@ -3,6 +3,8 @@
     python -m msretr.build            # or: from msretr.build import build_library; build_library()
 
 The shared library is written next to the sources (csrc/libmsretr.so) so that it travels with the tree.
+`--diag` builds csrc/libmsretr_diag.so with -DMSR_DIAG instead: the only build that reads the MSR_* environment
+knobs of the A/B tools (tools/ab_scan.py, tools/scan_once.py); the product library reads no environment variable.
 """
 import os
 import subprocess
@@ -41,18 +43,20 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force=False, verbose=False, save_temps=False):
+def build_library(force=False, verbose=False, save_temps=False, diag=False):
     hipcc = _hipcc()
+    lib = os.path.join(CSRC, "libmsretr_diag.so") if diag else LIB
+    suffix = ".diag.o" if diag else ".o"
     headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "msretr.h"))
     headers.append(os.path.join(HERE, "..", "include", "msretr_encoder.h"))
     objs, jobs = [], []
     for src, extra in UNITS.items():
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        o = os.path.join(CSRC, src.replace(".hip", suffix))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            cmd = [hipcc] + COMMON + extra + ["-c", s, "-o", o]
+            cmd = [hipcc] + COMMON + extra + (["-DMSR_DIAG"] if diag else []) + ["-c", s, "-o", o]
             if save_temps:
                 cmd.insert(1, "-save-temps=obj")
             jobs.append(cmd)
@@ -66,13 +70,14 @@ def build_library(force=False, verbose=False, save_temps=False):
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) // 2))) as pool:
             list(pool.map(run, jobs))
-    if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+    if force or _stale(lib, objs):
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True, cwd=CSRC)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv, verbose=True, save_temps="--save-temps" in sys.argv))
+    print(build_library(force="--force" in sys.argv, verbose=True, save_temps="--save-temps" in sys.argv,
+                        diag="--diag" in sys.argv))

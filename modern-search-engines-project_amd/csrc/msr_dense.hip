@@ -10,15 +10,12 @@
 // MFMA is only a label: lane (i = lane & 15, g = lane >> 4) loads E[row i][16t + 4g .. +3] and the query
 // image in LDS is stored in the same permuted order, so no data ever moves between lanes.
 //
-// Two decompositions live in this file:
-//   * dense_scan_v2_kernel ("wave streaming", the default; described at its definition): every wave streams
-//     its own span of rows, no workgroup barriers, also instantiated for bf16 rows (batched path);
-//   * dense_scan_kernel (the first version, scan_variant = 1, kept for A/B runs): one persistent 16-wave
-//     workgroup per span; a super-tile is 16 waves x 16 rows = 256 chunk rows: each wave multiplies its 16
-//     rows against all queries, writes the 16 x Q scores to LDS, and after a barrier the workgroup reduces the
-//     chunk scores to per-document maxima (a document that crosses a super-tile boundary is carried in LDS).
-// In both, spans are cut at document boundaries with equal chunk counts, so documents never cross spans and
-// no inter-workgroup communication exists.
+// dense_scan_v2_kernel ("wave streaming", described at its definition): every wave streams its own span of rows,
+// no workgroup barriers; also instantiated for bf16 rows (batched path, <= 32 queries or a per-document row limit).
+// Spans are cut at document boundaries with equal chunk counts, so documents never cross spans and no
+// inter-workgroup communication exists.  The default for calls without a row limit is the K-split kernel of
+// msr_dense_ks.hip; this kernel serves what that one does not take (row limit, interleaved layout, corpora that
+// fail its ring precondition).
 #include <stdlib.h>
 
 #include <type_traits>
@@ -29,155 +26,10 @@
 
 namespace {
 
-constexpr int SCAN_WAVES = 16;
-constexpr int SCAN_THREADS = SCAN_WAVES * 64;
-constexpr int ST_ROWS = SCAN_WAVES * 16;            // rows per super-tile
 constexpr int KSTEPS = MSR_DIM / 16;                // 48 float4 per lane per row group
 
-template <int QB> struct ScanLds {
-    static constexpr int NQP = 16 * QB;                         // padded query count
-    static constexpr int SROW = NQP + 1;                        // sbuf row stride in floats (bank spread)
-    static constexpr size_t q_bytes = (size_t)QB * KSTEPS * 64 * 16;
-    static constexpr size_t s_bytes = (size_t)ST_ROWS * SROW * 4;
-    static constexpr size_t c_bytes = (size_t)2 * NQP * 4;
-    static constexpr size_t total = q_bytes + ((s_bytes + 15) & ~(size_t)15) + c_bytes;
-};
-
-template <int QB, bool TILED>
-__global__ __launch_bounds__(SCAN_THREADS) void dense_scan_kernel(DenseIndex ix, const float* __restrict__ qn,
-                                                                   int nq, int max_chunks,
-                                                                   float* __restrict__ docscore) {
-    using L = ScanLds<QB>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4* Qs = (f32x4*)smem;                                   // [QB][KSTEPS][64] fragment order
-    float* sbuf = (float*)(smem + L::q_bytes);                  // [ST_ROWS][SROW]
-    float* carry = (float*)(smem + L::q_bytes + ((L::s_bytes + 15) & ~(size_t)15));   // [2][NQP]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = tid >> 6;
-    const int li = lane & 15;                                   // row inside the wave's 16-row group
-    const int lg = lane >> 4;                                   // k sub-block 0..3
-
-    // Query image: Qs[qb][t][l] = qn[16 qb + (l & 15)][16 t + 4 (l >> 4) .. +3]
-    for (int idx = tid; idx < QB * KSTEPS * 64; idx += SCAN_THREADS) {
-        const int l = idx & 63;
-        const int t = (idx >> 6) % KSTEPS;
-        const int qb = idx / (KSTEPS * 64);
-        Qs[idx] = *(const f32x4*)(qn + (size_t)(16 * qb + (l & 15)) * MSR_DIM + 16 * t + 4 * (l >> 4));
-    }
-    __syncthreads();
-
-    const int64_t C = ix.n_chunks;
-    const float NEG_INF = -__builtin_inff();
-
-    for (int s = blockIdx.x; s < ix.n_spans; s += gridDim.x) {
-        const int d0 = ix.span_doc[s], d1 = ix.span_doc[s + 1];
-        const int64_t c0 = ix.doc_off[d0], c1 = ix.doc_off[d1];
-        // chunk-less documents get -inf for every query
-        for (int d = d0 + tid; d < d1; d += SCAN_THREADS)
-            if (ix.doc_off[d + 1] == ix.doc_off[d])
-                for (int qq = 0; qq < nq; ++qq) docscore[(int64_t)qq * ix.score_stride + d] = NEG_INF;
-        int parity = 0;
-        for (int64_t st = c0 & ~(int64_t)15; st < c1; st += ST_ROWS) {
-            // ---- phase 1: 16 rows x NQP queries per wave on the f32 matrix cores -------------------
-            const int64_t row0 = st + 16 * w;
-            if (row0 < c1) {                                     // wave-uniform
-                const f32x4* p;
-                if (TILED) {
-                    p = (const f32x4*)(ix.emb + (size_t)(row0 >> 4) * (16 * MSR_DIM)) + lane;
-                } else {
-                    int64_t r = row0 + li;
-                    if (r > C - 1) r = C - 1;                    // clamp: masked out in phase 2
-                    p = (const f32x4*)(ix.emb + (size_t)r * MSR_DIM) + lg;
-                }
-                constexpr int PSTRIDE = TILED ? 64 : 4;          // f32x4 units between k-steps
-                f32x4 acc[QB];
-#pragma unroll
-                for (int qb = 0; qb < QB; ++qb) acc[qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                // Register double buffer of LB k-steps: the loads of batch n+1 are in flight while the
-                // matrix cores consume batch n (a 16 B/lane global load is asynchronous until its wait).
-                constexpr int LB = 8;
-                constexpr int NBATCH = KSTEPS / LB;
-                f32x4 buf0[LB], buf1[LB];
-#pragma unroll
-                for (int u = 0; u < LB; ++u) buf0[u] = p[(size_t)u * PSTRIDE];
-                __builtin_amdgcn_sched_barrier(0);               // keep the loads ahead of the MFMAs
-#pragma unroll
-                for (int nb = 0; nb < NBATCH; ++nb) {
-                    if (nb + 1 < NBATCH) {
-#pragma unroll
-                        for (int u = 0; u < LB; ++u) {
-                            const f32x4 x = p[(size_t)((nb + 1) * LB + u) * PSTRIDE];
-                            if (nb & 1) buf0[u] = x; else buf1[u] = x;
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-#pragma unroll
-                    for (int u = 0; u < LB; ++u) {
-                        const f32x4 a = (nb & 1) ? buf1[u] : buf0[u];
-                        const int t = nb * LB + u;
-#pragma unroll
-                        for (int qb = 0; qb < QB; ++qb) {
-                            const f32x4 bq = Qs[(qb * KSTEPS + t) * 64 + lane];
-                            acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq.x, acc[qb], 0, 0, 0);
-                            acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq.y, acc[qb], 0, 0, 0);
-                            acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq.z, acc[qb], 0, 0, 0);
-                            acc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq.w, acc[qb], 0, 0, 0);
-                        }
-                    }
-                }
-                // D layout: lane holds rows 4*lg + reg, column (query) li
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    int64_t r = row0 + 4 * lg + reg;
-                    if (r > C - 1) r = C - 1;
-                    const float inv = ix.inv_norm[r];
-#pragma unroll
-                    for (int qb = 0; qb < QB; ++qb)
-                        sbuf[(16 * w + 4 * lg + reg) * L::SROW + 16 * qb + li] = acc[qb][reg] * inv;
-                }
-            }
-            __syncthreads();
-            // ---- phase 2: per-document max over the rows of this super-tile -------------------------
-            {
-                const int pr = tid & (ST_ROWS - 1);
-                const int qg = tid >> 8;                         // 4 query groups of NQP/4
-                const int64_t r = st + pr;
-                const int64_t lo_valid = st > c0 ? st : c0;
-                const int64_t tile_end = st + ST_ROWS < c1 ? st + ST_ROWS : c1;
-                if (r >= lo_valid && r < tile_end) {
-                    const int d = ix.chunk_doc[r];
-                    const int64_t ds = ix.doc_off[d], de = ix.doc_off[d + 1];
-                    const int64_t first = ds > lo_valid ? ds : lo_valid;
-                    if (r == first) {                            // leader of document d in this tile
-                        const int64_t de_eff = (max_chunks > 0 && ds + max_chunks < de) ? ds + max_chunks : de;
-                        int64_t stop = de < tile_end ? de : tile_end;
-                        if (de_eff < stop) stop = de_eff;
-                        const bool continued = ds < lo_valid;    // started in an earlier super-tile
-                        const bool finished = de <= tile_end;
-                        constexpr int QPT = L::NQP / 4;
-#pragma unroll 1
-                        for (int u = 0; u < QPT; ++u) {
-                            const int qq = qg * QPT + u;
-                            if (qq >= nq) break;
-                            float m = continued ? carry[parity * L::NQP + qq] : NEG_INF;
-                            for (int64_t rr = r; rr < stop; ++rr)
-                                m = fmaxf(m, sbuf[(int)(rr - st) * L::SROW + qq]);
-                            if (finished) docscore[(int64_t)qq * ix.score_stride + d] = m;
-                            else carry[(parity ^ 1) * L::NQP + qq] = m;
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            parity ^= 1;
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------
-// Scan kernel, variant 2 ("wave streaming"): every WAVE streams its own span of row groups with no workgroup
+// Scan kernel ("wave streaming"): every WAVE streams its own span of row groups with no workgroup
 // barrier after the query image is loaded.  Per 16-row group: 64 B of every row per k-step as one 16 B/lane
 // load (register double buffer that runs ACROSS groups, so the next group's first batch is in flight during
 // this group's epilogue), the MFMAs, then the 16 x Q cosines go through a wave-private LDS tile so that lane
@@ -612,22 +464,15 @@ __global__ __launch_bounds__(64) void best_chunk_kernel(DenseIndex ix, const flo
     if (lane == 0) out_chunk[(int64_t)q * k + r] = (int32_t)arg;
 }
 
-// Diagnostic knob for timing experiments only (MSR_SCAN_DEBUG: bit 0 = drop the score-row stores).
+// Diagnostic build only (-DMSR_DIAG, tools/ab_scan.py): MSR_SCAN_DEBUG bit 0 drops the score-row stores for timing
+// experiments.  The product library reads no environment variable.
 static int scan_debug_flags() {
+#ifdef MSR_DIAG
     static const int v = [] { const char* e = getenv("MSR_SCAN_DEBUG"); return e ? atoi(e) : 0; }();
     return v;
-}
-
-template <int QB, bool TILED>
-hipError_t launch_scan(const DenseIndex& ix, const float* qn, int nq, int max_chunks, float* docscore,
-                       hipStream_t stream) {
-    const size_t lds = ScanLds<QB>::total;
-    hipError_t err = hipFuncSetAttribute((const void*)dense_scan_kernel<QB, TILED>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (err != hipSuccess) return err;
-    int grid = ix.n_spans;
-    dense_scan_kernel<QB, TILED><<<grid, SCAN_THREADS, lds, stream>>>(ix, qn, nq, max_chunks, docscore);
-    return hipGetLastError();
+#else
+    return 0;
+#endif
 }
 
 template <int QB, bool TILED, int LB, int WAVES = 8, int OBD = 32, int MODE = MODE_F32, int G = 1>
@@ -672,28 +517,23 @@ template <int QB>
 hipError_t launch_scan_bf16(const DenseIndex& ix, const float* qn, int nq, int max_chunks, float* docscore,
                             hipStream_t stream) {
     if constexpr (QB <= 2) return launch_scan_bf16_cfg<QB, 8, 32>(ix, qn, nq, max_chunks, docscore, stream);
-    // 48/64 queries: the query image takes 72/96 KB of LDS, which leaves room for either 4 waves with 32 staged
-    // documents or 8 waves with 8 (A/B knob for measurements: MSR_BF16_CFG = 0 | 1 | 2)
+    // 48/64 queries: the query image takes 72/96 KB of LDS, which leaves room for 4 waves with 32 staged documents
+#ifdef MSR_DIAG
+    // (A/B knob of the diagnostic build: 8 waves with 8 staged documents / direct stores / whole-group prefetch)
     static const int knob = [] { const char* v = getenv("MSR_BF16_CFG"); return v ? atoi(v) : 0; }();
     if (knob == 1) return launch_scan_bf16_cfg<QB, 8, 8>(ix, qn, nq, max_chunks, docscore, stream);
     if (knob == 2) return launch_scan_bf16_cfg<QB, 8, 0>(ix, qn, nq, max_chunks, docscore, stream);
-    if (knob == 3) return launch_scan_bf16_cfg<QB, 4, 32, 24>(ix, qn, nq, max_chunks, docscore, stream);   // whole-group prefetch
+    if (knob == 3) return launch_scan_bf16_cfg<QB, 4, 32, 24>(ix, qn, nq, max_chunks, docscore, stream);
+#endif
     return launch_scan_bf16_cfg<QB, 4, 32>(ix, qn, nq, max_chunks, docscore, stream);
 }
 
 template <int QB, bool TILED>
 hipError_t dispatch_variant(const DenseIndex& ix, const float* qn, int nq, int max_chunks, float* docscore,
                             hipStream_t stream) {
-    switch (ix.variant) {
-        // 0 is resolved by the engine at bind time to 7 (f16 split) or 2 (exact f32), see msr_bind_chunks
-        case 1: return launch_scan<QB, TILED>(ix, qn, nq, max_chunks, docscore, stream);                      // super-tile kernel
-        case 2: case 16: return launch_scan_v2<QB, TILED, 12>(ix, qn, nq, max_chunks, docscore, stream);     // exact f32 MFMA
-        case 5: return launch_scan_v2<QB, TILED, 12, 12, 16>(ix, qn, nq, max_chunks, docscore, stream);      // 3 waves/SIMD
-        case 8: return launch_scan_v2<QB, TILED, 24, 8, 32, MODE_F16X2>(ix, qn, nq, max_chunks, docscore, stream);
-        case 11: return launch_scan_v2<QB, TILED, 6, 8, 32, MODE_F16X2, 2>(ix, qn, nq, max_chunks, docscore, stream);
-        case 12: return launch_scan_v2<QB, TILED, 4, 8, 32, MODE_F32, 4>(ix, qn, nq, max_chunks, docscore, stream);   // 4 groups/unit
-        default: return launch_scan_v2<QB, TILED, 12, 8, 32, MODE_F16X2>(ix, qn, nq, max_chunks, docscore, stream);   // 7: f16 split
-    }
+    // the engine resolves scan_variant 0 at bind time to 7 / 14 (f16 split) or 2 (exact f32), see msr_bind_chunks
+    if (ix.variant == 2) return launch_scan_v2<QB, TILED, 12>(ix, qn, nq, max_chunks, docscore, stream);   // exact f32 MFMA
+    return launch_scan_v2<QB, TILED, 12, 8, 32, MODE_F16X2>(ix, qn, nq, max_chunks, docscore, stream);     // f16 split
 }
 
 // min / max of inv_norm over all rows (positive floats order like their bit patterns)
@@ -716,12 +556,12 @@ __global__ __launch_bounds__(256) void norm_range_kernel(const float* __restrict
 hipError_t msr_dense_scan(const DenseIndex& ix, const float* qn, int nq, int max_chunks, float* docscore,
                           hipStream_t stream) {
     if (nq <= 0 || ix.n_docs <= 0) return hipSuccess;
-    // variants 13 / 14: K-split kernel (msr_dense_ks.hip) for 17..64 queries / for any count
-    if (((ix.variant == 13 && nq > 16) || ix.variant == 14 || ix.variant == 15) && ix.wide_ok && ix.layout == 0 && max_chunks == 0)
+    // variants 14 / 15: K-split kernel (msr_dense_ks.hip), f16-split products
+    if ((ix.variant == 14 || ix.variant == 15) && ix.wide_ok && ix.layout == 0 && max_chunks == 0)
         return msr_dense_scan_wide(ix, qn, nq, docscore, stream);
     // exact f32 products: the K-split kernel pays off above 32 queries (matrix-core bound: 4.5 ms per 64 queries against
-    // 2 x 2.8 ms on the narrow kernel; at <= 32 queries the narrow kernel is faster); 16 = K-split for every count (A/B)
-    if (((ix.variant == 2 && nq > 32) || ix.variant == 16) && ix.wide_ok && ix.layout == 0 && max_chunks == 0)
+    // 2 x 2.8 ms on the narrow kernel; at <= 32 queries the narrow kernel is faster)
+    if (ix.variant == 2 && nq > 32 && ix.wide_ok && ix.layout == 0 && max_chunks == 0)
         return msr_dense_scan_wide_exact(ix, qn, nq, docscore, stream);
     if (nq > 32) return hipErrorInvalidValue;
     const bool tiled = ix.layout == 1;

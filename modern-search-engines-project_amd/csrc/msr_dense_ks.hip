@@ -187,6 +187,10 @@ __global__ __launch_bounds__(NWAVES * 64) void dense_ksplit_kernel(DenseIndex ix
 
     Meta mt_prev = {};
     __syncthreads();                                             // ring initialised
+    // A span (or a shard) may BEGIN with chunk-less documents: the bind-time check (wide_ok) only looks at the
+    // documents between consecutive rows, so write those leading blocks now -- otherwise next_b would lag behind the
+    // documents being folded (the loop retires at most two blocks per unit) and ring slots would alias.
+    flush_done(c0);
     if (g1 > g0) {
         f32x4 A[NBUF][NLU];
         Meta mtr[NBUF] = {};
@@ -313,9 +317,24 @@ __global__ __launch_bounds__(256) void presplit_kernel(const float* __restrict__
     }
 }
 
+// Diagnostic build only (-DMSR_DIAG): MSR_SCAN_DEBUG bit 0 drops the score-row stores (timing experiments).
 int scan_debug_flags() {
+#ifdef MSR_DIAG
     static const int v = [] { const char* e = getenv("MSR_SCAN_DEBUG"); return e ? atoi(e) : 0; }();
     return v;
+#else
+    return 0;
+#endif
+}
+
+// Diagnostic build only: MSR_KS_PIPE selects A/B instances of the K-split kernel; the product build returns `dflt`.
+int ks_pipe_knob(int dflt) {
+#ifdef MSR_DIAG
+    static const char* v = getenv("MSR_KS_PIPE");
+    return v ? atoi(v) : dflt;
+#else
+    return dflt;
+#endif
 }
 
 template <int QB, int MODE, int NBUF, int PIPE = 1, int RING_DOCS = MSR_WIDE_RING, int NWAVES = 8>
@@ -353,16 +372,19 @@ hipError_t msr_dense_scan_wide(const DenseIndex& ix, const float* qn, int nq, fl
     if (nq <= 0 || ix.n_docs <= 0) return hipSuccess;
     if (nq > 64 || ix.layout != 0 || !ix.wide_ok || !ix.row_meta) return hipErrorInvalidValue;
     // 64 queries: 12-way K split (2 k-steps per wave, 167 VGPRs: three waves per SIMD), 2-3 % faster than the 8-way split
-    // (profile r01_m); 32 queries: 8-way.  A/B knobs for measurements: MSR_KS_PIPE=8 -> 8 waves; 2 -> 8 waves with the
+    // (profile r01_m); 32 queries: 8-way.  Diagnostic build only: MSR_KS_PIPE=8 -> 8 waves; 2 -> 8 waves with the
     // reduction pipelined in waves 4..7 only (see PIPE in the kernel; no gain measured).
-    static const int pipe = [] { const char* v = getenv("MSR_KS_PIPE"); return v ? atoi(v) : 0; }();
+    const int pipe = ks_pipe_knob(0);
     if (ix.variant == 15 && ix.emb_presplit) {              // A/B variant: pre-split copy of the rows (+4 bytes per value of HBM)
         if (nq <= 32) return launch_ksplit<2, MODE_PRE, 3, 0>(ix, ix.emb_presplit, qn, nq, docscore, stream);
         return launch_ksplit<4, MODE_PRE, 2, 0, MSR_WIDE_RING, 12>(ix, ix.emb_presplit, qn, nq, docscore, stream);
     }
     if (nq <= 32) return launch_ksplit<2, MODE_F16X2, 3, 0>(ix, ix.emb, qn, nq, docscore, stream);   // (8 waves: 12 gain nothing here)
+#ifdef MSR_DIAG
     if (pipe == 2) return launch_ksplit<4, MODE_F16X2, 3, 2>(ix, ix.emb, qn, nq, docscore, stream);
     if (pipe == 8) return launch_ksplit<4, MODE_F16X2, 3, 0>(ix, ix.emb, qn, nq, docscore, stream);
+#endif
+    (void)pipe;
     return launch_ksplit<4, MODE_F16X2, 2, 0, MSR_WIDE_RING, 12>(ix, ix.emb, qn, nq, docscore, stream);
 }
 
@@ -380,11 +402,14 @@ hipError_t msr_dense_scan_bf16_wide(const DenseIndex& ix, const float* qn, int n
                                     hipStream_t stream) {
     if (nq <= 0 || ix.n_docs <= 0) return hipSuccess;
     if (nq > 128 || !ix.emb_bf16 || !ix.wide_ok || !ix.row_meta || (nq > 64 && !ix.wide_ok64)) return hipErrorInvalidValue;
-    static const int pipe = [] { const char* v = getenv("MSR_KS_PIPE"); return v ? atoi(v) : 1; }();
+    const int pipe = ks_pipe_knob(1);
     if (nq > 64) {
         // (PIPE would need 32 more registers than a wave has here)
         return launch_ksplit<8, MODE_BF16, 3, 0, 64>(ix, ix.emb_bf16, qn, nq, docscore, stream);
     }
+#ifdef MSR_DIAG
     if (!pipe) return launch_ksplit<4, MODE_BF16, 4, 0>(ix, ix.emb_bf16, qn, nq, docscore, stream);
+#endif
+    (void)pipe;
     return launch_ksplit<4, MODE_BF16, 4, 1>(ix, ix.emb_bf16, qn, nq, docscore, stream);
 }

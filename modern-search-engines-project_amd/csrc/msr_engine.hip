@@ -104,8 +104,9 @@ extern "C" int msr_create(const msr_config* cfg, msr_engine** out) {
         return fail(nullptr, MSR_ERR_INVALID, "msr_create: rerank_max_docs out of range [0, 1024]");
     if (cfg->scan_layout != 0 && cfg->scan_layout != 1)
         return fail(nullptr, MSR_ERR_INVALID, "msr_create: scan_layout must be 0 or 1");
-    if (cfg->scan_variant < 0 || cfg->scan_variant > 16)
-        return fail(nullptr, MSR_ERR_INVALID, "msr_create: scan_variant must be 0..16");
+    if (cfg->scan_variant != 0 && cfg->scan_variant != 2 && cfg->scan_variant != 7 && cfg->scan_variant != 14 &&
+        cfg->scan_variant != 15)
+        return fail(nullptr, MSR_ERR_INVALID, "msr_create: scan_variant must be 0, 2, 7, 14 or 15");
     int ndev = 0;
     hipError_t herr = hipGetDeviceCount(&ndev);
     if (herr != hipSuccess || ndev <= 0)
@@ -416,13 +417,13 @@ extern "C" int msr_interleave_rows(msr_engine* e, const float* src, int64_t n_ro
 extern "C" int msr_scan_arith(const msr_engine* e) {
     if (!e || !e->have_chunks) return -1;
     const int v = e->dense.variant;
-    return (v == 7 || v == 8 || v == 11 || v == 13 || v == 14 || v == 15) ? 1 : 0;
+    return (v == 7 || v == 14 || v == 15) ? 1 : 0;
 }
 
 extern "C" int msr_scan_width(const msr_engine* e) {
     if (!e || !e->have_chunks) return -1;
     const int v = e->dense.variant;
-    const bool wide = (v == 2 || (v >= 13 && v <= 16)) && e->dense.layout == 0 && e->dense.wide_ok;
+    const bool wide = (v == 2 || v == 14 || v == 15) && e->dense.layout == 0 && e->dense.wide_ok;
     return wide ? 64 : 32;
 }
 
@@ -494,7 +495,7 @@ extern "C" int msr_dense_topk(msr_engine* e, const float* q, int32_t n_queries, 
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     // one sweep of E serves up to 32 queries (wave-streaming kernel) or 64 (K-split kernel, variants 13 / 14)
-    const bool wide = (e->dense.variant == 2 || (e->dense.variant >= 13 && e->dense.variant <= 16)) && e->dense.layout == 0 &&
+    const bool wide = (e->dense.variant == 2 || e->dense.variant == 14 || e->dense.variant == 15) && e->dense.layout == 0 &&
                       e->dense.wide_ok && max_chunks_per_doc == 0;
     const int slice = wide ? 64 : 32;
     const int64_t N = e->dense.n_docs;
@@ -568,9 +569,13 @@ extern "C" int msr_dense_topk_bf16(msr_engine* e, const float* q, int32_t n_quer
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     const int64_t N = e->dense.n_docs;
     const float margin = 2.0f * 0.0078125f;                 // 2 * eps, eps = 2^-7 (see msr_batch.hip)
-    // 33..64 queries: K-split kernel (msr_dense_ks.hip).  A/B knob for measurements: MSR_BF16_WIDE=0 keeps the
-    // wave-streaming kernel everywhere.
+    // 33..128 queries: K-split kernel (msr_dense_ks.hip).  Diagnostic build only (-DMSR_DIAG): MSR_BF16_WIDE=0 keeps
+    // the wave-streaming kernel everywhere.
+#ifdef MSR_DIAG
     static const bool wide_knob = [] { const char* v = getenv("MSR_BF16_WIDE"); return !v || atoi(v) != 0; }();
+#else
+    const bool wide_knob = true;
+#endif
     const bool wide_able = wide_knob && e->dense.wide_ok && max_chunks_per_doc == 0;
     const int slice = wide_able && e->dense.wide_ok64 ? 128 : 64;
     for (int q0 = 0; q0 < n_queries; q0 += slice) {

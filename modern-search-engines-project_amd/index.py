@@ -77,7 +77,8 @@ class CorpusIndex:
         document has no urlsDB row.  Without URL metadata every document is its own group."""
         if self._url_group is None:
             if self.urls is None:
-                self._url_group = np.arange(self.n_docs, dtype=np.int32)
+                # group ids are GLOBAL: a shard reloaded from a snapshot must not collide with its neighbours
+                self._url_group = np.arange(self.doc_base, self.doc_base + self.n_docs, dtype=np.int32)
             else:
                 ids, out = {}, np.empty(self.n_docs, np.int32)
                 for i, u in enumerate(self.urls):
@@ -139,7 +140,8 @@ class CorpusIndex:
         arrs = dict(doc_ids=_np(self.doc_ids), doc_len=_np(self.doc_len), term_off=_np(self.term_off),
                     post_doc=_np(self.post_doc), post_tf=_np(self.post_tf), idf=_np(self.idf),
                     scalars=np.array([self.avgdl, self.total_docs, self.k1, self.b, self.doc_base,
-                                      self.n_docs_global], np.float64))
+                                      self.n_docs_global, self.row_base], np.float64),
+                    url_group=np.asarray(self.url_group(), np.int32))
         if self.doc_off is not None:
             arrs.update(doc_off=_np(self.doc_off), chunk_ids=_np(self.chunk_ids), emb=_np(self.emb))
         if self.vocab is not None:
@@ -153,7 +155,9 @@ class CorpusIndex:
         ix = CorpusIndex(doc_ids=z["doc_ids"], doc_len=z["doc_len"], term_off=z["term_off"],
                          post_doc=z["post_doc"], post_tf=z["post_tf"], idf=z["idf"], avgdl=float(s[0]),
                          total_docs=int(s[1]), k1=float(s[2]), b=float(s[3]), doc_base=int(s[4]),
-                         n_docs_global=int(s[5]))
+                         n_docs_global=int(s[5]), row_base=int(s[6]) if len(s) > 6 else 0)
+        if "url_group" in z:
+            ix._url_group = np.asarray(z["url_group"], np.int32)       # global group ids (a shard keeps the corpus-wide ones)
         if "doc_off" in z:
             ix.doc_off, ix.chunk_ids, ix.emb = z["doc_off"], z["chunk_ids"], z["emb"]
         if "vocab_terms" in z:
@@ -186,6 +190,7 @@ class CorpusIndex:
                 out[s0:s0 + step] = _np(a[s0:s0 + step])
             out.flush()
             del out
+        np.save(os.path.join(path, "url_group.npy"), np.asarray(self.url_group(), np.int32))   # GLOBAL group ids
         meta = dict(format="msretr-snapshot-1", arrays=present, avgdl=float(self.avgdl), total_docs=int(self.total_docs),
                     k1=float(self.k1), b=float(self.b), doc_base=int(self.doc_base), row_base=int(self.row_base),
                     n_docs_global=int(self.n_docs_global), vocab=list(self.vocab.keys()) if self.vocab is not None else None,
@@ -216,6 +221,10 @@ class CorpusIndex:
                 setattr(ix, n, arrs[n])
         if meta.get("vocab") is not None:
             ix.vocab = {t: i for i, t in enumerate(meta["vocab"])}
+        if os.path.exists(os.path.join(path, "url_group.npy")):
+            # the groups were numbered over the WHOLE corpus before sharding: recomputing them from a shard's own
+            # URLs would make unrelated documents of different shards share an id (rerank dedup keeps MIN(doc))
+            ix._url_group = np.load(os.path.join(path, "url_group.npy"), allow_pickle=False)
         if meta.get("has_docs"):
             ix.urls, ix.titles, ix.texts = [], [], []
             with open(os.path.join(path, "docs.jsonl"), encoding="utf-8") as f:

@@ -422,6 +422,28 @@ def cosine_fixture(ns):
     print("wrote cosine.npz", "dtype", np.asarray(sims).dtype)
 
 
+def cosine_unit_fixture(ns):
+    """All rows unit-norm (what indexer/indexer.py:165 stores), documents of 2..12 chunks, 40 queries: the shape on
+    which the engine's DEFAULT dense kernel (f16x2-split products) runs, so that kernel is compared with values the
+    reference's own get_new_similarity (reranker_api.py:273-287) produced.  expected[i][c] = cosine(query i, chunk c)."""
+    import pandas as pd
+    rng = np.random.default_rng(23)
+    n_chunks_of = rng.integers(2, 13, size=140)
+    doc_off = np.zeros(len(n_chunks_of) + 1, np.int32)
+    doc_off[1:] = np.cumsum(n_chunks_of)
+    E = unit_rows(rng, int(doc_off[-1]))
+    Q = 40
+    qs = np.empty((Q, 768), np.float32)
+    for i in range(Q):
+        base = E[int(rng.integers(0, len(E)))] if i % 2 == 0 else unit_rows(rng, 1)[0]
+        v = (base + 0.5 * unit_rows(rng, 1)[0]).astype(np.float32)
+        qs[i] = (v / np.linalg.norm(v) * rng.uniform(0.5, 15.0)).astype(np.float32)   # encoder output is not normalised
+    df = pd.DataFrame({"embedding": list(E)})
+    exp = np.stack([np.asarray(ns["get_new_similarity"](df, qs[i], 32), dtype=np.float32) for i in range(Q)])
+    np.savez_compressed(os.path.join(OUT, "cosine_unit.npz"), q=qs, E=E, doc_off=doc_off, expected=exp)
+    print("wrote cosine_unit.npz", exp.shape, exp.dtype)
+
+
 def rerank_fixtures(ns):
     rng = np.random.default_rng(11)
     cases = []
@@ -558,6 +580,7 @@ def main():
     bm25_random(search_fn, stats_fn, "bm25_random_b", seed=202, N=2500, V=1500, mean_len=45, nq=20)
     ns = load_reranker_namespace()
     cosine_fixture(ns)
+    cosine_unit_fixture(ns)
     rerank_fixtures(ns)
     diversification_fixture(ns)
     windows_fixture(ns)

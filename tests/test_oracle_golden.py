@@ -59,6 +59,21 @@ def test_cosine_matches_sklearn_float32():
     assert abs(float(got[123]) - float(z["single_123"])) < 1e-6
 
 
+def test_oracle_dense_matches_reference_on_unit_rows():
+    """cosine_unit.npz (reference get_new_similarity on unit-norm rows, 40 queries): the oracle's per-chunk cosines,
+    per-document maxima and ranking restate it."""
+    from oracle import dense_ref
+    z = np.load(os.path.join(G, "cosine_unit.npz"))
+    E, qs, exp, doc_off = z["E"], z["q"], z["expected"], z["doc_off"].astype(np.int64)
+    for i in (0, 7, 39):
+        got = rerank_ref.cosine_f32(qs[i], E)
+        np.testing.assert_allclose(got, exp[i], rtol=0, atol=1e-6)
+        best, arg = dense_ref.doc_scores(E, doc_off, qs[i], 0)
+        np.testing.assert_allclose(best, np.maximum.reduceat(exp[i], doc_off[:-1]), rtol=0, atol=1e-6)
+        oi, os_, oa = dense_ref.quick_search(E, doc_off, qs[i], 10)
+        assert np.all(np.diff(os_) <= 0) and len(oi) == 10
+
+
 # ------------------------------------------------------------------ rerank chain
 def _case_tables(c):
     z = np.load(os.path.join(G, f"rerank_{c['case']}.npz"))

@@ -13,8 +13,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+from msretr import _abi  # noqa: E402
+from msretr.build import build_library  # noqa: E402
 from msretr.engine import DeviceEngine  # noqa: E402
 from msretr.synthetic import synthetic_corpus  # noqa: E402
+
+if os.environ.get("MSR_DIAG_LIB"):       # A/B knobs (MSR_SCAN_DEBUG, MSR_KS_PIPE, ...) only exist in the -DMSR_DIAG build
+    _abi.LIB_PATH = build_library(diag=True)
 
 
 def main():
@@ -22,7 +27,7 @@ def main():
     ap.add_argument("--docs", type=int, default=1_000_000)
     ap.add_argument("--chunks", type=int, default=5_000_000)
     ap.add_argument("--rounds", type=int, default=7)
-    ap.add_argument("--configs", default="0:14,0:7,0:2,0:1", help="layout:variant list")
+    ap.add_argument("--configs", default="0:14,0:7,0:2,0:15", help="layout:variant list")
     ap.add_argument("--queries", default="1,16,32")
     ap.add_argument("--nonzero", type=int, default=-1,
                     help="diagnostic: keep only the first N query rows non-zero (the MFMA count stays, operand data changes)")

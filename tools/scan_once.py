@@ -8,8 +8,13 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
+from msretr import _abi  # noqa: E402
+from msretr.build import build_library  # noqa: E402
 from msretr.engine import DeviceEngine  # noqa: E402
 from msretr.synthetic import synthetic_corpus  # noqa: E402
+
+if os.environ.get("MSR_DIAG_LIB"):       # the MSR_* knobs only exist in the -DMSR_DIAG build
+    _abi.LIB_PATH = build_library(diag=True)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--variant", type=int, default=0)
