@@ -158,6 +158,17 @@ __global__ __launch_bounds__(1024) void rescore_final_kernel(const int32_t* __re
 
 }  // namespace
 
+hipError_t msr_batch_rescore(const DenseIndex& ix, const float* qn, int nq, int k, int max_chunks, int32_t* cand_doc,
+                             float* cand_score, int32_t* cand_chunk, int32_t* cand_n, int32_t* out_doc, float* out_score,
+                             int32_t* out_chunk, int32_t* out_n, hipStream_t stream) {
+    if (nq <= 0) return hipSuccess;
+    rescore_kernel<<<dim3(64, (unsigned)nq), BT_THREADS, 0, stream>>>(ix, qn, max_chunks, cand_doc, cand_n, cand_score,
+                                                                    cand_chunk);
+    rescore_final_kernel<<<nq, 1024, 0, stream>>>(cand_doc, cand_score, cand_chunk, cand_n, k, out_doc, out_score,
+                                                  out_chunk, out_n);
+    return hipGetLastError();
+}
+
 hipError_t msr_batch_finish(const DenseIndex& ix, const float* qn, int nq, int k, int max_chunks, float margin,
                             const float* scores, const float* top_score, const int32_t* top_n, int32_t* cand_doc,
                             float* cand_score, int32_t* cand_chunk, int32_t* cand_n, int32_t* out_doc,

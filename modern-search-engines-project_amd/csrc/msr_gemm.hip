@@ -1,0 +1,536 @@
+// K5 -- batched candidate generation as a tiled bf16 GEMM on the matrix cores (gfx950).
+//
+// BASELINE configs[4]: S = E (C x 768, bf16) . Q^T (768 x nq, bf16), f32 accumulate, for batches of hundreds to
+// thousands of queries.  Same mathematics as the cosine of the reference (reranker/reranker_api.py:285) and its
+// per-document max (:370) -- but at this batch size the work is a GEMM (7.86 TFLOP per 1024 queries at 5 M rows) and
+// the bound is the matrix pipe, not HBM.  The score matrix (5 M x 1024) is NEVER written anywhere:
+//
+//   pass 1 (sample)  the GEMM over every SS-th row tile; epilogue = per (tile, query) maximum only.  Tiles are cut at
+//                    document boundaries, so the k-th largest tile maximum is attained by k DIFFERENT documents:
+//                    a valid lower bound t_s <= t of the k-th largest per-document score.
+//   pass 2 (emit)    the GEMM over all tiles; epilogue = (a) the same tile maxima for ALL tiles (they give a much
+//                    tighter bound t' afterwards), (b) every (query, row, score) with score >= t_s - margin is
+//                    appended to a buffer private to the WAVE (scalar counter + lane prefix count, plain 16 B stores:
+//                    no atomic of any kind, nothing that would drain the load pipeline).
+//   finish           msr_gemm_finish: entries >= t' - margin are bucketed per query, reduced to per-document maxima,
+//                    and the survivors are re-scored exactly in f32 by the kernels of msr_batch.hip.
+//
+// Both operands are bf16 images of UNIT vectors (rows are normalised when the image is built), so every score is off
+// by at most eps = 2^-7 (msr_batch.hip) and margin = 2 eps makes the survivor set a superset of the exact top-k.
+//
+// Kernel shape (one persistent workgroup per CU, 8 waves, 256 x 256 output tile, K step 64):
+//   * LDS: 2 buffers x {A rows 0-127, A rows 128-255, B queries 0-127, B queries 128-255} x 16 KB = 128 KB, filled by
+//     global_load_lds_dwordx4 (no VGPR staging); image rows are 128 B with the 16 B chunk index XORed by (row >> 1) & 7
+//     -- applied to the per-lane SOURCE address, the LDS side of the DMA stays linear -- which makes every
+//     ds_read_b128 of an MFMA fragment conflict-free.
+//   * wave (wr, wc) owns rows {wr 64 .. +64} of both A halves and queries {wc 32 .. +32} of both B halves: 4 quadrants of
+//     64 x 32, one per phase, 16 v_mfma_f32_16x16x32_bf16 each; 128 accumulator registers.
+//   * per phase: [load segment: issue the DMA of one half-tile of the NEXT K step, read this quadrant's fragments,
+//     s_waitcnt vmcnt(4)] barrier [matrix segment: 16 MFMAs] barrier.  Waves 4-7 run one barrier behind waves 0-3, so on
+//     every SIMD one wave's matrix segment runs beside the other wave's load segment.  A half-tile is read two phases
+//     after it was issued, and always one barrier after the vmcnt wait of every wave that issued it.
+//   * the NT = nq / 256 workgroups that share a row tile sit on the same XCD (blockIdx % 8) and walk the same tile
+//     sequence, so E comes from HBM once per batch and from the XCD's L2 for the others.
+#include <type_traits>
+
+#include "msr_common.h"
+#include "msr_internal.h"
+#include "msr_frag.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+constexpr int GM_THREADS = 512;
+constexpr int GM_KT = MSR_DIM / 64;            // K steps per output tile
+constexpr int GM_HALF = 16384;                 // bytes of one half-tile image: 128 rows x 128 B
+constexpr int GM_LDS = 8 * GM_HALF;
+constexpr int GM_ROWB = MSR_DIM * 2;           // bytes per bf16 row
+
+struct GemmArgs {
+    const char* A;             // bf16 [rows + pad][768], unit rows
+    const char* B;             // bf16 [nq_pad][768], unit rows (zero rows as padding)
+    const int32_t* tile_row;   // [n_tiles + 1]
+    int t_first, t_stride, t_count;   // tiles of this pass: t_first + j t_stride, j < t_count
+    int nt;                    // query tiles (nq_pad / 256)
+    uint32_t* tmax;            // [nq_pad][tmax_stride] order-preserving uint of the tile maxima, column j; zero-filled
+    int tmax_stride;
+    const float* thr;          // [nq_pad] emit threshold (+inf: never)                       -- emit pass only
+    int4* wgbuf;               // [gridDim.x * 8 waves][wv_cap] {row, query, score bits, tile}  -- emit pass only
+    int wv_cap;
+    int32_t* wv_count;         // [gridDim.x * 8] entries each wave produced (may exceed wv_cap: overflow)
+};
+
+__device__ __forceinline__ void wait_vm4() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void wg_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 2, wc = w & 3;                 // waves 0-3 (wr = 0) lead, waves 4-7 follow one barrier behind
+    const int li16 = lane & 15, lg = lane >> 4;
+
+    // ---- which tiles: the nt workgroups of a row-tile group share blockIdx % 8 (one XCD under round-robin dispatch) ----
+    const int per_x = (int)gridDim.x >> 3;
+    const int xcd = (int)blockIdx.x & 7, li = (int)blockIdx.x >> 3;
+    const int gpx = per_x / a.nt;
+    const int mg = li / a.nt, nt = li - mg * a.nt;
+    int wave_cnt = 0;                                  // entries this wave has emitted (wave-uniform)
+    int4* wvbuf = EMIT ? a.wgbuf + ((size_t)blockIdx.x * 8 + w) * a.wv_cap : nullptr;
+    const int G = 8 * gpx, gid = xcd * gpx + mg;
+    const bool active = mg < gpx && gid < a.t_count;
+    if (!active) {                                     // workgroup-uniform
+        if (EMIT && lane == 0) a.wv_count[blockIdx.x * 8 + w] = 0;
+        return;
+    }
+    const int n_mine = (a.t_count - gid + G - 1) / G;
+
+    // ---- per-lane constants ----
+    uint32_t goff[2];                                  // DMA source offsets inside a 128-row half-tile
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int R = (2 * w + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (4 * i + (lane >> 4));       // (R >> 1) & 7 == 4 i + (lane >> 4)
+        goff[i] = (uint32_t)(R * GM_ROWB + c * 16);
+    }
+    uint32_t foff[2];                                  // fragment read offsets inside a 16-row block
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) foff[ks] = (uint32_t)(li16 * 128 + (((ks * 4 + lg) ^ ((lane >> 1) & 7)) << 4));
+    const uint32_t a_base = (uint32_t)(wr * 64 * 128), b_base = (uint32_t)(wc * 32 * 128);
+
+    auto stage = [&](const char* src, int slot) {      // one half-tile: 2 x 1 KiB per wave
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void*)(src + goff[i]), (lds_void*)(smem + slot + (2 * w + i) * 1024), 16, 0, 0);
+    };
+    auto slot_of = [](int d, int h) { return (d * 4 + h) * GM_HALF; };      // h: 0 A-lo, 1 A-hi, 2 B-lo, 3 B-hi
+
+    float thrv[2][2];
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+            thrv[nh][ni] = EMIT ? a.thr[nt * 256 + nh * 128 + wc * 32 + ni * 16 + li16] : 0.f;
+
+    // (make the compiler wait for these ordinary loads HERE: a pending VGPR load next to in-flight LDS-DMAs would make it
+    // drain the whole DMA pipeline at the first use, in every epilogue)
+    asm volatile("" :: "v"(thrv[0][0]), "v"(thrv[0][1]), "v"(thrv[1][0]), "v"(thrv[1][1]));
+
+    f32x4 acc[2][4][2][2];
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc[mh][mi][nh][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto tile_of = [&](int j) { return a.t_first + j * a.t_stride; };
+    int jt = gid;
+    int row0 = a.tile_row[tile_of(jt)], row_end = a.tile_row[tile_of(jt) + 1];
+    int jn = jt + G < a.t_count ? jt + G : jt;
+    int row0n = a.tile_row[tile_of(jn)];
+    const char* Bq = a.B + (size_t)(nt * 256) * GM_ROWB;
+
+    // ---- prologue: the first K step of the first tile ----
+    stage(a.A + (size_t)row0 * GM_ROWB, slot_of(0, 0));
+    stage(Bq, slot_of(0, 2));
+    stage(Bq + 128 * GM_ROWB, slot_of(0, 3));
+    stage(a.A + (size_t)(row0 + 128) * GM_ROWB, slot_of(0, 1));
+    wait_vm0();
+    wg_barrier();
+    if (wr == 1) wg_barrier();                         // the followers start one barrier late
+
+    bf16x8 af[4][2], bfr[2][2];
+    auto read_a = [&](int d, int mh) {
+        const char* p = smem + slot_of(d, mh) + a_base;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) af[mi][ks] = *(const bf16x8*)(p + mi * 2048 + foff[ks]);
+    };
+    auto read_b = [&](int d, int nh) {
+        const char* p = smem + slot_of(d, 2 + nh) + b_base;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) bfr[ni][ks] = *(const bf16x8*)(p + ni * 2048 + foff[ks]);
+    };
+    auto mma = [&](auto mh_c, auto nh_c) {
+        constexpr int mh = decltype(mh_c)::value, nh = decltype(nh_c)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mh][mi][nh][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][ks], bfr[ni][ks], acc[mh][mi][nh][ni], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    // One K step = 4 phases.  During K step u (buffer d) the half-tiles of step u + 1 are issued into buffer d ^ 1 in the
+    // order they will be needed: A-lo, B-lo, B-hi, A-hi; every wait leaves the two youngest half-tiles (4 DMAs) in flight.
+    auto kstep = [&](auto d_c, const char* An, const char* Bn) {
+        constexpr int d = decltype(d_c)::value;
+        // phase 0: quadrant (A-lo, B-lo)
+        stage(An, slot_of(d ^ 1, 0));
+        read_b(d, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(d, 0);
+        wait_vm4();
+        wg_barrier();
+        mma(I0{}, I0{});
+        wg_barrier();
+        // phase 1: (A-lo, B-hi)
+        stage(Bn, slot_of(d ^ 1, 2));
+        read_b(d, 1);
+        wait_vm4();
+        wg_barrier();
+        mma(I0{}, I1{});
+        wg_barrier();
+        // phase 2: (A-hi, B-hi)
+        stage(Bn + 128 * GM_ROWB, slot_of(d ^ 1, 3));
+        read_a(d, 1);
+        wait_vm4();
+        wg_barrier();
+        mma(I1{}, I1{});
+        wg_barrier();
+        // phase 3: (A-hi, B-lo)
+        stage(An + 128 * GM_ROWB, slot_of(d ^ 1, 1));
+        read_b(d, 0);
+        wait_vm4();
+        wg_barrier();
+        mma(I1{}, I0{});
+        wg_barrier();
+    };
+
+    const float NEG_INF = -__builtin_inff();
+    for (int it = 0; it < n_mine; ++it) {
+        const char* A0 = a.A + (size_t)row0 * GM_ROWB;
+        const char* A1 = a.A + (size_t)row0n * GM_ROWB;
+#pragma unroll 1
+        for (int k2 = 0; k2 < GM_KT / 2; ++k2) {
+            kstep(I0{}, A0 + (2 * k2 + 1) * 128, Bq + (2 * k2 + 1) * 128);
+            const bool last = k2 == GM_KT / 2 - 1;                         // the step after the last one opens the next tile
+            kstep(I1{}, last ? A1 : A0 + (2 * k2 + 2) * 128, last ? Bq : Bq + (2 * k2 + 2) * 128);
+        }
+        // ---- epilogue: accumulator (mh, mi, nh, ni)[rr] = row mh 128 + wr 64 + mi 16 + 4 lg + rr of the tile,
+        //      query nt 256 + nh 128 + wc 32 + ni 16 + li16 ----
+        const int n_valid = row_end - row0;                                // rows of THIS tile (the rest belongs to the next)
+        float cmax[2][2] = {{NEG_INF, NEG_INF}, {NEG_INF, NEG_INF}};
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int blk = mh * 128 + wr * 64 + mi * 16;
+                if (blk >= n_valid) continue;                              // wave-uniform
+                const int rb = blk + 4 * lg;
+                const bool part = blk + 16 > n_valid;                      // wave-uniform
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        f32x4 v = acc[mh][mi][nh][ni];
+                        if (part) {
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr)
+                                if (rb + rr >= n_valid) v[rr] = NEG_INF;
+                        }
+                        const float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                        cmax[nh][ni] = fmaxf(cmax[nh][ni], m);
+                        // Emission: every branch below is WAVE-UNIFORM (ballots), the position comes from a per-wave counter
+                        // kept in a scalar register and a prefix count over the emitting lanes -- no LDS or global atomic
+                        // (the compiler orders an LDS atomic behind ALL pending LDS-DMAs: s_waitcnt vmcnt(0))
+                        if (EMIT && __ballot(m >= thrv[nh][ni]) != 0) {
+                            const int q = nt * 256 + nh * 128 + wc * 32 + ni * 16 + li16;
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr) {
+                                const bool hit = v[rr] >= thrv[nh][ni];
+                                const unsigned long long hm = __ballot(hit);
+                                if (hm != 0) {
+                                    const int pos = wave_cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+                                    if (hit && pos < a.wv_cap)
+                                        wvbuf[pos] = make_int4(row0 + rb + rr, q, __float_as_int(v[rr]), tile_of(jt));
+                                    wave_cnt += __popcll(hm);
+                                }
+                            }
+                        }
+                    }
+            }
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                float m = cmax[nh][ni];
+                m = fmaxf(m, __shfl_xor(m, 16));
+                m = fmaxf(m, __shfl_xor(m, 32));
+                if (lg == 0 && m > NEG_INF)
+                    atomicMax(&a.tmax[(size_t)(nt * 256 + nh * 128 + wc * 32 + ni * 16 + li16) * a.tmax_stride + jt], msr_ord32(m));
+            }
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) acc[mh][mi][nh][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // next tile
+        jt = jn;
+        row0 = row0n;
+        row_end = a.tile_row[tile_of(jt) + 1];
+        jn = jt + G < a.t_count ? jt + G : jt;
+        row0n = a.tile_row[tile_of(jn)];
+    }
+    wait_vm0();                                        // the DMAs issued for a step that never runs
+    if (wr == 0) wg_barrier();                         // pairs with the followers' last barrier
+    if (EMIT && lane == 0) a.wv_count[blockIdx.x * 8 + w] = wave_cnt;
+}
+
+// ---- image builders -----------------------------------------------------------------------------------------------
+// dst[r] = bf16(src[r] * inv_norm[r]) for r < n_rows, zero rows up to n_pad (the GEMM reads 256 rows from a tile start)
+__global__ __launch_bounds__(256) void unit_bf16_rows_kernel(const float* __restrict__ src, const float* __restrict__ inv_norm,
+                                                              int64_t n_rows, int64_t n_pad, bf16x8* __restrict__ dst) {
+    const int64_t n8 = n_pad * (MSR_DIM / 8);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / (MSR_DIM / 8);
+        bf16x8 v;
+        if (r < n_rows) {
+            const float s = inv_norm ? inv_norm[r] : 1.0f;
+            const f32x4 x = ((const f32x4*)src)[2 * i], y = ((const f32x4*)src)[2 * i + 1];
+            v[0] = (__bf16)(x.x * s); v[1] = (__bf16)(x.y * s); v[2] = (__bf16)(x.z * s); v[3] = (__bf16)(x.w * s);
+            v[4] = (__bf16)(y.x * s); v[5] = (__bf16)(y.y * s); v[6] = (__bf16)(y.z * s); v[7] = (__bf16)(y.w * s);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.f;
+        }
+        dst[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void ord_to_float_kernel(uint32_t* __restrict__ x, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t u = x[i];
+    ((float*)x)[i] = u == 0 ? -__builtin_inff() : msr_unord32(u);        // 0: no tile wrote this cell
+}
+
+// thr[q] = (k-th largest tile maximum) - margin; fewer than k finite maxima (or a padding query): +inf, i.e. no emission,
+// and flag[q] = 1 so that the caller reports the query as "rerun on the exact path" (real queries only)
+__global__ __launch_bounds__(256) void gemm_thr_kernel(const float* __restrict__ top_score, const int32_t* __restrict__ top_n,
+                                                        int nq, int nq_pad, int k, float margin, float* __restrict__ thr,
+                                                        int32_t* __restrict__ flag) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq_pad) return;
+    float t = __builtin_inff();
+    int f = 0;
+    if (q < nq) {
+        if (top_n[q] >= k) t = top_score[(int64_t)q * k + (k - 1)] - margin;
+        else f = 1;
+    }
+    thr[q] = t;
+    if (flag) flag[q] = f;
+}
+
+// Workgroup buffers -> per-query lists of (row, score) with score >= thr2[q].
+__global__ __launch_bounds__(256) void gemm_bucket_kernel(const int4* __restrict__ wgbuf, int wg_cap,
+                                                           const int32_t* __restrict__ wg_count,   // (per wave)
+                                                           const float* __restrict__ thr2, int2* __restrict__ pairs,
+                                                           int pair_cap, int32_t* __restrict__ pair_n) {
+    const int wg = blockIdx.y;
+    int n = wg_count[wg];
+    if (n > wg_cap) n = wg_cap;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int4 e = wgbuf[(size_t)wg * wg_cap + i];
+        if (__int_as_float(e.z) >= thr2[e.y]) {
+            const int pos = atomicAdd(&pair_n[e.y], 1);
+            if (pos < pair_cap) pairs[(size_t)e.y * pair_cap + pos] = make_int2(e.x, e.z);
+        }
+    }
+}
+
+// One workgroup per query: (row, score) pairs -> per-document maxima -> documents within `margin` of the k-th largest
+// maximum -> candidate list for the exact f32 rescoring (msr_batch.hip).  Overflow anywhere: cand_n = MSR_SEL_CAP + 1,
+// which rescore_final_kernel reports as out_n = -1 (rerun on the exact path).
+constexpr int GM_PAIR_CAP = 4096;
+__global__ __launch_bounds__(1024) void gemm_cand_kernel(const int2* __restrict__ pairs, int32_t* __restrict__ pair_n,
+                                                          const int32_t* __restrict__ chunk_doc,
+                                                          const int32_t* __restrict__ wg_count, int n_wg, int wg_cap,
+                                                          const int32_t* __restrict__ flag, int k, float margin,
+                                                          int32_t* __restrict__ cand_doc, int32_t* __restrict__ cand_n) {
+    __shared__ uint64_t key[GM_PAIR_CAP];
+    __shared__ int s_heads, s_over;
+    const int q = blockIdx.x, t = threadIdx.x;
+    const int raw = pair_n[q];
+    if (t == 0) {
+        int over = raw > GM_PAIR_CAP || (flag && flag[q]);
+        for (int i = 0; i < n_wg && !over; ++i) over = wg_count[i] > wg_cap;
+        s_over = over;
+        s_heads = 0;
+    }
+    __syncthreads();
+    if (s_over) {
+        if (t == 0) { cand_n[q] = MSR_SEL_CAP + 1; pair_n[q] = 0; }
+        return;
+    }
+    int P = 64;
+    while (P < raw) P <<= 1;
+    auto sort_desc = [&]() {
+        for (int kk = 2; kk <= P; kk <<= 1)
+            for (int j = kk >> 1; j > 0; j >>= 1) {
+                for (int idx = t; idx < (P >> 1); idx += 1024) {
+                    const int i = ((idx & ~(j - 1)) << 1) | (idx & (j - 1));
+                    const int p = i | j;
+                    const bool desc = (i & kk) == 0;
+                    const uint64_t x = key[i], y = key[p];
+                    if (desc ? x < y : x > y) { key[i] = y; key[p] = x; }
+                }
+                __syncthreads();
+            }
+    };
+    // (1) by (document, score) descending: the first entry of a document's run is its maximum
+    for (int i = t; i < P; i += 1024) {
+        uint64_t kk = 0;
+        if (i < raw) {
+            const int2 e = pairs[(size_t)q * GM_PAIR_CAP + i];
+            kk = ((uint64_t)(uint32_t)(chunk_doc[e.x] + 1) << 32) | msr_ord32(__int_as_float(e.y));   // doc + 1: 0 is the pad key
+        }
+        key[i] = kk;
+    }
+    __syncthreads();
+    sort_desc();
+    // (2) heads only, keyed by (score, ~document); everything else becomes the pad key
+    uint64_t mine[GM_PAIR_CAP / 1024];
+#pragma unroll
+    for (int u = 0; u < GM_PAIR_CAP / 1024; ++u) {
+        const int i = t + u * 1024;
+        uint64_t kk = 0;
+        if (i < P && key[i] != 0 && (i == 0 || (key[i] >> 32) != (key[i - 1] >> 32)))
+            kk = ((uint64_t)(uint32_t)key[i] << 32) | (uint32_t)~(uint32_t)((key[i] >> 32) - 1);
+        mine[u] = kk;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < GM_PAIR_CAP / 1024; ++u) {
+        const int i = t + u * 1024;
+        if (i < P) {
+            key[i] = mine[u];
+            if (mine[u]) atomicAdd(&s_heads, 1);
+        }
+    }
+    __syncthreads();
+    sort_desc();
+    const int heads = s_heads;
+    // (3) the k-th largest per-document maximum is t (or -inf with fewer than k documents); keep >= t - margin
+    const float tk = heads >= k ? msr_unord32((uint32_t)(key[k - 1] >> 32)) : -__builtin_inff();
+    const float cut = tk - margin;
+    __shared__ int s_keep;
+    if (t == 0) s_keep = 0;
+    __syncthreads();
+    for (int i = t; i < heads; i += 1024)                                   // sorted: the kept ones are a prefix
+        if (msr_unord32((uint32_t)(key[i] >> 32)) >= cut) {
+            atomicAdd(&s_keep, 1);
+            if (i < MSR_SEL_CAP) cand_doc[(size_t)q * MSR_SEL_CAP + i] = (int32_t)~(uint32_t)key[i];
+        }
+    __syncthreads();
+    if (t == 0) { cand_n[q] = s_keep; pair_n[q] = 0; }
+}
+
+// qmat[q] = bf16(qn[q]) for q < nq, zero rows up to nq_pad
+__global__ __launch_bounds__(256) void qmat_kernel(const float* __restrict__ qn, int nq, int nq_pad, bf16x8* __restrict__ dst) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq_pad * (MSR_DIM / 8)) return;
+    const int q = i / (MSR_DIM / 8);
+    bf16x8 v;
+    if (q < nq) {
+        const f32x4 x = ((const f32x4*)qn)[2 * (size_t)i], y = ((const f32x4*)qn)[2 * (size_t)i + 1];
+        v[0] = (__bf16)x.x; v[1] = (__bf16)x.y; v[2] = (__bf16)x.z; v[3] = (__bf16)x.w;
+        v[4] = (__bf16)y.x; v[5] = (__bf16)y.y; v[6] = (__bf16)y.z; v[7] = (__bf16)y.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.f;
+    }
+    dst[i] = v;
+}
+
+hipError_t launch_gemm(bool emit, const GemmArgs& a, int grid, hipStream_t stream) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t err = hipFuncSetAttribute((const void*)gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GM_LDS);
+        if (err != hipSuccess) return err;
+        err = hipFuncSetAttribute((const void*)gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GM_LDS);
+        if (err != hipSuccess) return err;
+        attr_done = true;
+    }
+    if (emit) gemm_kernel<true><<<grid, GM_THREADS, GM_LDS, stream>>>(a);
+    else gemm_kernel<false><<<grid, GM_THREADS, GM_LDS, stream>>>(a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t msr_unit_bf16_rows(const float* src, const float* inv_norm, int64_t n_rows, int64_t n_pad, void* dst,
+                              hipStream_t stream) {
+    if (n_pad <= 0) return hipSuccess;
+    unit_bf16_rows_kernel<<<16384, 256, 0, stream>>>(src, inv_norm, n_rows, n_pad, (bf16x8*)dst);
+    return hipGetLastError();
+}
+
+int msr_gemm_pair_cap() { return GM_PAIR_CAP; }
+
+// The whole batched candidate path for nq <= g.max_queries queries (see the header of this file); ends with cand_doc /
+// cand_n filled for msr_batch_rescore.  qn: normalised f32 queries [nq][768].
+hipError_t msr_gemm_candidates(const GemmIndex& g, const DenseIndex& ix, const float* qn, int nq, int k, float margin,
+                               const SelScratch& sel, int32_t* cand_doc, int32_t* cand_n, hipEvent_t* ev,
+                               hipStream_t stream) {
+    const int nq_pad = (nq + 255) / 256 * 256;
+    const int nt = nq_pad / 256;
+    if (nq <= 0 || nq_pad > g.max_queries || k < 1 || g.n_tiles < 2 * k) return hipErrorInvalidValue;
+    const int grid = g.n_cus / 8 * 8;
+    if (grid < 8 || grid / 8 < nt) return hipErrorInvalidValue;
+    hipError_t err;
+    qmat_kernel<<<(nq_pad * (MSR_DIM / 8) + 255) / 256, 256, 0, stream>>>(qn, nq, nq_pad, (bf16x8*)g.qmat);
+    // ---- pass 1: every ss-th tile, tile maxima only ----
+    int ss = g.n_tiles / (8 * k);
+    ss = ss < 1 ? 1 : (ss > 16 ? 16 : ss);
+    const int n_s = (g.n_tiles - ss / 2 + ss - 1) / ss;                   // tiles ss/2, ss/2 + ss, ...
+    GemmArgs a{};
+    a.A = (const char*)g.emb_n; a.B = (const char*)g.qmat; a.tile_row = g.tile_row; a.nt = nt;
+    a.tmax = g.tmax; a.tmax_stride = g.tmax_stride;
+    a.t_first = ss / 2; a.t_stride = ss; a.t_count = n_s;
+    if ((err = hipMemsetAsync(g.tmax, 0, (size_t)nq_pad * g.tmax_stride * 4, stream)) != hipSuccess) return err;
+    if (ev && (err = hipEventRecord(ev[0], stream)) != hipSuccess) return err;
+    if ((err = launch_gemm(false, a, grid, stream)) != hipSuccess) return err;
+    if (ev && (err = hipEventRecord(ev[1], stream)) != hipSuccess) return err;
+    ord_to_float_kernel<<<(unsigned)(((int64_t)nq_pad * g.tmax_stride + 255) / 256), 256, 0, stream>>>(g.tmax, (int64_t)nq_pad * g.tmax_stride);
+    if ((err = msr_select_topk(32, g.tmax, n_s, g.tmax_stride, nq, k, sel, g.top_doc, g.top_score, g.top_n, stream)) != hipSuccess) return err;
+    gemm_thr_kernel<<<(nq_pad + 255) / 256, 256, 0, stream>>>(g.top_score, g.top_n, nq, nq_pad, k, margin, g.thr, g.flag);
+    // ---- pass 2: all tiles; maxima of all tiles + emission against the sample threshold ----
+    a.t_first = 0; a.t_stride = 1; a.t_count = g.n_tiles;
+    a.thr = g.thr; a.wgbuf = (int4*)g.wgbuf; a.wv_cap = g.wv_cap; a.wv_count = g.wv_count;
+    if ((err = hipMemsetAsync(g.tmax, 0, (size_t)nq_pad * g.tmax_stride * 4, stream)) != hipSuccess) return err;
+    if (ev && (err = hipEventRecord(ev[2], stream)) != hipSuccess) return err;
+    if ((err = launch_gemm(true, a, grid, stream)) != hipSuccess) return err;
+    if (ev && (err = hipEventRecord(ev[3], stream)) != hipSuccess) return err;
+    ord_to_float_kernel<<<(unsigned)(((int64_t)nq_pad * g.tmax_stride + 255) / 256), 256, 0, stream>>>(g.tmax, (int64_t)nq_pad * g.tmax_stride);
+    if ((err = msr_select_topk(32, g.tmax, g.n_tiles, g.tmax_stride, nq, k, sel, g.top_doc, g.top_score, g.top_n, stream)) != hipSuccess) return err;
+    gemm_thr_kernel<<<(nq_pad + 255) / 256, 256, 0, stream>>>(g.top_score, g.top_n, nq, nq_pad, k, margin, g.thr2, nullptr);
+    // ---- finish: bucket, per-document maxima, candidates ----
+    gemm_bucket_kernel<<<dim3(2, (unsigned)grid * 8), 256, 0, stream>>>((const int4*)g.wgbuf, g.wv_cap, g.wv_count, g.thr2,
+                                                                       (int2*)g.pairs, GM_PAIR_CAP, g.pair_n);
+    gemm_cand_kernel<<<nq, 1024, 0, stream>>>((const int2*)g.pairs, g.pair_n, ix.chunk_doc, g.wv_count, grid * 8, g.wv_cap,
+                                              g.flag, k, margin, cand_doc, cand_n);
+    return hipGetLastError();
+}

@@ -152,7 +152,41 @@ hipError_t msr_rerank_fuse_run(int nq, const int32_t* cand_doc, const double* ca
                                int32_t* out_doc, double* out_score, double* out_orig, int32_t* out_chunk,
                                int32_t* out_n, int32_t* out_rows, hipStream_t stream);
 
+// ---- K5 as a tiled GEMM (msr_gemm.hip): candidates for hundreds to thousands of queries per call ------------------
+struct GemmIndex {
+    const void* emb_n;         // bf16 [n_chunks + pad][768]: the rows NORMALISED, then rounded (zero rows as padding)
+    const int32_t* tile_row;   // [n_tiles + 1]: row tiles of <= 256 rows cut at document boundaries
+    int32_t n_tiles;
+    int32_t n_cus;
+    int32_t max_queries;       // queries per call the scratch below is sized for (multiple of 256)
+    void* qmat;                // bf16 [max_queries][768]
+    uint32_t* tmax;            // [max_queries][tmax_stride] tile maxima (order-preserving uint, then float in place)
+    int32_t tmax_stride;
+    int32_t* top_doc; float* top_score; int32_t* top_n;     // [max_queries][MSR_MAX_K] / [max_queries]
+    float* thr; float* thr2;   // [max_queries] emission threshold (sample bound) / final threshold (all tiles)
+    int32_t* flag;             // [max_queries] 1: the sample could not bound this query (rerun on the exact path)
+    void* wgbuf;               // [n_workgroups * 8 waves][wv_cap] x 16 B emitted (row, query, score, tile)
+    int32_t wv_cap;
+    int32_t* wv_count;         // [n_workgroups * 8]
+    void* pairs;               // [max_queries][msr_gemm_pair_cap()] x 8 B (row, score) after the final threshold
+    int32_t* pair_n;           // [max_queries], zero between calls
+};
+int msr_gemm_pair_cap();
+// dst[r] = bf16(src[r] * inv_norm[r]) (inv_norm null: 1), rows n_rows .. n_pad - 1 zero
+hipError_t msr_unit_bf16_rows(const float* src, const float* inv_norm, int64_t n_rows, int64_t n_pad, void* dst,
+                              hipStream_t stream);
+// qn: [nq][768] normalised f32 queries, nq <= g.max_queries.  Fills cand_doc[q][MSR_SEL_CAP] / cand_n[q] (cand_n =
+// MSR_SEL_CAP + 1: overflow, rerun that query on the exact path) for msr_batch_rescore.  ev (nullable): 4 events recorded
+// around the sample pass (0, 1) and the emit pass (2, 3).
+hipError_t msr_gemm_candidates(const GemmIndex& g, const DenseIndex& ix, const float* qn, int nq, int k, float margin,
+                               const SelScratch& sel, int32_t* cand_doc, int32_t* cand_n, hipEvent_t* ev,
+                               hipStream_t stream);
+
 // ---- K5: batched bf16 candidate scan finished exactly in f32 (msr_batch.hip) -----------------------
+// exact f32 rescoring + final sort of candidate lists that are already filled (cand_n zeroed on return)
+hipError_t msr_batch_rescore(const DenseIndex& ix, const float* qn, int nq, int k, int max_chunks, int32_t* cand_doc,
+                             float* cand_score, int32_t* cand_chunk, int32_t* cand_n, int32_t* out_doc, float* out_score,
+                             int32_t* out_chunk, int32_t* out_n, hipStream_t stream);
 hipError_t msr_batch_finish(const DenseIndex& ix, const float* qn, int nq, int k, int max_chunks, float margin,
                             const float* scores, const float* top_score, const int32_t* top_n, int32_t* cand_doc,
                             float* cand_score, int32_t* cand_chunk, int32_t* cand_n, int32_t* out_doc,
