@@ -109,8 +109,11 @@ int msr_scan_arith(const msr_engine* e);
  * (row-major layout, no per-document row limit, a corpus that meets its preconditions; both arithmetics), else 32;
  * -1 = no chunks bound. */
 int msr_scan_width(const msr_engine* e);
-/* The same for msr_dense_topk_bf16 (after msr_enable_bf16): 128, 64, or -1. */
+/* The same for the <= 128-query sweeps of msr_dense_topk_bf16 (after msr_enable_bf16): 128, 64, or -1. */
 int msr_batch_width(const msr_engine* e);
+/* 1 if calls of msr_dense_topk_bf16 with more than 128 queries run as the tiled matrix-core GEMM (every document fits a
+ * 256-row tile and the corpus has enough tiles), else 0 (such calls are served by repeated sweeps). */
+int msr_batch_gemm_ok(const msr_engine* e);
 
 /* Re-order row-major rows into the 16-row interleaved scan layout (dst may not alias src).
  * n_rows is padded up to a multiple of 16 in dst (pad rows zero): dst holds ceil16(n_rows)*768 floats. */
@@ -134,12 +137,14 @@ int msr_bm25_topk(msr_engine* e, const int32_t* q_term_off, const int32_t* q_ter
 int msr_dense_topk(msr_engine* e, const float* q, int32_t n_queries, int32_t k, int32_t max_chunks_per_doc,
                    int32_t* out_doc, float* out_score, int32_t* out_chunk, int32_t* out_n, void* stream);
 
-/* Batched variant of msr_dense_topk for throughput (BASELINE config 5): one sweep over a bf16 copy of the
- * embeddings (v_mfma_f32_16x16x32_bf16) serves up to 128 queries (msr_batch_width) and yields approximate scores with a proven
- * error bound; every document within twice that bound of the k-th approximate score is re-scored in f32 from
- * the f32 rows and the final top-k is exact (same ordering rule as msr_dense_topk).  A query whose candidate
- * set exceeds the engine's capacity (4096) comes back with out_n = -1: rerun it with msr_dense_topk.
- * msr_enable_bf16 builds the bf16 copy (+2 bytes per embedding value of HBM); row-major layout only. */
+/* Batched variant of msr_dense_topk for throughput (BASELINE config 5).  Candidates come from a bf16 image of the
+ * NORMALISED rows (v_mfma_f32_16x16x32_bf16, f32 accumulation), whose scores carry a proven error bound; every document
+ * within twice that bound of the k-th approximate score is re-scored in f32 from the f32 rows, so the final top-k is
+ * exact (same ordering rule as msr_dense_topk).  Up to 128 queries per call: one sweep of the image (msr_batch_width).
+ * More: a tiled GEMM, 1024 queries per pass over the image, that never writes the score matrix (msr_batch_gemm_ok; design
+ * in csrc/msr_gemm.hip).  A query whose candidate set exceeds the engine's capacity comes back with out_n = -1: rerun it
+ * with msr_dense_topk.  msr_enable_bf16 builds the image (+2 bytes per embedding value of HBM) and the scratch of the
+ * GEMM path (~0.8 GB); row-major layout only. */
 int msr_enable_bf16(msr_engine* e, void* stream);
 int msr_dense_topk_bf16(msr_engine* e, const float* q, int32_t n_queries, int32_t k, int32_t max_chunks_per_doc,
                         int32_t* out_doc, float* out_score, int32_t* out_chunk, int32_t* out_n, void* stream);
@@ -182,8 +187,14 @@ int msr_merge_topk(msr_engine* e, const int32_t* in_doc, const void* in_score, c
 /* Timing hooks for bench.py: while enabled, every launch of the dominant kernels is bracketed by a
  * hipEvent pair recorded on the caller's stream (ring of 256 launches per kernel).  msr_kernel_time_ms
  * blocks on the recorded events and returns the SUM of the launch durations and the number of launches
- * since msr_set_timing(e, 1).  which: 0 = dense scan kernel, 1 = BM25 TAAT kernel. */
+ * since msr_set_timing(e, 1).  which: 0 = dense scan kernel, 1 = BM25 TAAT kernel, 2 = GEMM emit pass (all row tiles),
+ * 3 = GEMM sample pass (every 16th tile). */
 int msr_set_timing(msr_engine* e, int32_t enabled);
+/* A/B hook for measurements (tools/gemm_check.py): selects between implementations that return IDENTICAL results.
+ * MSR_TUNE_GEMM_VERSION: 1 (default) = one 64 x 32 quadrant per phase, 2 = one (row half, k half) per phase with the A
+ * fragments prefetched during the matrix segment (measured 8 % slower).  Process-wide. */
+#define MSR_TUNE_GEMM_VERSION 1
+int msr_tune(msr_engine* e, int32_t key, int32_t value);
 int msr_kernel_time_ms(msr_engine* e, int32_t which, float* out_ms, int32_t* out_launches);
 
 #ifdef __cplusplus

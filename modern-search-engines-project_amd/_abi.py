@@ -48,6 +48,7 @@ _SIGNATURES = {
     "msr_enc_geglu": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
     "msr_enc_mean_pool": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "msr_batch_width": (C.c_int, [_P]),
+    "msr_batch_gemm_ok": (C.c_int, [_P]),
     "msr_interleave_rows": (C.c_int, [_P, _P, C.c_int64, _P, _P]),
     "msr_bm25_topk": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_double, _P, _P, _P, _P]),
     "msr_dense_topk": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
@@ -60,6 +61,7 @@ _SIGNATURES = {
                                   _P, _P, _P, _P, _P]),
     "msr_merge_topk": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "msr_set_timing": (C.c_int, [_P, C.c_int32]),
+    "msr_tune": (C.c_int, [_P, C.c_int32, C.c_int32]),
     "msr_kernel_time_ms": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
 }
 EXPORTS = tuple(_SIGNATURES)

@@ -1,11 +1,14 @@
 // K5 support -- exact finish of the bf16 candidate scan (gfx950).
 //
-// The bf16 sweep (dense_scan_v2_kernel<.., BF16>) gives every document an APPROXIMATE max-cosine s^ with
-// |s^ - s| <= eps, eps = 2^-7: both operands are rounded to 8 significant bits (relative error <= 2^-8 each), so
-// each product is off by at most ~2^-7 |e_i q_i| and, by Cauchy-Schwarz on unit vectors, the sum by at most 2^-7;
-// the f32 accumulation error is orders of magnitude smaller.  Let t = k-th largest s^.  Every document of the
-// exact top-k satisfies s^ >= t - 2 eps (proof in DESIGN.md), so
-//     candidates = { d : s^_d >= t - 2 eps }
+// The candidate generators (the K-split sweep of msr_dense_ks.hip for <= 128 queries, the tiled GEMM of msr_gemm.hip
+// above that) multiply bf16 images e^, q^ of the UNIT vectors e, q and give every document an APPROXIMATE max-cosine s^:
+//     |s^ - s| <= eps_q = ||e^ - e|| ||q^|| + ||e|| ||q^ - q|| (+ f32 accumulation)   (Cauchy-Schwarz, twice)
+// The two rounding-error norms are MEASURED, not assumed: max_r ||e^_r - e_r|| when the image is built
+// (unit_bf16_rows_kernel), ||q^ - q|| per query (batch_margin_kernel); on typical data eps_q is about half of the worst
+// case 2^-7, which more than halves the candidate sets.  Let t = k-th largest s^.  The k documents with the largest s^
+// have exact scores >= t - eps, so the exact k-th score sigma >= t - eps, and every document of the exact top-k has
+// s^ >= sigma - eps >= t - 2 eps.  Hence
+//     candidates = { d : s^_d >= t - 2 eps_q }          (margin = 2 eps_q + slack, msr_batch_margin)
 // is a superset of the exact top-k.  The kernels below compact that set, recompute the candidates' cosines in
 // f32 from the f32 rows (reranker_api.py:285 arithmetic), and sort them exactly.  If a query has more than
 // MSR_SEL_CAP candidates the call reports out_n = -1 for it and the host reruns it on the f32 scan.
@@ -22,13 +25,14 @@ __global__ __launch_bounds__(BT_THREADS) void thr_compact_kernel(const float* __
                                                                   int64_t stride,
                                                                   const float* __restrict__ top_score,
                                                                   const int32_t* __restrict__ top_n, int k,
-                                                                  float margin, int32_t* __restrict__ cand_doc,
+                                                                  const float* __restrict__ margin,
+                                                                  int32_t* __restrict__ cand_doc,
                                                                   int32_t* __restrict__ cand_n) {
     __shared__ int32_t s_doc[BT_STAGE];
     __shared__ int s_n, s_base;
     const int q = blockIdx.y;
     const int have = top_n[q];
-    const float thr = have >= k ? top_score[(int64_t)q * k + (k - 1)] - margin : -__builtin_inff();
+    const float thr = have >= k ? top_score[(int64_t)q * k + (k - 1)] - margin[q] : -__builtin_inff();
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
     const int64_t per = (n + gridDim.x - 1) / gridDim.x;
@@ -169,7 +173,7 @@ hipError_t msr_batch_rescore(const DenseIndex& ix, const float* qn, int nq, int 
     return hipGetLastError();
 }
 
-hipError_t msr_batch_finish(const DenseIndex& ix, const float* qn, int nq, int k, int max_chunks, float margin,
+hipError_t msr_batch_finish(const DenseIndex& ix, const float* qn, int nq, int k, int max_chunks, const float* margin,
                             const float* scores, const float* top_score, const int32_t* top_n, int32_t* cand_doc,
                             float* cand_score, int32_t* cand_chunk, int32_t* cand_n, int32_t* out_doc,
                             float* out_score, int32_t* out_chunk, int32_t* out_n, hipStream_t stream) {

@@ -18,6 +18,7 @@
 // fail its ring precondition).
 #include <stdlib.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "msr_common.h"
@@ -356,15 +357,8 @@ __global__ __launch_bounds__(256) void build_qimage_kernel(const float* __restri
     }
 }
 
-__global__ __launch_bounds__(256) void to_bf16_kernel(const float* __restrict__ src, int64_t n8,
-                                                       bf16x8* __restrict__ dst) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
-        const f32x4 a = ((const f32x4*)src)[2 * i], b = ((const f32x4*)src)[2 * i + 1];
-        bf16x8 v;
-        v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
-        v[4] = (__bf16)b.x; v[5] = (__bf16)b.y; v[6] = (__bf16)b.z; v[7] = (__bf16)b.w;
-        dst[i] = v;
-    }
+__global__ __launch_bounds__(256) void fill_f32_kernel(float* __restrict__ dst, int64_t n, float value) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = value;
 }
 
 __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restrict__ q, int nq,
@@ -600,12 +594,9 @@ hipError_t msr_dense_scan_bf16(const DenseIndex& ix, const float* qn, int nq, in
     return launch_scan_bf16<4>(ix, qn, nq, max_chunks, docscore, stream);
 }
 
-hipError_t msr_to_bf16(const float* src, int64_t n_elems, void* dst, hipStream_t stream) {
-    if (n_elems <= 0) return hipSuccess;
-    const int64_t n8 = n_elems / 8;                              // n_elems is a multiple of 768
-    int64_t blocks = (n8 + 255) / 256;
-    if (blocks > 65536) blocks = 65536;
-    to_bf16_kernel<<<(unsigned)blocks, 256, 0, stream>>>(src, n8, (bf16x8*)dst);
+hipError_t msr_fill_f32(float* dst, int64_t n, float value, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    fill_f32_kernel<<<(unsigned)std::min<int64_t>((n + 255) / 256, 65536), 256, 0, stream>>>(dst, n, value);
     return hipGetLastError();
 }
 

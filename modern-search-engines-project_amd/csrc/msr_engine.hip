@@ -47,13 +47,27 @@ struct msr_engine {
     int32_t* bt_top_doc = nullptr; float* bt_top_score = nullptr; int32_t* bt_top_n = nullptr;
     int32_t* bt_cand_doc = nullptr; float* bt_cand_score = nullptr; int32_t* bt_cand_chunk = nullptr;
     int32_t* bt_cand_n = nullptr;
+    // batched path as a tiled GEMM (msr_gemm.hip): unit-row bf16 image + tile table + scratch for GM_SLICE queries per pass
+    GemmIndex gemm{};
+    bool gemm_ok = false;
+    void* gm_emb_n = nullptr; int32_t* gm_tile_row = nullptr; void* gm_qmat = nullptr; uint32_t* gm_tmax = nullptr;
+    int32_t* gm_top_doc = nullptr; float* gm_top_score = nullptr; int32_t* gm_top_n = nullptr;
+    float* gm_thr = nullptr; float* gm_thr2 = nullptr; int32_t* gm_flag = nullptr; void* gm_wgbuf = nullptr;
+    int32_t* gm_wv_count = nullptr; void* gm_pairs = nullptr; int32_t* gm_pair_n = nullptr; float* gm_qn = nullptr;
+    SelScratch gm_sel{};
+    uint32_t* bf_err = nullptr;        // bits of the largest rounding-error norm of an image row (see msr_batch_margin)
+    float* bf_margin = nullptr;        // [GM_SLICE] candidate margin of each query of the current slice
+    float* bf_ones = nullptr;          // inverse norms of the unit-row image (all 1) for the <= 128-query bf16 sweeps
+    void* bf_row_meta = nullptr;       // {document, 1.0f} per row for the K-split bf16 sweeps
+    DenseIndex dense_bf16{};           // `dense` with the unit-row image, its inverse norms and row meta
     int n_cus = 256;
     // timing
     bool timing = false;
     static constexpr int EV_RING = 256;
-    hipEvent_t ev_start[2][EV_RING] = {};
-    hipEvent_t ev_stop[2][EV_RING] = {};
-    int ev_count[2] = {0, 0};          // launches recorded since msr_set_timing(1)
+    static constexpr int EV_KINDS = 4; // 0 dense scan, 1 BM25 TAAT, 2 GEMM emit pass, 3 GEMM sample pass
+    hipEvent_t ev_start[EV_KINDS][EV_RING] = {};
+    hipEvent_t ev_stop[EV_KINDS][EV_RING] = {};
+    int ev_count[EV_KINDS] = {0, 0, 0, 0};   // launches recorded since msr_set_timing(1)
 };
 
 static thread_local char g_create_err[512] = "";
@@ -75,6 +89,20 @@ static int fail(msr_engine* e, int code, const char* fmt, ...) {
 
 static void free_dev(void* p) {
     if (p) (void)hipFree(p);
+}
+
+static void free_gemm(msr_engine* e) {
+    free_dev(e->gm_emb_n); free_dev(e->gm_tile_row); free_dev(e->gm_qmat); free_dev(e->gm_tmax); free_dev(e->gm_top_doc);
+    free_dev(e->gm_top_score); free_dev(e->gm_top_n); free_dev(e->gm_thr); free_dev(e->gm_thr2); free_dev(e->gm_flag);
+    free_dev(e->gm_wgbuf); free_dev(e->gm_wv_count); free_dev(e->gm_pairs); free_dev(e->gm_pair_n); free_dev(e->gm_qn);
+    free_dev(e->gm_sel.hist); free_dev(e->gm_sel.state); free_dev(e->gm_sel.cand_hi); free_dev(e->gm_sel.cand_lo);
+    free_dev(e->gm_sel.cand_n); free_dev(e->bf_ones); free_dev(e->bf_row_meta); free_dev(e->bf_err); free_dev(e->bf_margin);
+    e->bf_err = nullptr; e->bf_margin = nullptr;
+    e->gm_emb_n = nullptr; e->gm_tile_row = nullptr; e->gm_qmat = nullptr; e->gm_tmax = nullptr; e->gm_top_doc = nullptr;
+    e->gm_top_score = nullptr; e->gm_top_n = nullptr; e->gm_thr = e->gm_thr2 = nullptr; e->gm_flag = nullptr;
+    e->gm_wgbuf = nullptr; e->gm_wv_count = nullptr; e->gm_pairs = nullptr; e->gm_pair_n = nullptr; e->gm_qn = nullptr;
+    e->gm_sel = SelScratch{}; e->bf_ones = nullptr; e->bf_row_meta = nullptr;
+    e->gemm_ok = false;
 }
 
 extern "C" int msr_abi_version(void) { return MSR_ABI_VERSION; }
@@ -146,7 +174,7 @@ extern "C" int msr_create(const msr_config* cfg, msr_engine** out) {
         if ((herr = hipMalloc((void**)&e->rerank_meta, nq * (size_t)cfg->rerank_max_docs * 3 * sizeof(int32_t))) != hipSuccess)
             return bail(MSR_ERR_NOMEM, "hipMalloc rerank_meta", herr);
     }
-    for (int w = 0; w < 2; ++w)
+    for (int w = 0; w < msr_engine::EV_KINDS; ++w)
         for (int j = 0; j < msr_engine::EV_RING; ++j) {
             if ((herr = hipEventCreate(&e->ev_start[w][j])) != hipSuccess) return bail(MSR_ERR_HIP, "hipEventCreate", herr);
             if ((herr = hipEventCreate(&e->ev_stop[w][j])) != hipSuccess) return bail(MSR_ERR_HIP, "hipEventCreate", herr);
@@ -162,7 +190,8 @@ extern "C" int msr_destroy(msr_engine* e) {
     free_dev(e->sel.cand_lo); free_dev(e->sel.cand_n); free_dev(e->rerank_cos); free_dev(e->rerank_meta);
     free_dev(e->bt_top_doc); free_dev(e->bt_top_score); free_dev(e->bt_top_n); free_dev(e->bt_cand_doc);
     free_dev(e->bt_cand_score); free_dev(e->bt_cand_chunk); free_dev(e->bt_cand_n);
-    for (int w = 0; w < 2; ++w)
+    free_gemm(e);
+    for (int w = 0; w < msr_engine::EV_KINDS; ++w)
         for (int j = 0; j < msr_engine::EV_RING; ++j) {
             if (e->ev_start[w][j]) (void)hipEventDestroy(e->ev_start[w][j]);
             if (e->ev_stop[w][j]) (void)hipEventDestroy(e->ev_stop[w][j]);
@@ -392,6 +421,7 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
                           e->emb_presplit, e->row_meta, wide_ok, wide_ok && wide_ok64, variant};
     free_dev(e->emb_bf16);                                // a new binding invalidates the bf16 copy
     e->emb_bf16 = nullptr;
+    free_gemm(e);
     e->have_chunks = true;
     return MSR_OK;
 }
@@ -435,12 +465,12 @@ extern "C" int msr_batch_width(const msr_engine* e) {
 extern "C" int msr_set_timing(msr_engine* e, int32_t enabled) {
     if (!e) return MSR_ERR_INVALID;
     e->timing = enabled != 0;
-    e->ev_count[0] = e->ev_count[1] = 0;
+    for (int w = 0; w < msr_engine::EV_KINDS; ++w) e->ev_count[w] = 0;
     return MSR_OK;
 }
 
 extern "C" int msr_kernel_time_ms(msr_engine* e, int32_t which, float* out_ms, int32_t* out_launches) {
-    if (!e || which < 0 || which > 1 || !out_ms) return e ? fail(e, MSR_ERR_INVALID, "msr_kernel_time_ms: bad argument") : MSR_ERR_INVALID;
+    if (!e || which < 0 || which >= msr_engine::EV_KINDS || !out_ms) return e ? fail(e, MSR_ERR_INVALID, "msr_kernel_time_ms: bad argument") : MSR_ERR_INVALID;
     const int n = std::min(e->ev_count[which], (int)msr_engine::EV_RING);
     if (n <= 0) return fail(e, MSR_ERR_INVALID, "msr_kernel_time_ms: no timed launch recorded");
     float total = 0.f;
@@ -529,7 +559,9 @@ static int rerank_args_ok(msr_engine* e, const char* fn, int32_t n_queries, int3
     return MSR_OK;
 }
 
-static constexpr int BT_SLICE = 128;                        // most queries per bf16 sweep
+static constexpr int BT_SLICE = 128;                        // most queries per bf16 K-split sweep
+static constexpr int GM_SLICE = 1024;                       // queries per pass of the GEMM path (4 query tiles of 256)
+static constexpr int GM_WV_CAP = 16384;                     // emitted entries per wave (x 8 waves x #CU x 16 B = 512 MB at 256 CUs)
 
 extern "C" int msr_enable_bf16(msr_engine* e, void* stream) {
     if (!e) return MSR_ERR_INVALID;
@@ -539,23 +571,101 @@ extern "C" int msr_enable_bf16(msr_engine* e, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     hipError_t herr;
-    const size_t n_el = (size_t)e->dense.n_chunks * MSR_DIM;
-    if ((herr = hipMalloc(&e->emb_bf16, n_el * 2)) != hipSuccess)
-        return fail(e, MSR_ERR_NOMEM, "bf16 embeddings (%zu bytes): %s", n_el * 2, hipGetErrorString(herr));
+    const int64_t C = e->dense.n_chunks, N = e->dense.n_docs;
+    // The image holds the rows NORMALISED and then rounded to bf16 (so a score needs no per-row scale and the error bound
+    // of msr_batch.hip is about unit vectors), padded with 512 zero rows: the GEMM reads 256 rows from any tile start.
+    const int64_t n_pad = C + 512;
+    if ((herr = hipMalloc(&e->emb_bf16, (size_t)n_pad * MSR_DIM * 2)) != hipSuccess)
+        return fail(e, MSR_ERR_NOMEM, "bf16 embeddings (%zu bytes): %s", (size_t)n_pad * MSR_DIM * 2, hipGetErrorString(herr));
     auto alloc = [&](void** p, size_t bytes) { return *p ? hipSuccess : hipMalloc(p, bytes); };
+    const size_t QS = GM_SLICE;                             // the candidate scratch serves both the sweeps and the GEMM path
     if ((herr = alloc((void**)&e->bt_top_doc, (size_t)BT_SLICE * MSR_MAX_K * 4)) != hipSuccess ||
         (herr = alloc((void**)&e->bt_top_score, (size_t)BT_SLICE * MSR_MAX_K * 4)) != hipSuccess ||
         (herr = alloc((void**)&e->bt_top_n, (size_t)BT_SLICE * 4)) != hipSuccess ||
-        (herr = alloc((void**)&e->bt_cand_doc, (size_t)BT_SLICE * MSR_SEL_CAP * 4)) != hipSuccess ||
-        (herr = alloc((void**)&e->bt_cand_score, (size_t)BT_SLICE * MSR_SEL_CAP * 4)) != hipSuccess ||
-        (herr = alloc((void**)&e->bt_cand_chunk, (size_t)BT_SLICE * MSR_SEL_CAP * 4)) != hipSuccess ||
-        (herr = alloc((void**)&e->bt_cand_n, (size_t)BT_SLICE * 4)) != hipSuccess)
+        (herr = alloc((void**)&e->bt_cand_doc, QS * MSR_SEL_CAP * 4)) != hipSuccess ||
+        (herr = alloc((void**)&e->bt_cand_score, QS * MSR_SEL_CAP * 4)) != hipSuccess ||
+        (herr = alloc((void**)&e->bt_cand_chunk, QS * MSR_SEL_CAP * 4)) != hipSuccess ||
+        (herr = alloc((void**)&e->bt_cand_n, QS * 4)) != hipSuccess ||
+        (herr = alloc((void**)&e->bf_ones, (size_t)C * 4)) != hipSuccess ||
+        (herr = alloc((void**)&e->bf_err, 4)) != hipSuccess ||
+        (herr = alloc((void**)&e->bf_margin, QS * 4)) != hipSuccess)
         return fail(e, MSR_ERR_NOMEM, "bf16 path scratch: %s", hipGetErrorString(herr));
-    HIP_TRY(e, hipMemsetAsync(e->bt_cand_n, 0, (size_t)BT_SLICE * 4, st));
-    HIP_TRY(e, msr_to_bf16(e->dense.emb, (int64_t)n_el, e->emb_bf16, st));
+    HIP_TRY(e, hipMemsetAsync(e->bt_cand_n, 0, QS * 4, st));
+    HIP_TRY(e, msr_unit_bf16_rows(e->dense.emb, e->dense.inv_norm, C, n_pad, e->emb_bf16, e->bf_err, st));
+    HIP_TRY(e, msr_fill_f32(e->bf_ones, C, 1.0f, st));
     e->dense.emb_bf16 = e->emb_bf16;
+    e->dense_bf16 = e->dense;
+    e->dense_bf16.inv_norm = e->bf_ones;
+    if (e->dense.wide_ok) {
+        if ((herr = alloc(&e->bf_row_meta, (size_t)(C + 16) * 8)) != hipSuccess)
+            return fail(e, MSR_ERR_NOMEM, "bf16 row meta: %s", hipGetErrorString(herr));
+        HIP_TRY(e, msr_pack_row_meta(e->chunk_doc, e->bf_ones, C, e->bf_row_meta, st));
+        e->dense_bf16.row_meta = e->bf_row_meta;
+    }
+    // ---- GEMM path: row tiles of <= 256 rows cut at document boundaries (a document longer than that: no GEMM path) ----
+    std::vector<int32_t> h_off((size_t)N + 1);
+    HIP_TRY(e, hipMemcpyAsync(h_off.data(), e->dense.doc_off, h_off.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(e, hipStreamSynchronize(st));
+    std::vector<int32_t> tiles;
+    bool ok = true;
+    {
+        int32_t start = 0;
+        tiles.push_back(0);
+        for (int64_t d = 0; d < N && ok; ++d) {
+            const int32_t end = h_off[d + 1];
+            if (end - h_off[d] > 256) ok = false;
+            if (end - start > 256) { tiles.push_back(h_off[d]); start = h_off[d]; }
+        }
+        if (tiles.back() != (int32_t)C) tiles.push_back((int32_t)C);
+    }
+    const int n_tiles = (int)tiles.size() - 1;
+    const int grid = e->n_cus / 8 * 8;
+    if (ok && n_tiles >= 64 && grid >= 32) {
+        const int stride = (n_tiles + 31) / 32 * 32;
+        const size_t nsel = GM_SLICE;
+        if ((herr = alloc((void**)&e->gm_tile_row, tiles.size() * 4)) != hipSuccess ||
+            (herr = alloc(&e->gm_qmat, (size_t)GM_SLICE * MSR_DIM * 2)) != hipSuccess ||
+            (herr = alloc((void**)&e->gm_qn, (size_t)GM_SLICE * MSR_DIM * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gm_tmax, (size_t)GM_SLICE * stride * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gm_top_doc, (size_t)GM_SLICE * MSR_MAX_K * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gm_top_score, (size_t)GM_SLICE * MSR_MAX_K * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gm_top_n, (size_t)GM_SLICE * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gm_thr, (size_t)GM_SLICE * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gm_thr2, (size_t)GM_SLICE * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gm_flag, (size_t)GM_SLICE * 4)) != hipSuccess ||
+            (herr = alloc(&e->gm_wgbuf, (size_t)grid * 8 * GM_WV_CAP * 16)) != hipSuccess ||
+            (herr = alloc((void**)&e->gm_wv_count, (size_t)grid * 8 * 4)) != hipSuccess ||
+            (herr = alloc(&e->gm_pairs, (size_t)GM_SLICE * msr_gemm_pair_cap() * 8)) != hipSuccess ||
+            (herr = alloc((void**)&e->gm_pair_n, (size_t)GM_SLICE * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gm_sel.hist, nsel * MSR_SEL_BINS * sizeof(uint32_t))) != hipSuccess ||
+            (herr = alloc((void**)&e->gm_sel.state, nsel * sizeof(SelState))) != hipSuccess ||
+            (herr = alloc((void**)&e->gm_sel.cand_hi, nsel * MSR_SEL_CAP * sizeof(uint64_t))) != hipSuccess ||
+            (herr = alloc((void**)&e->gm_sel.cand_lo, nsel * MSR_SEL_CAP * sizeof(uint32_t))) != hipSuccess ||
+            (herr = alloc((void**)&e->gm_sel.cand_n, nsel * sizeof(int32_t))) != hipSuccess)
+            return fail(e, MSR_ERR_NOMEM, "GEMM path scratch: %s", hipGetErrorString(herr));
+        HIP_TRY(e, hipMemcpyAsync(e->gm_tile_row, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(e, hipMemsetAsync(e->gm_pair_n, 0, (size_t)GM_SLICE * 4, st));
+        HIP_TRY(e, hipMemsetAsync(e->gm_sel.hist, 0, nsel * MSR_SEL_BINS * sizeof(uint32_t), st));
+        HIP_TRY(e, hipMemsetAsync(e->gm_sel.cand_n, 0, nsel * sizeof(int32_t), st));
+        HIP_TRY(e, hipStreamSynchronize(st));               // `tiles` goes out of scope
+        e->gemm = GemmIndex{e->emb_bf16, e->gm_tile_row, n_tiles, e->n_cus, GM_SLICE, e->gm_qmat, e->gm_tmax, stride,
+                            e->gm_top_doc, e->gm_top_score, e->gm_top_n, e->gm_thr, e->gm_thr2, e->gm_flag, e->gm_wgbuf,
+                            GM_WV_CAP, e->gm_wv_count, e->gm_pairs, e->gm_pair_n};
+        e->gemm_ok = true;
+    }
     return MSR_OK;
 }
+
+extern "C" int msr_tune(msr_engine* e, int32_t key, int32_t value) {
+    if (!e) return MSR_ERR_INVALID;
+    if (key == MSR_TUNE_GEMM_VERSION && value >= 1 && value <= 3) { msr_gemm_set_version(value); return MSR_OK; }
+#ifdef MSR_DIAG
+    if (key == 100) { msr_gemm_set_dbg(value); return MSR_OK; }      // timing experiments of the diagnostic build
+#endif
+    return fail(e, MSR_ERR_INVALID, "msr_tune: unknown key %d / value %d", key, value);
+}
+
+extern "C" int msr_batch_gemm_ok(const msr_engine* e) { return e && e->have_chunks && e->emb_bf16 && e->gemm_ok ? 1 : 0; }
 
 extern "C" int msr_dense_topk_bf16(msr_engine* e, const float* q, int32_t n_queries, int32_t k,
                                    int32_t max_chunks_per_doc, int32_t* out_doc, float* out_score, int32_t* out_chunk,
@@ -568,7 +678,29 @@ extern "C" int msr_dense_topk_bf16(msr_engine* e, const float* q, int32_t n_quer
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     const int64_t N = e->dense.n_docs;
-    const float margin = 2.0f * 0.0078125f;                 // 2 * eps, eps = 2^-7 (see msr_batch.hip)
+    // candidate margin: 2 eps_q from the measured rounding errors of the image and of each query (msr_batch.hip)
+    // More than 128 queries: the tiled GEMM (msr_gemm.hip), GM_SLICE queries per pair of passes.  It needs whole
+    // documents inside 256-row tiles, at least 2 k tiles (the sample bound) and no per-document row limit.
+    if (e->gemm_ok && max_chunks_per_doc == 0 && n_queries > BT_SLICE && e->gemm.n_tiles >= 2 * k) {
+        for (int q0 = 0; q0 < n_queries; q0 += GM_SLICE) {
+            const int nq = std::min(GM_SLICE, n_queries - q0);
+            HIP_TRY(e, msr_prep_queries(q + (int64_t)q0 * MSR_DIM, nq, e->gm_qn, nq, st));
+            HIP_TRY(e, msr_batch_margin(e->gm_qn, nq, e->bf_err, e->bf_margin, st));
+            hipEvent_t ev[4];
+            const bool timed = e->timing && e->ev_count[2] < msr_engine::EV_RING && e->ev_count[3] < msr_engine::EV_RING;
+            if (timed) {
+                ev[0] = e->ev_start[3][e->ev_count[3]]; ev[1] = e->ev_stop[3][e->ev_count[3]];
+                ev[2] = e->ev_start[2][e->ev_count[2]]; ev[3] = e->ev_stop[2][e->ev_count[2]];
+            }
+            HIP_TRY(e, msr_gemm_candidates(e->gemm, e->dense, e->gm_qn, nq, k, e->bf_margin, e->gm_sel, e->bt_cand_doc, e->bt_cand_n,
+                                           timed ? ev : nullptr, st));
+            if (timed) { e->ev_count[2]++; e->ev_count[3]++; }
+            HIP_TRY(e, msr_batch_rescore(e->dense, e->gm_qn, nq, k, 0, e->bt_cand_doc, e->bt_cand_score, e->bt_cand_chunk,
+                                         e->bt_cand_n, out_doc + (int64_t)q0 * k, out_score + (int64_t)q0 * k,
+                                         out_chunk ? out_chunk + (int64_t)q0 * k : nullptr, out_n + q0, st));
+        }
+        return MSR_OK;
+    }
     // 33..128 queries: K-split kernel (msr_dense_ks.hip).  Diagnostic build only (-DMSR_DIAG): MSR_BF16_WIDE=0 keeps
     // the wave-streaming kernel everywhere.
 #ifdef MSR_DIAG
@@ -584,10 +716,12 @@ extern "C" int msr_dense_topk_bf16(msr_engine* e, const float* q, int32_t n_quer
         // zero rows up to the query-block count of the kernel that runs
         const int nq_pad = wide ? (nq > 64 ? 128 : 64) : (nq + 15) / 16 * 16;
         HIP_TRY(e, msr_prep_queries(q + (int64_t)q0 * MSR_DIM, nq, e->qn, nq_pad, st));
+        HIP_TRY(e, msr_batch_margin(e->qn, nq, e->bf_err, e->bf_margin, st));
         const bool timed = e->timing && e->ev_count[0] < msr_engine::EV_RING;
         if (timed) HIP_TRY(e, hipEventRecord(e->ev_start[0][e->ev_count[0]], st));
-        if (wide) HIP_TRY(e, msr_dense_scan_bf16_wide(e->dense, e->qn, nq, (float*)e->score_rows, st));
-        else HIP_TRY(e, msr_dense_scan_bf16(e->dense, e->qn, nq, max_chunks_per_doc, (float*)e->score_rows, st));
+        // (the image holds unit rows: dense_bf16 carries inverse norms of 1)
+        if (wide) HIP_TRY(e, msr_dense_scan_bf16_wide(e->dense_bf16, e->qn, nq, (float*)e->score_rows, st));
+        else HIP_TRY(e, msr_dense_scan_bf16(e->dense_bf16, e->qn, nq, max_chunks_per_doc, (float*)e->score_rows, st));
         if (timed) {
             HIP_TRY(e, hipEventRecord(e->ev_stop[0][e->ev_count[0]], st));
             e->ev_count[0]++;
@@ -595,7 +729,7 @@ extern "C" int msr_dense_topk_bf16(msr_engine* e, const float* q, int32_t n_quer
         // k-th largest approximate score per query
         HIP_TRY(e, msr_select_topk(32, (const float*)e->score_rows, N, e->dense.score_stride, nq, k, e->sel, e->bt_top_doc,
                                    e->bt_top_score, e->bt_top_n, st));
-        HIP_TRY(e, msr_batch_finish(e->dense, e->qn, nq, k, max_chunks_per_doc, margin, (const float*)e->score_rows,
+        HIP_TRY(e, msr_batch_finish(e->dense, e->qn, nq, k, max_chunks_per_doc, e->bf_margin, (const float*)e->score_rows,
                                     e->bt_top_score, e->bt_top_n, e->bt_cand_doc, e->bt_cand_score, e->bt_cand_chunk,
                                     e->bt_cand_n, out_doc + (int64_t)q0 * k, out_score + (int64_t)q0 * k,
                                     out_chunk ? out_chunk + (int64_t)q0 * k : nullptr, out_n + q0, st));

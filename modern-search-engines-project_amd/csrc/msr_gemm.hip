@@ -45,7 +45,8 @@ typedef const __attribute__((address_space(1))) void glb_void;
 constexpr int GM_THREADS = 512;
 constexpr int GM_KT = MSR_DIM / 64;            // K steps per output tile
 constexpr int GM_HALF = 16384;                 // bytes of one half-tile image: 128 rows x 128 B
-constexpr int GM_LDS = 8 * GM_HALF;
+constexpr int GM_LDS = 8 * GM_HALF;             // versions 1, 2: 2 x (A-lo, A-hi, B-lo, B-hi)
+constexpr int GM_LDS3 = 10 * GM_HALF;           // version 3: 3 x (A-lo, A-hi) + 2 x (B-lo, B-hi) = all 160 KB
 constexpr int GM_ROWB = MSR_DIM * 2;           // bytes per bf16 row
 
 struct GemmArgs {
@@ -60,6 +61,8 @@ struct GemmArgs {
     int4* wgbuf;               // [gridDim.x * 8 waves][wv_cap] {row, query, score bits, tile}  -- emit pass only
     int wv_cap;
     int32_t* wv_count;         // [gridDim.x * 8] entries each wave produced (may exceed wv_cap: overflow)
+    int dbg;                   // -DMSR_DIAG builds only (timing experiments, results are wrong): bit 0 = every tile reads
+                               // the rows of tile 0 (A always from cache), bit 1 = B always K step 0
 };
 
 __device__ __forceinline__ void wait_vm4() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
@@ -70,7 +73,7 @@ __device__ __forceinline__ void wg_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <bool EMIT>
+template <bool EMIT, int VER>
 __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -106,7 +109,14 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
     for (int ks = 0; ks < 2; ++ks) foff[ks] = (uint32_t)(li16 * 128 + (((ks * 4 + lg) ^ ((lane >> 1) & 7)) << 4));
     const uint32_t a_base = (uint32_t)(wr * 64 * 128), b_base = (uint32_t)(wc * 32 * 128);
 
+#ifdef MSR_DIAG
+    const int dbg = a.dbg;                             // bit 2: no DMA after the prologue, bit 3: no MFMA, bit 4: no fragment reads
+#else
+    constexpr int dbg = 0;
+#endif
+    bool prologue = true;
     auto stage = [&](const char* src, int slot) {      // one half-tile: 2 x 1 KiB per wave
+        if ((dbg & 4) && !prologue) return;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_global_load_lds((glb_void*)(src + goff[i]), (lds_void*)(smem + slot + (2 * w + i) * 1024), 16, 0, 0);
@@ -135,23 +145,46 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
                 for (int ni = 0; ni < 2; ++ni) acc[mh][mi][nh][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     auto tile_of = [&](int j) { return a.t_first + j * a.t_stride; };
+#ifdef MSR_DIAG
+    auto first_row = [&](int j) { return (a.dbg & 1) ? 0 : a.tile_row[tile_of(j)]; };
+#else
+    auto first_row = [&](int j) { return a.tile_row[tile_of(j)]; };
+#endif
     int jt = gid;
-    int row0 = a.tile_row[tile_of(jt)], row_end = a.tile_row[tile_of(jt) + 1];
+    int row0 = first_row(jt), row_end = a.tile_row[tile_of(jt) + 1];
     int jn = jt + G < a.t_count ? jt + G : jt;
-    int row0n = a.tile_row[tile_of(jn)];
+    int row0n = first_row(jn);
     const char* Bq = a.B + (size_t)(nt * 256) * GM_ROWB;
 
-    // ---- prologue: the first K step of the first tile ----
-    stage(a.A + (size_t)row0 * GM_ROWB, slot_of(0, 0));
-    stage(Bq, slot_of(0, 2));
-    stage(Bq + 128 * GM_ROWB, slot_of(0, 3));
-    stage(a.A + (size_t)(row0 + 128) * GM_ROWB, slot_of(0, 1));
+    // ---- prologue: the first K step of the first tile (version 3: and the A halves of the second) ----
+    // version 3 slots: A buffer j (0..2) at j * 32 KB (lo, hi), B buffer d (0..1) at 96 KB + d * 32 KB (lo, hi)
+    auto a3 = [](int j, int hi) { return (2 * j + hi) * GM_HALF; };
+    auto b3 = [](int d, int hi) { return (6 + 2 * d + hi) * GM_HALF; };
+    if (VER == 3) {
+        stage(a.A + (size_t)row0 * GM_ROWB, a3(0, 0));
+        stage(Bq, b3(0, 0));
+        stage(a.A + (size_t)(row0 + 128) * GM_ROWB, a3(0, 1));
+        stage(Bq + 128 * GM_ROWB, b3(0, 1));
+        stage(a.A + (size_t)row0 * GM_ROWB + 128, a3(1, 0));
+        stage(a.A + (size_t)(row0 + 128) * GM_ROWB + 128, a3(1, 1));
+    } else {
+        stage(a.A + (size_t)row0 * GM_ROWB, slot_of(0, 0));
+        stage(Bq, slot_of(0, 2));
+        stage(Bq + 128 * GM_ROWB, slot_of(0, 3));
+        stage(a.A + (size_t)(row0 + 128) * GM_ROWB, slot_of(0, 1));
+    }
     wait_vm0();
     wg_barrier();
-    if (wr == 1) wg_barrier();                         // the followers start one barrier late
+    if (VER == 1 && wr == 1) wg_barrier();             // version 1: the followers start one barrier late
+    prologue = false;
 
-    bf16x8 af[4][2], bfr[2][2];
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    // ======== version 1: one 64 x 32 quadrant of the wave's tile per phase ========
+    bf16x8 af[4][2] = {}, bfr[2][2] = {};
     auto read_a = [&](int d, int mh) {
+        if (dbg & 16) return;
         const char* p = smem + slot_of(d, mh) + a_base;
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
@@ -159,6 +192,7 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
             for (int ks = 0; ks < 2; ++ks) af[mi][ks] = *(const bf16x8*)(p + mi * 2048 + foff[ks]);
     };
     auto read_b = [&](int d, int nh) {
+        if (dbg & 16) return;
         const char* p = smem + slot_of(d, 2 + nh) + b_base;
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
@@ -167,6 +201,7 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
     };
     auto mma = [&](auto mh_c, auto nh_c) {
         constexpr int mh = decltype(mh_c)::value, nh = decltype(nh_c)::value;
+        if (dbg & 8) return;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -177,12 +212,9 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
                     acc[mh][mi][nh][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][ks], bfr[ni][ks], acc[mh][mi][nh][ni], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-
     // One K step = 4 phases.  During K step u (buffer d) the half-tiles of step u + 1 are issued into buffer d ^ 1 in the
     // order they will be needed: A-lo, B-lo, B-hi, A-hi; every wait leaves the two youngest half-tiles (4 DMAs) in flight.
-    auto kstep = [&](auto d_c, const char* An, const char* Bn) {
+    auto kstep1 = [&](auto d_c, const char* An, const char* Bn) {
         constexpr int d = decltype(d_c)::value;
         // phase 0: quadrant (A-lo, B-lo)
         stage(An, slot_of(d ^ 1, 0));
@@ -216,19 +248,147 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
         wg_barrier();
     };
 
+    // ======== version 2: ONE barrier per K step ========
+    // Measured on version 1 (profiles/r02_gemm_knockout.md): with MFMAs, fragment reads and DMAs all removed the loop still
+    // takes 41 % of its time -- a workgroup barrier costs ~200 cycles during which no wave issues anything, and version 1
+    // has 96 of them per tile.  Here a K step is one uninterrupted stretch of 64 MFMAs per wave: all 8 DMAs of the NEXT
+    // step are issued first (into the other buffer, which every wave finished reading before the previous barrier),
+    // fly during the whole step, and are waited for (vmcnt(0)) right before the step's only barrier.  Inside the step a
+    // wave alternates fragment reads and 16-MFMA groups -- (row half, k half) sub-steps: 4 A + 4 B fragments, the next
+    // A fragments read into a second register set before the current MFMAs -- and the two waves of a SIMD drift apart
+    // freely, so one wave's LDS latency hides behind the other's MFMAs.  No stagger, 12 barriers per tile.
+    bf16x8 a0[4] = {}, a1[4] = {}, b4[4] = {};
+    auto rd_a = [&](bf16x8 (&dst)[4], int d, int mh, int ks) {
+        if (dbg & 16) return;
+        const char* p = smem + slot_of(d, mh) + a_base + foff[ks];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) dst[mi] = *(const bf16x8*)(p + mi * 2048);
+    };
+    auto rd_b = [&](int d, int ks) {
+        if (dbg & 16) return;
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                b4[nh * 2 + ni] = *(const bf16x8*)(smem + slot_of(d, 2 + nh) + b_base + ni * 2048 + foff[ks]);
+    };
+    auto mma2 = [&](const bf16x8 (&aa)[4], auto mh_c) {
+        constexpr int mh = decltype(mh_c)::value;
+        if (dbg & 8) return;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mh][mi][nh][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aa[mi], b4[nh * 2 + ni], acc[mh][mi][nh][ni], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto kstep2 = [&](auto d_c, const char* An, const char* Bn) {
+        constexpr int d = decltype(d_c)::value;
+        stage(An, slot_of(d ^ 1, 0));
+        stage(Bn, slot_of(d ^ 1, 2));
+        stage(An + 128 * GM_ROWB, slot_of(d ^ 1, 1));
+        stage(Bn + 128 * GM_ROWB, slot_of(d ^ 1, 3));
+        rd_b(d, 0);
+        rd_a(a0, d, 0, 0);
+        rd_a(a1, d, 1, 0);
+        mma2(a0, I0{});                                // (rows lo, k lo)
+        rd_a(a0, d, 0, 1);
+        mma2(a1, I1{});                                // (rows hi, k lo)
+        rd_b(d, 1);
+        rd_a(a1, d, 1, 1);
+        mma2(a0, I0{});                                // (rows lo, k hi)
+        mma2(a1, I1{});                                // (rows hi, k hi)
+        wait_vm0();
+        wg_barrier();
+    };
+
+    // ======== version 3: version 2 with the A rows THREE buffers deep ========
+    // Measured (profiles/r02_gemm_knockout.md): with only the DMAs left, a K step of version 2 takes 1.8 us -- the 64 KB
+    // of a step do not arrive within the step's 64 MFMAs; 78 % of the reads hit the XCD's L2 (the queries always, the
+    // rows for three of the four workgroups that share a row tile), but each step waits for its slowest line, and the
+    // row tile of the leading workgroup comes from HBM.  So the rows get two steps of flight: step u issues the queries
+    // of step u + 1 FIRST and the rows of step u + 2 after them; the wait before the barrier is vmcnt(4), which retires
+    // everything but those 4 youngest DMAs -- the in-order counter then never makes the rows wait for the queries.
+    // LDS: 3 x 32 KB of rows + 2 x 32 KB of queries = all 160 KB.
+    auto rd_a3 = [&](bf16x8 (&dst)[4], int j, int mh, int ks) {
+        if (dbg & 16) return;
+        const char* p = smem + a3(j, mh) + a_base + foff[ks];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) dst[mi] = *(const bf16x8*)(p + mi * 2048);
+    };
+    auto rd_b3 = [&](int d, int ks) {
+        if (dbg & 16) return;
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                b4[nh * 2 + ni] = *(const bf16x8*)(smem + b3(d, nh) + b_base + ni * 2048 + foff[ks]);
+    };
+    auto kstep3 = [&](auto j_c, auto d_c, const char* An2, const char* Bn1) {
+        constexpr int j = decltype(j_c)::value, d = decltype(d_c)::value;
+        stage(Bn1, b3(d ^ 1, 0));
+        stage(Bn1 + 128 * GM_ROWB, b3(d ^ 1, 1));
+        stage(An2, a3((j + 2) % 3, 0));
+        stage(An2 + 128 * GM_ROWB, a3((j + 2) % 3, 1));
+        rd_b3(d, 0);
+        rd_a3(a0, j, 0, 0);
+        rd_a3(a1, j, 1, 0);
+        mma2(a0, I0{});
+        rd_a3(a0, j, 0, 1);
+        mma2(a1, I1{});
+        rd_b3(d, 1);
+        rd_a3(a1, j, 1, 1);
+        mma2(a0, I0{});
+        mma2(a1, I1{});
+        wait_vm4();
+        wg_barrier();
+    };
+
     const float NEG_INF = -__builtin_inff();
     for (int it = 0; it < n_mine; ++it) {
         const char* A0 = a.A + (size_t)row0 * GM_ROWB;
         const char* A1 = a.A + (size_t)row0n * GM_ROWB;
+        if constexpr (VER == 3) {
+            using I2 = std::integral_constant<int, 2>;
+            // K step kt of this tile (kt = 6 k6 + s): rows of step kt + 2 (maybe of the next tile), queries of step kt + 1
+            auto a_src = [&](int kt2) { return kt2 < GM_KT ? A0 + kt2 * 128 : A1 + (kt2 - GM_KT) * 128; };
+            auto b_src = [&](int kt1) { return Bq + (kt1 < GM_KT ? kt1 : kt1 - GM_KT) * 128; };
+#pragma unroll 1
+            for (int k6 = 0; k6 < GM_KT / 6; ++k6) {
+                const int kt = 6 * k6;
+                kstep3(I0{}, I0{}, a_src(kt + 2), b_src(kt + 1));
+                kstep3(I1{}, I1{}, a_src(kt + 3), b_src(kt + 2));
+                kstep3(I2{}, I0{}, a_src(kt + 4), b_src(kt + 3));
+                kstep3(I0{}, I1{}, a_src(kt + 5), b_src(kt + 4));
+                kstep3(I1{}, I0{}, a_src(kt + 6), b_src(kt + 5));
+                kstep3(I2{}, I1{}, a_src(kt + 7), b_src(kt + 6));
+            }
+        } else {
 #pragma unroll 1
         for (int k2 = 0; k2 < GM_KT / 2; ++k2) {
-            kstep(I0{}, A0 + (2 * k2 + 1) * 128, Bq + (2 * k2 + 1) * 128);
             const bool last = k2 == GM_KT / 2 - 1;                         // the step after the last one opens the next tile
-            kstep(I1{}, last ? A1 : A0 + (2 * k2 + 2) * 128, last ? Bq : Bq + (2 * k2 + 2) * 128);
+            if constexpr (VER == 2) {
+                kstep2(I0{}, A0 + (2 * k2 + 1) * 128, Bq + (2 * k2 + 1) * 128);
+                kstep2(I1{}, last ? A1 : A0 + (2 * k2 + 2) * 128, last ? Bq : Bq + (2 * k2 + 2) * 128);
+            } else {
+                kstep1(I0{}, A0 + (2 * k2 + 1) * 128, Bq + (2 * k2 + 1) * 128);
+                kstep1(I1{}, last ? A1 : A0 + (2 * k2 + 2) * 128, last ? Bq : Bq + (2 * k2 + 2) * 128);
+            }
+        }
         }
         // ---- epilogue: accumulator (mh, mi, nh, ni)[rr] = row mh 128 + wr 64 + mi 16 + 4 lg + rr of the tile,
         //      query nt 256 + nh 128 + wc 32 + ni 16 + li16 ----
-        const int n_valid = row_end - row0;                                // rows of THIS tile (the rest belongs to the next)
+        int n_valid = row_end - row0;                                      // rows of THIS tile (the rest belongs to the next)
+#ifdef MSR_DIAG
+        if (a.dbg & 1) n_valid = 250;
+#endif
+        // (opaque copy of the lane's column index: keeps the compiler from hoisting the epilogue's address arithmetic
+        // out of the tile loop, where it would be spilled -- and a scratch reload waits for vmcnt(0), DMAs included)
+        int col_e = li16;
+        asm volatile("" : "+v"(col_e));
         float cmax[2][2] = {{NEG_INF, NEG_INF}, {NEG_INF, NEG_INF}};
 #pragma unroll
         for (int mh = 0; mh < 2; ++mh)
@@ -254,7 +414,7 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
                         // kept in a scalar register and a prefix count over the emitting lanes -- no LDS or global atomic
                         // (the compiler orders an LDS atomic behind ALL pending LDS-DMAs: s_waitcnt vmcnt(0))
                         if (EMIT && __ballot(m >= thrv[nh][ni]) != 0) {
-                            const int q = nt * 256 + nh * 128 + wc * 32 + ni * 16 + li16;
+                            const int q = nt * 256 + nh * 128 + wc * 32 + ni * 16 + col_e;
 #pragma unroll
                             for (int rr = 0; rr < 4; ++rr) {
                                 const bool hit = v[rr] >= thrv[nh][ni];
@@ -277,7 +437,7 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
                 m = fmaxf(m, __shfl_xor(m, 16));
                 m = fmaxf(m, __shfl_xor(m, 32));
                 if (lg == 0 && m > NEG_INF)
-                    atomicMax(&a.tmax[(size_t)(nt * 256 + nh * 128 + wc * 32 + ni * 16 + li16) * a.tmax_stride + jt], msr_ord32(m));
+                    atomicMax(&a.tmax[(size_t)(nt * 256 + nh * 128 + wc * 32 + ni * 16 + col_e) * a.tmax_stride + jt], msr_ord32(m));
             }
 #pragma unroll
         for (int mh = 0; mh < 2; ++mh)
@@ -292,31 +452,70 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
         row0 = row0n;
         row_end = a.tile_row[tile_of(jt) + 1];
         jn = jt + G < a.t_count ? jt + G : jt;
-        row0n = a.tile_row[tile_of(jn)];
+        row0n = first_row(jn);
     }
     wait_vm0();                                        // the DMAs issued for a step that never runs
-    if (wr == 0) wg_barrier();                         // pairs with the followers' last barrier
+    if (VER == 1 && wr == 0) wg_barrier();             // pairs with the followers' last barrier
     if (EMIT && lane == 0) a.wv_count[blockIdx.x * 8 + w] = wave_cnt;
 }
 
 // ---- image builders -----------------------------------------------------------------------------------------------
-// dst[r] = bf16(src[r] * inv_norm[r]) for r < n_rows, zero rows up to n_pad (the GEMM reads 256 rows from a tile start)
+// dst[r] = bf16(src[r] * inv_norm[r]) for r < n_rows, zero rows up to n_pad (the GEMM reads 256 rows from a tile start).
+// One wave per row at a time.  err_max (device word, bits of a non-negative float, atomicMax on the bits) receives
+// max_r || bf16(u_r) - u_r ||_2 with u_r the normalised row: the measured rounding error of the image, from which the
+// candidate margin is derived (msr_batch_margin) instead of the worst case 2^-8 ||u||.
 __global__ __launch_bounds__(256) void unit_bf16_rows_kernel(const float* __restrict__ src, const float* __restrict__ inv_norm,
-                                                              int64_t n_rows, int64_t n_pad, bf16x8* __restrict__ dst) {
-    const int64_t n8 = n_pad * (MSR_DIM / 8);
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
-        const int64_t r = i / (MSR_DIM / 8);
-        bf16x8 v;
-        if (r < n_rows) {
-            const float s = inv_norm ? inv_norm[r] : 1.0f;
-            const f32x4 x = ((const f32x4*)src)[2 * i], y = ((const f32x4*)src)[2 * i + 1];
-            v[0] = (__bf16)(x.x * s); v[1] = (__bf16)(x.y * s); v[2] = (__bf16)(x.z * s); v[3] = (__bf16)(x.w * s);
-            v[4] = (__bf16)(y.x * s); v[5] = (__bf16)(y.y * s); v[6] = (__bf16)(y.z * s); v[7] = (__bf16)(y.w * s);
-        } else {
+                                                              int64_t n_rows, int64_t n_pad, bf16x8* __restrict__ dst,
+                                                              uint32_t* __restrict__ err_max) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+    float worst = 0.f;
+    for (int64_t r = wave; r < n_pad; r += n_waves) {
+        float ss = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.f;
+        for (int h = 0; h < 2; ++h) {
+            const int c = lane + 64 * h;                            // 16 B chunk of the bf16 row: 96 per row
+            if (c >= MSR_DIM / 8) continue;
+            bf16x8 v;
+            if (r < n_rows) {
+                const float sc = inv_norm ? inv_norm[r] : 1.0f;
+                const f32x4 x = ((const f32x4*)(src + (size_t)r * MSR_DIM))[2 * c], y = ((const f32x4*)(src + (size_t)r * MSR_DIM))[2 * c + 1];
+                const float u[8] = {x.x * sc, x.y * sc, x.z * sc, x.w * sc, y.x * sc, y.y * sc, y.z * sc, y.w * sc};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    v[j] = (__bf16)u[j];
+                    const float d = (float)v[j] - u[j];
+                    ss += d * d;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.f;
+            }
+            dst[(size_t)r * (MSR_DIM / 8) + c] = v;
         }
-        dst[i] = v;
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+        worst = fmaxf(worst, ss);
+    }
+    if (lane == 0 && err_max) atomicMax(err_max, __float_as_uint(sqrtf(worst)));
+}
+
+// margin[q] = 2 eps_q + slack, eps_q = dE (1 + dq) + dq: |<e^, q^> - <e, q>| <= ||e^ - e|| ||q^|| + ||e|| ||q^ - q|| for
+// unit e, q; dE = max row error of the image (err_max), dq = || bf16(q) - q || of THIS query, measured here.  slack covers
+// the f32 accumulation of 768 products (<= 768 * 2^-24) and the rounding of the normalisations.
+__global__ __launch_bounds__(256) void batch_margin_kernel(const float* __restrict__ qn, int nq, const uint32_t* __restrict__ err_max,
+                                                            float* __restrict__ margin) {
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= nq) return;
+    float ss = 0.f;
+    for (int j = lane; j < MSR_DIM; j += 64) {
+        const float x = qn[(size_t)q * MSR_DIM + j];
+        const float d = (float)(__bf16)x - x;
+        ss += d * d;
+    }
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    if (lane == 0) {
+        const float dq = sqrtf(ss) * 1.0001f, dE = __uint_as_float(*err_max) * 1.0001f;
+        margin[q] = 2.0f * (dE * (1.0f + dq) + dq * 1.000001f) + 1.0e-4f;
     }
 }
 
@@ -330,14 +529,15 @@ __global__ __launch_bounds__(256) void ord_to_float_kernel(uint32_t* __restrict_
 // thr[q] = (k-th largest tile maximum) - margin; fewer than k finite maxima (or a padding query): +inf, i.e. no emission,
 // and flag[q] = 1 so that the caller reports the query as "rerun on the exact path" (real queries only)
 __global__ __launch_bounds__(256) void gemm_thr_kernel(const float* __restrict__ top_score, const int32_t* __restrict__ top_n,
-                                                        int nq, int nq_pad, int k, float margin, float* __restrict__ thr,
+                                                        int nq, int nq_pad, int k, const float* __restrict__ margin,
+                                                        float* __restrict__ thr,
                                                         int32_t* __restrict__ flag) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= nq_pad) return;
     float t = __builtin_inff();
     int f = 0;
     if (q < nq) {
-        if (top_n[q] >= k) t = top_score[(int64_t)q * k + (k - 1)] - margin;
+        if (top_n[q] >= k) t = top_score[(int64_t)q * k + (k - 1)] - margin[q];
         else f = 1;
     }
     thr[q] = t;
@@ -368,7 +568,8 @@ constexpr int GM_PAIR_CAP = 4096;
 __global__ __launch_bounds__(1024) void gemm_cand_kernel(const int2* __restrict__ pairs, int32_t* __restrict__ pair_n,
                                                           const int32_t* __restrict__ chunk_doc,
                                                           const int32_t* __restrict__ wg_count, int n_wg, int wg_cap,
-                                                          const int32_t* __restrict__ flag, int k, float margin,
+                                                          const int32_t* __restrict__ flag, int k,
+                                                          const float* __restrict__ margin,
                                                           int32_t* __restrict__ cand_doc, int32_t* __restrict__ cand_n) {
     __shared__ uint64_t key[GM_PAIR_CAP];
     __shared__ int s_heads, s_over;
@@ -435,7 +636,7 @@ __global__ __launch_bounds__(1024) void gemm_cand_kernel(const int2* __restrict_
     const int heads = s_heads;
     // (3) the k-th largest per-document maximum is t (or -inf with fewer than k documents); keep >= t - margin
     const float tk = heads >= k ? msr_unord32((uint32_t)(key[k - 1] >> 32)) : -__builtin_inff();
-    const float cut = tk - margin;
+    const float cut = tk - margin[q];
     __shared__ int s_keep;
     if (t == 0) s_keep = 0;
     __syncthreads();
@@ -465,34 +666,54 @@ __global__ __launch_bounds__(256) void qmat_kernel(const float* __restrict__ qn,
     dst[i] = v;
 }
 
-hipError_t launch_gemm(bool emit, const GemmArgs& a, int grid, hipStream_t stream) {
+int g_gemm_version = 3;
+int g_gemm_dbg = 0;
+
+template <bool EMIT, int VER>
+hipError_t launch_gemm_t(const GemmArgs& a, int grid, hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t err = hipFuncSetAttribute((const void*)gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GM_LDS);
-        if (err != hipSuccess) return err;
-        err = hipFuncSetAttribute((const void*)gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GM_LDS);
+        hipError_t err = hipFuncSetAttribute((const void*)gemm_kernel<EMIT, VER>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             VER == 3 ? GM_LDS3 : GM_LDS);
         if (err != hipSuccess) return err;
         attr_done = true;
     }
-    if (emit) gemm_kernel<true><<<grid, GM_THREADS, GM_LDS, stream>>>(a);
-    else gemm_kernel<false><<<grid, GM_THREADS, GM_LDS, stream>>>(a);
+    GemmArgs b = a;
+    b.dbg = g_gemm_dbg;
+    gemm_kernel<EMIT, VER><<<grid, GM_THREADS, VER == 3 ? GM_LDS3 : GM_LDS, stream>>>(b);
     return hipGetLastError();
+}
+
+hipError_t launch_gemm(bool emit, const GemmArgs& a, int grid, hipStream_t stream) {
+    if (g_gemm_version == 1) return emit ? launch_gemm_t<true, 1>(a, grid, stream) : launch_gemm_t<false, 1>(a, grid, stream);
+    if (g_gemm_version == 2) return emit ? launch_gemm_t<true, 2>(a, grid, stream) : launch_gemm_t<false, 2>(a, grid, stream);
+    return emit ? launch_gemm_t<true, 3>(a, grid, stream) : launch_gemm_t<false, 3>(a, grid, stream);
 }
 
 }  // namespace
 
 hipError_t msr_unit_bf16_rows(const float* src, const float* inv_norm, int64_t n_rows, int64_t n_pad, void* dst,
-                              hipStream_t stream) {
+                              uint32_t* err_max, hipStream_t stream) {
     if (n_pad <= 0) return hipSuccess;
-    unit_bf16_rows_kernel<<<16384, 256, 0, stream>>>(src, inv_norm, n_rows, n_pad, (bf16x8*)dst);
+    hipError_t err = err_max ? hipMemsetAsync(err_max, 0, 4, stream) : hipSuccess;
+    if (err != hipSuccess) return err;
+    unit_bf16_rows_kernel<<<8192, 256, 0, stream>>>(src, inv_norm, n_rows, n_pad, (bf16x8*)dst, err_max);
+    return hipGetLastError();
+}
+
+hipError_t msr_batch_margin(const float* qn, int nq, const uint32_t* err_max, float* margin, hipStream_t stream) {
+    if (nq <= 0) return hipSuccess;
+    batch_margin_kernel<<<(nq + 3) / 4, 256, 0, stream>>>(qn, nq, err_max, margin);
     return hipGetLastError();
 }
 
 int msr_gemm_pair_cap() { return GM_PAIR_CAP; }
+void msr_gemm_set_version(int v) { g_gemm_version = v >= 1 && v <= 3 ? v : 3; }
+void msr_gemm_set_dbg(int v) { g_gemm_dbg = v; }
 
 // The whole batched candidate path for nq <= g.max_queries queries (see the header of this file); ends with cand_doc /
 // cand_n filled for msr_batch_rescore.  qn: normalised f32 queries [nq][768].
-hipError_t msr_gemm_candidates(const GemmIndex& g, const DenseIndex& ix, const float* qn, int nq, int k, float margin,
+hipError_t msr_gemm_candidates(const GemmIndex& g, const DenseIndex& ix, const float* qn, int nq, int k, const float* margin,
                                const SelScratch& sel, int32_t* cand_doc, int32_t* cand_n, hipEvent_t* ev,
                                hipStream_t stream) {
     const int nq_pad = (nq + 255) / 256 * 256;
@@ -505,6 +726,9 @@ hipError_t msr_gemm_candidates(const GemmIndex& g, const DenseIndex& ix, const f
     // ---- pass 1: every ss-th tile, tile maxima only ----
     int ss = g.n_tiles / (8 * k);
     ss = ss < 1 ? 1 : (ss > 16 ? 16 : ss);
+#ifdef MSR_DIAG
+    if (g_gemm_dbg & 256) ss = 1;                      // timing experiments: the sample pass covers every tile
+#endif
     const int n_s = (g.n_tiles - ss / 2 + ss - 1) / ss;                   // tiles ss/2, ss/2 + ss, ...
     GemmArgs a{};
     a.A = (const char*)g.emb_n; a.B = (const char*)g.qmat; a.tile_row = g.tile_row; a.nt = nt;

@@ -125,7 +125,7 @@ hipError_t msr_build_qimage(int mode, const float* qn, int n_blocks, void* qimg,
 hipError_t msr_presplit_rows(const float* src, int64_t n_rows, void* dst, hipStream_t stream);
 // row_meta[i] = {chunk_doc[min(i, n-1)], inv_norm[min(i, n-1)]} for i in [0, n + 16)
 hipError_t msr_pack_row_meta(const int32_t* chunk_doc, const float* inv_norm, int64_t n, void* row_meta, hipStream_t stream);
-hipError_t msr_to_bf16(const float* src, int64_t n_elems, void* dst, hipStream_t stream);
+hipError_t msr_fill_f32(float* dst, int64_t n, float value, hipStream_t stream);
 // out2 (device, 2 words) <- bit patterns of min and max of inv_norm[0..n)
 hipError_t msr_inv_norm_range(const float* inv_norm, int64_t n, uint32_t* out2, hipStream_t stream);
 hipError_t msr_prep_queries(const float* q, int nq, float* qn, int nq_pad, hipStream_t stream);
@@ -172,13 +172,18 @@ struct GemmIndex {
     int32_t* pair_n;           // [max_queries], zero between calls
 };
 int msr_gemm_pair_cap();
+void msr_gemm_set_dbg(int v);       // honoured by -DMSR_DIAG builds only
+void msr_gemm_set_version(int v);   // 1 / 2: phase decompositions of the GEMM main loop (identical results)
 // dst[r] = bf16(src[r] * inv_norm[r]) (inv_norm null: 1), rows n_rows .. n_pad - 1 zero
+// err_max (device word, nullable) <- bits of max_r || bf16(u_r) - u_r ||, u_r the normalised row
 hipError_t msr_unit_bf16_rows(const float* src, const float* inv_norm, int64_t n_rows, int64_t n_pad, void* dst,
-                              hipStream_t stream);
+                              uint32_t* err_max, hipStream_t stream);
+// margin[q] = 2 (dE (1 + dq) + dq) + slack from the MEASURED rounding errors of the image (err_max) and of query q
+hipError_t msr_batch_margin(const float* qn, int nq, const uint32_t* err_max, float* margin, hipStream_t stream);
 // qn: [nq][768] normalised f32 queries, nq <= g.max_queries.  Fills cand_doc[q][MSR_SEL_CAP] / cand_n[q] (cand_n =
 // MSR_SEL_CAP + 1: overflow, rerun that query on the exact path) for msr_batch_rescore.  ev (nullable): 4 events recorded
 // around the sample pass (0, 1) and the emit pass (2, 3).
-hipError_t msr_gemm_candidates(const GemmIndex& g, const DenseIndex& ix, const float* qn, int nq, int k, float margin,
+hipError_t msr_gemm_candidates(const GemmIndex& g, const DenseIndex& ix, const float* qn, int nq, int k, const float* margin,
                                const SelScratch& sel, int32_t* cand_doc, int32_t* cand_n, hipEvent_t* ev,
                                hipStream_t stream);
 
@@ -187,7 +192,7 @@ hipError_t msr_gemm_candidates(const GemmIndex& g, const DenseIndex& ix, const f
 hipError_t msr_batch_rescore(const DenseIndex& ix, const float* qn, int nq, int k, int max_chunks, int32_t* cand_doc,
                              float* cand_score, int32_t* cand_chunk, int32_t* cand_n, int32_t* out_doc, float* out_score,
                              int32_t* out_chunk, int32_t* out_n, hipStream_t stream);
-hipError_t msr_batch_finish(const DenseIndex& ix, const float* qn, int nq, int k, int max_chunks, float margin,
+hipError_t msr_batch_finish(const DenseIndex& ix, const float* qn, int nq, int k, int max_chunks, const float* margin,
                             const float* scores, const float* top_score, const int32_t* top_n, int32_t* cand_doc,
                             float* cand_score, int32_t* cand_chunk, int32_t* cand_n, int32_t* out_doc,
                             float* out_score, int32_t* out_chunk, int32_t* out_n, hipStream_t stream);

@@ -148,6 +148,10 @@ class DeviceEngine:
         """Queries served by one bf16 sweep in dense_topk_batched (128 or 64; -1 before enable_bf16)."""
         return int(self.lib.msr_batch_width(self.handle))
 
+    def batch_gemm_ok(self):
+        """True if dense_topk_batched runs batches of more than 128 queries as the tiled matrix-core GEMM."""
+        return bool(self.lib.msr_batch_gemm_ok(self.handle))
+
     def scan_width(self):
         """Queries served by one sweep of the embedding matrix in dense_topk (64 with the K-split kernel, else 32)."""
         return int(self.lib.msr_scan_width(self.handle))
