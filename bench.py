@@ -35,6 +35,7 @@ import torch.distributed as dist  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3    # v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (the 5 PF headline figure includes 2:1 sparsity)
 
 
 def log(*a):
@@ -194,8 +195,9 @@ def main():
                     help="hybrid = the headline (BASELINE configs[2]); bm25 = stage 1 only (configs[1]: use --docs "
                          "100000 --chunks 0 --terms 200000 --queries-per-step 1024 --k1 100); dense = full scan only")
     ap.add_argument("--dense-mode", choices=["f32", "bf16"], default="f32",
-                    help="dense / hybrid workloads: bf16 = batched candidate sweep (64 queries/sweep) + exact f32 rescoring "
-                         "(BASELINE configs[4] shape: use --queries-per-step 1024)")
+                    help="dense / hybrid workloads: bf16 = batched candidates (<= 128 queries per step: one bf16 sweep; more: "
+                         "the tiled matrix-core GEMM, 1024 queries per pass) + exact f32 rescoring "
+                         "(BASELINE configs[4] shape: use --workload dense --queries-per-step 1024)")
     args = ap.parse_args()
     if args.workload == "bm25":
         args.chunks = 0
@@ -270,7 +272,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    scan_ms, scan_n = eng.kernel_time_ms(0) if args.workload != "bm25" else (0.0, 0)
+    gemm = args.workload != "bm25" and args.dense_mode == "bf16" and Q > 128 and eng.batch_gemm_ok()
+    if gemm:                                              # batches of more than 128 queries: the tiled GEMM (csrc/msr_gemm.hip)
+        scan_ms, scan_n = eng.kernel_time_ms(2)           # emit pass: every row tile
+        samp_ms, samp_n = eng.kernel_time_ms(3)           # sample pass: every 16th tile
+    else:
+        scan_ms, scan_n = eng.kernel_time_ms(0) if args.workload != "bm25" else (0.0, 0)
     bm_ms, bm_n = eng.kernel_time_ms(1) if args.workload != "dense" else (0.0, 0)
     eng.set_timing(False)
     if world > 1:
@@ -419,6 +426,9 @@ def main():
             wide_kernel = q_launch > 32                         # 33..64 queries per sweep run on the K-split kernel
             k_ms, k_n = scan_ms, scan_n
             kname = ("dense_ksplit_kernel" if wide_kernel else "dense_scan_v2_kernel") + ("<bf16>" if bf else "")
+            if gemm:
+                kname = "gemm_kernel<emit>"
+                alg_bytes = n_ch * 768 * 2 + min(Q, 1024) * 768 * 2     # E (bf16) once per 1024-query pass + the queries
         per_launch_ms = k_ms / max(1, k_n)
         achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -432,6 +442,16 @@ def main():
             roof.update({"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf / F32_MFMA_PEAK_TFLOPS, "algorithmic_flops_per_launch": flops,
                          "hbm_GBps": achieved})
+        if gemm:
+            # S = E . Q^T on the matrix cores: 2 * 768 flop per (row, query); queries padded to tiles of 256; the sample pass
+            # (every 16th row tile, + 1/16 of the flops) is reported beside it and is NOT counted as useful work
+            q_pass = (min(Q, 1024) + 255) // 256 * 256
+            flops = 2.0 * 768 * n_ch * q_pass
+            tf = flops / (per_launch_ms * 1e-3) / 1e12
+            roof.update({"bound": "mfma", "achieved": tf, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tf / BF16_MFMA_PEAK_TFLOPS, "algorithmic_flops_per_launch": flops,
+                         "queries_per_launch": q_pass, "hbm_GBps_algorithmic": achieved,
+                         "sample_pass_ms_per_launch": samp_ms / max(1, samp_n)})
         if args.workload == "hybrid":
             roof["bm25_taat_ms_per_launch"] = bm_ms / max(1, bm_n)
             # the stage-1 kernel against the same roofline (SURVEY 8d bytes: 8 B per posting of the query's terms + 4 B

@@ -50,7 +50,7 @@ struct msr_engine {
     // batched path as a tiled GEMM (msr_gemm.hip): unit-row bf16 image + tile table + scratch for GM_SLICE queries per pass
     GemmIndex gemm{};
     bool gemm_ok = false;
-    void* gm_emb_n = nullptr; int32_t* gm_tile_row = nullptr; void* gm_qmat = nullptr; uint32_t* gm_tmax = nullptr;
+    void* gm_emb_n = nullptr; int32_t* gm_tile_row = nullptr; void* gm_qmat = nullptr; float* gm_tmax = nullptr; float* gm_tmax_t = nullptr;
     int32_t* gm_top_doc = nullptr; float* gm_top_score = nullptr; int32_t* gm_top_n = nullptr;
     float* gm_thr = nullptr; float* gm_thr2 = nullptr; int32_t* gm_flag = nullptr; void* gm_wgbuf = nullptr;
     int32_t* gm_wv_count = nullptr; void* gm_pairs = nullptr; int32_t* gm_pair_n = nullptr; float* gm_qn = nullptr;
@@ -92,13 +92,13 @@ static void free_dev(void* p) {
 }
 
 static void free_gemm(msr_engine* e) {
-    free_dev(e->gm_emb_n); free_dev(e->gm_tile_row); free_dev(e->gm_qmat); free_dev(e->gm_tmax); free_dev(e->gm_top_doc);
+    free_dev(e->gm_emb_n); free_dev(e->gm_tile_row); free_dev(e->gm_qmat); free_dev(e->gm_tmax); free_dev(e->gm_tmax_t); free_dev(e->gm_top_doc);
     free_dev(e->gm_top_score); free_dev(e->gm_top_n); free_dev(e->gm_thr); free_dev(e->gm_thr2); free_dev(e->gm_flag);
     free_dev(e->gm_wgbuf); free_dev(e->gm_wv_count); free_dev(e->gm_pairs); free_dev(e->gm_pair_n); free_dev(e->gm_qn);
     free_dev(e->gm_sel.hist); free_dev(e->gm_sel.state); free_dev(e->gm_sel.cand_hi); free_dev(e->gm_sel.cand_lo);
     free_dev(e->gm_sel.cand_n); free_dev(e->bf_ones); free_dev(e->bf_row_meta); free_dev(e->bf_err); free_dev(e->bf_margin);
     e->bf_err = nullptr; e->bf_margin = nullptr;
-    e->gm_emb_n = nullptr; e->gm_tile_row = nullptr; e->gm_qmat = nullptr; e->gm_tmax = nullptr; e->gm_top_doc = nullptr;
+    e->gm_emb_n = nullptr; e->gm_tile_row = nullptr; e->gm_qmat = nullptr; e->gm_tmax = nullptr; e->gm_tmax_t = nullptr; e->gm_top_doc = nullptr;
     e->gm_top_score = nullptr; e->gm_top_n = nullptr; e->gm_thr = e->gm_thr2 = nullptr; e->gm_flag = nullptr;
     e->gm_wgbuf = nullptr; e->gm_wv_count = nullptr; e->gm_pairs = nullptr; e->gm_pair_n = nullptr; e->gm_qn = nullptr;
     e->gm_sel = SelScratch{}; e->bf_ones = nullptr; e->bf_row_meta = nullptr;
@@ -627,6 +627,7 @@ extern "C" int msr_enable_bf16(msr_engine* e, void* stream) {
             (herr = alloc(&e->gm_qmat, (size_t)GM_SLICE * MSR_DIM * 2)) != hipSuccess ||
             (herr = alloc((void**)&e->gm_qn, (size_t)GM_SLICE * MSR_DIM * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gm_tmax, (size_t)GM_SLICE * stride * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gm_tmax_t, (size_t)n_tiles * 2 * GM_SLICE * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gm_top_doc, (size_t)GM_SLICE * MSR_MAX_K * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gm_top_score, (size_t)GM_SLICE * MSR_MAX_K * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gm_top_n, (size_t)GM_SLICE * 4)) != hipSuccess ||
@@ -649,7 +650,7 @@ extern "C" int msr_enable_bf16(msr_engine* e, void* stream) {
         HIP_TRY(e, hipMemsetAsync(e->gm_sel.cand_n, 0, nsel * sizeof(int32_t), st));
         HIP_TRY(e, hipStreamSynchronize(st));               // `tiles` goes out of scope
         e->gemm = GemmIndex{e->emb_bf16, e->gm_tile_row, n_tiles, e->n_cus, GM_SLICE, e->gm_qmat, e->gm_tmax, stride,
-                            e->gm_top_doc, e->gm_top_score, e->gm_top_n, e->gm_thr, e->gm_thr2, e->gm_flag, e->gm_wgbuf,
+                            e->gm_tmax_t, e->gm_top_doc, e->gm_top_score, e->gm_top_n, e->gm_thr, e->gm_thr2, e->gm_flag, e->gm_wgbuf,
                             GM_WV_CAP, e->gm_wv_count, e->gm_pairs, e->gm_pair_n};
         e->gemm_ok = true;
     }

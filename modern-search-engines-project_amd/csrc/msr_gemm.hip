@@ -55,8 +55,9 @@ struct GemmArgs {
     const int32_t* tile_row;   // [n_tiles + 1]
     int t_first, t_stride, t_count;   // tiles of this pass: t_first + j t_stride, j < t_count
     int nt;                    // query tiles (nq_pad / 256)
-    uint32_t* tmax;            // [nq_pad][tmax_stride] order-preserving uint of the tile maxima, column j; zero-filled
-    int tmax_stride;
+    float* tmax_t;             // [t_count][2 wave rows][nq_pad] maxima of the tile's rows owned by wave row 0 / 1 (every cell
+                               // is written exactly once per pass, 64 B per store; gemm_tmax_kernel transposes and joins them)
+    int nq_pad;
     const float* thr;          // [nq_pad] emit threshold (+inf: never)                       -- emit pass only
     int4* wgbuf;               // [gridDim.x * 8 waves][wv_cap] {row, query, score bits, tile}  -- emit pass only
     int wv_cap;
@@ -65,6 +66,17 @@ struct GemmArgs {
                                // the rows of tile 0 (A always from cache), bit 1 = B always K step 0
 };
 
+// max(a, b, c) without the canonicalising v_max x, x that fmaxf() drags in (inputs here are never signalling NaNs)
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float max2_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ void wait_vm4() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void wg_barrier() {
@@ -272,8 +284,9 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
             for (int ni = 0; ni < 2; ++ni)
                 b4[nh * 2 + ni] = *(const bf16x8*)(smem + slot_of(d, 2 + nh) + b_base + ni * 2048 + foff[ks]);
     };
-    auto mma2 = [&](const bf16x8 (&aa)[4], auto mh_c) {
+    auto mma2 = [&](const bf16x8 (&aa)[4], auto mh_c, auto zero_c) {
         constexpr int mh = decltype(mh_c)::value;
+        constexpr bool ZERO = decltype(zero_c)::value != 0;     // first touch of these accumulators in a tile: C = 0
         if (dbg & 8) return;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -282,7 +295,8 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
             for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    acc[mh][mi][nh][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aa[mi], b4[nh * 2 + ni], acc[mh][mi][nh][ni], 0, 0, 0);
+                    acc[mh][mi][nh][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        aa[mi], b4[nh * 2 + ni], ZERO ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[mh][mi][nh][ni], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
     auto kstep2 = [&](auto d_c, const char* An, const char* Bn) {
@@ -294,13 +308,13 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
         rd_b(d, 0);
         rd_a(a0, d, 0, 0);
         rd_a(a1, d, 1, 0);
-        mma2(a0, I0{});                                // (rows lo, k lo)
+        mma2(a0, I0{}, I0{});                          // (rows lo, k lo)
         rd_a(a0, d, 0, 1);
-        mma2(a1, I1{});                                // (rows hi, k lo)
+        mma2(a1, I1{}, I0{});                          // (rows hi, k lo)
         rd_b(d, 1);
         rd_a(a1, d, 1, 1);
-        mma2(a0, I0{});                                // (rows lo, k hi)
-        mma2(a1, I1{});                                // (rows hi, k hi)
+        mma2(a0, I0{}, I0{});                          // (rows lo, k hi)
+        mma2(a1, I1{}, I0{});                          // (rows hi, k hi)
         wait_vm0();
         wg_barrier();
     };
@@ -327,7 +341,7 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
             for (int ni = 0; ni < 2; ++ni)
                 b4[nh * 2 + ni] = *(const bf16x8*)(smem + b3(d, nh) + b_base + ni * 2048 + foff[ks]);
     };
-    auto kstep3 = [&](auto j_c, auto d_c, const char* An2, const char* Bn1) {
+    auto kstep3 = [&](auto j_c, auto d_c, auto first_c, const char* An2, const char* Bn1) {
         constexpr int j = decltype(j_c)::value, d = decltype(d_c)::value;
         stage(Bn1, b3(d ^ 1, 0));
         stage(Bn1 + 128 * GM_ROWB, b3(d ^ 1, 1));
@@ -336,13 +350,13 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
         rd_b3(d, 0);
         rd_a3(a0, j, 0, 0);
         rd_a3(a1, j, 1, 0);
-        mma2(a0, I0{});
+        mma2(a0, I0{}, first_c);                       // the first K step of a tile starts its sums from 0: no clearing pass
         rd_a3(a0, j, 0, 1);
-        mma2(a1, I1{});
+        mma2(a1, I1{}, first_c);
         rd_b3(d, 1);
         rd_a3(a1, j, 1, 1);
-        mma2(a0, I0{});
-        mma2(a1, I1{});
+        mma2(a0, I0{}, I0{});
+        mma2(a1, I1{}, I0{});
         wait_vm4();
         wg_barrier();
     };
@@ -357,14 +371,14 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
             auto a_src = [&](int kt2) { return kt2 < GM_KT ? A0 + kt2 * 128 : A1 + (kt2 - GM_KT) * 128; };
             auto b_src = [&](int kt1) { return Bq + (kt1 < GM_KT ? kt1 : kt1 - GM_KT) * 128; };
 #pragma unroll 1
-            for (int k6 = 0; k6 < GM_KT / 6; ++k6) {
+            for (int k6 = 0; k6 < GM_KT / 6; ++k6) {     // (all 12 steps spelled out cost 90 spilled registers)
                 const int kt = 6 * k6;
-                kstep3(I0{}, I0{}, a_src(kt + 2), b_src(kt + 1));
-                kstep3(I1{}, I1{}, a_src(kt + 3), b_src(kt + 2));
-                kstep3(I2{}, I0{}, a_src(kt + 4), b_src(kt + 3));
-                kstep3(I0{}, I1{}, a_src(kt + 5), b_src(kt + 4));
-                kstep3(I1{}, I0{}, a_src(kt + 6), b_src(kt + 5));
-                kstep3(I2{}, I1{}, a_src(kt + 7), b_src(kt + 6));
+                kstep3(I0{}, I0{}, I0{}, a_src(kt + 2), b_src(kt + 1));
+                kstep3(I1{}, I1{}, I0{}, a_src(kt + 3), b_src(kt + 2));
+                kstep3(I2{}, I0{}, I0{}, a_src(kt + 4), b_src(kt + 3));
+                kstep3(I0{}, I1{}, I0{}, a_src(kt + 5), b_src(kt + 4));
+                kstep3(I1{}, I0{}, I0{}, a_src(kt + 6), b_src(kt + 5));
+                kstep3(I2{}, I1{}, I0{}, a_src(kt + 7), b_src(kt + 6));
             }
         } else {
 #pragma unroll 1
@@ -395,7 +409,7 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
                 const int blk = mh * 128 + wr * 64 + mi * 16;
-                if (blk >= n_valid) continue;                              // wave-uniform
+                if (blk >= n_valid || (dbg & 32)) continue;                // wave-uniform
                 const int rb = blk + 4 * lg;
                 const bool part = blk + 16 > n_valid;                      // wave-uniform
 #pragma unroll
@@ -403,13 +417,14 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni) {
                         f32x4 v = acc[mh][mi][nh][ni];
-                        if (part) {
+                        if (part) {                                        // (at most one block per wave and tile)
+                            asm volatile("" ::: "memory");                 // a real branch: do not predicate this into every block
 #pragma unroll
                             for (int rr = 0; rr < 4; ++rr)
                                 if (rb + rr >= n_valid) v[rr] = NEG_INF;
                         }
-                        const float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-                        cmax[nh][ni] = fmaxf(cmax[nh][ni], m);
+                        const float m = max3_raw(max2_raw(v[0], v[1]), v[2], v[3]);
+                        cmax[nh][ni] = max2_raw(cmax[nh][ni], m);
                         // Emission: every branch below is WAVE-UNIFORM (ballots), the position comes from a per-wave counter
                         // kept in a scalar register and a prefix count over the emitting lanes -- no LDS or global atomic
                         // (the compiler orders an LDS atomic behind ALL pending LDS-DMAs: s_waitcnt vmcnt(0))
@@ -433,11 +448,15 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
         for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
+                // max over the 4 lanes that hold the same query (lane, lane ^ 16, lane ^ 32, lane ^ 48): two lane-swap
+                // instructions, no LDS round trip
                 float m = cmax[nh][ni];
-                m = fmaxf(m, __shfl_xor(m, 16));
-                m = fmaxf(m, __shfl_xor(m, 32));
-                if (lg == 0 && m > NEG_INF)
-                    atomicMax(&a.tmax[(size_t)(nt * 256 + nh * 128 + wc * 32 + ni * 16 + col_e) * a.tmax_stride + jt], msr_ord32(m));
+                auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+                m = max2_raw(__uint_as_float(s32[0]), __uint_as_float(s32[1]));
+                auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+                m = max2_raw(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
+                if (lg == 0 && !(dbg & 64))
+                    a.tmax_t[((size_t)jt * 2 + wr) * a.nq_pad + nt * 256 + nh * 128 + wc * 32 + ni * 16 + col_e] = m;
             }
 #pragma unroll
         for (int mh = 0; mh < 2; ++mh)
@@ -519,11 +538,25 @@ __global__ __launch_bounds__(256) void batch_margin_kernel(const float* __restri
     }
 }
 
-__global__ __launch_bounds__(256) void ord_to_float_kernel(uint32_t* __restrict__ x, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t u = x[i];
-    ((float*)x)[i] = u == 0 ? -__builtin_inff() : msr_unord32(u);        // 0: no tile wrote this cell
+// out[q][j] = max(in[j][0][q], in[j][1][q]): the tile maxima as one row per query for the top-k select (32 x 32 LDS transpose)
+__global__ __launch_bounds__(256) void gemm_tmax_kernel(const float* __restrict__ in, int n_j, int nq_pad,
+                                                         float* __restrict__ out, int out_stride) {
+    __shared__ float t[32][33];
+    const int j0 = blockIdx.x * 32, q0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;                 // 32 x 8
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int j = j0 + ty + 8 * r;
+        float v = -__builtin_inff();
+        if (j < n_j) v = fmaxf(in[((size_t)j * 2) * nq_pad + q0 + tx], in[((size_t)j * 2 + 1) * nq_pad + q0 + tx]);
+        t[ty + 8 * r][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int q = q0 + ty + 8 * r, j = j0 + tx;
+        if (j < n_j) out[(size_t)q * out_stride + j] = t[tx][ty + 8 * r];
+    }
 }
 
 // thr[q] = (k-th largest tile maximum) - margin; fewer than k finite maxima (or a padding query): +inf, i.e. no emission,
@@ -732,23 +765,21 @@ hipError_t msr_gemm_candidates(const GemmIndex& g, const DenseIndex& ix, const f
     const int n_s = (g.n_tiles - ss / 2 + ss - 1) / ss;                   // tiles ss/2, ss/2 + ss, ...
     GemmArgs a{};
     a.A = (const char*)g.emb_n; a.B = (const char*)g.qmat; a.tile_row = g.tile_row; a.nt = nt;
-    a.tmax = g.tmax; a.tmax_stride = g.tmax_stride;
+    a.tmax_t = g.tmax_t; a.nq_pad = nq_pad;
     a.t_first = ss / 2; a.t_stride = ss; a.t_count = n_s;
-    if ((err = hipMemsetAsync(g.tmax, 0, (size_t)nq_pad * g.tmax_stride * 4, stream)) != hipSuccess) return err;
     if (ev && (err = hipEventRecord(ev[0], stream)) != hipSuccess) return err;
     if ((err = launch_gemm(false, a, grid, stream)) != hipSuccess) return err;
     if (ev && (err = hipEventRecord(ev[1], stream)) != hipSuccess) return err;
-    ord_to_float_kernel<<<(unsigned)(((int64_t)nq_pad * g.tmax_stride + 255) / 256), 256, 0, stream>>>(g.tmax, (int64_t)nq_pad * g.tmax_stride);
+    gemm_tmax_kernel<<<dim3((n_s + 31) / 32, nq_pad / 32), 256, 0, stream>>>(g.tmax_t, n_s, nq_pad, (float*)g.tmax, g.tmax_stride);
     if ((err = msr_select_topk(32, g.tmax, n_s, g.tmax_stride, nq, k, sel, g.top_doc, g.top_score, g.top_n, stream)) != hipSuccess) return err;
     gemm_thr_kernel<<<(nq_pad + 255) / 256, 256, 0, stream>>>(g.top_score, g.top_n, nq, nq_pad, k, margin, g.thr, g.flag);
     // ---- pass 2: all tiles; maxima of all tiles + emission against the sample threshold ----
     a.t_first = 0; a.t_stride = 1; a.t_count = g.n_tiles;
     a.thr = g.thr; a.wgbuf = (int4*)g.wgbuf; a.wv_cap = g.wv_cap; a.wv_count = g.wv_count;
-    if ((err = hipMemsetAsync(g.tmax, 0, (size_t)nq_pad * g.tmax_stride * 4, stream)) != hipSuccess) return err;
     if (ev && (err = hipEventRecord(ev[2], stream)) != hipSuccess) return err;
     if ((err = launch_gemm(true, a, grid, stream)) != hipSuccess) return err;
     if (ev && (err = hipEventRecord(ev[3], stream)) != hipSuccess) return err;
-    ord_to_float_kernel<<<(unsigned)(((int64_t)nq_pad * g.tmax_stride + 255) / 256), 256, 0, stream>>>(g.tmax, (int64_t)nq_pad * g.tmax_stride);
+    gemm_tmax_kernel<<<dim3((g.n_tiles + 31) / 32, nq_pad / 32), 256, 0, stream>>>(g.tmax_t, g.n_tiles, nq_pad, (float*)g.tmax, g.tmax_stride);
     if ((err = msr_select_topk(32, g.tmax, g.n_tiles, g.tmax_stride, nq, k, sel, g.top_doc, g.top_score, g.top_n, stream)) != hipSuccess) return err;
     gemm_thr_kernel<<<(nq_pad + 255) / 256, 256, 0, stream>>>(g.top_score, g.top_n, nq, nq_pad, k, margin, g.thr2, nullptr);
     // ---- finish: bucket, per-document maxima, candidates ----

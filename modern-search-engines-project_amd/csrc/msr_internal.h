@@ -160,8 +160,9 @@ struct GemmIndex {
     int32_t n_cus;
     int32_t max_queries;       // queries per call the scratch below is sized for (multiple of 256)
     void* qmat;                // bf16 [max_queries][768]
-    uint32_t* tmax;            // [max_queries][tmax_stride] tile maxima (order-preserving uint, then float in place)
+    float* tmax;               // [max_queries][tmax_stride] tile maxima, one row per query (input of the top-k select)
     int32_t tmax_stride;
+    float* tmax_t;             // [n_tiles][2][max_queries] as the GEMM epilogue stores them (see GemmArgs::tmax_t)
     int32_t* top_doc; float* top_score; int32_t* top_n;     // [max_queries][MSR_MAX_K] / [max_queries]
     float* thr; float* thr2;   // [max_queries] emission threshold (sample bound) / final threshold (all tiles)
     int32_t* flag;             // [max_queries] 1: the sample could not bound this query (rerun on the exact path)

@@ -181,3 +181,31 @@ def test_fullsize_batched_bf16_equals_exact(world):
     assert float((got[1] - ex[1]).abs().max()) <= 2e-6
     assert bool(((got[0] == ex[0]) | ((got[1] - ex[1]).abs() <= 2e-6)).all())
     assert float((got[0] == ex[0]).float().mean()) > 0.995
+
+
+def test_fullsize_gemm_1024_queries_equals_exact(world):
+    """BASELINE configs[4] shape on one GPU: 1024 queries x 5 M chunks through the tiled GEMM path; a sample of the
+    batch is compared with the exact f32 scan, the rest through size-independent properties."""
+    eng, ix, dev = world["eng"], world["ix"], world["dev"]
+    eng.enable_bf16()
+    assert eng.batch_gemm_ok()
+    g = torch.Generator(device="cpu"); g.manual_seed(21)
+    rows = torch.randint(0, N_CHUNKS, (1024,), generator=g)
+    noise = torch.nn.functional.normalize(torch.randn((1024, 768), generator=g), dim=1).to(dev)
+    q = (ix.emb[rows.to(dev)] + 0.5 * noise) * 9.0
+    got = eng.dense_topk_batched(q, k=100)
+    assert bool((got[3] == 100).all())
+    assert bool((torch.diff(got[1], dim=1) <= 0).all())                            # sorted
+    eq = torch.diff(got[1], dim=1) == 0
+    assert bool((torch.diff(got[0], dim=1)[eq] > 0).all())                         # ties: ascending index
+    assert float(got[1][:, 0].min()) > 0.8                                         # the planted chunk is found
+    lo = ix.doc_off[got[0].long()].long(); hi = ix.doc_off[got[0].long() + 1].long()
+    assert bool(((got[2] >= lo) & (got[2] < hi)).all())                            # arg-max chunk inside its document
+    sel = torch.arange(0, 1024, 8, device=dev)                                     # 128 of the queries against the exact scan
+    ex = eng.dense_topk(q[sel], k=100)
+    assert float((got[1][sel] - ex[1]).abs().max()) <= 2e-6
+    assert bool(((got[0][sel] == ex[0]) | ((got[1][sel] - ex[1]).abs() <= 2e-6)).all())
+    assert float((got[0][sel] == ex[0]).float().mean()) > 0.995
+    again = eng.dense_topk_batched(q, k=100)                                       # idempotent, bit for bit
+    for x, y in zip(got, again):
+        assert torch.equal(x, y)

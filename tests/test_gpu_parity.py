@@ -343,6 +343,71 @@ def test_dense_cosine_golden(mods):
         eng.close()
 
 
+def test_batched_gemm_path_equals_exact_scan(mods):
+    """More than 128 queries: msr_dense_topk_bf16 runs the tiled matrix-core GEMM (csrc/msr_gemm.hip: sample pass, emit
+    pass, per-document maxima, exact f32 rescoring).  Its top-k must be the exact scan's: same scores to f32 rounding,
+    same documents except where two scores are within rounding of each other.  Covers: query counts that do and do not
+    fill the 256-query tiles (1, 2 and 3 tiles), k = 10 (sample stride > 1) and k = 100 (every tile sampled), chunk-less
+    documents, an exact hit, a zero query, and all three main-loop versions (identical results)."""
+    rng = np.random.default_rng(77)
+    n_docs = 60000
+    n = rng.integers(0, 9, size=n_docs)                    # 0..8 chunks: chunk-less documents included
+    n[1000:1300] = 0
+    n[5] = 200                                             # a long document, still inside one 256-row tile
+    doc_off = np.zeros(n_docs + 1, np.int64); doc_off[1:] = np.cumsum(n)
+    C = int(doc_off[-1])
+    emb_t = torch.randn((C, 768), generator=torch.Generator().manual_seed(3))
+    emb_t /= emb_t.norm(dim=1, keepdim=True)
+    emb_t[123] *= 1.7                                      # rows need not be unit norm (range [0.5, 2] keeps the default path)
+    emb = emb_t.numpy()
+    ix = mods["CorpusIndex"](doc_ids=np.arange(n_docs, dtype=np.int64), doc_off=doc_off.astype(np.int32),
+                             chunk_ids=np.arange(C, dtype=np.int64), emb=emb, total_docs=n_docs)
+    eng = mods["DeviceEngine"](ix, max_queries=64, max_k=100, rerank_max_docs=0)
+    eng.enable_bf16()
+    assert eng.batch_gemm_ok()
+    q = rng.standard_normal((700, 768)).astype(np.float32) * rng.uniform(0.5, 12, size=(700, 1)).astype(np.float32)
+    q[0] = emb[4567] * 3.0                                 # an exact hit
+    q[1] = 0.0                                             # zero query: cosine 0 everywhere
+    q[2:40] = emb[rng.integers(0, C, 38)] + 0.4 * q[2:40] / np.linalg.norm(q[2:40], axis=1, keepdims=True)
+    for Q, k in ((129, 100), (300, 10), (700, 100), (512, 100)):
+        exact = [x.cpu().numpy() for x in eng.dense_topk(q[:Q], k=k)]
+        for ver in ((3, 1, 2) if Q == 300 else (3,)):
+            eng._check(eng.lib.msr_tune(eng.handle, 1, ver))
+            got = [x.cpu().numpy() for x in eng.dense_topk_batched(q[:Q], k=k)]
+            assert np.array_equal(got[3], exact[3])
+            assert np.abs(got[1] - exact[1]).max() <= 2e-6
+            same = got[0] == exact[0]
+            assert same.mean() > 0.99
+            assert np.all(same | (np.abs(got[1] - exact[1]) <= 2e-6))
+            # where the documents agree the arg-max chunk agrees too, unless two chunks of the document tie within rounding
+            agree = (got[2] == exact[2]) | ~same
+            assert agree.mean() > 0.999
+        eng._check(eng.lib.msr_tune(eng.handle, 1, 3))
+    # zero query: every cosine is exactly 0 -> the k lowest-indexed documents that have chunks, in order
+    z = [x.cpu().numpy() for x in eng.dense_topk_batched(q[:200], k=100)]
+    has = np.nonzero(n > 0)[0][:100]
+    assert z[3][1] == 100 and z[0][1].tolist() == has.tolist() and np.all(z[1][1] == 0.0)
+    eng.close()
+
+
+def test_batched_path_without_gemm_preconditions(mods):
+    """A document longer than 256 chunks cannot live inside one row tile: the engine keeps batches of more than 128
+    queries on the sweeps (msr_batch_gemm_ok = 0) and the result is still the exact scan's."""
+    rng = np.random.default_rng(78)
+    doc_off, emb = _rand_chunked(rng, 3000, 6, big=((7, 300),))
+    ix = mods["CorpusIndex"](doc_ids=np.arange(3000, dtype=np.int64), doc_off=doc_off.astype(np.int32),
+                             chunk_ids=np.arange(doc_off[-1], dtype=np.int64), emb=emb, total_docs=3000)
+    eng = mods["DeviceEngine"](ix, max_queries=64, max_k=50, rerank_max_docs=0)
+    eng.enable_bf16()
+    assert not eng.batch_gemm_ok()
+    q = rng.standard_normal((150, 768)).astype(np.float32)
+    a = [x.cpu().numpy() for x in eng.dense_topk_batched(q, k=50)]
+    b = [x.cpu().numpy() for x in eng.dense_topk(q, k=50)]
+    assert np.array_equal(a[3], b[3]) and np.abs(a[1] - b[1]).max() <= 2e-6
+    assert np.all((a[0] == b[0]) | (np.abs(a[1] - b[1]) <= 2e-6))
+    eng.close()
+
+
 # ------------------------------------------------------------------------------------------------ rerank
 def _rerank_case_index(mods, c):
     z = np.load(os.path.join(G, f"rerank_{c['case']}.npz"))
