@@ -4,7 +4,7 @@ synthetic 1 M-document / 5 M x 768 f32-chunk corpus resident in HBM (BASELINE.js
 
 A STEP = one pass of the whole hot path over one batch of `--queries-per-step` (default 128) queries:
     stage 1  BM25 term-at-a-time + top-1000                        (msr_bm25_topk)
-    stage 2  dense full scan: q x chunk cosine, per-doc max-pool, top-100   (msr_dense_topk; one sweep of E per 64 queries)
+    stage 2  dense full scan: q x chunk cosine, per-doc max-pool, top-100   (msr_dense_topk; ONE pass over E per 128 queries)
     fuse     reference rerank chain on the stage-1 candidates -> top-100     (msr_rerank_gather + _fuse)
 With N > 1 GPUs the corpus is doc-sharded and, by default, the batch is 128 queries PER GPU: every GPU sweeps 1/N of
 the rows for N times the queries, i.e. the same work per GPU and step at every N -- reported as "scaling": "weak"
@@ -171,7 +171,7 @@ def main():
     ap.add_argument("--chunks", type=int, default=5_000_000)
     ap.add_argument("--terms", type=int, default=1_000_000)
     ap.add_argument("--queries-per-step", type=int, default=0,
-                    help="queries per step (the dense stage sweeps E once per 64 of them); 0 = 128 per GPU: with the "
+                    help="queries per step (the dense stage reads E once per 128 of them); 0 = 128 per GPU: with the "
                          "corpus sharded N ways and the batch N times larger, every GPU does the same work per step "
                          "at every N (weak scaling); an explicit value keeps the batch fixed (strong scaling)")
     ap.add_argument("--k1", type=int, default=1000, help="stage-1 candidates (config.py:13)")
@@ -426,6 +426,8 @@ def main():
             wide_kernel = q_launch > 32                         # 33..64 queries per sweep run on the K-split kernel
             k_ms, k_n = scan_ms, scan_n
             kname = ("dense_ksplit_kernel" if wide_kernel else "dense_scan_v2_kernel") + ("<bf16>" if bf else "")
+            if not bf and q_launch > 64:
+                kname = "gemm_f32_kernel<emit>"                 # 65..128 queries: one GEMM pass over the f32 rows
             if gemm:
                 kname = "gemm_kernel<emit>"
                 alg_bytes = n_ch * 768 * 2 + min(Q, 1024) * 768 * 2     # E (bf16) once per 1024-query pass + the queries

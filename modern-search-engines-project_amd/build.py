@@ -25,6 +25,7 @@ UNITS = {
     "msr_rerank.hip": ["-ffp-contract=off"],
     "msr_batch.hip": [],
     "msr_gemm.hip": [],
+    "msr_gemm_f32.hip": [],
     "msr_encoder.hip": ["-ffp-contract=off"],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]

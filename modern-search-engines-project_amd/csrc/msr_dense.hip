@@ -94,6 +94,7 @@ __global__ __launch_bounds__(WAVES * 64) void dense_scan_v2_kernel(DenseIndex ix
 
     const int s = blockIdx.x * WAVES + w;
     if (s >= n_wspans) return;                                   // wave-uniform
+    if (ix.gate && *ix.gate == 0) return;                        // a fallback launch that is not needed (msr_engine.hip)
     const int64_t C = ix.n_chunks;
     const float NEG_INF = -__builtin_inff();
     const int d0 = wspan[s], d1 = wspan[s + 1];
@@ -426,6 +427,7 @@ __global__ __launch_bounds__(64) void best_chunk_kernel(DenseIndex ix, const flo
                                                          const int32_t* __restrict__ out_n,
                                                          int32_t* __restrict__ out_chunk) {
     const int q = blockIdx.y, r = blockIdx.x, lane = threadIdx.x;
+    if (ix.gate && *ix.gate == 0) return;
     if (r >= out_n[q]) {
         if (lane == 0) out_chunk[(int64_t)q * k + r] = -1;
         return;

@@ -75,6 +75,7 @@ __global__ __launch_bounds__(NWAVES * 64) void dense_ksplit_kernel(DenseIndex ix
     const bool pw = red && (PIPE == 1 || (PIPE == 2 && w >= 4));
     const int s = blockIdx.x;
     if (s >= ix.n_spans) return;                                 // workgroup-uniform
+    if (ix.gate && *ix.gate == 0) return;                        // a fallback launch that is not needed (msr_engine.hip)
     const int64_t C = ix.n_chunks;
     const float NEG_INF = -__builtin_inff();
     const int d0 = ix.span_doc[s], d1 = ix.span_doc[s + 1];

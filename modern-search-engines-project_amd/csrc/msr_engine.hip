@@ -47,10 +47,21 @@ struct msr_engine {
     int32_t* bt_top_doc = nullptr; float* bt_top_score = nullptr; int32_t* bt_top_n = nullptr;
     int32_t* bt_cand_doc = nullptr; float* bt_cand_score = nullptr; int32_t* bt_cand_chunk = nullptr;
     int32_t* bt_cand_n = nullptr;
+    // row tiles of <= 256 rows cut at document boundaries (both GEMM paths); built when the chunks are bound
+    int32_t* tile_row = nullptr;
+    int n_tiles = 0;
+    bool tiles_ok = false;             // every document fits one tile
+    // default scan for 65..128 queries as a tiled GEMM over the f32 rows (msr_gemm_f32.hip)
+    GemmF32Index gf{};
+    bool gf_ok = false;
+    float* gf_inv_pad = nullptr; void* gf_qimg = nullptr; float* gf_tmax_t = nullptr; float* gf_tmax = nullptr;
+    int32_t* gf_top_doc = nullptr; float* gf_top_score = nullptr; int32_t* gf_top_n = nullptr;
+    float* gf_thr = nullptr; float* gf_thr2 = nullptr; int32_t* gf_flag = nullptr; void* gf_wvbuf = nullptr;
+    int32_t* gf_wv_count = nullptr; void* gf_pairs = nullptr; int32_t* gf_pair_n = nullptr; int32_t* gf_gate = nullptr;
     // batched path as a tiled GEMM (msr_gemm.hip): unit-row bf16 image + tile table + scratch for GM_SLICE queries per pass
     GemmIndex gemm{};
     bool gemm_ok = false;
-    void* gm_emb_n = nullptr; int32_t* gm_tile_row = nullptr; void* gm_qmat = nullptr; float* gm_tmax = nullptr; float* gm_tmax_t = nullptr;
+    void* gm_emb_n = nullptr; void* gm_qmat = nullptr; float* gm_tmax = nullptr; float* gm_tmax_t = nullptr;
     int32_t* gm_top_doc = nullptr; float* gm_top_score = nullptr; int32_t* gm_top_n = nullptr;
     float* gm_thr = nullptr; float* gm_thr2 = nullptr; int32_t* gm_flag = nullptr; void* gm_wgbuf = nullptr;
     int32_t* gm_wv_count = nullptr; void* gm_pairs = nullptr; int32_t* gm_pair_n = nullptr; float* gm_qn = nullptr;
@@ -92,17 +103,29 @@ static void free_dev(void* p) {
 }
 
 static void free_gemm(msr_engine* e) {
-    free_dev(e->gm_emb_n); free_dev(e->gm_tile_row); free_dev(e->gm_qmat); free_dev(e->gm_tmax); free_dev(e->gm_tmax_t); free_dev(e->gm_top_doc);
+    free_dev(e->gm_emb_n); free_dev(e->gm_qmat); free_dev(e->gm_tmax); free_dev(e->gm_tmax_t); free_dev(e->gm_top_doc);
     free_dev(e->gm_top_score); free_dev(e->gm_top_n); free_dev(e->gm_thr); free_dev(e->gm_thr2); free_dev(e->gm_flag);
     free_dev(e->gm_wgbuf); free_dev(e->gm_wv_count); free_dev(e->gm_pairs); free_dev(e->gm_pair_n); free_dev(e->gm_qn);
     free_dev(e->gm_sel.hist); free_dev(e->gm_sel.state); free_dev(e->gm_sel.cand_hi); free_dev(e->gm_sel.cand_lo);
     free_dev(e->gm_sel.cand_n); free_dev(e->bf_ones); free_dev(e->bf_row_meta); free_dev(e->bf_err); free_dev(e->bf_margin);
     e->bf_err = nullptr; e->bf_margin = nullptr;
-    e->gm_emb_n = nullptr; e->gm_tile_row = nullptr; e->gm_qmat = nullptr; e->gm_tmax = nullptr; e->gm_tmax_t = nullptr; e->gm_top_doc = nullptr;
+    e->gm_emb_n = nullptr; e->gm_qmat = nullptr; e->gm_tmax = nullptr; e->gm_tmax_t = nullptr; e->gm_top_doc = nullptr;
     e->gm_top_score = nullptr; e->gm_top_n = nullptr; e->gm_thr = e->gm_thr2 = nullptr; e->gm_flag = nullptr;
     e->gm_wgbuf = nullptr; e->gm_wv_count = nullptr; e->gm_pairs = nullptr; e->gm_pair_n = nullptr; e->gm_qn = nullptr;
     e->gm_sel = SelScratch{}; e->bf_ones = nullptr; e->bf_row_meta = nullptr;
     e->gemm_ok = false;
+}
+
+static void free_gf(msr_engine* e) {
+    free_dev(e->tile_row); free_dev(e->gf_inv_pad); free_dev(e->gf_qimg); free_dev(e->gf_tmax_t); free_dev(e->gf_tmax);
+    free_dev(e->gf_top_doc); free_dev(e->gf_top_score); free_dev(e->gf_top_n); free_dev(e->gf_thr); free_dev(e->gf_thr2);
+    free_dev(e->gf_flag); free_dev(e->gf_wvbuf); free_dev(e->gf_wv_count); free_dev(e->gf_pairs); free_dev(e->gf_pair_n);
+    free_dev(e->gf_gate);
+    e->tile_row = nullptr; e->gf_inv_pad = nullptr; e->gf_qimg = nullptr; e->gf_tmax_t = nullptr; e->gf_tmax = nullptr;
+    e->gf_top_doc = nullptr; e->gf_top_score = nullptr; e->gf_top_n = nullptr; e->gf_thr = e->gf_thr2 = nullptr;
+    e->gf_flag = nullptr; e->gf_wvbuf = nullptr; e->gf_wv_count = nullptr; e->gf_pairs = nullptr; e->gf_pair_n = nullptr;
+    e->gf_gate = nullptr;
+    e->n_tiles = 0; e->tiles_ok = false; e->gf_ok = false;
 }
 
 extern "C" int msr_abi_version(void) { return MSR_ABI_VERSION; }
@@ -191,6 +214,7 @@ extern "C" int msr_destroy(msr_engine* e) {
     free_dev(e->bt_top_doc); free_dev(e->bt_top_score); free_dev(e->bt_top_n); free_dev(e->bt_cand_doc);
     free_dev(e->bt_cand_score); free_dev(e->bt_cand_chunk); free_dev(e->bt_cand_n);
     free_gemm(e);
+    free_gf(e);
     for (int w = 0; w < msr_engine::EV_KINDS; ++w)
         for (int j = 0; j < msr_engine::EV_RING; ++j) {
             if (e->ev_start[w][j]) (void)hipEventDestroy(e->ev_start[w][j]);
@@ -418,10 +442,61 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
     HIP_TRY(e, hipStreamSynchronize(st));                 // spans vector goes out of scope
     e->dense = DenseIndex{emb, doc_off, e->chunk_doc, inv_norm, e->span_doc, n_chunks, n_docs, (n_docs + 31) / 32 * 32, n_spans,
                           e->cfg.scan_layout, e->wspan_doc, n_wspans, e->wspan12_doc, n_wspans12, e->qimg, nullptr,
-                          e->emb_presplit, e->row_meta, wide_ok, wide_ok && wide_ok64, variant};
+                          e->emb_presplit, e->row_meta, wide_ok, wide_ok && wide_ok64, nullptr, variant};
     free_dev(e->emb_bf16);                                // a new binding invalidates the bf16 copy
     e->emb_bf16 = nullptr;
     free_gemm(e);
+    free_gf(e);
+    // ---- row tiles for the GEMM paths: <= 256 rows, cut at document boundaries (a longer document: no GEMM paths) ----
+    {
+        std::vector<int32_t> tiles;
+        bool ok = true;
+        int32_t start = 0;
+        tiles.push_back(0);
+        for (int64_t d = 0; d < n_docs && ok; ++d) {
+            const int32_t end = h_off[d + 1];
+            if (end - h_off[d] > 256) ok = false;
+            if (end - start > 256) { tiles.push_back(h_off[d]); start = h_off[d]; }
+        }
+        if (tiles.back() != (int32_t)n_chunks) tiles.push_back((int32_t)n_chunks);
+        if (ok) {
+            if ((herr = hipMalloc((void**)&e->tile_row, tiles.size() * 4)) != hipSuccess)
+                return fail(e, MSR_ERR_NOMEM, "tile table: %s", hipGetErrorString(herr));
+            HIP_TRY(e, hipMemcpyAsync(e->tile_row, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(e, hipStreamSynchronize(st));
+            e->n_tiles = (int)tiles.size() - 1;
+            e->tiles_ok = true;
+        }
+    }
+    // the default (f16x2-split) scan of 65..128 queries runs as a GEMM over the f32 rows when the corpus allows it
+    if (e->tiles_ok && variant == 14 && e->n_tiles >= 64) {
+        const int n_tiles = e->n_tiles, nw = e->n_cus * 8, stride = (n_tiles + 31) / 32 * 32;
+        constexpr int GF_WV_CAP = 4096;
+        auto alloc = [&](void** p, size_t bytes) { return hipMalloc(p, bytes); };
+        if ((herr = alloc((void**)&e->gf_inv_pad, (size_t)(n_chunks + 512) * 4)) != hipSuccess ||
+            (herr = alloc(&e->gf_qimg, (size_t)24 * 16384)) != hipSuccess ||
+            (herr = alloc((void**)&e->gf_tmax_t, (size_t)n_tiles * 4 * 128 * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gf_tmax, (size_t)128 * stride * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gf_top_doc, (size_t)128 * MSR_MAX_K * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gf_top_score, (size_t)128 * MSR_MAX_K * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gf_top_n, 128 * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gf_thr, 128 * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gf_thr2, 128 * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gf_flag, 128 * 4)) != hipSuccess ||
+            (herr = alloc(&e->gf_wvbuf, (size_t)nw * GF_WV_CAP * 16)) != hipSuccess ||
+            (herr = alloc((void**)&e->gf_wv_count, (size_t)nw * 4)) != hipSuccess ||
+            (herr = alloc(&e->gf_pairs, (size_t)128 * 4096 * 8)) != hipSuccess ||
+            (herr = alloc((void**)&e->gf_pair_n, 128 * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gf_gate, 4)) != hipSuccess)
+            return fail(e, MSR_ERR_NOMEM, "GEMM scan scratch: %s", hipGetErrorString(herr));
+        HIP_TRY(e, msr_pad_inv_norm(inv_norm, n_chunks, n_chunks + 512, e->gf_inv_pad, st));
+        HIP_TRY(e, hipMemsetAsync(e->gf_pair_n, 0, 128 * 4, st));
+        HIP_TRY(e, hipMemsetAsync(e->gf_gate, 0, 4, st));
+        e->gf = GemmF32Index{e->tile_row, n_tiles, e->n_cus, e->gf_inv_pad, e->gf_qimg, e->gf_tmax_t, e->gf_tmax, stride,
+                             e->gf_top_doc, e->gf_top_score, e->gf_top_n, e->gf_thr, e->gf_thr2, e->gf_flag, e->gf_wvbuf,
+                             GF_WV_CAP, e->gf_wv_count, e->gf_pairs, e->gf_pair_n};
+        e->gf_ok = true;
+    }
     e->have_chunks = true;
     return MSR_OK;
 }
@@ -454,6 +529,7 @@ extern "C" int msr_scan_width(const msr_engine* e) {
     if (!e || !e->have_chunks) return -1;
     const int v = e->dense.variant;
     const bool wide = (v == 2 || v == 14 || v == 15) && e->dense.layout == 0 && e->dense.wide_ok;
+    if (e->gf_ok && wide) return 128;                       // GEMM over the f32 rows for batches of more than 64 queries
     return wide ? 64 : 32;
 }
 
@@ -524,28 +600,67 @@ extern "C" int msr_dense_topk(msr_engine* e, const float* q, int32_t n_queries, 
     if (n_queries == 0) return MSR_OK;
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(e, hipSetDevice(e->cfg.device));
-    // one sweep of E serves up to 32 queries (wave-streaming kernel) or 64 (K-split kernel, variants 13 / 14)
+    // one sweep of E serves up to 32 queries (wave-streaming kernel) or 64 (K-split kernel); batches of more than 64
+    // queries run as a GEMM over the f32 rows, 128 queries per pass (msr_gemm_f32.hip), when the corpus allows it
     const bool wide = (e->dense.variant == 2 || e->dense.variant == 14 || e->dense.variant == 15) && e->dense.layout == 0 &&
                       e->dense.wide_ok && max_chunks_per_doc == 0;
-    const int slice = wide ? 64 : 32;
+    const bool gemm = wide && e->gf_ok && e->dense.variant == 14 && e->gf.n_tiles >= 2 * k;
     const int64_t N = e->dense.n_docs;
-    for (int q0 = 0; q0 < n_queries; q0 += slice) {
-        const int nq = std::min(slice, n_queries - q0);
-        // zero rows up to the query-block count of the kernel that runs (1, 2 or 4 blocks of 16)
-        const int nq_pad = nq > 32 ? 64 : (nq > 16 || (wide && e->dense.variant >= 14)) ? 32 : 16;
-        const bool timed = e->timing && e->ev_count[0] < msr_engine::EV_RING;
-        HIP_TRY(e, msr_prep_queries(q + (int64_t)q0 * MSR_DIM, nq, e->qn, nq_pad, st));
-        if (timed) HIP_TRY(e, hipEventRecord(e->ev_start[0][e->ev_count[0]], st));
-        HIP_TRY(e, msr_dense_scan(e->dense, e->qn, nq, max_chunks_per_doc, (float*)e->score_rows, st));
-        if (timed) {
-            HIP_TRY(e, hipEventRecord(e->ev_stop[0][e->ev_count[0]], st));
-            e->ev_count[0]++;
+    // sweeps for queries [q0, q0 + cnt): `gate` non-null = fallback launches that only do work when *gate != 0
+    auto sweeps = [&](int q0, int cnt, const int32_t* gate) -> int {
+        const int slice = wide ? 64 : 32;
+        DenseIndex ix = e->dense;
+        ix.gate = gate;
+        SelScratch sel = e->sel;
+        sel.gate = gate;
+        for (int s0 = q0; s0 < q0 + cnt; s0 += slice) {
+            const int nq = std::min(slice, q0 + cnt - s0);
+            // zero rows up to the query-block count of the kernel that runs (1, 2 or 4 blocks of 16)
+            const int nq_pad = nq > 32 ? 64 : (nq > 16 || (wide && e->dense.variant >= 14)) ? 32 : 16;
+            const bool timed = !gate && e->timing && e->ev_count[0] < msr_engine::EV_RING;
+            HIP_TRY(e, msr_prep_queries(q + (int64_t)s0 * MSR_DIM, nq, e->qn, nq_pad, st));
+            if (timed) HIP_TRY(e, hipEventRecord(e->ev_start[0][e->ev_count[0]], st));
+            HIP_TRY(e, msr_dense_scan(ix, e->qn, nq, max_chunks_per_doc, (float*)e->score_rows, st));
+            if (timed) {
+                HIP_TRY(e, hipEventRecord(e->ev_stop[0][e->ev_count[0]], st));
+                e->ev_count[0]++;
+            }
+            HIP_TRY(e, msr_select_topk(32, e->score_rows, N, e->dense.score_stride, nq, k, sel, out_doc + (int64_t)s0 * k,
+                                       out_score + (int64_t)s0 * k, out_n + s0, st));
+            if (out_chunk)
+                HIP_TRY(e, msr_best_chunk(ix, e->qn, nq, k, max_chunks_per_doc, out_doc + (int64_t)s0 * k,
+                                          out_n + s0, out_chunk + (int64_t)s0 * k, st));
         }
-        HIP_TRY(e, msr_select_topk(32, e->score_rows, N, e->dense.score_stride, nq, k, e->sel, out_doc + (int64_t)q0 * k,
-                                   out_score + (int64_t)q0 * k, out_n + q0, st));
-        if (out_chunk)
-            HIP_TRY(e, msr_best_chunk(e->dense, e->qn, nq, k, max_chunks_per_doc, out_doc + (int64_t)q0 * k,
-                                      out_n + q0, out_chunk + (int64_t)q0 * k, st));
+        return MSR_OK;
+    };
+    int q0 = 0;
+    while (q0 < n_queries) {
+        const int left = n_queries - q0;
+        if (gemm && left > 64) {
+            const int nq = std::min(128, left);
+            HIP_TRY(e, msr_prep_queries(q + (int64_t)q0 * MSR_DIM, nq, e->qn, nq, st));
+            HIP_TRY(e, hipMemsetAsync(e->gf_gate, 0, 4, st));
+            hipEvent_t ev[4];
+            const bool timed = e->timing && e->ev_count[0] < msr_engine::EV_RING && e->ev_count[3] < msr_engine::EV_RING;
+            if (timed) {
+                ev[0] = e->ev_start[3][e->ev_count[3]]; ev[1] = e->ev_stop[3][e->ev_count[3]];
+                ev[2] = e->ev_start[0][e->ev_count[0]]; ev[3] = e->ev_stop[0][e->ev_count[0]];
+            }
+            HIP_TRY(e, msr_gemm_f32_topk(e->gf, e->dense, e->qn, nq, k, e->sel, out_doc + (int64_t)q0 * k,
+                                         out_score + (int64_t)q0 * k, out_chunk ? out_chunk + (int64_t)q0 * k : nullptr,
+                                         out_n + q0, e->gf_gate, timed ? ev : nullptr, st));
+            if (timed) { e->ev_count[0]++; e->ev_count[3]++; }
+            // A query whose entries overflowed (huge tie groups) raised the gate: the same batch once more on the sweeps,
+            // which handle any input; when the gate is down (the normal case) these launches return at once.
+            int rc = sweeps(q0, nq, e->gf_gate);
+            if (rc) return rc;
+            q0 += nq;
+        } else {
+            const int nq = std::min(wide ? 64 : 32, left);
+            int rc = sweeps(q0, nq, nullptr);
+            if (rc) return rc;
+            q0 += nq;
+        }
     }
     return MSR_OK;
 }
@@ -571,7 +686,7 @@ extern "C" int msr_enable_bf16(msr_engine* e, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     hipError_t herr;
-    const int64_t C = e->dense.n_chunks, N = e->dense.n_docs;
+    const int64_t C = e->dense.n_chunks;
     // The image holds the rows NORMALISED and then rounded to bf16 (so a score needs no per-row scale and the error bound
     // of msr_batch.hip is about unit vectors), padded with 512 zero rows: the GEMM reads 256 rows from any tile start.
     const int64_t n_pad = C + 512;
@@ -602,29 +717,14 @@ extern "C" int msr_enable_bf16(msr_engine* e, void* stream) {
         HIP_TRY(e, msr_pack_row_meta(e->chunk_doc, e->bf_ones, C, e->bf_row_meta, st));
         e->dense_bf16.row_meta = e->bf_row_meta;
     }
-    // ---- GEMM path: row tiles of <= 256 rows cut at document boundaries (a document longer than that: no GEMM path) ----
-    std::vector<int32_t> h_off((size_t)N + 1);
-    HIP_TRY(e, hipMemcpyAsync(h_off.data(), e->dense.doc_off, h_off.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(e, hipStreamSynchronize(st));
-    std::vector<int32_t> tiles;
-    bool ok = true;
-    {
-        int32_t start = 0;
-        tiles.push_back(0);
-        for (int64_t d = 0; d < N && ok; ++d) {
-            const int32_t end = h_off[d + 1];
-            if (end - h_off[d] > 256) ok = false;
-            if (end - start > 256) { tiles.push_back(h_off[d]); start = h_off[d]; }
-        }
-        if (tiles.back() != (int32_t)C) tiles.push_back((int32_t)C);
-    }
-    const int n_tiles = (int)tiles.size() - 1;
+    // ---- GEMM path: needs the row tiles built at bind time (every document inside one 256-row tile) ----
+    const bool ok = e->tiles_ok;
+    const int n_tiles = e->n_tiles;
     const int grid = e->n_cus / 8 * 8;
     if (ok && n_tiles >= 64 && grid >= 32) {
         const int stride = (n_tiles + 31) / 32 * 32;
         const size_t nsel = GM_SLICE;
-        if ((herr = alloc((void**)&e->gm_tile_row, tiles.size() * 4)) != hipSuccess ||
-            (herr = alloc(&e->gm_qmat, (size_t)GM_SLICE * MSR_DIM * 2)) != hipSuccess ||
+        if ((herr = alloc(&e->gm_qmat, (size_t)GM_SLICE * MSR_DIM * 2)) != hipSuccess ||
             (herr = alloc((void**)&e->gm_qn, (size_t)GM_SLICE * MSR_DIM * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gm_tmax, (size_t)GM_SLICE * stride * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gm_tmax_t, (size_t)n_tiles * 2 * GM_SLICE * 4)) != hipSuccess ||
@@ -644,12 +744,10 @@ extern "C" int msr_enable_bf16(msr_engine* e, void* stream) {
             (herr = alloc((void**)&e->gm_sel.cand_lo, nsel * MSR_SEL_CAP * sizeof(uint32_t))) != hipSuccess ||
             (herr = alloc((void**)&e->gm_sel.cand_n, nsel * sizeof(int32_t))) != hipSuccess)
             return fail(e, MSR_ERR_NOMEM, "GEMM path scratch: %s", hipGetErrorString(herr));
-        HIP_TRY(e, hipMemcpyAsync(e->gm_tile_row, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, st));
         HIP_TRY(e, hipMemsetAsync(e->gm_pair_n, 0, (size_t)GM_SLICE * 4, st));
         HIP_TRY(e, hipMemsetAsync(e->gm_sel.hist, 0, nsel * MSR_SEL_BINS * sizeof(uint32_t), st));
         HIP_TRY(e, hipMemsetAsync(e->gm_sel.cand_n, 0, nsel * sizeof(int32_t), st));
-        HIP_TRY(e, hipStreamSynchronize(st));               // `tiles` goes out of scope
-        e->gemm = GemmIndex{e->emb_bf16, e->gm_tile_row, n_tiles, e->n_cus, GM_SLICE, e->gm_qmat, e->gm_tmax, stride,
+        e->gemm = GemmIndex{e->emb_bf16, e->tile_row, n_tiles, e->n_cus, GM_SLICE, e->gm_qmat, e->gm_tmax, stride,
                             e->gm_tmax_t, e->gm_top_doc, e->gm_top_score, e->gm_top_n, e->gm_thr, e->gm_thr2, e->gm_flag, e->gm_wgbuf,
                             GM_WV_CAP, e->gm_wv_count, e->gm_pairs, e->gm_pair_n};
         e->gemm_ok = true;

@@ -36,11 +36,9 @@
 #include "msr_common.h"
 #include "msr_internal.h"
 #include "msr_frag.h"
+#include "msr_gemm_dev.h"
 
 namespace {
-
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void glb_void;
 
 constexpr int GM_THREADS = 512;
 constexpr int GM_KT = MSR_DIM / 64;            // K steps per output tile
@@ -65,25 +63,6 @@ struct GemmArgs {
     int dbg;                   // -DMSR_DIAG builds only (timing experiments, results are wrong): bit 0 = every tile reads
                                // the rows of tile 0 (A always from cache), bit 1 = B always K step 0
 };
-
-// max(a, b, c) without the canonicalising v_max x, x that fmaxf() drags in (inputs here are never signalling NaNs)
-__device__ __forceinline__ float max3_raw(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ float max2_raw(float a, float b) {
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ void wait_vm4() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void wg_barrier() {
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-}
 
 template <bool EMIT, int VER>
 __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
@@ -538,8 +517,8 @@ __global__ __launch_bounds__(256) void batch_margin_kernel(const float* __restri
     }
 }
 
-// out[q][j] = max(in[j][0][q], in[j][1][q]): the tile maxima as one row per query for the top-k select (32 x 32 LDS transpose)
-__global__ __launch_bounds__(256) void gemm_tmax_kernel(const float* __restrict__ in, int n_j, int nq_pad,
+// out[q][j] = max_p in[j][p][q]: the tile maxima as one row per query for the top-k select (32 x 32 LDS transpose)
+__global__ __launch_bounds__(256) void gemm_tmax_kernel(const float* __restrict__ in, int n_j, int parts, int nq_pad,
                                                          float* __restrict__ out, int out_stride) {
     __shared__ float t[32][33];
     const int j0 = blockIdx.x * 32, q0 = blockIdx.y * 32;
@@ -548,7 +527,8 @@ __global__ __launch_bounds__(256) void gemm_tmax_kernel(const float* __restrict_
     for (int r = 0; r < 4; ++r) {
         const int j = j0 + ty + 8 * r;
         float v = -__builtin_inff();
-        if (j < n_j) v = fmaxf(in[((size_t)j * 2) * nq_pad + q0 + tx], in[((size_t)j * 2 + 1) * nq_pad + q0 + tx]);
+        if (j < n_j)
+            for (int p = 0; p < parts; ++p) v = fmaxf(v, in[((size_t)j * parts + p) * nq_pad + q0 + tx]);
         t[ty + 8 * r][tx] = v;
     }
     __syncthreads();
@@ -570,7 +550,7 @@ __global__ __launch_bounds__(256) void gemm_thr_kernel(const float* __restrict__
     float t = __builtin_inff();
     int f = 0;
     if (q < nq) {
-        if (top_n[q] >= k) t = top_score[(int64_t)q * k + (k - 1)] - margin[q];
+        if (top_n[q] >= k) t = top_score[(int64_t)q * k + (k - 1)] - (margin ? margin[q] : 0.0f);
         else f = 1;
     }
     thr[q] = t;
@@ -741,6 +721,23 @@ hipError_t msr_batch_margin(const float* qn, int nq, const uint32_t* err_max, fl
 }
 
 int msr_gemm_pair_cap() { return GM_PAIR_CAP; }
+
+hipError_t msr_gemm_tmax(const float* tmax_t, int n_j, int parts, int nq_pad, float* out, int out_stride, hipStream_t stream) {
+    if (n_j <= 0 || nq_pad <= 0) return hipSuccess;
+    gemm_tmax_kernel<<<dim3((n_j + 31) / 32, nq_pad / 32), 256, 0, stream>>>(tmax_t, n_j, parts, nq_pad, out, out_stride);
+    return hipGetLastError();
+}
+hipError_t msr_gemm_thr(const float* top_score, const int32_t* top_n, int nq, int nq_pad, int k, const float* margin,
+                        float* thr, int32_t* flag, hipStream_t stream) {
+    gemm_thr_kernel<<<(nq_pad + 255) / 256, 256, 0, stream>>>(top_score, top_n, nq, nq_pad, k, margin, thr, flag);
+    return hipGetLastError();
+}
+hipError_t msr_gemm_bucket(const void* wvbuf, int wv_cap, const int32_t* wv_count, int n_waves, const float* thr2,
+                           void* pairs, int32_t* pair_n, hipStream_t stream) {
+    gemm_bucket_kernel<<<dim3(2, (unsigned)n_waves), 256, 0, stream>>>((const int4*)wvbuf, wv_cap, wv_count, thr2, (int2*)pairs,
+                                                                      GM_PAIR_CAP, pair_n);
+    return hipGetLastError();
+}
 void msr_gemm_set_version(int v) { g_gemm_version = v >= 1 && v <= 3 ? v : 3; }
 void msr_gemm_set_dbg(int v) { g_gemm_dbg = v; }
 
@@ -770,7 +767,7 @@ hipError_t msr_gemm_candidates(const GemmIndex& g, const DenseIndex& ix, const f
     if (ev && (err = hipEventRecord(ev[0], stream)) != hipSuccess) return err;
     if ((err = launch_gemm(false, a, grid, stream)) != hipSuccess) return err;
     if (ev && (err = hipEventRecord(ev[1], stream)) != hipSuccess) return err;
-    gemm_tmax_kernel<<<dim3((n_s + 31) / 32, nq_pad / 32), 256, 0, stream>>>(g.tmax_t, n_s, nq_pad, (float*)g.tmax, g.tmax_stride);
+    gemm_tmax_kernel<<<dim3((n_s + 31) / 32, nq_pad / 32), 256, 0, stream>>>(g.tmax_t, n_s, 2, nq_pad, (float*)g.tmax, g.tmax_stride);
     if ((err = msr_select_topk(32, g.tmax, n_s, g.tmax_stride, nq, k, sel, g.top_doc, g.top_score, g.top_n, stream)) != hipSuccess) return err;
     gemm_thr_kernel<<<(nq_pad + 255) / 256, 256, 0, stream>>>(g.top_score, g.top_n, nq, nq_pad, k, margin, g.thr, g.flag);
     // ---- pass 2: all tiles; maxima of all tiles + emission against the sample threshold ----
@@ -779,7 +776,7 @@ hipError_t msr_gemm_candidates(const GemmIndex& g, const DenseIndex& ix, const f
     if (ev && (err = hipEventRecord(ev[2], stream)) != hipSuccess) return err;
     if ((err = launch_gemm(true, a, grid, stream)) != hipSuccess) return err;
     if (ev && (err = hipEventRecord(ev[3], stream)) != hipSuccess) return err;
-    gemm_tmax_kernel<<<dim3((g.n_tiles + 31) / 32, nq_pad / 32), 256, 0, stream>>>(g.tmax_t, g.n_tiles, nq_pad, (float*)g.tmax, g.tmax_stride);
+    gemm_tmax_kernel<<<dim3((g.n_tiles + 31) / 32, nq_pad / 32), 256, 0, stream>>>(g.tmax_t, g.n_tiles, 2, nq_pad, (float*)g.tmax, g.tmax_stride);
     if ((err = msr_select_topk(32, g.tmax, g.n_tiles, g.tmax_stride, nq, k, sel, g.top_doc, g.top_score, g.top_n, stream)) != hipSuccess) return err;
     gemm_thr_kernel<<<(nq_pad + 255) / 256, 256, 0, stream>>>(g.top_score, g.top_n, nq, nq_pad, k, margin, g.thr2, nullptr);
     // ---- finish: bucket, per-document maxima, candidates ----

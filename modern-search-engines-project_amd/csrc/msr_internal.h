@@ -23,6 +23,8 @@ struct SelScratch {
     uint64_t* cand_hi;   // [nq][MSR_SEL_CAP]
     uint32_t* cand_lo;   // [nq][MSR_SEL_CAP]
     int32_t* cand_n;     // [nq], all zero between calls
+    const int32_t* gate; // optional device word: when non-null and *gate == 0 every kernel of the select returns at once
+                         // (fallback launches that are only needed when an earlier kernel raised the flag)
 };
 
 // Select the top-k of scores[q][0..n) (row stride `stride` elements) for q in [0, nq).
@@ -100,6 +102,7 @@ struct DenseIndex {
                                // (the K-split kernels' ring of per-document maxima cannot wrap onto live slots) and any
                                // 16-row group <= 32 documents (at most two finished blocks per unit)
     int32_t wide_ok64;         // the same with a ring of 64 documents (128-query bf16 sweeps)
+    const int32_t* gate;       // optional device word: when non-null and *gate == 0 the scan / best-chunk kernels return at once
     int32_t variant;           // scan kernel: 14 = K-split kernel, f16-split products, <= 64 queries per sweep (default when
                                // the row norms and wide_ok allow it; 13 = the same for 17..64 queries only), 7 = wave
                                // streaming with f16-split products, 2 = wave streaming, exact f32 MFMA (default otherwise),
@@ -173,6 +176,12 @@ struct GemmIndex {
     int32_t* pair_n;           // [max_queries], zero between calls
 };
 int msr_gemm_pair_cap();
+// pieces of the candidate pipeline shared with the f32-class GEMM (msr_gemm_f32.hip)
+hipError_t msr_gemm_tmax(const float* tmax_t, int n_j, int parts, int nq_pad, float* out, int out_stride, hipStream_t stream);
+hipError_t msr_gemm_thr(const float* top_score, const int32_t* top_n, int nq, int nq_pad, int k, const float* margin,
+                        float* thr, int32_t* flag, hipStream_t stream);     // margin null: 0
+hipError_t msr_gemm_bucket(const void* wvbuf, int wv_cap, const int32_t* wv_count, int n_waves, const float* thr2,
+                           void* pairs, int32_t* pair_n, hipStream_t stream);
 void msr_gemm_set_dbg(int v);       // honoured by -DMSR_DIAG builds only
 void msr_gemm_set_version(int v);   // 1 / 2: phase decompositions of the GEMM main loop (identical results)
 // dst[r] = bf16(src[r] * inv_norm[r]) (inv_norm null: 1), rows n_rows .. n_pad - 1 zero
@@ -187,6 +196,29 @@ hipError_t msr_batch_margin(const float* qn, int nq, const uint32_t* err_max, fl
 hipError_t msr_gemm_candidates(const GemmIndex& g, const DenseIndex& ix, const float* qn, int nq, int k, const float* margin,
                                const SelScratch& sel, int32_t* cand_doc, int32_t* cand_n, hipEvent_t* ev,
                                hipStream_t stream);
+
+// ---- K2 for 65 .. 128 queries: the default (f16x2-split) scan as a tiled GEMM over the f32 rows (msr_gemm_f32.hip) ----
+struct GemmF32Index {
+    const int32_t* tile_row;   // [n_tiles + 1] (the tile table of the bf16 GEMM: whole documents, <= 256 rows)
+    int32_t n_tiles;
+    int32_t n_cus;
+    const float* inv_pad;      // [n_chunks + 512] inverse row norms, padded with 1
+    void* qimg;                // 24 x 16 KB query image (f16 hi | lo pieces)
+    float* tmax_t;             // [n_tiles][4][128]
+    float* tmax;               // [128][tmax_stride]
+    int32_t tmax_stride;
+    int32_t* top_doc; float* top_score; int32_t* top_n;     // [128][MSR_MAX_K] / [128]
+    float* thr; float* thr2; int32_t* flag;                 // [128]
+    void* wvbuf; int32_t wv_cap; int32_t* wv_count;          // [n_cus * 8][wv_cap] x 16 B / [n_cus * 8]
+    void* pairs; int32_t* pair_n;                            // [128][4096] x 8 B / [128], zero between calls
+};
+hipError_t msr_pad_inv_norm(const float* inv, int64_t n, int64_t n_pad, float* out, hipStream_t stream);
+// Top-k of up to 128 normalised queries qn in one pass over the f32 rows; out_n[q] = -1 and *gate |= 1 for a query whose
+// entries overflowed (caller: rerun the batch on the sweeps, gated on *gate).  ev (nullable): events around the sample
+// pass (0, 1) and the emit pass (2, 3).
+hipError_t msr_gemm_f32_topk(const GemmF32Index& g, const DenseIndex& ix, const float* qn, int nq, int k,
+                             const SelScratch& sel, int32_t* out_doc, float* out_score, int32_t* out_chunk,
+                             int32_t* out_n, int32_t* gate, hipEvent_t* ev, hipStream_t stream);
 
 // ---- K5: batched bf16 candidate scan finished exactly in f32 (msr_batch.hip) -----------------------
 // exact f32 rescoring + final sort of candidate lists that are already filled (cand_n zeroed on return)

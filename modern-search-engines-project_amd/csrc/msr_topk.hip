@@ -124,8 +124,9 @@ template <typename T>
 __global__ __launch_bounds__(SEL_THREADS) void sel_hist_kernel(const T* __restrict__ scores, int64_t n_dense,
                                                                 int64_t stride, RowView view, int digit,
                                                                 const SelState* __restrict__ st,
-                                                                uint32_t* __restrict__ hist) {
+                                                                uint32_t* __restrict__ hist, const int32_t* __restrict__ gate) {
     constexpr int SB = ScoreTraits<T>::SB;
+    if (gate && *gate == 0) return;                              // a fallback launch that is not needed
     const int q = blockIdx.y;
     SelState S;
     S.pref_hi = S.mask_hi = 0; S.pref_lo = S.mask_lo = 0; S.done = 0;
@@ -173,7 +174,9 @@ __global__ __launch_bounds__(SEL_THREADS) void sel_hist_kernel(const T* __restri
 // One workgroup per query: consume the global histogram of `digit` (and leave it zeroed), update the state.
 template <int SB>
 __global__ __launch_bounds__(SCAN_THREADS) void sel_scan_kernel(SelState* __restrict__ st,
-                                                                 uint32_t* __restrict__ hist, int digit, int k) {
+                                                                 uint32_t* __restrict__ hist, int digit, int k,
+                                                                 const int32_t* __restrict__ gate) {
+    if (gate && *gate == 0) return;
     __shared__ uint32_t h[MSR_SEL_BINS];
     __shared__ uint32_t suf[SCAN_THREADS + 1];
     __shared__ SelState S_sh;
@@ -210,7 +213,9 @@ __global__ __launch_bounds__(SEL_THREADS) void sel_compact_kernel(const T* __res
                                                                    const SelState* __restrict__ st,
                                                                    uint64_t* __restrict__ cand_hi,
                                                                    uint32_t* __restrict__ cand_lo,
-                                                                   int32_t* __restrict__ cand_n) {
+                                                                   int32_t* __restrict__ cand_n,
+                                                                   const int32_t* __restrict__ gate) {
+    if (gate && *gate == 0) return;
     constexpr int STAGE = 1024;                                  // staged matches per workgroup (12 KB of LDS)
     __shared__ uint64_t s_hi[STAGE];
     __shared__ uint32_t s_lo[STAGE];
@@ -308,8 +313,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void sel_final_kernel(const T* __rest
                                                                   int32_t* __restrict__ cand_n, int k,
                                                                   int32_t* __restrict__ out_doc,
                                                                   T* __restrict__ out_score,
-                                                                  int32_t* __restrict__ out_n) {
+                                                                  int32_t* __restrict__ out_n,
+                                                                  const int32_t* __restrict__ gate) {
     constexpr int SB = ScoreTraits<T>::SB;
+    if (gate && *gate == 0) return;
     __shared__ uint64_t khi[MSR_SEL_CAP];
     __shared__ uint32_t klo[MSR_SEL_CAP];
     __shared__ uint32_t suf[SCAN_THREADS + 1];
@@ -394,13 +401,13 @@ hipError_t select_impl(const T* scores, int64_t n, int64_t stride, RowView view,
     dim3 grid((unsigned)parts, (unsigned)nq);
     // two streaming histogram passes (24 key bits), one compaction, one exact sort: 6 launches
     for (int d = 0; d < 2; ++d) {
-        sel_hist_kernel<T><<<grid, SEL_THREADS, 0, stream>>>(scores, n, stride, view, d, sc.state, sc.hist);
-        sel_scan_kernel<SB><<<nq, SCAN_THREADS, 0, stream>>>(sc.state, sc.hist, d, k);
+        sel_hist_kernel<T><<<grid, SEL_THREADS, 0, stream>>>(scores, n, stride, view, d, sc.state, sc.hist, sc.gate);
+        sel_scan_kernel<SB><<<nq, SCAN_THREADS, 0, stream>>>(sc.state, sc.hist, d, k, sc.gate);
     }
     sel_compact_kernel<T><<<grid, SEL_THREADS, 0, stream>>>(scores, n, stride, view, sc.state, sc.cand_hi, sc.cand_lo,
-                                                             sc.cand_n);
+                                                             sc.cand_n, sc.gate);
     sel_final_kernel<T><<<nq, SCAN_THREADS, 0, stream>>>(scores, n, stride, view, sc.state, sc.cand_hi, sc.cand_lo,
-                                                          sc.cand_n, k, out_doc, out_score, out_n);
+                                                          sc.cand_n, k, out_doc, out_score, out_n, sc.gate);
     return hipGetLastError();
 }
 

@@ -33,8 +33,9 @@ def test_default_line_has_the_contract_fields():
     assert "model" not in d["config"] and d["config"]["workload"].startswith("hybrid: 60000 docs")
     assert "f64" in d["dtype"] and d["outputs_sane"] is True and d["bm25_parity_vs_cpu"] is True
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "dense_ksplit_kernel"
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "traffic" in r and r["launches"] == 6   # 2 sweeps x 3 steps
+    # 128 queries per step: ONE pass of the GEMM scan over the f32 rows (csrc/msr_gemm_f32.hip) per step
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "gemm_f32_kernel<emit>"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "traffic" in r and r["launches"] == 3   # 1 pass x 3 steps
     assert r["bm25_taat"]["launches"] == 3
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "queries/sec" and c["sample"]
