@@ -183,6 +183,15 @@ int msr_rerank_fuse(msr_engine* e, int32_t n_queries, const int32_t* cand_doc, c
 int msr_merge_topk(msr_engine* e, const int32_t* in_doc, const void* in_score, const int32_t* in_n,
                    int32_t n_parts, int32_t n_queries, int32_t k, int32_t score_bits, int32_t* out_doc,
                    void* out_score, int32_t* out_n, void* stream);
+/* The same with (a) an optional 32-bit payload per entry that travels with it: in_payload [n_parts][n_queries][k] ->
+ * out_payload [n_queries][k] (-1 past out_n; both NULL: none) -- the dense lists carry their arg-max chunk row this way, so
+ * the per-document arg-max of reranker_api.py:370 survives the merge without a second lookup; (b) part_stride_bytes != 0
+ * (a multiple of 8): part p of EVERY input array starts that many bytes after part p - 1, i.e. the arrays are read in place
+ * from the receive buffer of ONE all-gather whose per-rank record is [doc | score | n | payload ...]; 0: contiguous arrays. */
+int msr_merge_topk_payload(msr_engine* e, const int32_t* in_doc, const void* in_score, const int32_t* in_n,
+                           const int32_t* in_payload, int32_t n_parts, int64_t part_stride_bytes, int32_t n_queries,
+                           int32_t k, int32_t score_bits, int32_t* out_doc, void* out_score, int32_t* out_n,
+                           int32_t* out_payload, void* stream);
 
 /* Timing hooks for bench.py: while enabled, every launch of the dominant kernels is bracketed by a
  * hipEvent pair recorded on the caller's stream (ring of 256 launches per kernel).  msr_kernel_time_ms

@@ -475,7 +475,7 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
         auto alloc = [&](void** p, size_t bytes) { return hipMalloc(p, bytes); };
         if ((herr = alloc((void**)&e->gf_inv_pad, (size_t)(n_chunks + 512) * 4)) != hipSuccess ||
             (herr = alloc(&e->gf_qimg, (size_t)24 * 16384)) != hipSuccess ||
-            (herr = alloc((void**)&e->gf_tmax_t, (size_t)n_tiles * 4 * 128 * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gf_tmax_t, (size_t)n_tiles * 8 * 128 * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gf_tmax, (size_t)128 * stride * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gf_top_doc, (size_t)128 * MSR_MAX_K * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gf_top_score, (size_t)128 * MSR_MAX_K * 4)) != hipSuccess ||
@@ -760,6 +760,7 @@ extern "C" int msr_tune(msr_engine* e, int32_t key, int32_t value) {
     if (key == MSR_TUNE_GEMM_VERSION && value >= 1 && value <= 3) { msr_gemm_set_version(value); return MSR_OK; }
 #ifdef MSR_DIAG
     if (key == 100) { msr_gemm_set_dbg(value); return MSR_OK; }      // timing experiments of the diagnostic build
+    if (key == 101) { msr_gemm_f32_set_dbg(value); return MSR_OK; }
 #endif
     return fail(e, MSR_ERR_INVALID, "msr_tune: unknown key %d / value %d", key, value);
 }
@@ -903,16 +904,25 @@ extern "C" int msr_rerank(msr_engine* e, const float* q, int32_t n_queries, cons
     return MSR_OK;
 }
 
-extern "C" int msr_merge_topk(msr_engine* e, const int32_t* in_doc, const void* in_score, const int32_t* in_n,
-                              int32_t n_parts, int32_t n_queries, int32_t k, int32_t score_bits, int32_t* out_doc,
-                              void* out_score, int32_t* out_n, void* stream) {
+extern "C" int msr_merge_topk_payload(msr_engine* e, const int32_t* in_doc, const void* in_score, const int32_t* in_n,
+                                      const int32_t* in_payload, int32_t n_parts, int64_t part_stride_bytes,
+                                      int32_t n_queries, int32_t k, int32_t score_bits, int32_t* out_doc, void* out_score,
+                                      int32_t* out_n, int32_t* out_payload, void* stream) {
     if (!e) return MSR_ERR_INVALID;
     if (!in_doc || !in_score || !in_n || !out_doc || !out_score || !out_n || n_parts < 1 || n_parts > 64 ||
-        n_queries < 0 || k < 1 || k > MSR_MAX_K || (score_bits != 32 && score_bits != 64) || (int64_t)n_parts * k > 8192)
+        n_queries < 0 || k < 1 || k > MSR_MAX_K || (score_bits != 32 && score_bits != 64) || (int64_t)n_parts * k > 8192 ||
+        (in_payload != nullptr) != (out_payload != nullptr) || part_stride_bytes < 0 || (part_stride_bytes & 7))
         return fail(e, MSR_ERR_INVALID, "msr_merge_topk: bad argument (n_parts=%d, k=%d)", n_parts, k);
     if (n_queries == 0) return MSR_OK;
     HIP_TRY(e, hipSetDevice(e->cfg.device));
-    HIP_TRY(e, msr_merge_lists(score_bits, in_doc, in_score, in_n, n_parts, n_queries, k, out_doc, out_score, out_n,
-                               (hipStream_t)stream));
+    HIP_TRY(e, msr_merge_lists(score_bits, in_doc, in_score, in_n, in_payload, n_parts, part_stride_bytes, n_queries, k, out_doc,
+                               out_score, out_n, out_payload, (hipStream_t)stream));
     return MSR_OK;
+}
+
+extern "C" int msr_merge_topk(msr_engine* e, const int32_t* in_doc, const void* in_score, const int32_t* in_n,
+                              int32_t n_parts, int32_t n_queries, int32_t k, int32_t score_bits, int32_t* out_doc,
+                              void* out_score, int32_t* out_n, void* stream) {
+    return msr_merge_topk_payload(e, in_doc, in_score, in_n, nullptr, n_parts, 0, n_queries, k, score_bits, out_doc, out_score,
+                                  out_n, nullptr, stream);
 }

@@ -39,10 +39,12 @@ hipError_t msr_select_topk_list(const double* scores, const int32_t* idx, const 
                                 int64_t stride, int nq, int k, const SelScratch& sc, int32_t* out_doc,
                                 double* out_score, int32_t* out_n, hipStream_t stream);
 
-// Merge lists: in_* [n_parts][nq][k]; see msretr.h msr_merge_topk.
+// Merge lists: in_* [n_parts][nq][k]; see msretr.h msr_merge_topk.  in_pay / out_pay (nullable): a 32-bit payload per entry
+// that travels with it (the arg-max chunk row of a dense result).  part_stride_bytes != 0: part p of EVERY input array starts
+// that many bytes after part p - 1 (the receive buffer of one all-gather: [rank][packed segments]), else contiguous.
 hipError_t msr_merge_lists(int score_bits, const int32_t* in_doc, const void* in_score, const int32_t* in_n,
-                           int n_parts, int nq, int k, int32_t* out_doc, void* out_score, int32_t* out_n,
-                           hipStream_t stream);
+                           const int32_t* in_pay, int n_parts, int64_t part_stride_bytes, int nq, int k, int32_t* out_doc,
+                           void* out_score, int32_t* out_n, int32_t* out_pay, hipStream_t stream);
 
 // error text of handle-less entry points, read back with msr_last_error(NULL) (msr_engine.hip)
 int msr_fail_global(int code, const char* fmt, ...);
@@ -204,7 +206,7 @@ struct GemmF32Index {
     int32_t n_cus;
     const float* inv_pad;      // [n_chunks + 512] inverse row norms, padded with 1
     void* qimg;                // 24 x 16 KB query image (f16 hi | lo pieces)
-    float* tmax_t;             // [n_tiles][4][128]
+    float* tmax_t;             // [n_tiles][8 waves][128]
     float* tmax;               // [128][tmax_stride]
     int32_t tmax_stride;
     int32_t* top_doc; float* top_score; int32_t* top_n;     // [128][MSR_MAX_K] / [128]
@@ -212,6 +214,7 @@ struct GemmF32Index {
     void* wvbuf; int32_t wv_cap; int32_t* wv_count;          // [n_cus * 8][wv_cap] x 16 B / [n_cus * 8]
     void* pairs; int32_t* pair_n;                            // [128][4096] x 8 B / [128], zero between calls
 };
+void msr_gemm_f32_set_dbg(int v);   // honoured by -DMSR_DIAG builds only
 hipError_t msr_pad_inv_norm(const float* inv, int64_t n, int64_t n_pad, float* out, hipStream_t stream);
 // Top-k of up to 128 normalised queries qn in one pass over the f32 rows; out_n[q] = -1 and *gate |= 1 for a query whose
 // entries overflowed (caller: rerun the batch on the sweeps, gated on *gate).  ev (nullable): events around the sample

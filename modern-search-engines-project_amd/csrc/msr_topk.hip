@@ -412,13 +412,36 @@ hipError_t select_impl(const T* scores, int64_t n, int64_t stride, RowView view,
 }
 
 // ---- merge of per-shard lists ---------------------------------------------------------------------
+// (hi, lo) keys with a 32-bit payload that travels with its key (the arg-max chunk row of a dense result)
+template <int THREADS>
+__device__ void bitonic_desc_pay(uint64_t* khi, uint32_t* klo, int32_t* pay, int P) {
+    for (int kk = 2; kk <= P; kk <<= 1) {
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int idx = threadIdx.x; idx < (P >> 1); idx += THREADS) {
+                const int i = ((idx & ~(j - 1)) << 1) | (idx & (j - 1));
+                const int p = i | j;
+                const bool desc = (i & kk) == 0;
+                const uint64_t ah = khi[i], bh = khi[p];
+                const uint32_t al = klo[i], bl = klo[p];
+                if (desc ? key_less(ah, al, bh, bl) : key_less(bh, bl, ah, al)) {
+                    khi[i] = bh; klo[i] = bl; khi[p] = ah; klo[p] = al;
+                    const int32_t t = pay[i]; pay[i] = pay[p]; pay[p] = t;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(SCAN_THREADS) void merge_kernel(const int32_t* __restrict__ in_doc,
                                                               const T* __restrict__ in_score,
-                                                              const int32_t* __restrict__ in_n, int n_parts,
-                                                              int nq, int k, int32_t* __restrict__ out_doc,
+                                                              const int32_t* __restrict__ in_n,
+                                                              const int32_t* __restrict__ in_pay, int n_parts,
+                                                              int64_t pstride, int nq, int k, int32_t* __restrict__ out_doc,
                                                               T* __restrict__ out_score,
-                                                              int32_t* __restrict__ out_n) {
+                                                              int32_t* __restrict__ out_n,
+                                                              int32_t* __restrict__ out_pay) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int q = blockIdx.x;
     const int total = n_parts * k;
@@ -426,35 +449,48 @@ __global__ __launch_bounds__(SCAN_THREADS) void merge_kernel(const int32_t* __re
     while (P < total) P <<= 1;
     uint64_t* khi = (uint64_t*)smem;
     uint32_t* klo = (uint32_t*)(smem + (size_t)P * 8);
+    int32_t* pay = (int32_t*)(smem + (size_t)P * 12);            // (only touched when in_pay is given)
     __shared__ int n_valid;
+    // part p of every array starts pstride BYTES after part p - 1 (pstride = 0: the parts are contiguous arrays)
+    auto part = [&](const auto* base, int p, int64_t elems) {
+        typedef decltype(base) PT;
+        return pstride ? (PT)((const char*)base + (int64_t)p * pstride) : base + (int64_t)p * elems;
+    };
     if (threadIdx.x == 0) {
         int s = 0;
         for (int p = 0; p < n_parts; ++p) {
-            int c = in_n[p * nq + q];
+            int c = part(in_n, p, nq)[q];
             s += c < 0 ? 0 : (c > k ? k : c);
         }
         n_valid = s;
     }
     for (int i = threadIdx.x; i < P; i += SCAN_THREADS) {
-        uint64_t h = 0; uint32_t l = 0;
+        uint64_t h = 0; uint32_t l = 0; int32_t v = -1;
         if (i < total) {
             const int p = i / k, r = i % k;
-            int c = in_n[p * nq + q];
+            int c = part(in_n, p, nq)[q];
             if (r < c) {
-                const int64_t off = ((int64_t)p * nq + q) * k + r;
-                const T s = in_score[off];
-                if (msr_valid(s)) { h = ScoreTraits<T>::ord(s); l = ~(uint32_t)in_doc[off]; }
+                const int64_t off = (int64_t)q * k + r;
+                const T s = part(in_score, p, (int64_t)nq * k)[off];
+                if (msr_valid(s)) {
+                    h = ScoreTraits<T>::ord(s);
+                    l = ~(uint32_t)part(in_doc, p, (int64_t)nq * k)[off];
+                    if (in_pay) v = part(in_pay, p, (int64_t)nq * k)[off];
+                }
             }
         }
         khi[i] = h; klo[i] = l;
+        if (in_pay) pay[i] = v;
     }
     __syncthreads();
-    bitonic_desc<SCAN_THREADS>(khi, klo, P);
+    if (in_pay) bitonic_desc_pay<SCAN_THREADS>(khi, klo, pay, P);
+    else bitonic_desc<SCAN_THREADS>(khi, klo, P);
     const int n_sel = n_valid < k ? n_valid : k;
     for (int i = threadIdx.x; i < k; i += SCAN_THREADS) {
         const bool ok = i < n_sel && !(khi[i] == 0 && klo[i] == 0);
         out_doc[(int64_t)q * k + i] = ok ? (int32_t)~klo[i] : -1;
         out_score[(int64_t)q * k + i] = ok ? ScoreTraits<T>::unord(khi[i]) : ScoreTraits<T>::neg_inf();
+        if (out_pay) out_pay[(int64_t)q * k + i] = ok && in_pay ? pay[i] : -1;
     }
     if (threadIdx.x == 0) out_n[q] = n_sel;
 }
@@ -478,23 +514,23 @@ hipError_t msr_select_topk_list(const double* scores, const int32_t* idx, const 
 }
 
 hipError_t msr_merge_lists(int score_bits, const int32_t* in_doc, const void* in_score, const int32_t* in_n,
-                           int n_parts, int nq, int k, int32_t* out_doc, void* out_score, int32_t* out_n,
-                           hipStream_t stream) {
+                           const int32_t* in_pay, int n_parts, int64_t part_stride_bytes, int nq, int k, int32_t* out_doc,
+                           void* out_score, int32_t* out_n, int32_t* out_pay, hipStream_t stream) {
     const int total = n_parts * k;
     int P = 64;
     while (P < total) P <<= 1;
-    const size_t lds = (size_t)P * 12;
+    const size_t lds = (size_t)P * (in_pay ? 16 : 12);
     if (lds > 150 * 1024) return hipErrorInvalidValue;
     if (score_bits == 32) {
         if (lds > 48 * 1024)
             (void)hipFuncSetAttribute((const void*)merge_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        merge_kernel<float><<<nq, SCAN_THREADS, lds, stream>>>(in_doc, (const float*)in_score, in_n, n_parts, nq, k,
-                                                               out_doc, (float*)out_score, out_n);
+        merge_kernel<float><<<nq, SCAN_THREADS, lds, stream>>>(in_doc, (const float*)in_score, in_n, in_pay, n_parts,
+                                                               part_stride_bytes, nq, k, out_doc, (float*)out_score, out_n, out_pay);
     } else {
         if (lds > 48 * 1024)
             (void)hipFuncSetAttribute((const void*)merge_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        merge_kernel<double><<<nq, SCAN_THREADS, lds, stream>>>(in_doc, (const double*)in_score, in_n, n_parts, nq, k,
-                                                                out_doc, (double*)out_score, out_n);
+        merge_kernel<double><<<nq, SCAN_THREADS, lds, stream>>>(in_doc, (const double*)in_score, in_n, in_pay, n_parts,
+                                                                part_stride_bytes, nq, k, out_doc, (double*)out_score, out_n, out_pay);
     }
     return hipGetLastError();
 }

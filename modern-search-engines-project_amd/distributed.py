@@ -5,8 +5,10 @@ CorpusIndex.shard).  Global statistics (idf, avgdl) are replicated, so a shard's
 to the unsharded ones.  Per query batch:
 
   1. every rank: BM25 top-k1 and dense top-k2 over its shard                 (msr_bm25_topk / msr_dense_topk)
-  2. ONE all-gather of the packed per-shard lists (k1*(4+8) + k2*(4+4+4) bytes per query)
-  3. every rank: the same deterministic merge (score desc, doc index asc)    (msr_merge_topk)
+  2. ONE all-gather of the packed per-shard lists (k1*(4+8) + k2*(4+4+4) bytes per query), send and receive buffers
+     allocated once per batch shape
+  3. every rank: the same deterministic merge (score desc, doc index asc), reading the gathered records in place; the
+     arg-max chunk row of a dense entry rides along as the merge payload          (msr_merge_topk_payload)
   4. reference-exact rerank of the GLOBAL stage-1 candidates: each rank computes the cosines of the
      candidates it owns (msr_rerank_gather), one all-reduce (integer SUM over the raw bits: exactly one rank
      contributes non-zero bits per candidate, so the sum is a select), and every rank runs the float64 chain (msr_rerank_fuse).
@@ -18,10 +20,46 @@ import torch
 import torch.distributed as dist
 
 
+_SEGS = (("b_doc", torch.int32, "k1"), ("b_score", torch.float64, "k1"), ("b_n", torch.int32, None),
+         ("d_doc", torch.int32, "k2"), ("d_score", torch.float32, "k2"), ("d_chunk", torch.int32, "k2"),
+         ("d_n", torch.int32, None))
+
+
+class _Exchange:
+    """The record one rank contributes to the all-gather -- [b_doc | b_score | b_n | d_doc | d_score | d_chunk | d_n], every
+    segment 8-byte aligned -- and the receive buffer [world][record], allocated ONCE per (Q, k1, k2, device).  The merge
+    kernels read the gathered segments in place (msr_merge_topk_payload with part_stride_bytes = len(record))."""
+
+    def __init__(self, world, Q, k1, k2, device):
+        self.off, o = {}, 0
+        for name, dt, kk in _SEGS:
+            n = Q * (k1 if kk == "k1" else k2 if kk == "k2" else 1)
+            self.off[name] = (o, n, dt)
+            o += (n * torch.empty(0, dtype=dt).element_size() + 7) // 8 * 8
+        self.record = o
+        self.world, self.Q, self.k1, self.k2 = world, Q, k1, k2
+        self.send = torch.zeros(o, dtype=torch.uint8, device=device)
+        self.recv = torch.zeros(world * o, dtype=torch.uint8, device=device) if world > 1 else self.send
+        self.rerank = {}                                  # M -> int32 buffer of the all-reduce
+
+    def _view(self, buf, base, name):
+        o, n, dt = self.off[name]
+        es = torch.empty(0, dtype=dt).element_size()
+        v = buf[base + o: base + o + n * es].view(dt)
+        kk = dict((a, c) for a, _, c in _SEGS)[name]
+        return v.view(self.Q, self.k1 if kk == "k1" else self.k2) if kk else v
+
+    def out(self, name):                                  # this rank's segment (the kernels write their results here)
+        return self._view(self.send, 0, name)
+
+    def part(self, g, name):                              # rank g's segment of the gathered buffer
+        return self._view(self.recv, g * self.record, name)
+
+
 class ShardedEngine:
-    """`engine` is a DeviceEngine bound to this rank's shard (or any object with the same five methods:
-    bm25_topk, dense_topk, merge_topk, rerank_gather, rerank_fuse -- the CPU tests pass an oracle-backed
-    stand-in to exercise the exchange logic under gloo)."""
+    """`engine` is a DeviceEngine bound to this rank's shard (or any object with the same methods: bm25_topk, dense_topk,
+    merge_gathered, rerank_gather, rerank_fuse -- the CPU tests pass an oracle-backed stand-in to exercise the exchange
+    logic under gloo)."""
 
     def __init__(self, engine, doc_base, row_base, group=None):
         self.engine = engine
@@ -30,21 +68,26 @@ class ShardedEngine:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self._ex = {}
 
     # ------------------------------------------------------------------ exchange helpers
+    def _exchange(self, Q, k1, k2, device):
+        key = (Q, k1, k2, str(device), self.world)
+        if key not in self._ex:
+            self._ex[key] = _Exchange(self.world, Q, k1, k2, device)
+        return self._ex[key]
+
     def _allgather_bytes(self, parts):
-        """parts: list of tensors -> list (per rank) of lists of tensors with the same shapes/dtypes.
-        One collective: everything is packed into a single byte buffer (8-byte aligned segments, so the
-        float64 scores can be viewed in place on the receiving side)."""
-        segs, sizes = [], []
-        for p in parts:
-            b = p.contiguous().view(torch.uint8).reshape(-1)
-            pad = (-b.numel()) % 8
-            if pad:
-                b = torch.cat([b, torch.zeros(pad, dtype=torch.uint8, device=b.device)])
-            segs.append(b)
-            sizes.append(b.numel())
-        flat = torch.cat(segs)
+        """parts: list of tensors -> list (per rank) of lists of tensors with the same shapes/dtypes.  One collective:
+        everything is packed into a single byte buffer (8-byte aligned segments).  General-purpose helper (bench.py's
+        single-stage workloads, tests); the hot path (search) uses the preallocated _Exchange instead."""
+        sizes = [(p.numel() * p.element_size() + 7) // 8 * 8 for p in parts]
+        flat = torch.zeros(sum(sizes), dtype=torch.uint8, device=parts[0].device)
+        o = 0
+        for p, sz in zip(parts, sizes):
+            nb = p.numel() * p.element_size()
+            flat[o:o + nb].copy_(p.contiguous().view(torch.uint8).reshape(-1))
+            o += sz
         out = torch.empty(self.world * flat.numel(), dtype=torch.uint8, device=flat.device)
         dist.all_gather_into_tensor(out, flat, group=self.group)
         out = out.view(self.world, flat.numel())
@@ -62,6 +105,13 @@ class ShardedEngine:
     def _globalise(idx, base):
         return idx if base == 0 else torch.where(idx >= 0, idx + base, idx)
 
+    @staticmethod
+    def _globalise_into(dst, idx, base):
+        if base == 0:
+            dst.copy_(idx)
+        else:
+            torch.where(idx >= 0, idx + base, idx, out=dst)
+
     # ------------------------------------------------------------------ the sharded hot path
     def search(self, term_lists, qvec, k1=1000, k2=100, min_score=0.0, max_chunks_per_doc=0, rerank=True,
                packed=None, dense_batched=False, **rerank_params):
@@ -69,31 +119,41 @@ class ShardedEngine:
         b_doc, b_score, b_n = e.bm25_topk(term_lists, k=k1, min_score=min_score, packed=packed)
         dense = e.dense_topk_batched if dense_batched else e.dense_topk
         d_doc, d_score, d_chunk, d_n = dense(qvec, k=k2, max_chunks_per_doc=max_chunks_per_doc)
-        b_doc = self._globalise(b_doc, self.doc_base)
-        d_doc = self._globalise(d_doc, self.doc_base)
-        d_chunk = self._globalise(d_chunk, self.row_base)
         if self.world > 1:
-            parts = self._allgather_bytes([b_doc, b_score, b_n, d_doc, d_score, d_chunk, d_n])
-            stack = lambda j: torch.stack([p[j] for p in parts])
-            b_doc, b_score, b_n = e.merge_topk(stack(0), stack(1), stack(2), k1)
-            g_doc, g_score, g_chunk, g_n = stack(3), stack(4), stack(5), stack(6)
-            d_doc, d_score, d_n = e.merge_topk(g_doc, g_score, g_n, k2)
-            # the arg-max chunk travels with its document: look it up among the gathered lists
-            flat_doc = g_doc.permute(1, 0, 2).reshape(g_doc.shape[1], -1)
-            flat_chunk = g_chunk.permute(1, 0, 2).reshape(g_doc.shape[1], -1)
-            hit = (flat_doc.unsqueeze(1) == d_doc.unsqueeze(2)) & (d_doc.unsqueeze(2) >= 0)
-            pos = hit.to(torch.int8).argmax(dim=2)
-            d_chunk = torch.where(d_doc >= 0, torch.gather(flat_chunk, 1, pos), torch.full_like(d_doc, -1))
+            Q = int(b_doc.shape[0])
+            ex = self._exchange(Q, k1, k2, b_doc.device)
+            # this rank's record: local indices -> global, written straight into the preallocated send buffer
+            self._globalise_into(ex.out("b_doc"), b_doc, self.doc_base)
+            ex.out("b_score").copy_(b_score)
+            ex.out("b_n").copy_(b_n)
+            self._globalise_into(ex.out("d_doc"), d_doc, self.doc_base)
+            ex.out("d_score").copy_(d_score)
+            self._globalise_into(ex.out("d_chunk"), d_chunk, self.row_base)
+            ex.out("d_n").copy_(d_n)
+            dist.all_gather_into_tensor(ex.recv, ex.send, group=self.group)          # THE collective of stage 1 + 2
+            # identical deterministic merge on every rank, reading the gathered records in place; the arg-max chunk of a
+            # dense entry travels with it as the merge payload
+            b_doc, b_score, b_n, _ = e.merge_gathered(ex, "b_doc", "b_score", "b_n", None, k1)
+            d_doc, d_score, d_n, d_chunk = e.merge_gathered(ex, "d_doc", "d_score", "d_n", "d_chunk", k2)
+        else:
+            b_doc = self._globalise(b_doc, self.doc_base)
+            d_doc = self._globalise(d_doc, self.doc_base)
+            d_chunk = self._globalise(d_chunk, self.row_base)
         out = dict(bm25=(b_doc, b_score, b_n), dense=(d_doc, d_score, d_chunk, d_n))
         if rerank:
             cos, meta = e.rerank_gather(qvec, b_doc, b_n, doc_base=self.doc_base, row_base=self.row_base,
                                         max_chunks=rerank_params.get("max_chunks", 10))
             if self.world > 1:
-                buf = torch.cat([cos.view(torch.int32).reshape(-1), meta.reshape(-1)])
+                nc, nm = cos.numel(), meta.numel()
+                buf = ex.rerank.get((nc, nm))
+                if buf is None:
+                    buf = ex.rerank[(nc, nm)] = torch.empty(nc + nm, dtype=torch.int32, device=cos.device)
+                buf[:nc].copy_(cos.view(torch.int32).reshape(-1))
+                buf[nc:].copy_(meta.reshape(-1))
                 # integer SUM of the raw bits: exactly one rank holds non-zero bits per word, so the sum IS that word
                 # (RCCL/NCCL has no bitwise reduce op; float SUM would also be exact here but -0.0 + 0.0 is not)
                 dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
-                cos = buf[:cos.numel()].view(torch.float32).reshape(cos.shape)
-                meta = buf[cos.numel():].reshape(meta.shape)
+                cos = buf[:nc].view(torch.float32).reshape(cos.shape)
+                meta = buf[nc:].reshape(meta.shape)
             out["rerank"] = e.rerank_fuse(b_doc, b_score, b_n, cos, meta, **rerank_params)
         return out

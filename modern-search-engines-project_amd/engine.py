@@ -285,6 +285,21 @@ class DeviceEngine:
                                             _ptr(out_n), self._stream()))
         return out_doc, out_score, out_n
 
+    def merge_gathered(self, ex, doc, score, n, payload, k):
+        """Merge the `world` records of an all-gather IN PLACE (distributed._Exchange): the kernel reads segment `doc` /
+        `score` / `n` (/ `payload`) of every rank's record through a byte stride.  -> (doc, score, n, payload | None)."""
+        sc0 = ex.part(0, score)
+        Q = ex.Q
+        bits = 64 if sc0.dtype == torch.float64 else 32
+        out_doc = torch.empty((Q, k), dtype=torch.int32, device=self.device)
+        out_score = torch.empty((Q, k), dtype=sc0.dtype, device=self.device)
+        out_n = torch.empty((Q,), dtype=torch.int32, device=self.device)
+        out_pay = torch.empty((Q, k), dtype=torch.int32, device=self.device) if payload else None
+        self._check(self.lib.msr_merge_topk_payload(
+            self.handle, _ptr(ex.part(0, doc)), _ptr(sc0), _ptr(ex.part(0, n)), _ptr(ex.part(0, payload)) if payload else _ptr(None),
+            ex.world, ex.record, Q, k, bits, _ptr(out_doc), _ptr(out_score), _ptr(out_n), _ptr(out_pay), self._stream()))
+        return out_doc, out_score, out_n, out_pay
+
     # ------------------------------------------------------------------ timing hooks (bench.py)
     def set_timing(self, on):
         self._check(self.lib.msr_set_timing(self.handle, 1 if on else 0))

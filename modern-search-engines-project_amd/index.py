@@ -167,7 +167,7 @@ class CorpusIndex:
     # ------------------------------------------------------------------ snapshot directory (memory-mappable)
     _ARRAYS = ("doc_ids", "doc_len", "term_off", "post_doc", "post_tf", "idf", "doc_off", "chunk_ids", "emb")
 
-    def save_dir(self, path, block_rows=1 << 18):
+    def save_dir(self, path, block_rows=1 << 18, skip=()):
         """Export format for the reference's tables: one little-endian `.npy` per array + `meta.json`
         (+ `docs.jsonl` with url / title / text per document when present).  Every array is written through a
         memory map in blocks, so a 15 GB embedding matrix that lives on the GPU is never held twice on the host.
@@ -182,6 +182,8 @@ class CorpusIndex:
             if a is None:
                 continue
             present.append(name)
+            if name in skip:                                   # already written in place (from_duckdb(snapshot_dir=...))
+                continue
             shape = tuple(int(x) for x in a.shape)
             dt = np.dtype(str(a.dtype).replace("torch.", "")) if hasattr(a, "detach") else np.asarray(a[:0]).dtype
             out = np.lib.format.open_memmap(os.path.join(path, name + ".npy"), mode="w+", dtype=dt, shape=shape)
@@ -235,12 +237,18 @@ class CorpusIndex:
 
     # ------------------------------------------------------------------ DuckDB (the reference's store)
     @staticmethod
-    def from_duckdb(db_path, with_text=True, connect=None):
-        """Read the reference's tables once.  `duckdb` is not installable in the build container: the loader is written
-        against the DDL cited in the module docstring and is exercised there through `connect`, a callable that returns
-        a DuckDB-style connection (`.execute(sql).fetchall()` / `.fetchnumpy()`); tests/test_host_logic.py passes a
-        sqlite3 adapter over tables created with the reference's own column names.  Default: duckdb, read-only
-        (search_api.py:32,48)."""
+    def from_duckdb(db_path, with_text=True, connect=None, snapshot_dir=None, block_docs=1 << 16):
+        """Read the reference's tables ONCE into contiguous arrays, column-wise (no per-row Python work on the big tables):
+          * postings: the term -> id join and both orderings happen in SQL, the three numeric columns come back through
+            fetchnumpy(); document ids are mapped to dense indices with one np.searchsorted; CSR offsets with np.bincount;
+          * embeddings: fetched block-wise by document-id range (the reference's idx on chunks_optimized.doc_id serves it)
+            and written straight into the destination matrix -- a `.npy` memory map under `snapshot_dir` when given, so a
+            15 GB matrix is never held as Python lists and the snapshot (save_dir format) is complete when this returns.
+        `duckdb` is not installable in the build container: the loader is written against the DDL cited in the module
+        docstring and is exercised there through `connect`, a callable that returns a DuckDB-style connection
+        (`.execute(sql, params).fetchall()` / `.fetchnumpy()`); tests/test_host_logic.py passes a sqlite3 adapter over
+        tables created with the reference's own column names.  Default: duckdb, read-only (search_api.py:32,48)."""
+        import os
         if connect is None:
             import duckdb  # noqa: deliberately unguarded: fails loudly where duckdb is absent
             con = duckdb.connect(db_path, read_only=True)
@@ -248,41 +256,73 @@ class CorpusIndex:
             con = connect(db_path)
         docs = con.execute("SELECT doc_id, doc_length FROM bm25_doc_stats ORDER BY doc_id").fetchnumpy()
         stats = dict(con.execute("SELECT stat_name, stat_value FROM bm25_corpus_stats").fetchall())
-        terms = con.execute("SELECT term, idf_score FROM bm25_term_stats ORDER BY term").fetchall()
-        vocab = {t: i for i, (t, _) in enumerate(terms)}
-        url_rows = con.execute("SELECT id, url, title, text FROM urlsDB ORDER BY id").fetchall() if with_text else \
-            con.execute("SELECT id, url, title, NULL FROM urlsDB ORDER BY id").fetchall()
+        tcols = con.execute("SELECT term, idf_score FROM bm25_term_stats ORDER BY term").fetchnumpy()
+        term_names = [str(t) for t in np.asarray(tcols["term"]).tolist()]
+        vocab = {t: i for i, t in enumerate(term_names)}
+        idf_raw = np.ma.filled(np.ma.masked_invalid(np.ma.array(
+            [np.nan if v is None else v for v in np.asarray(tcols["idf_score"], dtype=object).tolist()], dtype=np.float64)), 0.0)
         ch = con.execute("SELECT c.chunk_id, c.doc_id FROM chunks_optimized c ORDER BY c.doc_id, c.chunk_id").fetchnumpy()
-        all_ids = np.union1d(np.union1d(docs["doc_id"].astype(np.int64), ch["doc_id"].astype(np.int64)),
-                             np.array([r[0] for r in url_rows], np.int64))
-        rank = {int(d): i for i, d in enumerate(all_ids)}
-        doc_len = np.zeros(len(all_ids), np.int32)
-        doc_len[[rank[int(d)] for d in docs["doc_id"]]] = docs["doc_length"].astype(np.int32)
-        tf = con.execute("SELECT tf.term, tf.doc_id, tf.freq FROM bm25_term_freq tf JOIN bm25_doc_stats ds "
-                         "ON tf.doc_id = ds.doc_id ORDER BY tf.term, tf.doc_id").fetchnumpy()
-        t_id = np.array([vocab.get(t, -1) for t in tf["term"]], np.int64)
-        keep = t_id >= 0
-        t_id, p_doc, p_tf = t_id[keep], tf["doc_id"][keep], tf["freq"][keep]
-        order = np.lexsort((p_doc, t_id))
-        t_id, p_doc, p_tf = t_id[order], p_doc[order], p_tf[order]
+        ch_doc = np.asarray(ch["doc_id"], np.int64)
+        url_ids = np.asarray(con.execute("SELECT id FROM urlsDB ORDER BY id").fetchnumpy()["id"], np.int64)
+        doc_stat_ids = np.asarray(docs["doc_id"], np.int64)
+        all_ids = np.union1d(np.union1d(doc_stat_ids, ch_doc), url_ids)
+        n_docs = len(all_ids)
+        doc_len = np.zeros(n_docs, np.int32)
+        doc_len[np.searchsorted(all_ids, doc_stat_ids)] = np.asarray(docs["doc_length"]).astype(np.int32)
+        # postings: (term rank, doc_id, freq) already in (term, doc) order; only documents with a doc_stats row (:443)
+        tf = con.execute(
+            "SELECT ts.rn AS term_id, tf.doc_id AS doc_id, tf.freq AS freq FROM bm25_term_freq tf "
+            "JOIN (SELECT term, ROW_NUMBER() OVER (ORDER BY term) - 1 AS rn FROM bm25_term_stats) ts ON tf.term = ts.term "
+            "JOIN bm25_doc_stats ds ON tf.doc_id = ds.doc_id ORDER BY ts.rn, tf.doc_id").fetchnumpy()
+        t_id = np.asarray(tf["term_id"], np.int64)
         term_off = np.zeros(len(vocab) + 1, np.int64)
         term_off[1:] = np.cumsum(np.bincount(t_id, minlength=len(vocab)))
-        emb_rows = con.execute("SELECT e.embedding FROM embeddings e JOIN chunks_optimized c ON e.chunk_id = c.chunk_id "
-                               "ORDER BY c.doc_id, c.chunk_id").fetchnumpy()["embedding"]
-        cnt = np.bincount(np.array([rank[int(d)] for d in ch["doc_id"]], np.int64), minlength=len(all_ids))
-        umap = {int(r[0]): r for r in url_rows}
-        ix = CorpusIndex(doc_ids=all_ids, doc_len=doc_len, term_off=term_off,
-                         post_doc=np.array([rank[int(d)] for d in p_doc], np.int32), post_tf=p_tf.astype(np.int32),
-                         idf=np.array([0.0 if v is None else v for _, v in terms], np.float32),
+        post_doc = np.searchsorted(all_ids, np.asarray(tf["doc_id"], np.int64)).astype(np.int32)
+        post_tf = np.asarray(tf["freq"]).astype(np.int32)
+        del tf, t_id
+        # chunk layout
+        ch_rank = np.searchsorted(all_ids, ch_doc)
+        cnt = np.bincount(ch_rank, minlength=n_docs)
+        doc_off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+        n_chunks = int(doc_off[-1])
+        # embeddings, block by block of documents, straight into the destination
+        if snapshot_dir is not None:
+            os.makedirs(snapshot_dir, exist_ok=True)
+            emb = np.lib.format.open_memmap(os.path.join(snapshot_dir, "emb.npy"), mode="w+", dtype=np.float32, shape=(n_chunks, DIM))
+        else:
+            emb = np.empty((n_chunks, DIM), np.float32)
+        for b0 in range(0, n_docs, block_docs):
+            b1 = min(n_docs, b0 + block_docs)
+            r0, r1 = int(doc_off[b0]), int(doc_off[b1])
+            if r1 == r0:
+                continue
+            col = con.execute(
+                "SELECT e.embedding AS embedding FROM embeddings e JOIN chunks_optimized c ON e.chunk_id = c.chunk_id "
+                "WHERE c.doc_id >= ? AND c.doc_id <= ? ORDER BY c.doc_id, c.chunk_id",
+                (int(all_ids[b0]), int(all_ids[b1 - 1]))).fetchnumpy()["embedding"]
+            block = np.asarray(col)
+            if block.dtype == object:                             # one array per row (LIST / ARRAY columns)
+                block = np.stack(block.tolist()) if len(block) else np.zeros((0, DIM), np.float32)
+            if block.shape != (r1 - r0, DIM):
+                raise ValueError(f"embeddings of documents {all_ids[b0]}..{all_ids[b1 - 1]}: got {block.shape}, chunk table says {(r1 - r0, DIM)}")
+            emb[r0:r1] = block.astype(np.float32, copy=False)
+        # urlsDB text columns: python strings by nature; one pass, positions by searchsorted
+        url_rows = con.execute("SELECT id, url, title, text FROM urlsDB ORDER BY id").fetchall() if with_text else \
+            con.execute("SELECT id, url, title, NULL FROM urlsDB ORDER BY id").fetchall()
+        urls, titles, texts = [None] * n_docs, [None] * n_docs, [None] * n_docs
+        pos = np.searchsorted(all_ids, np.fromiter((r[0] for r in url_rows), np.int64, len(url_rows)))
+        for p, r in zip(pos.tolist(), url_rows):
+            urls[p], titles[p], texts[p] = r[1], r[2], r[3]
+        ix = CorpusIndex(doc_ids=all_ids, doc_len=doc_len, term_off=term_off, post_doc=post_doc, post_tf=post_tf,
+                         idf=idf_raw.astype(np.float32),                       # NULL -> 0.0 (:426)
                          avgdl=float(np.float32(stats.get("avg_doc_length", 1.0))),
-                         total_docs=int(stats.get("total_docs", len(docs["doc_id"]))), vocab=vocab,
-                         doc_off=np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32),
-                         chunk_ids=ch["chunk_id"].astype(np.int64),
-                         emb=np.stack([np.asarray(v, np.float32) for v in emb_rows]) if len(emb_rows) else np.zeros((0, DIM), np.float32),
-                         urls=[umap[int(d)][1] if int(d) in umap else None for d in all_ids],
-                         titles=[umap[int(d)][2] if int(d) in umap else None for d in all_ids],
-                         texts=[umap[int(d)][3] if int(d) in umap else None for d in all_ids])
+                         total_docs=int(stats.get("total_docs", len(doc_stat_ids))), vocab=vocab,
+                         doc_off=doc_off, chunk_ids=np.asarray(ch["chunk_id"], np.int64), emb=emb,
+                         urls=urls, titles=titles, texts=texts)
         ix.n_docs_global = ix.n_docs
+        if snapshot_dir is not None:
+            emb.flush()
+            ix.save_dir(snapshot_dir, skip=("emb",))              # the matrix is already in place
         return ix
 
     # ------------------------------------------------------------------ doc-range sharding

@@ -159,6 +159,46 @@ def rerank(urls, chunk_id, chunk_doc, emb, qvec, doc_ids, similarities, smoothin
     return (resp, stages) if return_stages else resp
 
 
+def rerank_chain_pandas(chunk_rows, qvec, doc_ids, similarities, smoothing=0.15, batch_size=32):
+    """The /rerank arithmetic in the reference's OWN shape -- a pandas DataFrame of chunk rows, a merge with the BM25
+    scores, iterrows() feeding 32-row cosine batches, Python-list min-max, groupby().apply() for the positional weight,
+    groupby().idxmax() and sort_values() (reranker_api.py:357-372, with :273-334) -- restated, not imported.  Used as the
+    'literal' CPU baseline and cross-checked against rerank() above.
+    chunk_rows: list of (doc_id, chunk_id, embedding[768]) for the candidates' first <= 10 chunks.
+    -> list of (doc_id, chunk_id, new_similarity, old_similarity) sorted by new_similarity descending."""
+    import pandas as pd
+    df = pd.DataFrame({"doc_id": [int(r[0]) for r in chunk_rows], "chunk_id": [int(r[1]) for r in chunk_rows],
+                       "embedding": [r[2] for r in chunk_rows]})
+    sim_df = pd.DataFrame({"doc_id": [int(d) for d in doc_ids], "old_similarity": [float(x) for x in similarities]})
+    df = df.merge(sim_df, on="doc_id", how="left")                                  # :357
+    sims, batch = [], []
+    for _, row in df.iterrows():                                                    # :273-287
+        batch.append(np.array(row["embedding"]))
+        if len(batch) == batch_size:
+            sims.extend(cosine_f32(qvec, np.array(batch)).tolist())
+            batch = []
+    if batch:
+        sims.extend(cosine_f32(qvec, np.array(batch)).tolist())
+    df["new_similarity"] = normalise(sims)                                          # :358-360
+    df["old_similarity"] = normalise(df["old_similarity"].tolist())                 # :361
+    df["new_similarity"] = df["new_similarity"] * (1 - smoothing) + df["old_similarity"] * smoothing   # :362
+
+    def weigh(group):                                                               # :299-334
+        if len(group) == 1:
+            return group
+        group = group.sort_values("chunk_id").reset_index(drop=True)
+        best = int(group["new_similarity"].idxmax())
+        ratio = best / max(1, len(group) - 1)
+        adj = MAX_BOOST - (MAX_BOOST + MAX_DECAY) * ratio
+        group.loc[best, "new_similarity"] = float(np.clip(group.loc[best, "new_similarity"] + adj, 0.0, 1.0))
+        return group
+
+    df = pd.concat([weigh(g) for _, g in df.groupby("doc_id", sort=True)], ignore_index=True)   # :367 (groupby.apply)
+    best = df.loc[df.groupby("doc_id")["new_similarity"].idxmax()]                  # :370
+    best = best.sort_values(["new_similarity", "doc_id"], ascending=[False, True])  # :372 (ties: this build's doc order)
+    return [(int(r.doc_id), int(r.chunk_id), float(r.new_similarity), float(r.old_similarity)) for r in best.itertuples()]
+
+
 def create_sliding_windows(tokens, window_size, step_size):
     """reranker_api.py:239-260 (identical copy at indexer/embedder.py:65-87)."""
     if len(tokens) <= window_size:

@@ -46,6 +46,25 @@ class OracleEngine:
             od[q, :len(a)], os_[q, :len(a)], on[q] = a, b, len(a)
         return torch.as_tensor(od), torch.as_tensor(os_), torch.as_tensor(on)
 
+    def merge_gathered(self, ex, doc, score, n, payload, k):
+        """Stand-in for DeviceEngine.merge_gathered: same in-place reading of the gathered records, merge by the oracle,
+        payload looked up from the merged (doc, part) -- documents are owned by exactly one shard."""
+        G, Q = ex.world, ex.Q
+        docs = np.stack([_np(ex.part(g, doc)) for g in range(G)])
+        scores = np.stack([_np(ex.part(g, score)) for g in range(G)])
+        ns = np.stack([_np(ex.part(g, n)) for g in range(G)])
+        od, os_, on = [_np(x) for x in self.merge_topk(docs, scores, ns, k)]
+        op = None
+        if payload:
+            pays = np.stack([_np(ex.part(g, payload)) for g in range(G)])
+            op = np.full((Q, k), -1, np.int32)
+            for q in range(Q):
+                look = {int(docs[g, q, r]): int(pays[g, q, r]) for g in range(G) for r in range(ns[g, q])}
+                for r in range(on[q]):
+                    op[q, r] = look[int(od[q, r])]
+            op = torch.as_tensor(op)
+        return torch.as_tensor(od), torch.as_tensor(os_), torch.as_tensor(on), op
+
     def rerank_gather(self, qvec, cand_doc_global, cand_n, doc_base=0, row_base=0, max_chunks=10):
         q, cand, cn = _np(qvec), _np(cand_doc_global), _np(cand_n)
         Q, M = cand.shape

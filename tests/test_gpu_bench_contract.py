@@ -39,6 +39,9 @@ def test_default_line_has_the_contract_fields():
     assert r["bm25_taat"]["launches"] == 3
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "queries/sec" and c["sample"]
+    for leg in ("port", "vectorised", "literal"):          # three legs, p50 per query, cores stated
+        assert c[leg]["p50_ms"] > 0 and c[leg]["value"] > 0 and c[leg]["cores"] >= 1 and c[leg]["queries"] == 2, leg
+    assert c["literal"]["cores"] == 1 and c["p50_ms"] == c["port"]["p50_ms"]
     v = d["variant_bf16_candidates"]
     assert v["value"] > 0 and v["top100_equals_default_path_within_2e-6"] is True
 

@@ -184,3 +184,48 @@ def test_dense_quick_search_matches_bruteforce():
         assert idx.tolist() == [b[1] for b in brute[:20]]
         assert arg.tolist() == [b[2] for b in brute[:20]]
         assert np.all(np.diff(sc) <= 0)
+
+
+def test_pandas_shaped_chain_equals_the_restatement():
+    """rerank_chain_pandas (the reference's DataFrame / iterrows / groupby shape, used as the literal CPU baseline) gives
+    the pooled stage of rerank(), which is pinned to the reference's own stage outputs above."""
+    for c in _load("rerank_chain.json")["cases"]:
+        urls, cid, cdoc, emb, q = _case_tables(c)
+        resp, st = rerank_ref.rerank(urls, cid, cdoc, emb, q, c["doc_ids"], c["similarities"], return_stages=True,
+                                     diversification=False, top_k=10 ** 6)
+        kept, rows = rerank_ref.fetch_candidates(urls, cid, cdoc, [int(d) for d in c["doc_ids"]])
+        old_of = {}
+        for d, s_ in zip(c["doc_ids"], c["similarities"]):
+            old_of.setdefault(int(d), float(s_))
+        kept = [d for d in kept if d in old_of]
+        chunk_rows = [(d, int(cid[r]), emb[r]) for d in kept for r in rows[d]]
+        lit = rerank_ref.rerank_chain_pandas(chunk_rows, q, [int(d) for d in c["doc_ids"]], c["similarities"])
+        pooled = st["pooled"]
+        assert [x[0] for x in lit] == [x[0] for x in pooled] and [x[1] for x in lit] == [x[1] for x in pooled]
+        assert max(abs(a[2] - b[2]) for a, b in zip(lit, pooled)) < 1e-12
+
+
+def test_c_port_equals_the_numpy_restatement():
+    """oracle/orc_*.c (the C port timed as cpu_baseline) against the numpy restatement that the goldens pin: BM25 bitwise --
+    on a corpus large enough for the OpenMP path (one document range per thread), with every thread count -- and the
+    dense top-k within float32 rounding."""
+    from msretr.synthetic import synthetic_corpus, synthetic_queries
+    from oracle import c_oracle, dense_ref
+    ix = synthetic_corpus(70000, n_chunks=0, n_terms=30000, seed=31)
+    terms, _ = synthetic_queries(ix, 6, seed=32)
+    z = {k: np.ascontiguousarray(getattr(ix, k).numpy()) for k in ("term_off", "post_doc", "post_tf", "doc_len", "idf")}
+    z["avgdl"] = ix.avgdl
+    for threads in (1, 3, 8):
+        c_oracle.set_threads(threads)
+        for t in terms:
+            ut, qtf = bm25_ref.prepare_query(t, z["term_off"])
+            a, b = c_oracle.bm25_topk(z, ut, qtf, 1000, 0.0, ix.k1, ix.b)
+            oi, os_ = bm25_ref.topk(z, t, 1000)
+            assert a.tolist() == oi.tolist() and b.tolist() == os_.tolist()
+    small = synthetic_corpus(3000, n_chunks=14000, n_terms=500, seed=33)
+    _, qv = synthetic_queries(small, 3, seed=34)
+    emb, off = small.emb.numpy(), small.doc_off.numpy()
+    for i in range(3):
+        a, b, c_ = c_oracle.dense_topk(emb, off, qv[i].numpy(), 50)
+        oi, os_, oc = dense_ref.quick_search(emb, off, qv[i].numpy(), 50)
+        assert np.abs(b - os_).max() <= 2e-6 and (a == oi).mean() > 0.95

@@ -26,15 +26,20 @@ def _corpus():
     return ix, terms, qvec
 
 
-def _run(rank, world, port, ret):
+def _run(rank, world, port, ret, snap_dir=None):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from msretr.distributed import ShardedEngine
+        from msretr.index import CorpusIndex
         from oracle_engine import OracleEngine
         ix, terms, qvec = _corpus()
         sh = ix.shard(rank, world)
+        if snap_dir:                                  # every rank serves its shard from a snapshot it reloaded
+            d = os.path.join(snap_dir, f"shard{rank}")
+            sh.save_dir(d)
+            sh = CorpusIndex.load_dir(d, mmap=False)
         se = ShardedEngine(OracleEngine(sh), sh.doc_base, sh.row_base)
         assert se.world == world and se.rank == rank
         out = se.search([sh.term_ids(t) for t in terms], qvec, k1=200, k2=50)
@@ -44,15 +49,19 @@ def _run(rank, world, port, ret):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_sharded_equals_unsharded():
+@pytest.mark.parametrize("via_snapshot", [False, True])
+def test_two_rank_sharded_equals_unsharded(via_snapshot, tmp_path):
+    """via_snapshot: the shards go through save_dir / load_dir first -- the URL groups must stay the corpus-wide ones
+    (a shard that renumbered them from its own URLs would dedup unrelated documents of different shards against each
+    other: round-1 advisor finding)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from msretr.distributed import ShardedEngine
     from oracle_engine import OracleEngine
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    port = 29500 + os.getpid() % 2000
-    mp.spawn(_run, args=(world, port, ret), nprocs=world, join=True)
+    port = 29500 + os.getpid() % 2000 + (7 if via_snapshot else 0)
+    mp.spawn(_run, args=(world, port, ret, str(tmp_path) if via_snapshot else None), nprocs=world, join=True)
     ix, terms, qvec = _corpus()
     ref = ShardedEngine(OracleEngine(ix), 0, 0).search([ix.term_ids(t) for t in terms], qvec, k1=200, k2=50)
     ref = {k: [x.numpy() for x in v] for k, v in ref.items()}

@@ -10,7 +10,12 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
+from msretr import _abi  # noqa: E402
+from msretr.build import build_library  # noqa: E402
 from msretr.engine import DeviceEngine  # noqa: E402
+
+if os.environ.get("MSR_DIAG_LIB"):       # timing experiments (--dbg) only exist in the -DMSR_DIAG build
+    _abi.LIB_PATH = build_library(diag=True)
 from msretr.synthetic import synthetic_corpus  # noqa: E402
 
 ap = argparse.ArgumentParser()
@@ -19,6 +24,7 @@ ap.add_argument("--chunks", type=int, default=1_000_000)
 ap.add_argument("--queries", type=int, default=128)
 ap.add_argument("--k", type=int, default=100)
 ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--dbg", type=int, default=0)
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 ix = synthetic_corpus(a.docs, n_chunks=a.chunks, device=dev, with_postings=False)
@@ -36,6 +42,8 @@ same = got[0] == ref[0]
 print(json.dumps({"n_equal": bool(torch.equal(got[3], ref[3])), "max_abs_score_diff": d_err, "doc_agreement": float(same.float().mean()),
                   "near_tie_only": bool((same | ((got[1] - ref[1]).abs() <= 2e-6)).all()),
                   "chunk_agreement": float(((got[2] == ref[2]) | ~same).float().mean())}), flush=True)
+if a.dbg:
+    e._check(e.lib.msr_tune(e.handle, 101, a.dbg))
 for name, fn in (("gemm_128", lambda: e.dense_topk(q, k=a.k)),
                  ("sweeps_2x64", lambda: [e.dense_topk(q[s:s + 64], k=a.k) for s in range(0, a.queries, 64)])):
     ts = []
