@@ -588,12 +588,13 @@ __global__ __launch_bounds__(1024) void gemm_cand_kernel(const int2* __restrict_
     __shared__ int s_heads, s_over;
     const int q = blockIdx.x, t = threadIdx.x;
     const int raw = pair_n[q];
-    if (t == 0) {
-        int over = raw > GM_PAIR_CAP || (flag && flag[q]);
-        for (int i = 0; i < n_wg && !over; ++i) over = wg_count[i] > wg_cap;
-        s_over = over;
-        s_heads = 0;
-    }
+    // (all threads scan the per-wave counts: one thread walking 2048 words with a data-dependent exit took 0.12 ms)
+    int over = raw > GM_PAIR_CAP || (flag && flag[q]);
+    for (int i = t; i < n_wg; i += 1024) over |= wg_count[i] > wg_cap;
+    if (t == 0) s_heads = 0;
+    s_over = 0;
+    __syncthreads();
+    if (over) s_over = 1;
     __syncthreads();
     if (s_over) {
         if (t == 0) { cand_n[q] = MSR_SEL_CAP + 1; pair_n[q] = 0; }

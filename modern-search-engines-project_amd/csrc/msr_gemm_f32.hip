@@ -369,12 +369,13 @@ __global__ __launch_bounds__(1024) void gemm_f32_final_kernel(const int2* __rest
     __shared__ int s_over, s_heads;
     const int q = blockIdx.x, t = threadIdx.x;
     const int raw = pair_n[q];
-    if (t == 0) {
-        int over = raw > GF_PAIR_CAP || flag[q];
-        for (int i = 0; i < n_waves && !over; ++i) over = wv_count[i] > wv_cap;
-        s_over = over;
-        s_heads = 0;
-    }
+    // (all threads scan the per-wave counts: one thread walking 2048 words with a data-dependent exit took 0.12 ms)
+    int over = raw > GF_PAIR_CAP || flag[q];
+    for (int i = t; i < n_waves; i += 1024) over |= wv_count[i] > wv_cap;
+    if (t == 0) s_heads = 0;
+    s_over = 0;
+    __syncthreads();
+    if (over) s_over = 1;
     __syncthreads();
     if (s_over) {
         for (int i = t; i < k; i += 1024) {

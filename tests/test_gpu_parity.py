@@ -786,3 +786,44 @@ def test_queries_txt_end_to_end_matches_oracle(mods, tmp_path):
         mism += a[2] != url
     assert mism <= 2                       # a near-tie may swap two neighbours
     rt.engine.close()
+
+
+def test_http_routes_on_the_gpu_retriever(mods, tmp_path):
+    """server.py over a REAL Retriever (HIP kernels behind every route): /api/search shape, /api/batch_search and
+    /api/batch_search_file (search_api.py:204-367) produce the same lines as Retriever.batch_search_to_file, /rerank
+    returns the reranker's response for stage-1 output and 401 for unknown documents (reranker_api.py:348-349)."""
+    import importlib.util
+    from fastapi.testclient import TestClient
+    spec = importlib.util.spec_from_file_location("demo", os.path.join(os.path.dirname(__file__), "..", "examples", "run_queries_txt.py"))
+    demo = importlib.util.module_from_spec(spec); spec.loader.exec_module(demo)
+    from msretr.retriever import Retriever
+    from msretr.server import create_app
+    from msretr.text import simple_tokenize
+    ix = demo.synthetic_crawl(n_docs=1200)
+    rt = Retriever(embedder=demo.fake_encoder(), indexer=ix, tokenizer=simple_tokenize, max_queries=8, max_k=1000)
+    qf = tmp_path / "queries.txt"
+    qf.write_text("".join(f"{i + 1}\t{q}\n" for i, q in enumerate(demo.DEFAULT_QUERIES)), encoding="utf-8")
+    direct = tmp_path / "direct.txt"
+    n_direct = rt.batch_search_to_file(str(qf), str(direct))
+    out = tmp_path / "batch_search_results.txt"
+    c = TestClient(create_app(rt, queries_file=str(qf), results_file=str(out)))
+    r = c.post("/api/search", json={"query": demo.DEFAULT_QUERIES[0], "top_k": 1000, "query_id": "q1"})
+    assert r.status_code == 200
+    docs = r.json()["documents"]
+    assert 0 < len(docs) <= 100 and [d["rank"] for d in docs] == list(range(1, len(docs) + 1))
+    assert set(docs[0]) == {"query_id", "rank", "url", "score", "title", "snippet", "domain", "doc_id"}
+    assert all(docs[i]["score"] >= docs[i + 1]["score"] for i in range(len(docs) - 1))
+    b = c.post("/api/batch_search").json()
+    assert b["total_queries"] == len(demo.DEFAULT_QUERIES) and b["total_results"] == n_direct
+    f = c.post("/api/batch_search_file").json()
+    assert f["total_results"] == n_direct and f["output_file"] == str(out)
+    assert out.read_text(encoding="utf-8") == direct.read_text(encoding="utf-8")
+    assert [x["formatted_line"] for x in b["results"]] == direct.read_text(encoding="utf-8").splitlines()
+    s1 = rt.bm25.search(demo.DEFAULT_QUERIES[0] + " tübingen", top_k=50)
+    if s1:
+        rr = c.post("/rerank", json={"doc_ids": [str(x["doc_id"]) for x in s1], "similarities": [x["score"] for x in s1],
+                                      "query": demo.DEFAULT_QUERIES[0]})
+        assert rr.status_code == 200 and set(rr.json()) >= {"document_scores", "top_windows", "total_documents", "total_windows"}
+    assert c.post("/rerank", json={"doc_ids": ["999999999"], "similarities": [1.0], "query": "x"}).status_code == 401
+    assert c.get("/api/health").json() == {"status": "healthy", "search_engine_ready": True}
+    rt.engine.close()

@@ -316,3 +316,106 @@ def test_http_facade_shapes_and_status_codes():
     assert b["total_queries"] == 2 and b["results"][1]["formatted_line"] == "2\t1\tu\t0.500"
     assert c.get("/api/health").json()["status"] == "healthy"
     assert TestClient(create_app(FakeRetriever(), queries_file="/nonexistent")).post("/api/batch_search").status_code == 404
+    # /api/batch_search_file (search_api.py:331-367): same run, lines written to a file, errors passed through
+    out = f.name + ".results"
+    c2 = TestClient(create_app(FakeRetriever(), queries_file=f.name, results_file=out))
+    r = c2.post("/api/batch_search_file").json()
+    assert r["total_queries"] == 2 and r["total_results"] == 2 and r["output_file"] == out
+    assert r["format"] == "query_num<tab>rank<tab>url<tab>score per line"
+    assert open(out, encoding="utf-8").read() == "1\t1\tu\t0.500\n2\t1\tu\t0.500\n"
+    assert TestClient(create_app(FakeRetriever(), queries_file="/nonexistent")).post("/api/batch_search_file").status_code == 404
+    assert "api/search" in c.get("/").text
+
+
+def test_duckdb_loader_is_columnar_at_ten_million_postings(tmp_path):
+    """CorpusIndex.from_duckdb at >= 1e7 postings (round-1 finding: per-posting Python loops and np.stack of
+    every embedding cell could not stream the BASELINE shape).  The loader now pulls numeric columns only (the term -> id
+    join and both sort orders happen in SQL), maps documents with one searchsorted, and writes the embeddings block by
+    block straight into the snapshot's memory-mapped matrix; checked against the arrays the tables were generated from,
+    then the snapshot is reloaded.  Through a sqlite3 adapter (duckdb is not installable here)."""
+    import sqlite3
+    import time
+    from msretr.index import CorpusIndex
+    rng = np.random.default_rng(5)
+    N, V, per = 100_000, 50_000, 102
+    db = str(tmp_path / "big.sqlite")
+    con = sqlite3.connect(db)
+    con.executescript("""
+        PRAGMA journal_mode=OFF; PRAGMA synchronous=OFF;
+        CREATE TABLE bm25_doc_stats (doc_id INTEGER PRIMARY KEY, doc_length INTEGER);
+        CREATE TABLE bm25_term_freq (doc_id INTEGER, term TEXT, freq INTEGER, PRIMARY KEY (doc_id, term)) WITHOUT ROWID;
+        CREATE TABLE bm25_term_stats (term TEXT PRIMARY KEY, doc_freq INTEGER, total_freq INTEGER, idf_score REAL);
+        CREATE TABLE bm25_corpus_stats (stat_name TEXT PRIMARY KEY, stat_value REAL);
+        CREATE TABLE chunks_optimized (chunk_id BIGINT PRIMARY KEY, doc_id BIGINT, chunk_text TEXT);
+        CREATE TABLE embeddings (chunk_id BIGINT PRIMARY KEY, embedding BLOB);
+        CREATE TABLE urlsDB (id BIGINT PRIMARY KEY, url TEXT UNIQUE, title TEXT, text TEXT);
+    """)
+    doc_ids = np.cumsum(rng.integers(1, 4, size=N)) + 10
+    base, stride = rng.integers(0, V, size=N), rng.integers(1, 400, size=N) * 2 + 1
+    terms = np.sort((base[:, None] + np.arange(per)[None, :] * stride[:, None]) % V, axis=1)
+    keep = np.ones_like(terms, bool); keep[:, 1:] = terms[:, 1:] != terms[:, :-1]
+    dd, tt = np.repeat(doc_ids, per)[keep.ravel()], terms.ravel()[keep.ravel()]
+    ff = rng.integers(1, 5, size=len(dd))
+    assert len(dd) >= 10_000_000
+    names = np.array([f"t{v:05d}" for v in range(V)])
+    con.executemany("INSERT INTO bm25_term_freq VALUES (?,?,?)", zip(dd.tolist(), names[tt].tolist(), ff.tolist()))
+    dl = rng.integers(50, 500, size=N)
+    con.executemany("INSERT INTO bm25_doc_stats VALUES (?,?)", zip(doc_ids.tolist(), dl.tolist()))
+    df = np.bincount(tt, minlength=V)
+    idf = np.log10((N - df + 0.5) / (df + 0.5)).astype(np.float32)
+    con.executemany("INSERT INTO bm25_term_stats VALUES (?,?,?,?)",
+                    [(names[v], int(df[v]), int(df[v]), None if v % 997 == 0 else float(idf[v])) for v in range(V) if df[v] > 0])
+    con.executemany("INSERT INTO bm25_corpus_stats VALUES (?,?)", [("avg_doc_length", 275.5), ("total_docs", float(N))])
+    C = 5000
+    cd = np.sort(rng.choice(doc_ids, size=C))
+    emb = rng.standard_normal((C, 768)).astype(np.float32)
+    con.executemany("INSERT INTO chunks_optimized VALUES (?,?,?)", [(i, int(d), "") for i, d in enumerate(cd)])
+    con.executemany("INSERT INTO embeddings VALUES (?,?)", [(i, emb[i].tobytes()) for i in range(C)])
+    con.executemany("INSERT INTO urlsDB VALUES (?,?,?,?)", [(int(d), f"http://x/{int(d)}", "t", "x") for d in doc_ids[:2000]])
+    con.commit(); con.close()
+
+    class Cur:
+        def __init__(self, cur):
+            self.cur = cur
+
+        def fetchall(self):
+            return self.cur.fetchall()
+
+        def fetchnumpy(self):
+            rows = self.cur.fetchall()
+            out = {}
+            for i, d in enumerate(self.cur.description):
+                col = [r[i] for r in rows]
+                if d[0] == "embedding":
+                    arr = np.empty(len(col), dtype=object)
+                    arr[:] = [np.frombuffer(b, np.float32) for b in col]
+                    out[d[0]] = arr
+                else:
+                    out[d[0]] = np.array(col)
+            return out
+
+    class Conn:
+        def __init__(self, path):
+            self.con = sqlite3.connect(path)
+
+        def execute(self, sql, params=()):
+            return Cur(self.con.execute(sql, params))
+
+    snap = str(tmp_path / "snap")
+    t0 = time.time()
+    ix = CorpusIndex.from_duckdb(db, connect=Conn, snapshot_dir=snap, block_docs=20000)
+    print(f"from_duckdb: {len(ix.post_doc)} postings in {time.time() - t0:.1f}s")
+    present = np.nonzero(df > 0)[0]
+    assert ix.n_terms == len(present) and list(ix.vocab) == names[present].tolist()
+    order = np.lexsort((np.searchsorted(ix.doc_ids, dd), tt))
+    assert np.array_equal(ix.post_doc, np.searchsorted(ix.doc_ids, dd)[order].astype(np.int32))
+    assert np.array_equal(ix.post_tf, ff[order].astype(np.int32))
+    assert np.array_equal(np.diff(ix.term_off), df[present])
+    exp_idf = np.where(present % 997 == 0, 0.0, idf[present]).astype(np.float32)          # NULL -> 0.0 (:426)
+    assert np.array_equal(ix.idf, exp_idf)
+    assert np.array_equal(ix.doc_len, dl.astype(np.int32)) and ix.avgdl == float(np.float32(275.5))
+    assert ix.n_chunks == C and np.array_equal(np.asarray(ix.emb), emb)                     # chunk ids ascend with (doc, chunk)
+    assert ix.urls[0] == f"http://x/{int(doc_ids[0])}" and ix.urls[5000] is None
+    back = CorpusIndex.load_dir(snap)
+    assert np.array_equal(back.post_doc, ix.post_doc) and np.array_equal(np.asarray(back.emb), emb)
+    assert back.url_group().tolist() == ix.url_group().tolist()

@@ -25,7 +25,8 @@ def stats(stats_csv, trace_csv, out):
     rows = list(csv.DictReader(open(stats_csv)))
     ours = [r for r in rows if any(k in r["Name"] for k in ("dense_scan", "dense_ksplit", "build_qimage", "thr_compact", "rescore", "bm25_taat", "sel_", "rerank_", "best_chunk",
                                                              "prep_queries", "merge_kernel", "interleave", "row_inv_norm",
-                                                             "fill_chunk_doc"))]
+                                                             "fill_chunk_doc", "gemm_", "build_qimg", "qmat_kernel", "batch_margin",
+                                                             "unit_bf16", "pad_inv"))]
     lines = ["| kernel | calls | avg us | min us | max us | total ms |", "|---|---|---|---|---|---|"]
     for r in sorted(ours, key=lambda r: -float(r["TotalDurationNs"])):
         lines.append(f"| {short(r['Name'])} | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['MinNs']) / 1e3:.1f} | "
