@@ -193,6 +193,16 @@ int msr_merge_topk_payload(msr_engine* e, const int32_t* in_doc, const void* in_
                            int32_t k, int32_t score_bits, int32_t* out_doc, void* out_score, int32_t* out_n,
                            int32_t* out_payload, void* stream);
 
+/* BM25 index build on the GPU (handle-less, OFFLINE: unlike every other entry point this one allocates
+ * its own workspace and synchronises the stream).  Replaces the term counting and table writes of BM25.build_index
+ * (indexer/bm25_indexer.py:16-54, 203-250; doc_freq :130-147) given pre-tokenised documents: document i (documents in
+ * ascending doc_id order, only those with at least one token) owns tok_ids[tok_off[i] .. tok_off[i+1]), term ids in
+ * [0, n_terms).  Writes term_off[n_terms + 1] and, when capacity >= the number of postings, post_doc / post_tf (CSR by term,
+ * documents ascending inside a term, tf = occurrences).  *n_postings [host] always receives the number of postings: call
+ * once with capacity 0 to size the arrays, then again.  All arrays are device pointers. */
+int msr_build_postings(const int64_t* tok_off, const int32_t* tok_ids, int64_t n_docs, int32_t n_terms, int64_t* term_off,
+                       int32_t* post_doc, int32_t* post_tf, int64_t capacity, int64_t* n_postings, void* stream);
+
 /* Timing hooks for bench.py: while enabled, every launch of the dominant kernels is bracketed by a
  * hipEvent pair recorded on the caller's stream (ring of 256 launches per kernel).  msr_kernel_time_ms
  * blocks on the recorded events and returns the SUM of the launch durations and the number of launches

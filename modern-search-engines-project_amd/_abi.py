@@ -62,6 +62,7 @@ _SIGNATURES = {
     "msr_merge_topk": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "msr_merge_topk_payload": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P,
                                          _P, _P]),
+    "msr_build_postings": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, _P, C.c_int64, C.POINTER(C.c_int64), _P]),
     "msr_set_timing": (C.c_int, [_P, C.c_int32]),
     "msr_tune": (C.c_int, [_P, C.c_int32, C.c_int32]),
     "msr_kernel_time_ms": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),

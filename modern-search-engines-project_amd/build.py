@@ -26,6 +26,7 @@ UNITS = {
     "msr_batch.hip": [],
     "msr_gemm.hip": [],
     "msr_gemm_f32.hip": [],
+    "msr_build.hip": [],
     "msr_encoder.hip": ["-ffp-contract=off"],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]

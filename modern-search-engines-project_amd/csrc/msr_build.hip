@@ -1,0 +1,366 @@
+// BM25 index build on the GPU -- hand-written kernels, no library sort / scan.
+//
+// Input: the token-id stream of the documents that get a bm25_doc_stats row, in ascending doc_id order (document i owns
+// tok_ids[tok_off[i] .. tok_off[i+1]); term ids in [0, n_terms)).  Output: the tables BM25.build_index writes
+// (indexer/bm25_indexer.py:16-54 term counting, :203-250 bm25_term_freq rows, :130-147 doc_freq) in the engine's layout:
+// CSR by term, documents ascending inside a term, tf = occurrences of the term in the document.
+//
+//   1. unique_kernel      one workgroup per CHUNK of <= 4096 tokens of one document: bitonic sort of the chunk's term ids in
+//                         LDS, run lengths = (term, tf) pairs.  Run twice: count, then (after an exclusive scan of the
+//                         counts) write -- the "forward index" in document order.
+//   2. radix passes       STABLE least-significant-digit radix sort of the forward index by term id, 8 bits per pass
+//                         (hist_kernel: 256-bin LDS histogram per 4096-entry block; scan; scatter_kernel: each wave ranks
+//                         its 64 entries among the equal digits with 8 ballots, waves of a block in order).  Stability
+//                         keeps the document order inside every term -- no (term, document) key, no second sort.
+//   3. combine_kernel     only when a document was longer than one chunk: its chunks' entries of one term are adjacent
+//                         after the sort; add their tf into the first and drop the rest.
+//   4. df / term_off      term boundaries of the sorted entries give doc_freq without atomics; exclusive scan -> offsets.
+// scan: three-kernel exclusive scan (4096 per block, block sums scanned by one block, offsets added), used for the chunk
+// counts, the radix histograms (bin-major [256][blocks]) and doc_freq.
+//
+// This is an offline step: the entry point allocates its workspace, synchronises, and returns the number of postings.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../include/msretr.h"
+#include "msr_internal.h"
+
+namespace {
+
+constexpr int CH = 4096;                 // tokens per chunk (16 KB of LDS)
+constexpr int RB = 4096;                 // entries per radix block
+constexpr int SB = 4096;                 // elements per scan block
+
+#define BUILD_TRY(call)                                                                                      \
+    do {                                                                                                     \
+        hipError_t _e = (call);                                                                              \
+        if (_e != hipSuccess) { rc = msr_fail_global(MSR_ERR_HIP, "%s: %s", #call, hipGetErrorString(_e)); goto done; } \
+    } while (0)
+
+// ---- exclusive scan of int64 -----------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void scan_block_kernel(const int64_t* __restrict__ in, int64_t n, int64_t* __restrict__ out,
+                                                           int64_t* __restrict__ block_sum) {
+    __shared__ int64_t s[1024];
+    const int t = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * SB + (int64_t)t * 4;
+    int64_t v[4], run = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = base + j < n ? in[base + j] : 0; run += v[j]; }
+    s[t] = run;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int64_t add = t >= off ? s[t - off] : 0;
+        __syncthreads();
+        s[t] += add;
+        __syncthreads();
+    }
+    int64_t ex = s[t] - run;                                    // exclusive prefix of this thread's 4 elements
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (base + j < n) out[base + j] = ex;
+        ex += v[j];
+    }
+    if (t == 1023 && block_sum) block_sum[blockIdx.x] = s[1023];
+}
+__global__ void scan_total_kernel(const int64_t* in, const int64_t* out, int64_t n, int64_t* total) { *total = out[n - 1] + in[n - 1]; }
+__global__ __launch_bounds__(1024) void scan_add_kernel(int64_t* __restrict__ out, int64_t n, const int64_t* __restrict__ block_off) {
+    const int64_t base = (int64_t)blockIdx.x * SB + (int64_t)threadIdx.x * 4;
+    const int64_t add = block_off[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (base + j < n) out[base + j] += add;
+}
+// out[0..n) = exclusive scan of in[0..n); tmp: >= 2 * ceil(n / SB) + 2 * ceil(n / SB^2) + 8 words.  *total (device,
+// nullable) <- sum of all elements.  Two levels: n <= SB^3.
+hipError_t exclusive_scan(const int64_t* in, int64_t n, int64_t* out, int64_t* tmp, int64_t* total, hipStream_t st) {
+    if (n <= 0) {
+        if (total) return hipMemsetAsync(total, 0, 8, st);
+        return hipSuccess;
+    }
+    const int64_t nb = (n + SB - 1) / SB;
+    int64_t* sums = tmp;
+    int64_t* sums_scan = tmp + nb;
+    scan_block_kernel<<<(unsigned)nb, 1024, 0, st>>>(in, n, out, sums);
+    if (nb > 1) {
+        const int64_t nb2 = (nb + SB - 1) / SB;
+        int64_t* sums2 = sums_scan + nb;
+        int64_t* sums2_scan = sums2 + nb2;
+        scan_block_kernel<<<(unsigned)nb2, 1024, 0, st>>>(sums, nb, sums_scan, sums2);
+        if (nb2 > 1) {
+            scan_block_kernel<<<1, 1024, 0, st>>>(sums2, nb2, sums2_scan, nullptr);      // nb2 <= SB
+            scan_add_kernel<<<(unsigned)nb2, 1024, 0, st>>>(sums_scan, nb, sums2_scan);
+        }
+        scan_add_kernel<<<(unsigned)nb, 1024, 0, st>>>(out, n, sums_scan);
+    }
+    if (total) scan_total_kernel<<<1, 1, 0, st>>>(in, out, n, total);
+    return hipGetLastError();
+}
+
+// ---- 1. per-chunk sort + run lengths -----------------------------------------------------------------------------
+// chunk c: tokens [c_start[c], c_start[c] + c_len[c]) of document c_doc[c].  WRITE = false: cnt[c] <- number of distinct
+// terms; WRITE = true: the (term, doc, tf) entries at out_off[c].
+template <bool WRITE>
+__global__ __launch_bounds__(256) void unique_kernel(const int32_t* __restrict__ tok, const int64_t* __restrict__ c_start,
+                                                      const int32_t* __restrict__ c_len, const int32_t* __restrict__ c_doc,
+                                                      int64_t* __restrict__ cnt, const int64_t* __restrict__ out_off,
+                                                      int32_t* __restrict__ o_term, int32_t* __restrict__ o_doc,
+                                                      int32_t* __restrict__ o_tf) {
+    __shared__ uint32_t key[CH];
+    __shared__ int s_n;
+    const int c = blockIdx.x, t = threadIdx.x;
+    const int len = c_len[c];
+    const int64_t start = c_start[c];
+    int P = 64;
+    while (P < len) P <<= 1;
+    for (int i = t; i < P; i += 256) key[i] = i < len ? (uint32_t)tok[start + i] : 0xFFFFFFFFu;
+    if (t == 0) s_n = 0;
+    __syncthreads();
+    for (int kk = 2; kk <= P; kk <<= 1)
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int idx = t; idx < (P >> 1); idx += 256) {
+                const int i = ((idx & ~(j - 1)) << 1) | (idx & (j - 1));
+                const int p = i | j;
+                const bool asc = (i & kk) == 0;
+                const uint32_t a = key[i], b = key[p];
+                if (asc ? a > b : a < b) { key[i] = b; key[p] = a; }
+            }
+            __syncthreads();
+        }
+    // heads of runs: position among the heads by a block-wide count (order inside a chunk is irrelevant: the radix
+    // sort only needs the entries of a DOCUMENT to stay together in document order, and they do, chunk by chunk)
+    if (!WRITE) {
+        int mine = 0;
+        for (int i = t; i < len; i += 256) mine += i == 0 || key[i] != key[i - 1];
+        atomicAdd(&s_n, mine);
+        __syncthreads();
+        if (t == 0) cnt[c] = s_n;
+    } else {
+        const int64_t o = out_off[c];
+        const int32_t d = c_doc[c];
+        for (int i = t; i < len; i += 256) {
+            if (i == 0 || key[i] != key[i - 1]) {
+                int e = i + 1;
+                while (e < len && key[e] == key[i]) ++e;           // run length (runs are short except for very common terms)
+                const int pos = atomicAdd(&s_n, 1);
+                o_term[o + pos] = (int32_t)key[i];
+                o_doc[o + pos] = d;
+                o_tf[o + pos] = e - i;
+            }
+        }
+    }
+}
+
+// ---- 2. stable LSD radix sort by term, 8 bits per pass ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void hist_kernel(const int32_t* __restrict__ term, int64_t n, int shift, int64_t n_blocks,
+                                                    int64_t* __restrict__ hist /*[256][n_blocks]*/) {
+    __shared__ int h[256];
+    const int t = threadIdx.x;
+    h[t] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RB;
+    for (int i = t; i < RB; i += 256)
+        if (base + i < n) atomicAdd(&h[((uint32_t)term[base + i] >> shift) & 255], 1);
+    __syncthreads();
+    hist[(int64_t)t * n_blocks + blockIdx.x] = h[t];
+}
+// One workgroup per block of RB entries, 4 waves; wave w owns entries [w RB/4, (w+1) RB/4) and walks them 64 at a time IN
+// ORDER, so "position among equal digits" = entries of earlier waves + earlier rounds of this wave + lower lanes of this
+// round: stable.
+__global__ __launch_bounds__(256) void scatter_kernel(const int32_t* __restrict__ term, const int32_t* __restrict__ doc,
+                                                       const int32_t* __restrict__ tf, int64_t n, int shift, int64_t n_blocks,
+                                                       const int64_t* __restrict__ hist_scan /*[256][n_blocks]*/,
+                                                       int32_t* __restrict__ o_term, int32_t* __restrict__ o_doc,
+                                                       int32_t* __restrict__ o_tf) {
+    __shared__ int wcnt[4][256];                                  // digits counted by each wave (first: totals, then: running)
+    __shared__ int64_t gbase[256];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int64_t base = (int64_t)blockIdx.x * RB + (int64_t)w * (RB / 4);
+    for (int i = t; i < 4 * 256; i += 256) (&wcnt[0][0])[i] = 0;
+    gbase[t] = hist_scan[(int64_t)t * n_blocks + blockIdx.x];
+    __syncthreads();
+    for (int r = 0; r < RB / 4; r += 64) {                        // totals per wave
+        const int64_t i = base + r + lane;
+        if (i < n) atomicAdd(&wcnt[w][((uint32_t)term[i] >> shift) & 255], 1);
+    }
+    __syncthreads();
+    if (t < 256) {                                                // exclusive prefix over the 4 waves, per digit
+        int run = 0;
+        for (int k = 0; k < 4; ++k) { const int c = wcnt[k][t]; wcnt[k][t] = run; run += c; }
+    }
+    __syncthreads();
+    for (int r = 0; r < RB / 4; r += 64) {
+        const int64_t i = base + r + lane;
+        const bool ok = i < n;
+        const int32_t tm = ok ? term[i] : 0;
+        const uint32_t dg = ok ? (((uint32_t)tm >> shift) & 255) : 256u;     // 256: matches nobody
+        // lanes with the same digit: 8 ballots (+ validity)
+        unsigned long long same = __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long m = __ballot((dg >> b) & 1);
+            same &= ((dg >> b) & 1) ? m : ~m;
+        }
+        if (ok) {
+            const unsigned long long lower = same & ((1ull << lane) - 1ull);
+            const int rank = __popcll(lower);
+            const int before = wcnt[w][dg];                        // (read by every lane of the group before the leader's update:
+            __builtin_amdgcn_wave_barrier();                       //  LDS operations of one wave execute in order)
+            const int64_t pos = gbase[dg] + before + rank;
+            o_term[pos] = tm;
+            o_doc[pos] = doc[i];
+            o_tf[pos] = tf[i];
+            if (lower == 0) wcnt[w][dg] = before + __popcll(same); // the group's lowest lane
+        }
+    }
+}
+
+// ---- 3. combine chunks of one document ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dup_flag_kernel(const int32_t* __restrict__ term, const int32_t* __restrict__ doc, int64_t n,
+                                                        int64_t* __restrict__ keep) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) keep[i] = !(i > 0 && term[i] == term[i - 1] && doc[i] == doc[i - 1]);
+}
+__global__ __launch_bounds__(256) void dup_merge_kernel(const int32_t* __restrict__ term, const int32_t* __restrict__ doc,
+                                                         const int32_t* __restrict__ tf, int64_t n, const int64_t* __restrict__ keep,
+                                                         const int64_t* __restrict__ pos, int32_t* __restrict__ o_term,
+                                                         int32_t* __restrict__ o_doc, int32_t* __restrict__ o_tf) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !keep[i]) return;
+    int32_t s = tf[i];
+    for (int64_t j = i + 1; j < n && !keep[j]; ++j) s += tf[j];
+    o_term[pos[i]] = term[i]; o_doc[pos[i]] = doc[i]; o_tf[pos[i]] = s;
+}
+
+// ---- 4. doc_freq from the term boundaries of the sorted entries -------------------------------------------------------
+__global__ __launch_bounds__(256) void df_kernel(const int32_t* __restrict__ term, int64_t n, int64_t* __restrict__ first,
+                                                  int64_t* __restrict__ df) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int32_t t = term[i];
+    if (i == 0 || term[i - 1] != t) first[t] = i;
+    if (i == n - 1 || term[i + 1] != t) df[t] = i + 1;             // end; turned into a count by df_finish_kernel
+}
+__global__ __launch_bounds__(256) void df_finish_kernel(const int64_t* __restrict__ first, int64_t* __restrict__ df, int64_t n_terms) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < n_terms && df[t] > 0) df[t] -= first[t];
+}
+
+}  // namespace
+
+extern "C" int msr_build_postings(const int64_t* tok_off, const int32_t* tok_ids, int64_t n_docs, int32_t n_terms,
+                                  int64_t* term_off, int32_t* post_doc, int32_t* post_tf, int64_t capacity,
+                                  int64_t* n_postings, void* stream) {
+    if (!tok_off || n_docs < 0 || n_terms < 1 || !term_off || !n_postings || (capacity > 0 && (!post_doc || !post_tf)))
+        return msr_fail_global(MSR_ERR_INVALID, "msr_build_postings: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = MSR_OK;
+    std::vector<int64_t> h_off((size_t)n_docs + 1), c_start;
+    std::vector<int32_t> c_len, c_doc;
+    int64_t *d_cstart = nullptr, *d_cnt = nullptr, *d_coff = nullptr, *d_tmp = nullptr, *d_total = nullptr, *d_hist = nullptr,
+            *d_hscan = nullptr, *d_keep = nullptr, *d_pos = nullptr, *d_first = nullptr, *d_df = nullptr;
+    int32_t *d_clen = nullptr, *d_cdoc = nullptr, *a_term = nullptr, *a_doc = nullptr, *a_tf = nullptr, *b_term = nullptr,
+            *b_doc = nullptr, *b_tf = nullptr;
+    int64_t P = 0, n_tok = 0, n_chunks = 0, n_blocks = 0, tmp_words = 0;
+    bool split = false;
+    int bits = 0;
+    {
+        BUILD_TRY(hipMemcpyAsync(h_off.data(), tok_off, h_off.size() * 8, hipMemcpyDeviceToHost, st));
+        BUILD_TRY(hipStreamSynchronize(st));
+        n_tok = h_off[n_docs];
+        if (h_off[0] != 0 || n_tok < 0) { rc = msr_fail_global(MSR_ERR_INVALID, "msr_build_postings: tok_off must start at 0"); goto done; }
+        if (n_tok > 0 && !tok_ids) { rc = msr_fail_global(MSR_ERR_INVALID, "msr_build_postings: null tok_ids"); goto done; }
+        for (int64_t d = 0; d < n_docs; ++d) {
+            const int64_t len = h_off[d + 1] - h_off[d];
+            if (len < 0) { rc = msr_fail_global(MSR_ERR_INVALID, "msr_build_postings: tok_off not monotone"); goto done; }
+            if (len > CH) split = true;
+            for (int64_t s = 0; s < len; s += CH) {
+                c_start.push_back(h_off[d] + s);
+                c_len.push_back((int32_t)std::min<int64_t>(CH, len - s));
+                c_doc.push_back((int32_t)d);
+            }
+        }
+        n_chunks = (int64_t)c_start.size();
+    }
+    if (n_chunks == 0) {                                           // no tokens at all
+        BUILD_TRY(hipMemsetAsync(term_off, 0, ((size_t)n_terms + 1) * 8, st));
+        BUILD_TRY(hipStreamSynchronize(st));
+        *n_postings = 0;
+        return MSR_OK;
+    }
+    tmp_words = 4 * ((std::max<int64_t>(std::max<int64_t>(n_chunks, n_terms + 1), 256 * ((n_tok + RB - 1) / RB + 1)) + SB - 1) / SB + 4) + 64;
+    BUILD_TRY(hipMalloc((void**)&d_cstart, n_chunks * 8));
+    BUILD_TRY(hipMalloc((void**)&d_clen, n_chunks * 4));
+    BUILD_TRY(hipMalloc((void**)&d_cdoc, n_chunks * 4));
+    BUILD_TRY(hipMalloc((void**)&d_cnt, n_chunks * 8));
+    BUILD_TRY(hipMalloc((void**)&d_coff, n_chunks * 8));
+    BUILD_TRY(hipMalloc((void**)&d_tmp, tmp_words * 8));
+    BUILD_TRY(hipMalloc((void**)&d_total, 8));
+    BUILD_TRY(hipMemcpyAsync(d_cstart, c_start.data(), n_chunks * 8, hipMemcpyHostToDevice, st));
+    BUILD_TRY(hipMemcpyAsync(d_clen, c_len.data(), n_chunks * 4, hipMemcpyHostToDevice, st));
+    BUILD_TRY(hipMemcpyAsync(d_cdoc, c_doc.data(), n_chunks * 4, hipMemcpyHostToDevice, st));
+    unique_kernel<false><<<(unsigned)n_chunks, 256, 0, st>>>(tok_ids, d_cstart, d_clen, d_cdoc, d_cnt, nullptr, nullptr, nullptr, nullptr);
+    BUILD_TRY(hipGetLastError());
+    BUILD_TRY(exclusive_scan(d_cnt, n_chunks, d_coff, d_tmp, d_total, st));
+    BUILD_TRY(hipMemcpyAsync(&P, d_total, 8, hipMemcpyDeviceToHost, st));
+    BUILD_TRY(hipStreamSynchronize(st));
+    BUILD_TRY(hipMalloc((void**)&a_term, std::max<int64_t>(P, 1) * 4));
+    BUILD_TRY(hipMalloc((void**)&a_doc, std::max<int64_t>(P, 1) * 4));
+    BUILD_TRY(hipMalloc((void**)&a_tf, std::max<int64_t>(P, 1) * 4));
+    BUILD_TRY(hipMalloc((void**)&b_term, std::max<int64_t>(P, 1) * 4));
+    BUILD_TRY(hipMalloc((void**)&b_doc, std::max<int64_t>(P, 1) * 4));
+    BUILD_TRY(hipMalloc((void**)&b_tf, std::max<int64_t>(P, 1) * 4));
+    unique_kernel<true><<<(unsigned)n_chunks, 256, 0, st>>>(tok_ids, d_cstart, d_clen, d_cdoc, nullptr, d_coff, a_term, a_doc, a_tf);
+    BUILD_TRY(hipGetLastError());
+    // ---- stable radix passes over the term id ----
+    while ((1ll << bits) < n_terms) ++bits;
+    n_blocks = (P + RB - 1) / RB;
+    BUILD_TRY(hipMalloc((void**)&d_hist, 256 * n_blocks * 8));
+    BUILD_TRY(hipMalloc((void**)&d_hscan, 256 * n_blocks * 8));
+    for (int shift = 0; shift < bits; shift += 8) {
+        hist_kernel<<<(unsigned)n_blocks, 256, 0, st>>>(a_term, P, shift, n_blocks, d_hist);
+        BUILD_TRY(exclusive_scan(d_hist, 256 * n_blocks, d_hscan, d_tmp, nullptr, st));
+        scatter_kernel<<<(unsigned)n_blocks, 256, 0, st>>>(a_term, a_doc, a_tf, P, shift, n_blocks, d_hscan, b_term, b_doc, b_tf);
+        BUILD_TRY(hipGetLastError());
+        std::swap(a_term, b_term); std::swap(a_doc, b_doc); std::swap(a_tf, b_tf);
+    }
+    // ---- documents that were split into chunks: merge their entries per term ----
+    if (split) {
+        BUILD_TRY(hipMalloc((void**)&d_keep, P * 8));
+        BUILD_TRY(hipMalloc((void**)&d_pos, P * 8));
+        dup_flag_kernel<<<(unsigned)((P + 255) / 256), 256, 0, st>>>(a_term, a_doc, P, d_keep);
+        BUILD_TRY(exclusive_scan(d_keep, P, d_pos, d_tmp, d_total, st));
+        dup_merge_kernel<<<(unsigned)((P + 255) / 256), 256, 0, st>>>(a_term, a_doc, a_tf, P, d_keep, d_pos, b_term, b_doc, b_tf);
+        BUILD_TRY(hipMemcpyAsync(&P, d_total, 8, hipMemcpyDeviceToHost, st));
+        BUILD_TRY(hipStreamSynchronize(st));
+        std::swap(a_term, b_term); std::swap(a_doc, b_doc); std::swap(a_tf, b_tf);
+    }
+    // ---- doc_freq, offsets, output ----
+    BUILD_TRY(hipMalloc((void**)&d_first, ((size_t)n_terms + 1) * 8));
+    BUILD_TRY(hipMalloc((void**)&d_df, ((size_t)n_terms + 1) * 8));
+    BUILD_TRY(hipMemsetAsync(d_df, 0, ((size_t)n_terms + 1) * 8, st));
+    if (P > 0) {
+        df_kernel<<<(unsigned)((P + 255) / 256), 256, 0, st>>>(a_term, P, d_first, d_df);
+        df_finish_kernel<<<(unsigned)((n_terms + 255) / 256), 256, 0, st>>>(d_first, d_df, n_terms);
+    }
+    BUILD_TRY(exclusive_scan(d_df, (int64_t)n_terms + 1, term_off, d_tmp, nullptr, st));
+    if (P > capacity) {
+        BUILD_TRY(hipStreamSynchronize(st));
+        *n_postings = P;                                            // the caller sizes its arrays from this and calls again
+        rc = capacity > 0 ? msr_fail_global(MSR_ERR_INVALID, "msr_build_postings: capacity %lld < %lld postings", (long long)capacity, (long long)P) : MSR_OK;
+        goto done;
+    }
+    BUILD_TRY(hipMemcpyAsync(post_doc, a_doc, P * 4, hipMemcpyDeviceToDevice, st));
+    BUILD_TRY(hipMemcpyAsync(post_tf, a_tf, P * 4, hipMemcpyDeviceToDevice, st));
+    BUILD_TRY(hipStreamSynchronize(st));
+    *n_postings = P;
+done:
+    (void)hipStreamSynchronize(st);
+    for (void* p : {(void*)d_cstart, (void*)d_cnt, (void*)d_coff, (void*)d_tmp, (void*)d_total, (void*)d_hist, (void*)d_hscan, (void*)d_keep,
+                    (void*)d_pos, (void*)d_first, (void*)d_df, (void*)d_clen, (void*)d_cdoc, (void*)a_term, (void*)a_doc, (void*)a_tf,
+                    (void*)b_term, (void*)b_doc, (void*)b_tf})
+        if (p) (void)hipFree(p);
+    return rc;
+}

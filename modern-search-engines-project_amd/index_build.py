@@ -59,11 +59,15 @@ def bm25_index_from_token_ids(doc_ids, tok_off, tok_ids, n_terms, device="cpu", 
 
     doc_ids int64 [N]; tok_off int64 [N+1]; tok_ids int32 [T] with document i's tokens at tok_off[i]:tok_off[i+1], term
     ids in [0, n_terms).  Documents without tokens get no row (bm25_indexer.py:224); documents are numbered by
-    ascending doc_id; inside a term the postings ascend by document.  This is an offline step and uses torch's device
-    primitives (sort / unique_consecutive / bincount), not hand-written kernels; idf is evaluated on the host with the
-    same float64 log10 -> float32 rounding as bm25_index_from_tokens so that the two builders agree bit for bit."""
+    ascending doc_id; inside a term the postings ascend by document.  On a GPU device the tables come from the hand-written
+    kernels of csrc/msr_build.hip (per-document sort + run lengths, stable radix sort by term, boundary-based doc_freq,
+    three-kernel scans; msr_build_postings); on the CPU device torch's sort / unique_consecutive / bincount restate the same
+    build (host-side reference for the tests).  idf is evaluated on the host with the same float64 log10 -> float32
+    rounding as bm25_index_from_tokens so that all builders agree bit for bit."""
     import torch
     dev = torch.device(device)
+    if dev.type == "cuda":
+        return _bm25_index_from_token_ids_hip(doc_ids, tok_off, tok_ids, n_terms, dev, k1, b, vocab)
     ids = torch.as_tensor(np.asarray(doc_ids, np.int64))
     off = torch.as_tensor(np.asarray(tok_off, np.int64)).to(dev)
     tok = (tok_ids if torch.is_tensor(tok_ids) else torch.as_tensor(np.asarray(tok_ids, np.int32))).to(dev)
@@ -93,5 +97,56 @@ def bm25_index_from_token_ids(doc_ids, tok_off, tok_ids, n_terms, device="cpu", 
     ix = CorpusIndex(doc_ids=ids[keep.cpu()].numpy(), doc_len=doc_len, term_off=term_off, post_doc=p_doc.to(torch.int32),
                      post_tf=tf.to(torch.int32), idf=torch.as_tensor(idf).to(dev), avgdl=avgdl, total_docs=N, k1=k1, b=b,
                      vocab=vocab)
+    ix.n_docs_global = N
+    return ix
+
+
+def _bm25_index_from_token_ids_hip(doc_ids, tok_off, tok_ids, n_terms, dev, k1, b, vocab):
+    """bm25_index_from_token_ids on the GPU through the C ABI (msr_build_postings); no fallback."""
+    import ctypes as C
+
+    import torch
+
+    from . import _abi
+    lib = _abi.load()
+    ids = np.asarray(doc_ids, np.int64)
+    if len(set(ids.tolist())) != len(ids):
+        raise ValueError("duplicate doc_id")
+    off = np.asarray(tok_off.cpu() if torch.is_tensor(tok_off) else tok_off, np.int64)
+    tok = (tok_ids if torch.is_tensor(tok_ids) else torch.as_tensor(np.asarray(tok_ids, np.int32))).to(dev, torch.int32).contiguous()
+    if tok.numel() and (int(tok.min()) < 0 or int(tok.max()) >= n_terms):
+        raise ValueError("token id outside [0, n_terms)")
+    lens = np.diff(off)
+    order = np.argsort(ids, kind="stable")
+    keep = order[lens[order] > 0]                                           # documents with tokens, ascending doc_id
+    N = len(keep)
+    # the kernels want the kept documents' tokens back to back in that order: one gather of token ranges (skipped when the
+    # input already is in that shape)
+    if N == len(ids) and np.array_equal(keep, np.arange(N)):
+        k_off, k_tok = off, tok
+    else:
+        k_off = np.zeros(N + 1, np.int64); k_off[1:] = np.cumsum(lens[keep])
+        src = torch.as_tensor(np.repeat(off[keep] - k_off[:-1], lens[keep]) + np.arange(k_off[-1]), device=dev)
+        k_tok = tok[src].contiguous()
+    d_off = torch.as_tensor(k_off).to(dev)
+    term_off = torch.empty(n_terms + 1, dtype=torch.int64, device=dev)
+    n_post = C.c_int64(0)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None and t.numel() else C.c_void_p(0)
+    with torch.cuda.device(dev):
+        _abi.check(None, lib.msr_build_postings(ptr(d_off), ptr(k_tok), N, int(n_terms), ptr(term_off), C.c_void_p(0), C.c_void_p(0), 0,
+                                                C.byref(n_post), stream))
+        P = int(n_post.value)
+        post_doc = torch.empty(max(P, 1), dtype=torch.int32, device=dev)
+        post_tf = torch.empty(max(P, 1), dtype=torch.int32, device=dev)
+        _abi.check(None, lib.msr_build_postings(ptr(d_off), ptr(k_tok), N, int(n_terms), ptr(term_off), ptr(post_doc), ptr(post_tf), max(P, 1),
+                                                C.byref(n_post), stream))
+    df_h = np.diff(term_off.cpu().numpy())
+    n_real = float(np.float32(N))
+    idf = np.array([np.float32(math.log10((n_real - int(c) + 0.5) / (int(c) + 0.5))) for c in df_h], np.float32)
+    doc_len = torch.as_tensor(lens[keep].astype(np.int32)).to(dev)
+    avgdl = float(np.float32(lens[keep].astype(np.float64).mean())) if N else 0.0
+    ix = CorpusIndex(doc_ids=ids[keep], doc_len=doc_len, term_off=term_off, post_doc=post_doc[:P], post_tf=post_tf[:P],
+                     idf=torch.as_tensor(idf).to(dev), avgdl=avgdl, total_docs=N, k1=k1, b=b, vocab=vocab)
     ix.n_docs_global = N
     return ix

@@ -827,3 +827,48 @@ def test_http_routes_on_the_gpu_retriever(mods, tmp_path):
     assert c.post("/rerank", json={"doc_ids": ["999999999"], "similarities": [1.0], "query": "x"}).status_code == 401
     assert c.get("/api/health").json() == {"status": "healthy", "search_engine_ready": True}
     rt.engine.close()
+
+
+def test_index_build_kernels_equal_the_reference_tables(mods):
+    """msr_build_postings (per-document sort + run lengths, stable radix sort by term, boundary doc_freq --
+    csrc/msr_build.hip) against the dict-based builder that is pinned to the reference's tables (bm25_indexer.py:16-54,
+    203-250, 130-147): postings, lengths, offsets, idf bits and avgdl identical.  Covers unsorted doc ids, token-less
+    documents (no row), documents longer than one 4096-token chunk (their chunks' counts are merged), a term present
+    in every document, and vocabularies that need 1, 2 and 3 radix passes."""
+    from msretr.index_build import bm25_index_from_token_ids, bm25_index_from_tokens
+    rng = np.random.default_rng(19)
+    for n, V, long_docs in ((300, 200, ()), (700, 40_000, (5, 77)), (400, 300_000, (9,))):
+        doc_ids = rng.permutation(np.arange(1000, 1000 + 3 * n, 3))[:n]          # unsorted, with gaps
+        lens = rng.integers(0, 120, size=n)
+        lens[[3, 11]] = 0                                                         # token-less documents: no row
+        for d in long_docs:
+            lens[d] = int(rng.integers(5000, 13000))                             # 2..4 chunks
+        toks = []
+        for l in lens:
+            t = np.minimum(rng.zipf(1.2, size=l), V - 1).astype(np.int64)
+            t[rng.random(l) < 0.3] = rng.integers(0, V, size=int((rng.random(l) < 0.3).sum())) if l else 0
+            if l:
+                t[0] = 0                                                          # term 0 in every document
+            toks.append(t.tolist())
+        ref = bm25_index_from_tokens(doc_ids, [[f"w{t}" for t in tl] for tl in toks])
+        ids_of = {k: v for k, v in ref.vocab.items()}                             # the dict builder's numbering
+        tok_off = np.zeros(n + 1, np.int64); tok_off[1:] = np.cumsum(lens)
+        tok_ids = np.array([ids_of[f"w{t}"] for tl in toks for t in tl], np.int32)
+        got = bm25_index_from_token_ids(doc_ids, tok_off, tok_ids, len(ref.vocab), device="cuda")
+        assert got.total_docs == ref.total_docs == int((lens > 0).sum()) and got.avgdl == ref.avgdl
+        for name in ("doc_ids", "doc_len", "term_off", "post_doc", "post_tf"):
+            a = getattr(got, name)
+            a = a.cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+            assert np.array_equal(a, np.asarray(getattr(ref, name))), (name, n, V)
+        assert np.array_equal(got.idf.cpu().numpy().view(np.uint32), ref.idf.view(np.uint32))
+    # and the built index serves queries: BM25 top-k over it equals the oracle on the reference-shaped tables
+    eng = mods["DeviceEngine"](got, max_queries=4, max_k=50, rerank_max_docs=0)
+    z = {k: (getattr(got, k).cpu().numpy() if torch.is_tensor(getattr(got, k)) else np.asarray(getattr(got, k)))
+         for k in ("doc_ids", "doc_len", "term_off", "post_doc", "post_tf", "idf")}
+    z["avgdl"] = got.avgdl
+    qs = [[0, 5, 17], [3, 3, 250], [1]]
+    doc, score, cnt = [x.cpu().numpy() for x in eng.bm25_topk(qs, k=50)]
+    for i, t in enumerate(qs):
+        oi, os_ = mods["bm25_ref"].topk(z, t, 50)
+        assert doc[i, :cnt[i]].tolist() == oi.tolist() and score[i, :cnt[i]].tolist() == os_.tolist()
+    eng.close()
