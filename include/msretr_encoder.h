@@ -6,8 +6,8 @@
  * are fetched by NAME there; here they come from a local directory (or are random for tests), see
  * modern-search-engines-project_amd/encoder.py.
  *
- * The matrix products of the transformer are plain library GEMMs (hipBLASLt through torch.matmul / addmm); everything
- * between them is hand-written HIP and lives behind the entry points below.  All tensors are float32, row-major, device
+ * The whole forward pass is hand-written HIP behind the entry points below: the four matrix products of a layer
+ * (msr_enc_linear, exact-f32 matrix cores, weights streamed once) and everything between them.  All tensors are float32, row-major, device
  * pointers owned by the caller; functions are stateless (no engine handle), enqueue on `stream`, never synchronise, and
  * return 0 or a negative msr_status (msr_last_error(NULL) holds the text).
  *
@@ -45,6 +45,14 @@ int msr_enc_geglu(const float* u, float* y, int64_t n_rows, int32_t half, void* 
  * L2 norm afterwards (sentence-transformers normalize_embeddings). */
 int msr_enc_mean_pool(const float* h, const int32_t* seq_off, int32_t n_seq, int32_t dim, int32_t normalize, float* out,
                       void* stream);
+
+/* y[t][o] = sum_i x[t][i] * w[o][i] (+ resid[t][o] when resid != NULL; resid may alias y): torch.nn.Linear without bias,
+ * the form of every projection of the model (Wqkv 2304x768, attention Wo 768x768, mlp Wi 2304x768, mlp Wo 768x1152).
+ * x is [n_tok][n_in], w [n_out][n_in] (the checkpoint's layout), y / resid [n_tok][n_out]; n_out % 32 == 0,
+ * n_in % 128 == 0, pointers 16-byte aligned.  Exact f32 products with f32 accumulation (v_mfma_f32_16x16x4_f32); the
+ * summation order is fixed, so results are reproducible run to run. */
+int msr_enc_linear(const float* x, const float* w, const float* resid, float* y, int32_t n_tok, int32_t n_out,
+                   int32_t n_in, void* stream);
 
 #ifdef __cplusplus
 }

@@ -46,6 +46,7 @@ _SIGNATURES = {
     "msr_enc_layernorm": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
     "msr_enc_attention": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P]),
     "msr_enc_geglu": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
+    "msr_enc_linear": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "msr_enc_mean_pool": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "msr_batch_width": (C.c_int, [_P]),
     "msr_batch_gemm_ok": (C.c_int, [_P]),

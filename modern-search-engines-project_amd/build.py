@@ -24,6 +24,7 @@ UNITS = {
     "msr_dense_ks.hip": [],
     "msr_rerank.hip": ["-ffp-contract=off"],
     "msr_batch.hip": [],
+    "msr_enc_linear.hip": [],
     "msr_gemm.hip": [],
     "msr_gemm_f32.hip": [],
     "msr_build.hip": [],

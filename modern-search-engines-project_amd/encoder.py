@@ -7,9 +7,10 @@ The model is ModernBERT-base (embedder_training/train.py fine-tunes answerdotai/
 from a LOCAL directory in the Hugging Face layout (`model.safetensors`, optional `tokenizer.json`, optional
 sentence-transformers `modules.json`), or are random for tests and benchmarks.
 
-Division of labour: the matrix products are plain library GEMMs (hipBLASLt through torch.matmul / addmm); everything
-between them -- embedding lookup + LayerNorm, LayerNorm, rotary embedding + attention, GeGLU, masked mean pooling -- is
-hand-written HIP behind the C ABI of include/msretr_encoder.h.  There is no CPU fallback: without the library the class
+The whole forward pass is hand-written HIP behind the C ABI of include/msretr_encoder.h: the matrix products
+(msr_enc_linear: skinny products on the exact-f32 matrix cores, each weight read once per 128 tokens) and everything
+between them -- embedding lookup + LayerNorm, LayerNorm, rotary embedding + attention, GeGLU, masked mean pooling; torch
+only owns the buffers and the hipGraph.  There is no CPU fallback: without the library the class
 raises.  Parity: tests/test_gpu_encoder.py compares the output with transformers' ModernBertModel (the reference's
 dependency) on the same random weights.
 """
@@ -159,23 +160,33 @@ class QueryEncoder:
         graph.replay()
         return s_out.clone()
 
+    def _linear(self, x, weight, y, resid=None):
+        """y = x . weight^T (+ resid): msr_enc_linear, the HIP skinny product (weights streamed once, exact-f32 MFMA)."""
+        n_out, n_in = weight.shape
+        self._check(self.lib.msr_enc_linear(_ptr(x), _ptr(weight), _ptr(resid), _ptr(y), int(x.shape[0]), int(n_out),
+                                            int(n_in), self._stream()))
+        return y
+
     def _forward(self, ids, seq_off, n_seq, n_tok, normalize, out):
         w, st = self.w, self._stream
-        h = self._ln(None, w["embeddings.norm.weight"], ids=ids)                      # lookup + LayerNorm (HIP)
-        att = torch.empty((n_tok, HIDDEN), dtype=torch.float32, device=self.device)
-        act = torch.empty((n_tok, INTER), dtype=torch.float32, device=self.device)
+        h = self._ln(None, w["embeddings.norm.weight"], ids=ids)                      # lookup + LayerNorm
+        new = lambda cols: torch.empty((n_tok, cols), dtype=torch.float32, device=self.device)
+        qkv, att, u, act = new(3 * HIDDEN), new(HIDDEN), new(2 * INTER), new(INTER)
         for l in range(self.layers):
             p = f"layers.{l}."
             glob = l % GLOBAL_EVERY == 0
             x = h if l == 0 else self._ln(h, w[p + "attn_norm.weight"])               # layer 0 has no attn_norm
-            qkv = x @ w[p + "attn.Wqkv.weight"].t()                                   # library GEMM
+            self._linear(x, w[p + "attn.Wqkv.weight"], qkv)
             self._check(self.lib.msr_enc_attention(_ptr(qkv), _ptr(seq_off), n_seq, HEADS, _ptr(self.inv_freq[glob]),
                                                    0 if glob else LOCAL_WINDOW // 2, _ptr(att), st()))
-            h = torch.addmm(h, att, w[p + "attn.Wo.weight"].t())                      # library GEMM + residual
+            if l == 0:
+                h = self._linear(att, w[p + "attn.Wo.weight"], new(HIDDEN), resid=h)  # (x is h in layer 0: keep it intact)
+            else:
+                self._linear(att, w[p + "attn.Wo.weight"], h, resid=h)                # h += att . Wo^T
             x = self._ln(h, w[p + "mlp_norm.weight"])
-            u = x @ w[p + "mlp.Wi.weight"].t()
+            self._linear(x, w[p + "mlp.Wi.weight"], u)
             self._check(self.lib.msr_enc_geglu(_ptr(u), _ptr(act), n_tok, INTER, st()))
-            h = torch.addmm(h, act, w[p + "mlp.Wo.weight"].t())
+            self._linear(act, w[p + "mlp.Wo.weight"], h, resid=h)                     # h += act . Wo^T
         h = self._ln(h, w["final_norm.weight"])
         self._check(self.lib.msr_enc_mean_pool(_ptr(h), _ptr(seq_off), n_seq, HIDDEN, int(normalize), _ptr(out), st()))
         return out

@@ -89,6 +89,38 @@ def test_encoder_kernels_against_torch_ops(enc_world):
     assert b"dim=100" in lib.msr_last_error(None)
 
 
+def test_encoder_linear_against_float64(enc_world):
+    """msr_enc_linear (the skinny matrix product of every projection) against a float64 product: all four shapes of a
+    layer, token counts on both sides of every tile size, residual in place, rows past the end untouched."""
+    import ctypes as C
+    _, enc = enc_world
+    lib, dev = enc.lib, enc.device
+    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    S = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device="cpu"); g.manual_seed(23)
+    for n_out, n_in in ((2304, 768), (768, 768), (768, 1152)):
+        w = (torch.randn(n_out, n_in, generator=g) * 0.05).to(dev)
+        for n_tok in (1, 5, 16, 17, 33, 64, 100, 128, 129, 300):
+            x = torch.randn(n_tok, n_in, generator=g).to(dev)
+            r = torch.randn(n_tok, n_out, generator=g).to(dev)
+            want = x.double() @ w.double().t()
+            y = torch.full((n_tok + 3, n_out), 7.0, device=dev)                    # 3 guard rows
+            assert lib.msr_enc_linear(P(x), P(w), None, P(y), n_tok, n_out, n_in, S) == 0
+            scale = float(want.abs().max())
+            assert float((y[:n_tok].double() - want).abs().max()) <= 2e-6 * scale, (n_out, n_in, n_tok)
+            assert bool((y[n_tok:] == 7.0).all())
+            h = r.clone()
+            assert lib.msr_enc_linear(P(x), P(w), P(h), P(h), n_tok, n_out, n_in, S) == 0     # h += x . w^T
+            assert float((h.double() - (want + r.double())).abs().max()) <= 2e-6 * scale
+            again = r.clone()
+            assert lib.msr_enc_linear(P(x), P(w), P(again), P(again), n_tok, n_out, n_in, S) == 0
+            assert torch.equal(h, again)                                           # fixed summation order
+    x = torch.randn(4, 768, generator=g).to(dev); w = torch.randn(48, 768, generator=g).to(dev); y = torch.empty(4, 48, device=dev)
+    assert lib.msr_enc_linear(P(x), P(w), None, P(y), 4, 48, 768, S) < 0 and b"n_out=48" in lib.msr_last_error(None)
+    assert lib.msr_enc_linear(P(x), P(w), None, P(y), 4, 32, 100, S) < 0
+    assert lib.msr_enc_linear(P(x), P(w), None, P(y), 0, 32, 768, S) == 0
+
+
 def test_encoder_rejects_what_it_cannot_do(enc_world):
     _, enc = enc_world
     with pytest.raises(ValueError):

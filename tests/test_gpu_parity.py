@@ -837,7 +837,8 @@ def test_index_build_kernels_equal_the_reference_tables(mods):
     in every document, and vocabularies that need 1, 2 and 3 radix passes."""
     from msretr.index_build import bm25_index_from_token_ids, bm25_index_from_tokens
     rng = np.random.default_rng(19)
-    for n, V, long_docs in ((300, 200, ()), (700, 40_000, (5, 77)), (400, 300_000, (9,))):
+    for n, V, long_docs, p_uni in ((300, 200, (), 0.3), (700, 40_000, (5, 77), 0.3),
+                                   (400, 300_000, tuple(range(9, 400, 30)), 0.9)):
         doc_ids = rng.permutation(np.arange(1000, 1000 + 3 * n, 3))[:n]          # unsorted, with gaps
         lens = rng.integers(0, 120, size=n)
         lens[[3, 11]] = 0                                                         # token-less documents: no row
@@ -846,12 +847,14 @@ def test_index_build_kernels_equal_the_reference_tables(mods):
         toks = []
         for l in lens:
             t = np.minimum(rng.zipf(1.2, size=l), V - 1).astype(np.int64)
-            t[rng.random(l) < 0.3] = rng.integers(0, V, size=int((rng.random(l) < 0.3).sum())) if l else 0
+            m = rng.random(l) < p_uni
+            t[m] = rng.integers(0, V, size=int(m.sum()))
             if l:
                 t[0] = 0                                                          # term 0 in every document
             toks.append(t.tolist())
         ref = bm25_index_from_tokens(doc_ids, [[f"w{t}" for t in tl] for tl in toks])
         ids_of = {k: v for k, v in ref.vocab.items()}                             # the dict builder's numbering
+        assert (len(ref.vocab) > 65536) == (V == 300_000)                         # the last case needs a third radix pass
         tok_off = np.zeros(n + 1, np.int64); tok_off[1:] = np.cumsum(lens)
         tok_ids = np.array([ids_of[f"w{t}"] for tl in toks for t in tl], np.int32)
         got = bm25_index_from_token_ids(doc_ids, tok_off, tok_ids, len(ref.vocab), device="cuda")
