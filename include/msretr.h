@@ -209,10 +209,9 @@ int msr_build_postings(const int64_t* tok_off, const int32_t* tok_ids, int64_t n
  * since msr_set_timing(e, 1).  which: 0 = dense scan kernel, 1 = BM25 TAAT kernel, 2 = GEMM emit pass (all row tiles),
  * 3 = GEMM sample pass (every 16th tile). */
 int msr_set_timing(msr_engine* e, int32_t enabled);
-/* A/B hook for measurements (tools/gemm_check.py): selects between implementations that return IDENTICAL results.
- * MSR_TUNE_GEMM_VERSION: 1 (default) = one 64 x 32 quadrant per phase, 2 = one (row half, k half) per phase with the A
- * fragments prefetched during the matrix segment (measured 8 % slower).  Process-wide. */
-#define MSR_TUNE_GEMM_VERSION 1
+/* Measurement hook of the DIAGNOSTIC build (libmsretr_diag.so, -DMSR_DIAG: knock-out switches of the GEMM kernels,
+ * tools/gemm_check.py --dbg).  The product library knows no key and returns MSR_ERR_INVALID: it has no switches, no
+ * environment variables and one implementation per kernel. */
 int msr_tune(msr_engine* e, int32_t key, int32_t value);
 int msr_kernel_time_ms(msr_engine* e, int32_t which, float* out_ms, int32_t* out_launches);
 

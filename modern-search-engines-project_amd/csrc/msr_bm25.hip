@@ -1,17 +1,25 @@
 // K1 -- BM25 term-at-a-time scoring over HBM-resident CSR postings (gfx950).
 //
 // Replaces the per-query SQL fetch + Python grouping + scoring loop of the reference
-// (indexer/bm25_indexer.py:434-481).  The dense doc index is cut into tiles of TILE documents; one
-// workgroup owns one (tile, query) pair and keeps the tile's float64 accumulators in LDS.  It first locates
-// the tile's slice of every query term's posting list (two loads from the skip table for long lists, a
-// wave-wide 64-ary search for short ones; one term per wave side by side), then, IN QUERY ORDER, streams each slice with coalesced loads; a document occurs at most once per posting list
-// (PRIMARY KEY (doc_id, term), :100-104), so the read-modify-write of acc[doc] needs no atomics, and a
-// barrier between terms makes the float64 summation order equal to the reference's (:466-478).
-// The arithmetic is written operation by operation as Python evaluates it and this file is compiled with
-// -ffp-contract=off, so scores are bit-identical to the oracle.
+// (indexer/bm25_indexer.py:434-481).  The dense doc index is cut into tiles of TILE documents.  A workgroup owns one
+// tile and FOUR queries: its four waves score one query each, every wave with its own float64 accumulators in LDS,
+// sharing the tile's length norms k1 (1 - b + b dl / avgdl) (computed once per workgroup, also in LDS).  A wave
+//   1. looks its query's terms up lane-parallel (lane j = term j: offsets, idf, query frequency, skip-table row),
+//   2. finds the tile's slice of every posting list: two loads from the skip table for long lists, the whole list for
+//      lists of <= 64 postings, and ONE round of 64 probes for the lists in between (a covering range; postings outside
+//      the tile are masked when applied),
+//   3. fetches the first 64 postings of the first TPRE slices side by side, then accumulates IN QUERY ORDER.  A wave's
+//      LDS operations execute in order, so the float64 summation order of every document equals the reference's
+//      (:466-478) WITHOUT a barrier between terms; a document occurs at most once per posting list (PRIMARY KEY
+//      (doc_id, term), :100-104), so the read-modify-write of acc[doc] needs no atomics,
+//   4. appends the touched documents with score >= min_score to the query's candidate list (ballot prefix, one
+//      reservation per wave).
+// The only workgroup barrier is the one that publishes the length norms.  The arithmetic is written operation by
+// operation as Python evaluates it and this file is compiled with -ffp-contract=off, so scores are bit-identical to
+// the oracle.
 //
-// HBM traffic per query: 8 B per posting of the query's terms + 4 B per document (doc_len) + 12 B per
-// candidate document (the (score, doc) list consumed by the top-k select).
+// HBM traffic per query: 8 B per posting of the query's terms + 1 B per document (doc_len, shared by four queries) +
+// 12 B per candidate document (the (score, doc) list consumed by the top-k select).
 #include "msr_common.h"
 #include "msr_internal.h"
 
@@ -19,191 +27,208 @@ namespace {
 
 constexpr int BM25_TILE = MSR_BM25_TILE;
 constexpr int BM25_THREADS = 256;
-constexpr int BM25_MAX_TERMS = 64;                            // MSR_MAX_QUERY_TERMS
+constexpr int BM25_QPW = BM25_THREADS / 64;                   // queries per workgroup (one per wave)
+constexpr int BM25_MAX_TERMS = 64;                            // MSR_MAX_QUERY_TERMS: one lane per term
 constexpr uint64_t UNTOUCHED = 0x7FF8DEADBEEF0001ull;   // a quiet-NaN payload no computation produces
 
-// First index in [s, e) with a[idx] >= target (e if none).  Executed by one full wave.
-__device__ __forceinline__ int64_t wave_lower_bound(const int32_t* __restrict__ a, int64_t s, int64_t e,
-                                                    int32_t target) {
-    const int lane = threadIdx.x & 63;
-    while (e - s > 64) {
-        const int64_t len = e - s;
-        const int64_t chunk = (len + 63) >> 6;
-        int64_t idx = s + (int64_t)(lane + 1) * chunk - 1;
-        if (idx > e - 1) idx = e - 1;
-        const bool ge = a[idx] >= target;
-        const unsigned long long m = __ballot(ge);
-        if (m == 0) return e;
-        const int f = __ffsll((long long)m) - 1;
-        const int64_t idx_f = __shfl(idx, f);
-        const int64_t idx_p = __shfl(idx, f > 0 ? f - 1 : 0);
-        if (f > 0) s = idx_p + 1;
-        e = idx_f;                                   // a[idx_f] >= target: the answer is in [s, idx_f]
-        if (e <= s) return s;
-    }
-    const int64_t i = s + lane;
-    const bool ge = i < e && a[i] >= target;
-    const unsigned long long m = __ballot(ge);
-    if (m == 0) return e;
-    return s + (__ffsll((long long)m) - 1);
+__device__ __forceinline__ int64_t lane_i64(int64_t v, int j) {          // v of lane j (j wave-uniform)
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)v, j);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), j);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ double lane_f64(double v, int j) {
+    return __longlong_as_double(lane_i64(__double_as_longlong(v), j));
 }
 
 __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
                                                                   const int32_t* __restrict__ q_term_off,
                                                                   const int32_t* __restrict__ q_terms,
                                                                   const int32_t* __restrict__ q_qtf,
-                                                                  int q_first, double min_score,
+                                                                  int q_first, int nq, double min_score,
                                                                   double* __restrict__ cand_score,
                                                                   int32_t* __restrict__ cand_doc,
                                                                   int32_t* __restrict__ cand_n) {
-    __shared__ double acc[BM25_TILE];
-    __shared__ int32_t dl[BM25_TILE];
-    __shared__ int64_t slice[2 * BM25_MAX_TERMS];                // [term slot][begin, end) of the tile's postings
-    const int tid = threadIdx.x;
-    // grid = (queries, tiles): consecutive workgroups score the SAME tile for different queries, so the tile's document
+    __shared__ double acc_all[BM25_QPW][BM25_TILE];
+    __shared__ double dn[BM25_TILE];                         // k1 * (1 - b + b * doc_length / avg_doc_length)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // grid = (query groups, tiles): consecutive workgroups score the SAME tile for other queries, so the tile's document
     // lengths and the slices of the terms the queries share (the city term is in every query, search_api.py:155-166)
     // are served by the L2 after the first of them
-    const int q = blockIdx.x;                        // row of `scores`
+    const int q = blockIdx.x * BM25_QPW + wave;              // row of the candidate lists
+    const bool live = q < nq;                                // (wave-uniform)
     const int tile = blockIdx.y;
     const int64_t lo = (int64_t)tile * BM25_TILE;
     const int64_t hi = lo + BM25_TILE < ix.n_docs ? lo + BM25_TILE : ix.n_docs;
     const int n = (int)(hi - lo);
-    // the tile's document lengths: issued now, parked in registers while the posting slices are located (both are
-    // chains of dependent loads; side by side their latencies overlap), written to LDS afterwards
+    double* acc = acc_all[wave];
+    const double k1 = ix.k1, b = ix.b, avgdl = ix.avgdl;
+    const double k1p1 = k1 + 1.0;                    // self.k1 + 1
+    const double omb = 1.0 - b;                      // 1 - self.b
+    // the tile's document lengths: issued first, parked in registers while the slices are located
     int32_t dl_reg[BM25_TILE / BM25_THREADS];
 #pragma unroll
     for (int u = 0; u < BM25_TILE / BM25_THREADS; ++u) {
         const int i = tid + u * BM25_THREADS;
         dl_reg[u] = i < n ? ix.doc_len[lo + i] : 0;
     }
-    const double k1 = ix.k1, b = ix.b, avgdl = ix.avgdl;
-    const double k1p1 = k1 + 1.0;                    // self.k1 + 1
-    const double omb = 1.0 - b;                      // 1 - self.b
-    const int t0 = q_term_off[q_first + q];
-    int t1 = q_term_off[q_first + q + 1];
-    if (t1 - t0 > BM25_MAX_TERMS) t1 = t0 + BM25_MAX_TERMS;      // the host never sends more
-    // Locate the tile's slice of every posting list first, one term per wave at a time: the searches are
-    // chains of dependent loads, so running them for all terms side by side hides most of their latency.
-    {
-        const int wv = tid >> 6;
-        for (int j = t0 + wv; j < t1; j += BM25_THREADS / 64) {
-            const int32_t t = q_terms[j];
-            int64_t ps = 0, pe = 0;
+    // ---- 1. the query's terms, lane j = term j ----
+    int nt = 0;
+    int64_t ps_v = 0, pe_v = 0;                      // [begin, end) of term j's postings to look at in this tile
+    double idf_v = 0.0, qtf_v = 0.0;
+    bool medium = false;
+    if (live) {
+        const int t0 = q_term_off[q_first + q];
+        nt = q_term_off[q_first + q + 1] - t0;
+        if (nt > BM25_MAX_TERMS) nt = BM25_MAX_TERMS;        // the host never sends more
+        if (lane < nt) {
+            const int32_t t = q_terms[t0 + lane];
             if (t >= 0 && t < ix.n_terms) {
                 const int64_t s = ix.term_off[t], e = ix.term_off[t + 1];
                 if (e > s) {
+                    idf_v = (double)ix.idf[t];
+                    qtf_v = (double)q_qtf[t0 + lane];
                     const int h = ix.heavy_id ? ix.heavy_id[t] : -1;
                     if (h >= 0) {                            // long list: the slice comes from the skip table
                         const uint32_t* row = ix.tile_off + (int64_t)h * (ix.n_tiles + 1) + tile;
-                        ps = s + row[0];
-                        pe = s + row[1];
+                        ps_v = s + row[0];
+                        pe_v = s + row[1];
                     } else {
-                        ps = wave_lower_bound(ix.post_doc, s, e, (int32_t)lo);
-                        pe = wave_lower_bound(ix.post_doc, ps, e, (int32_t)hi);
+                        ps_v = s;                            // short list: all of it (postings of other tiles are masked)
+                        pe_v = e;
+                        medium = e - s > 64;
                     }
                 }
             }
-            if ((tid & 63) == 0) { slice[2 * (j - t0)] = ps; slice[2 * (j - t0) + 1] = pe; }
         }
     }
+    // ---- 2. lists of 65 .. HEAVY_DF-1 postings: one round of 64 probes narrows [ps, pe) to the chunks that can hold
+    //         documents of this tile; MED lists side by side (the probes are independent loads) ----
+    {
+        constexpr int MED = 4;
+        unsigned long long todo = __ballot(medium);
+        while (todo) {
+            int jj[MED];
+            int64_t s_[MED], e_[MED], ch_[MED];
+            int32_t probe[MED];
 #pragma unroll
-    for (int u = 0; u < BM25_TILE / BM25_THREADS; ++u) {
-        const int i = tid + u * BM25_THREADS;
-        acc[i] = __longlong_as_double((long long)UNTOUCHED);
-        dl[i] = dl_reg[u];
+            for (int m = 0; m < MED; ++m) {
+                jj[m] = todo ? __ffsll((long long)todo) - 1 : -1;
+                if (todo) todo &= todo - 1;
+                probe[m] = 0; s_[m] = e_[m] = ch_[m] = 0;
+                if (jj[m] >= 0) {                            // wave-uniform
+                    s_[m] = lane_i64(ps_v, jj[m]);
+                    e_[m] = lane_i64(pe_v, jj[m]);
+                    ch_[m] = (e_[m] - s_[m] + 63) >> 6;
+                    int64_t idx = s_[m] + (int64_t)(lane + 1) * ch_[m] - 1;     // last posting of chunk `lane`
+                    if (idx > e_[m] - 1) idx = e_[m] - 1;
+                    probe[m] = ix.post_doc[idx];
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < MED; ++m) {
+                if (jj[m] < 0) continue;                     // wave-uniform
+                const unsigned long long ge_lo = __ballot(probe[m] >= (int32_t)lo);
+                const unsigned long long ge_hi = __ballot((int64_t)probe[m] >= hi);
+                int64_t ps = e_[m], pe = e_[m];              // nothing >= lo: empty
+                if (ge_lo) {
+                    ps = s_[m] + (int64_t)(__ffsll((long long)ge_lo) - 1) * ch_[m];
+                    if (ps > e_[m]) ps = e_[m];
+                    if (ge_hi) {
+                        pe = s_[m] + (int64_t)(__ffsll((long long)ge_hi)) * ch_[m];
+                        if (pe > e_[m]) pe = e_[m];
+                    }
+                }
+                if (lane == jj[m]) { ps_v = ps; pe_v = pe; }
+            }
+        }
     }
+    // ---- 3. prefetch: the first 64 postings of the first TPRE slices (for most terms: the whole slice) ----
+    constexpr int TPRE = 8;
+    int32_t pd0[TPRE], ptf0[TPRE];
+#pragma unroll
+    for (int j = 0; j < TPRE; ++j) {
+        pd0[j] = -1; ptf0[j] = 0;
+        if (j < nt) {                                        // wave-uniform
+            const int64_t i = lane_i64(ps_v, j) + lane;
+            if (i < lane_i64(pe_v, j)) { pd0[j] = ix.post_doc[i]; ptf0[j] = ix.post_tf[i]; }
+        }
+    }
+    // accumulators of this wave's query; the length norms of the tile (shared by the four waves)
+#pragma unroll
+    for (int u = 0; u < BM25_TILE / 64; ++u) acc[lane + 64 * u] = __longlong_as_double((long long)UNTOUCHED);
+#pragma unroll
+    for (int u = 0; u < BM25_TILE / BM25_THREADS; ++u)
+        dn[tid + u * BM25_THREADS] = k1 * (omb + (b * (double)dl_reg[u]) / avgdl);
     __syncthreads();
     // One posting: the reference's arithmetic, operation by operation (:472-478).
     auto apply = [&](int32_t pdoc, int32_t ptf, double idf, double qtf) {
-        const int d = pdoc - (int32_t)lo;
+        const uint32_t d = (uint32_t)(pdoc - (int32_t)lo);
+        if (d >= (uint32_t)n) return;                        // a posting of another tile (covering ranges), or none
         const double tf = (double)ptf;
-        const double dlen = (double)dl[d];
         // tf_component = (tf * (k1 + 1)) / (tf + k1 * (1 - b + b * doc_length / avg_doc_length))
-        const double comp = (tf * k1p1) / (tf + k1 * (omb + (b * dlen) / avgdl));
+        const double comp = (tf * k1p1) / (tf + dn[d]);
         // term_score = idf * tf_component * query_term_freq[term]; bm25_score += term_score
         const double c = (idf * comp) * qtf;
         const double a = acc[d];
         acc[d] = ((uint64_t)__double_as_longlong(a) == UNTOUCHED ? 0.0 : a) + c;
     };
-    // The rest of a slice, U postings per thread and round: all loads of a round are issued before the first is used.
+    // The rest of a slice, U x 64 postings per round: all loads of a round are issued before the first is used.
     auto stream = [&](int64_t from, int64_t pe, double idf, double qtf) {
         constexpr int U = 4;
-        for (int64_t i0 = from + tid; i0 < pe; i0 += (int64_t)U * BM25_THREADS) {
+        for (int64_t base = from; base < pe; base += (int64_t)U * 64) {
             int32_t pd[U], ptf[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int64_t i = i0 + (int64_t)u * BM25_THREADS;
+                const int64_t i = base + lane + (int64_t)u * 64;
                 pd[u] = i < pe ? ix.post_doc[i] : -1;
                 ptf[u] = i < pe ? ix.post_tf[i] : 0;
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (pd[u] >= 0) apply(pd[u], ptf[u], idf, qtf);
+            for (int u = 0; u < U; ++u) apply(pd[u], ptf[u], idf, qtf);
         }
     };
-    // The first 256 postings of the first TPRE terms' slices (for most terms: the whole slice) are fetched side by
-    // side BEFORE the ordered accumulation starts, together with the terms' idf and query frequency: otherwise every
-    // term costs a round trip to memory between two barriers.  The accumulation itself stays IN QUERY ORDER with a
-    // barrier between terms: the float64 sums must match the reference's (:466-478).
-    constexpr int TPRE = 6;
-    int32_t pd0[TPRE], ptf0[TPRE];
-    double idf0[TPRE], qtf0[TPRE];
 #pragma unroll
-    for (int jj = 0; jj < TPRE; ++jj) {
-        pd0[jj] = -1; ptf0[jj] = 0; idf0[jj] = 0.0; qtf0[jj] = 0.0;
-        if (t0 + jj < t1) {
-            const int64_t ps = slice[2 * jj], pe = slice[2 * jj + 1];
-            if (pe > ps) {
-                const int32_t t = q_terms[t0 + jj];
-                idf0[jj] = (double)ix.idf[t];
-                qtf0[jj] = (double)q_qtf[t0 + jj];
-                const int64_t i = ps + tid;
-                if (i < pe) { pd0[jj] = ix.post_doc[i]; ptf0[jj] = ix.post_tf[i]; }
-            }
-        }
+    for (int j = 0; j < TPRE; ++j) {
+        if (j >= nt) break;                                  // wave-uniform
+        const int64_t ps = lane_i64(ps_v, j), pe = lane_i64(pe_v, j);
+        if (pe <= ps) continue;
+        const double idf = lane_f64(idf_v, j), qtf = lane_f64(qtf_v, j);
+        apply(pd0[j], ptf0[j], idf, qtf);
+        if (pe - ps > 64) stream(ps + 64, pe, idf, qtf);
     }
+    for (int j = TPRE; j < nt; ++j) {
+        const int64_t ps = lane_i64(ps_v, j), pe = lane_i64(pe_v, j);
+        if (pe <= ps) continue;
+        stream(ps, pe, lane_f64(idf_v, j), lane_f64(qtf_v, j));
+    }
+    if (!live) return;
+    // ---- 4. the tile's candidates (touched by a posting AND score >= min_score, :461,480) as (score, doc) pairs
+    //         appended to the query's list: one reservation per wave.  Most documents of a tile are not candidates, so
+    //         this replaces an 8 B/document dense row by 12 B per candidate. ----
+    int total = 0;
+    unsigned long long flags[BM25_TILE / 64];
 #pragma unroll
-    for (int jj = 0; jj < TPRE; ++jj) {
-        if (t0 + jj >= t1) break;                                // block-uniform
-        const int64_t ps = slice[2 * jj], pe = slice[2 * jj + 1];
-        if (pe <= ps) continue;                                  // block-uniform
-        if (pd0[jj] >= 0) apply(pd0[jj], ptf0[jj], idf0[jj], qtf0[jj]);
-        stream(ps + BM25_THREADS, pe, idf0[jj], qtf0[jj]);
-        __syncthreads();
-    }
-    for (int j = t0 + TPRE; j < t1; ++j) {
-        const int64_t ps = slice[2 * (j - t0)], pe = slice[2 * (j - t0) + 1];
-        if (pe <= ps) continue;                                  // block-uniform
-        const int32_t t = q_terms[j];
-        stream(ps, pe, (double)ix.idf[t], (double)q_qtf[j]);
-        __syncthreads();
-    }
-    // Emit the tile's candidates (touched by a posting AND score >= min_score, :461,480) as (score, doc) pairs
-    // appended to the query's list: one reservation per workgroup.  Most documents of a tile are not
-    // candidates, so this replaces an 8 B/document dense row by 12 B per candidate.
-    __shared__ int s_cnt, s_base;
-    if (tid == 0) s_cnt = 0;
-    __syncthreads();
-    int mine = 0;
-    for (int i = tid; i < n; i += BM25_THREADS) {
+    for (int u = 0; u < BM25_TILE / 64; ++u) {
+        const int i = lane + 64 * u;
         const double a = acc[i];
-        mine += ((uint64_t)__double_as_longlong(a) != UNTOUCHED && a >= min_score) ? 1 : 0;
+        flags[u] = __ballot(i < n && (uint64_t)__double_as_longlong(a) != UNTOUCHED && a >= min_score);
+        total += __popcll(flags[u]);
     }
-    int pos = mine ? atomicAdd(&s_cnt, mine) : 0;
-    __syncthreads();
-    if (tid == 0 && s_cnt) s_base = atomicAdd(&cand_n[q], s_cnt);
-    __syncthreads();
-    if (mine) {
-        const int64_t o = (int64_t)q * ix.n_docs + s_base + pos;
-        int w = 0;
-        for (int i = tid; i < n; i += BM25_THREADS) {
-            const double a = acc[i];
-            if ((uint64_t)__double_as_longlong(a) != UNTOUCHED && a >= min_score) {
-                cand_score[o + w] = a;
-                cand_doc[o + w] = (int32_t)(lo + i);
-                ++w;
-            }
+    if (total == 0) return;                                  // wave-uniform
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&cand_n[q], total);
+    base = __builtin_amdgcn_readfirstlane(base);
+    const int64_t o = (int64_t)q * ix.n_docs + base;
+    int run = 0;
+#pragma unroll
+    for (int u = 0; u < BM25_TILE / 64; ++u) {
+        if ((flags[u] >> lane) & 1) {
+            const int i = lane + 64 * u;
+            const int w = run + __popcll(flags[u] & ((1ull << lane) - 1));
+            cand_score[o + w] = acc[i];
+            cand_doc[o + w] = (int32_t)(lo + i);
         }
+        run += __popcll(flags[u]);
     }
 }
 
@@ -274,8 +299,8 @@ hipError_t msr_bm25_scores(const Bm25Index& ix, const int32_t* q_term_off, const
                            const int32_t* q_qtf, int q_first, int nq, double min_score, double* cand_score,
                            int32_t* cand_doc, int32_t* cand_n, hipStream_t stream) {
     if (nq <= 0 || ix.n_docs <= 0) return hipSuccess;
-    dim3 grid((unsigned)nq, (unsigned)((ix.n_docs + BM25_TILE - 1) / BM25_TILE));
-    bm25_taat_kernel<<<grid, BM25_THREADS, 0, stream>>>(ix, q_term_off, q_terms, q_qtf, q_first, min_score, cand_score,
+    dim3 grid((unsigned)((nq + BM25_QPW - 1) / BM25_QPW), (unsigned)((ix.n_docs + BM25_TILE - 1) / BM25_TILE));
+    bm25_taat_kernel<<<grid, BM25_THREADS, 0, stream>>>(ix, q_term_off, q_terms, q_qtf, q_first, nq, min_score, cand_score,
                                                         cand_doc, cand_n);
     return hipGetLastError();
 }

@@ -9,7 +9,7 @@
 //     operand; lane (n = lane & 15, g = lane >> 4) loads w[row n][16t + 4g .. +3] and x[token n][16t + 4g .. +3] --
 //     one 16-byte load feeds four MFMAs, the k index of an MFMA is only a label, no data moves between lanes.
 //   * a workgroup owns RB x 16 weight rows and NTB x 16 tokens; its 4 waves split K in four slices (a weight element is
-//     read from HBM once per token tile -- once in all when T <= 128), partial sums meet in LDS in a fixed order
+//     read from HBM once; token tiles beyond the first find it in L2), partial sums meet in LDS in a fixed order
 //     (wave 0..3: the result does not depend on scheduling), the residual is added there and lane (n, g) writes
 //     y[token n][16 rb + 4g .. +3] as one 16-byte store.
 //   * N / (16 RB) x ceil(T / (16 NTB)) workgroups: 48..144 for a single query (latency-bound: 22 x 4 of these sit in
@@ -23,7 +23,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int NTB, int RB>
+template <int NTB, int RB, int PF>
 __global__ __launch_bounds__(256) void enc_linear_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* resid, float* y,   // (resid may alias y)
                                                          int n_tok, int n_out, int n_in) {
@@ -52,26 +52,34 @@ __global__ __launch_bounds__(256) void enc_linear_kernel(const float* __restrict
 #pragma unroll
         for (int tb = 0; tb < NTB; ++tb) acc[r][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // two k-steps of 16 per iteration (host checks n_in % 128 == 0): 2 (RB + NTB) loads in flight ahead of 8 RB NTB MFMAs
-    const int steps = kslice >> 5;
-    for (int t = 0; t < steps; ++t) {
-        f32x4 a[2][RB], b[2][NTB];
+    // k-steps of 16; the operands of PF steps are in flight ahead of the MFMAs (a ring of PF register sets, statically
+    // indexed: the loop body is unrolled PF times)
+    const int steps = kslice >> 4;
+    f32x4 a[PF][RB], b[PF][NTB];
+    auto load = [&](int p, int t) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int r = 0; r < RB; ++r) a[p][r] = *reinterpret_cast<const f32x4*>(wp[r] + 16 * t);
 #pragma unroll
-            for (int r = 0; r < RB; ++r) a[h][r] = *reinterpret_cast<const f32x4*>(wp[r] + 32 * t + 16 * h);
+        for (int tb = 0; tb < NTB; ++tb) b[p][tb] = *reinterpret_cast<const f32x4*>(xp[tb] + 16 * t);
+    };
 #pragma unroll
-            for (int tb = 0; tb < NTB; ++tb) b[h][tb] = *reinterpret_cast<const f32x4*>(xp[tb] + 32 * t + 16 * h);
+    for (int p = 0; p < PF; ++p)
+        if (p < steps) load(p, p);
+    for (int t0 = 0; t0 < steps; t0 += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const int t = t0 + p;
+            if (t < steps) {                                  // (uniform)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int r = 0; r < RB; ++r)
+#pragma unroll
+                        for (int tb = 0; tb < NTB; ++tb)
+                            acc[r][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p][r][c], b[p][tb][c], acc[r][tb], 0, 0, 0);
+                if (t + PF < steps) load(p, t + PF);
+            }
         }
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int r = 0; r < RB; ++r)
-#pragma unroll
-                    for (int tb = 0; tb < NTB; ++tb)
-                        acc[r][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[h][r][c], b[h][tb][c], acc[r][tb], 0, 0, 0);
     }
 
 #pragma unroll
@@ -98,11 +106,11 @@ __global__ __launch_bounds__(256) void enc_linear_kernel(const float* __restrict
         }
 }
 
-template <int NTB, int RB>
+template <int NTB, int RB, int PF>
 void launch(const float* x, const float* w, const float* resid, float* y, int n_tok, int n_out, int n_in,
             hipStream_t stream) {
     const dim3 grid((unsigned)(n_out / (16 * RB)), (unsigned)((n_tok + 16 * NTB - 1) / (16 * NTB)));
-    enc_linear_kernel<NTB, RB><<<grid, 256, 0, stream>>>(x, w, resid, y, n_tok, n_out, n_in);
+    enc_linear_kernel<NTB, RB, PF><<<grid, 256, 0, stream>>>(x, w, resid, y, n_tok, n_out, n_in);
 }
 
 }  // namespace
@@ -117,13 +125,13 @@ extern "C" int msr_enc_linear(const float* x, const float* w, const float* resid
         return msr_fail_global(MSR_ERR_INVALID, "msr_enc_linear: pointers must be 16-byte aligned");
     if (n_tok == 0) return MSR_OK;
     hipStream_t s = (hipStream_t)stream;
-    // token-block count per workgroup: the smallest that covers the tokens (fewer idle MFMAs for a single query);
-    // batches use 128-token tiles with 32 weight rows per workgroup, which halves the L2 traffic of x
-    if (n_tok <= 16) launch<1, 1>(x, w, resid, y, n_tok, n_out, n_in, s);
-    else if (n_tok <= 32) launch<2, 1>(x, w, resid, y, n_tok, n_out, n_in, s);
-    else if (n_tok <= 64) launch<4, 1>(x, w, resid, y, n_tok, n_out, n_in, s);
-    else if (n_tok <= 128) launch<8, 1>(x, w, resid, y, n_tok, n_out, n_in, s);
-    else launch<8, 2>(x, w, resid, y, n_tok, n_out, n_in, s);
+    // token blocks per workgroup: the smallest that covers a single query's tokens (fewer idle MFMAs; the whole K slice
+    // of a wave is in flight at once), 64-token tiles beyond that; batches (> 128 tokens) take 32 weight rows per
+    // workgroup, which halves the L2 traffic of x
+    if (n_tok <= 16) launch<1, 1, 6>(x, w, resid, y, n_tok, n_out, n_in, s);
+    else if (n_tok <= 32) launch<2, 1, 4>(x, w, resid, y, n_tok, n_out, n_in, s);
+    else if (n_tok <= 128) launch<4, 1, 3>(x, w, resid, y, n_tok, n_out, n_in, s);
+    else launch<4, 2, 3>(x, w, resid, y, n_tok, n_out, n_in, s);
     const hipError_t err = hipGetLastError();
     return err == hipSuccess ? MSR_OK : msr_fail_global(MSR_ERR_HIP, "msr_enc_linear: %s", hipGetErrorString(err));
 }

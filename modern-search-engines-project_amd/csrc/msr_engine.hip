@@ -757,7 +757,6 @@ extern "C" int msr_enable_bf16(msr_engine* e, void* stream) {
 
 extern "C" int msr_tune(msr_engine* e, int32_t key, int32_t value) {
     if (!e) return MSR_ERR_INVALID;
-    if (key == MSR_TUNE_GEMM_VERSION && value >= 1 && value <= 3) { msr_gemm_set_version(value); return MSR_OK; }
 #ifdef MSR_DIAG
     if (key == 100) { msr_gemm_set_dbg(value); return MSR_OK; }      // timing experiments of the diagnostic build
     if (key == 101) { msr_gemm_f32_set_dbg(value); return MSR_OK; }

@@ -15,22 +15,24 @@
 //   finish           msr_gemm_finish: entries >= t' - margin are bucketed per query, reduced to per-document maxima,
 //                    and the survivors are re-scored exactly in f32 by the kernels of msr_batch.hip.
 //
-// Both operands are bf16 images of UNIT vectors (rows are normalised when the image is built), so every score is off
-// by at most eps = 2^-7 (msr_batch.hip) and margin = 2 eps makes the survivor set a superset of the exact top-k.
+// Both operands are bf16 images of UNIT vectors (rows are normalised when the image is built).  The margin is MEASURED,
+// not a worst case: unit_bf16_rows_kernel records dE = the largest rounding-error norm |e - bf16(e)| over all rows,
+// batch_margin_kernel computes dq the same way per query, and by Cauchy-Schwarz every score is off by at most
+// eps_q = dE (1 + dq) + dq; margin_q = 2 eps_q + 1e-4 makes the survivor set a superset of the exact top-k
+// (derivation: DESIGN.md section 3, K5).  Typical: margin 0.0046 instead of the worst-case 2^-6.
 //
-// Kernel shape (one persistent workgroup per CU, 8 waves, 256 x 256 output tile, K step 64):
-//   * LDS: 2 buffers x {A rows 0-127, A rows 128-255, B queries 0-127, B queries 128-255} x 16 KB = 128 KB, filled by
-//     global_load_lds_dwordx4 (no VGPR staging); image rows are 128 B with the 16 B chunk index XORed by (row >> 1) & 7
-//     -- applied to the per-lane SOURCE address, the LDS side of the DMA stays linear -- which makes every
-//     ds_read_b128 of an MFMA fragment conflict-free.
-//   * wave (wr, wc) owns rows {wr 64 .. +64} of both A halves and queries {wc 32 .. +32} of both B halves: 4 quadrants of
-//     64 x 32, one per phase, 16 v_mfma_f32_16x16x32_bf16 each; 128 accumulator registers.
-//   * per phase: [load segment: issue the DMA of one half-tile of the NEXT K step, read this quadrant's fragments,
-//     s_waitcnt vmcnt(4)] barrier [matrix segment: 16 MFMAs] barrier.  Waves 4-7 run one barrier behind waves 0-3, so on
-//     every SIMD one wave's matrix segment runs beside the other wave's load segment.  A half-tile is read two phases
-//     after it was issued, and always one barrier after the vmcnt wait of every wave that issued it.
+// Kernel shape (one persistent workgroup per CU, 8 waves, 256 x 256 output tile, K step 64; details at the K loop):
+//   * LDS, all 160 KB: 3 buffers x {A rows 0-127, A rows 128-255} + 2 buffers x {B queries 0-127, B queries 128-255},
+//     16 KB each, filled by global_load_lds_dwordx4 (no VGPR staging); image rows are 128 B with the 16 B chunk index
+//     XORed by (row >> 1) & 7 -- applied to the per-lane SOURCE address, the LDS side of the DMA stays linear -- which
+//     makes every ds_read_b128 of an MFMA fragment conflict-free (SQ_LDS_BANK_CONFLICT = 0 measured).
+//   * wave (wr, wc) owns rows {wr 64 .. +64} of both A halves and queries {wc 32 .. +32} of both B halves: a 128 x 64
+//     piece, 64 v_mfma_f32_16x16x32_bf16 per K step, 128 accumulator registers.
+//   * per K step: issue the queries of step + 1 and the rows of step + 2, then 4 x (fragment reads, 16 MFMAs),
+//     s_waitcnt vmcnt(4), ONE barrier.
 //   * the NT = nq / 256 workgroups that share a row tile sit on the same XCD (blockIdx % 8) and walk the same tile
-//     sequence, so E comes from HBM once per batch and from the XCD's L2 for the others.
+//     sequence, so E comes from HBM once per batch and from the XCD's L2 for the others (measured: 8.9 GB of HBM reads
+//     per 1024 queries for 7.68 GB of rows).
 #include <type_traits>
 
 #include "msr_common.h"
@@ -43,8 +45,7 @@ namespace {
 constexpr int GM_THREADS = 512;
 constexpr int GM_KT = MSR_DIM / 64;            // K steps per output tile
 constexpr int GM_HALF = 16384;                 // bytes of one half-tile image: 128 rows x 128 B
-constexpr int GM_LDS = 8 * GM_HALF;             // versions 1, 2: 2 x (A-lo, A-hi, B-lo, B-hi)
-constexpr int GM_LDS3 = 10 * GM_HALF;           // version 3: 3 x (A-lo, A-hi) + 2 x (B-lo, B-hi) = all 160 KB
+constexpr int GM_LDS3 = 10 * GM_HALF;           // 3 x (A-lo, A-hi) + 2 x (B-lo, B-hi) = all 160 KB
 constexpr int GM_ROWB = MSR_DIM * 2;           // bytes per bf16 row
 
 struct GemmArgs {
@@ -64,12 +65,12 @@ struct GemmArgs {
                                // the rows of tile 0 (A always from cache), bit 1 = B always K step 0
 };
 
-template <bool EMIT, int VER>
+template <bool EMIT>
 __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = w >> 2, wc = w & 3;                 // waves 0-3 (wr = 0) lead, waves 4-7 follow one barrier behind
+    const int wr = w >> 2, wc = w & 3;                 // the wave's 128 x 64 piece of the 256 x 256 tile: rows wr, queries wc
     const int li16 = lane & 15, lg = lane >> 4;
 
     // ---- which tiles: the nt workgroups of a row-tile group share blockIdx % 8 (one XCD under round-robin dispatch) ----
@@ -112,7 +113,6 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
         for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_global_load_lds((glb_void*)(src + goff[i]), (lds_void*)(smem + slot + (2 * w + i) * 1024), 16, 0, 0);
     };
-    auto slot_of = [](int d, int h) { return (d * 4 + h) * GM_HALF; };      // h: 0 A-lo, 1 A-hi, 2 B-lo, 3 B-hi
 
     float thrv[2][2];
 #pragma unroll
@@ -147,122 +147,31 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
     int row0n = first_row(jn);
     const char* Bq = a.B + (size_t)(nt * 256) * GM_ROWB;
 
-    // ---- prologue: the first K step of the first tile (version 3: and the A halves of the second) ----
-    // version 3 slots: A buffer j (0..2) at j * 32 KB (lo, hi), B buffer d (0..1) at 96 KB + d * 32 KB (lo, hi)
+    // ---- prologue: the first K step of the first tile and the row halves of the second ----
+    // LDS slots: row buffer j (0..2) at j * 32 KB (lo, hi), query buffer d (0..1) at 96 KB + d * 32 KB (lo, hi)
     auto a3 = [](int j, int hi) { return (2 * j + hi) * GM_HALF; };
     auto b3 = [](int d, int hi) { return (6 + 2 * d + hi) * GM_HALF; };
-    if (VER == 3) {
-        stage(a.A + (size_t)row0 * GM_ROWB, a3(0, 0));
-        stage(Bq, b3(0, 0));
-        stage(a.A + (size_t)(row0 + 128) * GM_ROWB, a3(0, 1));
-        stage(Bq + 128 * GM_ROWB, b3(0, 1));
-        stage(a.A + (size_t)row0 * GM_ROWB + 128, a3(1, 0));
-        stage(a.A + (size_t)(row0 + 128) * GM_ROWB + 128, a3(1, 1));
-    } else {
-        stage(a.A + (size_t)row0 * GM_ROWB, slot_of(0, 0));
-        stage(Bq, slot_of(0, 2));
-        stage(Bq + 128 * GM_ROWB, slot_of(0, 3));
-        stage(a.A + (size_t)(row0 + 128) * GM_ROWB, slot_of(0, 1));
-    }
+    stage(a.A + (size_t)row0 * GM_ROWB, a3(0, 0));
+    stage(Bq, b3(0, 0));
+    stage(a.A + (size_t)(row0 + 128) * GM_ROWB, a3(0, 1));
+    stage(Bq + 128 * GM_ROWB, b3(0, 1));
+    stage(a.A + (size_t)row0 * GM_ROWB + 128, a3(1, 0));
+    stage(a.A + (size_t)(row0 + 128) * GM_ROWB + 128, a3(1, 1));
     wait_vm0();
     wg_barrier();
-    if (VER == 1 && wr == 1) wg_barrier();             // version 1: the followers start one barrier late
     prologue = false;
 
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
 
-    // ======== version 1: one 64 x 32 quadrant of the wave's tile per phase ========
-    bf16x8 af[4][2] = {}, bfr[2][2] = {};
-    auto read_a = [&](int d, int mh) {
-        if (dbg & 16) return;
-        const char* p = smem + slot_of(d, mh) + a_base;
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) af[mi][ks] = *(const bf16x8*)(p + mi * 2048 + foff[ks]);
-    };
-    auto read_b = [&](int d, int nh) {
-        if (dbg & 16) return;
-        const char* p = smem + slot_of(d, 2 + nh) + b_base;
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) bfr[ni][ks] = *(const bf16x8*)(p + ni * 2048 + foff[ks]);
-    };
-    auto mma = [&](auto mh_c, auto nh_c) {
-        constexpr int mh = decltype(mh_c)::value, nh = decltype(nh_c)::value;
-        if (dbg & 8) return;
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    acc[mh][mi][nh][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][ks], bfr[ni][ks], acc[mh][mi][nh][ni], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-    };
-    // One K step = 4 phases.  During K step u (buffer d) the half-tiles of step u + 1 are issued into buffer d ^ 1 in the
-    // order they will be needed: A-lo, B-lo, B-hi, A-hi; every wait leaves the two youngest half-tiles (4 DMAs) in flight.
-    auto kstep1 = [&](auto d_c, const char* An, const char* Bn) {
-        constexpr int d = decltype(d_c)::value;
-        // phase 0: quadrant (A-lo, B-lo)
-        stage(An, slot_of(d ^ 1, 0));
-        read_b(d, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        read_a(d, 0);
-        wait_vm4();
-        wg_barrier();
-        mma(I0{}, I0{});
-        wg_barrier();
-        // phase 1: (A-lo, B-hi)
-        stage(Bn, slot_of(d ^ 1, 2));
-        read_b(d, 1);
-        wait_vm4();
-        wg_barrier();
-        mma(I0{}, I1{});
-        wg_barrier();
-        // phase 2: (A-hi, B-hi)
-        stage(Bn + 128 * GM_ROWB, slot_of(d ^ 1, 3));
-        read_a(d, 1);
-        wait_vm4();
-        wg_barrier();
-        mma(I1{}, I1{});
-        wg_barrier();
-        // phase 3: (A-hi, B-lo)
-        stage(An + 128 * GM_ROWB, slot_of(d ^ 1, 1));
-        read_b(d, 0);
-        wait_vm4();
-        wg_barrier();
-        mma(I1{}, I0{});
-        wg_barrier();
-    };
-
-    // ======== version 2: ONE barrier per K step ========
-    // Measured on version 1 (profiles/r02_gemm_knockout.md): with MFMAs, fragment reads and DMAs all removed the loop still
-    // takes 41 % of its time -- a workgroup barrier costs ~200 cycles during which no wave issues anything, and version 1
-    // has 96 of them per tile.  Here a K step is one uninterrupted stretch of 64 MFMAs per wave: all 8 DMAs of the NEXT
-    // step are issued first (into the other buffer, which every wave finished reading before the previous barrier),
-    // fly during the whole step, and are waited for (vmcnt(0)) right before the step's only barrier.  Inside the step a
-    // wave alternates fragment reads and 16-MFMA groups -- (row half, k half) sub-steps: 4 A + 4 B fragments, the next
-    // A fragments read into a second register set before the current MFMAs -- and the two waves of a SIMD drift apart
-    // freely, so one wave's LDS latency hides behind the other's MFMAs.  No stagger, 12 barriers per tile.
+    // ======== the K loop: ONE barrier per K step, rows three buffers deep ========
+    // History (profiles/r02_gemm_knockout.md): a first version ran one 64 x 32 quadrant per phase with 8 barriers per
+    // K step; with MFMAs, fragment reads and DMAs all removed it still took 41 % of its time -- a workgroup barrier
+    // costs ~200 cycles during which no wave issues anything.  Now a K step is one uninterrupted stretch of 64 MFMAs
+    // per wave: inside it a wave alternates fragment reads and 16-MFMA groups -- (row half, k half) sub-steps: 4 A +
+    // 4 B fragments, the next A fragments read into a second register set before the current MFMAs -- and the two
+    // waves of a SIMD drift apart freely, so one wave's LDS latency hides behind the other's MFMAs.  12 barriers per tile.
     bf16x8 a0[4] = {}, a1[4] = {}, b4[4] = {};
-    auto rd_a = [&](bf16x8 (&dst)[4], int d, int mh, int ks) {
-        if (dbg & 16) return;
-        const char* p = smem + slot_of(d, mh) + a_base + foff[ks];
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) dst[mi] = *(const bf16x8*)(p + mi * 2048);
-    };
-    auto rd_b = [&](int d, int ks) {
-        if (dbg & 16) return;
-#pragma unroll
-        for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-                b4[nh * 2 + ni] = *(const bf16x8*)(smem + slot_of(d, 2 + nh) + b_base + ni * 2048 + foff[ks]);
-    };
     auto mma2 = [&](const bf16x8 (&aa)[4], auto mh_c, auto zero_c) {
         constexpr int mh = decltype(mh_c)::value;
         constexpr bool ZERO = decltype(zero_c)::value != 0;     // first touch of these accumulators in a tile: C = 0
@@ -278,33 +187,12 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
                         aa[mi], b4[nh * 2 + ni], ZERO ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[mh][mi][nh][ni], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
-    auto kstep2 = [&](auto d_c, const char* An, const char* Bn) {
-        constexpr int d = decltype(d_c)::value;
-        stage(An, slot_of(d ^ 1, 0));
-        stage(Bn, slot_of(d ^ 1, 2));
-        stage(An + 128 * GM_ROWB, slot_of(d ^ 1, 1));
-        stage(Bn + 128 * GM_ROWB, slot_of(d ^ 1, 3));
-        rd_b(d, 0);
-        rd_a(a0, d, 0, 0);
-        rd_a(a1, d, 1, 0);
-        mma2(a0, I0{}, I0{});                          // (rows lo, k lo)
-        rd_a(a0, d, 0, 1);
-        mma2(a1, I1{}, I0{});                          // (rows hi, k lo)
-        rd_b(d, 1);
-        rd_a(a1, d, 1, 1);
-        mma2(a0, I0{}, I0{});                          // (rows lo, k hi)
-        mma2(a1, I1{}, I0{});                          // (rows hi, k hi)
-        wait_vm0();
-        wg_barrier();
-    };
-
-    // ======== version 3: version 2 with the A rows THREE buffers deep ========
-    // Measured (profiles/r02_gemm_knockout.md): with only the DMAs left, a K step of version 2 takes 1.8 us -- the 64 KB
-    // of a step do not arrive within the step's 64 MFMAs; 78 % of the reads hit the XCD's L2 (the queries always, the
-    // rows for three of the four workgroups that share a row tile), but each step waits for its slowest line, and the
-    // row tile of the leading workgroup comes from HBM.  So the rows get two steps of flight: step u issues the queries
-    // of step u + 1 FIRST and the rows of step u + 2 after them; the wait before the barrier is vmcnt(4), which retires
-    // everything but those 4 youngest DMAs -- the in-order counter then never makes the rows wait for the queries.
+    // With only the DMAs left, a K step with two buffers took 1.8 us -- the 64 KB of a step do not arrive within the
+    // step's 64 MFMAs; 78 % of the reads hit the XCD's L2 (the queries always, the rows for three of the four workgroups
+    // that share a row tile), but each step waits for its slowest line, and the row tile of the leading workgroup comes
+    // from HBM.  So the rows get two steps of flight: step u issues the queries of step u + 1 FIRST and the rows of step
+    // u + 2 after them; the wait before the barrier is vmcnt(4), which retires everything but those 4 youngest DMAs --
+    // the in-order counter then never makes the rows wait for the queries.
     // LDS: 3 x 32 KB of rows + 2 x 32 KB of queries = all 160 KB.
     auto rd_a3 = [&](bf16x8 (&dst)[4], int j, int mh, int ks) {
         if (dbg & 16) return;
@@ -344,7 +232,7 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
     for (int it = 0; it < n_mine; ++it) {
         const char* A0 = a.A + (size_t)row0 * GM_ROWB;
         const char* A1 = a.A + (size_t)row0n * GM_ROWB;
-        if constexpr (VER == 3) {
+        {
             using I2 = std::integral_constant<int, 2>;
             // K step kt of this tile (kt = 6 k6 + s): rows of step kt + 2 (maybe of the next tile), queries of step kt + 1
             auto a_src = [&](int kt2) { return kt2 < GM_KT ? A0 + kt2 * 128 : A1 + (kt2 - GM_KT) * 128; };
@@ -359,18 +247,6 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
                 kstep3(I1{}, I0{}, I0{}, a_src(kt + 6), b_src(kt + 5));
                 kstep3(I2{}, I1{}, I0{}, a_src(kt + 7), b_src(kt + 6));
             }
-        } else {
-#pragma unroll 1
-        for (int k2 = 0; k2 < GM_KT / 2; ++k2) {
-            const bool last = k2 == GM_KT / 2 - 1;                         // the step after the last one opens the next tile
-            if constexpr (VER == 2) {
-                kstep2(I0{}, A0 + (2 * k2 + 1) * 128, Bq + (2 * k2 + 1) * 128);
-                kstep2(I1{}, last ? A1 : A0 + (2 * k2 + 2) * 128, last ? Bq : Bq + (2 * k2 + 2) * 128);
-            } else {
-                kstep1(I0{}, A0 + (2 * k2 + 1) * 128, Bq + (2 * k2 + 1) * 128);
-                kstep1(I1{}, last ? A1 : A0 + (2 * k2 + 2) * 128, last ? Bq : Bq + (2 * k2 + 2) * 128);
-            }
-        }
         }
         // ---- epilogue: accumulator (mh, mi, nh, ni)[rr] = row mh 128 + wr 64 + mi 16 + 4 lg + rr of the tile,
         //      query nt 256 + nh 128 + wc 32 + ni 16 + li16 ----
@@ -453,7 +329,6 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
         row0n = first_row(jn);
     }
     wait_vm0();                                        // the DMAs issued for a step that never runs
-    if (VER == 1 && wr == 0) wg_barrier();             // pairs with the followers' last barrier
     if (EMIT && lane == 0) a.wv_count[blockIdx.x * 8 + w] = wave_cnt;
 }
 
@@ -680,28 +555,25 @@ __global__ __launch_bounds__(256) void qmat_kernel(const float* __restrict__ qn,
     dst[i] = v;
 }
 
-int g_gemm_version = 3;
 int g_gemm_dbg = 0;
 
-template <bool EMIT, int VER>
+template <bool EMIT>
 hipError_t launch_gemm_t(const GemmArgs& a, int grid, hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t err = hipFuncSetAttribute((const void*)gemm_kernel<EMIT, VER>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             VER == 3 ? GM_LDS3 : GM_LDS);
+        hipError_t err = hipFuncSetAttribute((const void*)gemm_kernel<EMIT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             GM_LDS3);
         if (err != hipSuccess) return err;
         attr_done = true;
     }
     GemmArgs b = a;
     b.dbg = g_gemm_dbg;
-    gemm_kernel<EMIT, VER><<<grid, GM_THREADS, VER == 3 ? GM_LDS3 : GM_LDS, stream>>>(b);
+    gemm_kernel<EMIT><<<grid, GM_THREADS, GM_LDS3, stream>>>(b);
     return hipGetLastError();
 }
 
 hipError_t launch_gemm(bool emit, const GemmArgs& a, int grid, hipStream_t stream) {
-    if (g_gemm_version == 1) return emit ? launch_gemm_t<true, 1>(a, grid, stream) : launch_gemm_t<false, 1>(a, grid, stream);
-    if (g_gemm_version == 2) return emit ? launch_gemm_t<true, 2>(a, grid, stream) : launch_gemm_t<false, 2>(a, grid, stream);
-    return emit ? launch_gemm_t<true, 3>(a, grid, stream) : launch_gemm_t<false, 3>(a, grid, stream);
+    return emit ? launch_gemm_t<true>(a, grid, stream) : launch_gemm_t<false>(a, grid, stream);
 }
 
 }  // namespace
@@ -739,7 +611,6 @@ hipError_t msr_gemm_bucket(const void* wvbuf, int wv_cap, const int32_t* wv_coun
                                                                       GM_PAIR_CAP, pair_n);
     return hipGetLastError();
 }
-void msr_gemm_set_version(int v) { g_gemm_version = v >= 1 && v <= 3 ? v : 3; }
 void msr_gemm_set_dbg(int v) { g_gemm_dbg = v; }
 
 // The whole batched candidate path for nq <= g.max_queries queries (see the header of this file); ends with cand_doc /

@@ -64,7 +64,7 @@ struct Bm25Index {
     const uint32_t* tile_off;  // [n_heavy][n_tiles + 1], relative to term_off[t]
     int32_t n_tiles;
 };
-constexpr int MSR_BM25_TILE = 2048;          // documents per BM25 tile
+constexpr int MSR_BM25_TILE = 1024;          // documents per BM25 tile
 constexpr int MSR_BM25_HEAVY_DF = 2048;      // posting lists at least this long get a skip-table row
 hipError_t msr_bm25_build_skip(const Bm25Index& ix, const int32_t* heavy_terms, int n_heavy, uint32_t* tile_off,
                                hipStream_t stream);
@@ -185,7 +185,6 @@ hipError_t msr_gemm_thr(const float* top_score, const int32_t* top_n, int nq, in
 hipError_t msr_gemm_bucket(const void* wvbuf, int wv_cap, const int32_t* wv_count, int n_waves, const float* thr2,
                            void* pairs, int32_t* pair_n, hipStream_t stream);
 void msr_gemm_set_dbg(int v);       // honoured by -DMSR_DIAG builds only
-void msr_gemm_set_version(int v);   // 1 / 2: phase decompositions of the GEMM main loop (identical results)
 // dst[r] = bf16(src[r] * inv_norm[r]) (inv_norm null: 1), rows n_rows .. n_pad - 1 zero
 // err_max (device word, nullable) <- bits of max_r || bf16(u_r) - u_r ||, u_r the normalised row
 hipError_t msr_unit_bf16_rows(const float* src, const float* inv_norm, int64_t n_rows, int64_t n_pad, void* dst,

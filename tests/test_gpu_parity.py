@@ -348,7 +348,7 @@ def test_batched_gemm_path_equals_exact_scan(mods):
     pass, per-document maxima, exact f32 rescoring).  Its top-k must be the exact scan's: same scores to f32 rounding,
     same documents except where two scores are within rounding of each other.  Covers: query counts that do and do not
     fill the 256-query tiles (1, 2 and 3 tiles), k = 10 (sample stride > 1) and k = 100 (every tile sampled), chunk-less
-    documents, an exact hit, a zero query, and all three main-loop versions (identical results)."""
+    documents, an exact hit, a zero query; a repeated call returns identical results."""
     rng = np.random.default_rng(77)
     n_docs = 60000
     n = rng.integers(0, 9, size=n_docs)                    # 0..8 chunks: chunk-less documents included
@@ -371,9 +371,11 @@ def test_batched_gemm_path_equals_exact_scan(mods):
     q[2:40] = emb[rng.integers(0, C, 38)] + 0.4 * q[2:40] / np.linalg.norm(q[2:40], axis=1, keepdims=True)
     for Q, k in ((129, 100), (300, 10), (700, 100), (512, 100)):
         exact = [x.cpu().numpy() for x in eng.dense_topk(q[:Q], k=k)]
-        for ver in ((3, 1, 2) if Q == 300 else (3,)):
-            eng._check(eng.lib.msr_tune(eng.handle, 1, ver))
+        for rep in range(2 if Q == 300 else 1):
             got = [x.cpu().numpy() for x in eng.dense_topk_batched(q[:Q], k=k)]
+            if rep:
+                assert all(np.array_equal(a_, b_) for a_, b_ in zip(got, first))
+            first = got
             assert np.array_equal(got[3], exact[3])
             assert np.abs(got[1] - exact[1]).max() <= 2e-6
             same = got[0] == exact[0]
@@ -382,7 +384,7 @@ def test_batched_gemm_path_equals_exact_scan(mods):
             # where the documents agree the arg-max chunk agrees too, unless two chunks of the document tie within rounding
             agree = (got[2] == exact[2]) | ~same
             assert agree.mean() > 0.999
-        eng._check(eng.lib.msr_tune(eng.handle, 1, 3))
+    assert eng.lib.msr_tune(eng.handle, 1, 3) < 0           # the product library has no tuning keys
     # zero query: every cosine is exactly 0 -> the k lowest-indexed documents that have chunks, in order
     z = [x.cpu().numpy() for x in eng.dense_topk_batched(q[:200], k=100)]
     has = np.nonzero(n > 0)[0][:100]
