@@ -6,8 +6,9 @@
  * are fetched by NAME there; here they come from a local directory (or are random for tests), see
  * modern-search-engines-project_amd/encoder.py.
  *
- * The whole forward pass is hand-written HIP behind the entry points below: the four matrix products of a layer
- * (msr_enc_linear, exact-f32 matrix cores, weights streamed once) and everything between them.  All tensors are float32, row-major, device
+ * For a query (<= 128 tokens) the whole forward pass is hand-written HIP behind the entry points below: the four matrix
+ * products of a layer (msr_enc_linear, exact-f32 matrix cores, weights streamed once) and everything between them;
+ * encoder.py hands larger batches' products to the library GEMM (hipBLASLt), which wins there.  All tensors are float32, row-major, device
  * pointers owned by the caller; functions are stateless (no engine handle), enqueue on `stream`, never synchronise, and
  * return 0 or a negative msr_status (msr_last_error(NULL) holds the text).
  *

@@ -7,10 +7,11 @@ The model is ModernBERT-base (embedder_training/train.py fine-tunes answerdotai/
 from a LOCAL directory in the Hugging Face layout (`model.safetensors`, optional `tokenizer.json`, optional
 sentence-transformers `modules.json`), or are random for tests and benchmarks.
 
-The whole forward pass is hand-written HIP behind the C ABI of include/msretr_encoder.h: the matrix products
-(msr_enc_linear: skinny products on the exact-f32 matrix cores, each weight read once per 128 tokens) and everything
-between them -- embedding lookup + LayerNorm, LayerNorm, rotary embedding + attention, GeGLU, masked mean pooling; torch
-only owns the buffers and the hipGraph.  There is no CPU fallback: without the library the class
+For a query (<= 128 tokens in all) the whole forward pass is hand-written HIP behind the C ABI of
+include/msretr_encoder.h: the matrix products (msr_enc_linear: skinny products on the exact-f32 matrix cores, each weight
+read once) and everything between them -- embedding lookup + LayerNorm, LayerNorm, rotary embedding + attention, GeGLU,
+masked mean pooling; torch owns the buffers and the hipGraph.  Batches of more than 128 tokens keep the library GEMM
+(hipBLASLt through torch.mm / addmm) for the products -- a plain GEMM at that size -- and the same HIP kernels between.  There is no CPU fallback: without the library the class
 raises.  Parity: tests/test_gpu_encoder.py compares the output with transformers' ModernBertModel (the reference's
 dependency) on the same random weights.
 """
@@ -26,6 +27,7 @@ from . import _abi
 HIDDEN, HEADS, LAYERS, INTER, VOCAB = 768, 12, 22, 1152, 50368
 GLOBAL_EVERY, LOCAL_WINDOW, THETA_GLOBAL, THETA_LOCAL, EPS = 3, 128, 160000.0, 10000.0, 1e-5
 MAX_SEQ = 128                                               # msr_enc_attention: tokens per sequence
+LINEAR_HIP_MAX_TOKENS = 128                                 # msr_enc_linear up to here, library GEMM beyond (see _linear)
 
 
 def _ptr(t):
@@ -161,8 +163,19 @@ class QueryEncoder:
         return s_out.clone()
 
     def _linear(self, x, weight, y, resid=None):
-        """y = x . weight^T (+ resid): msr_enc_linear, the HIP skinny product (weights streamed once, exact-f32 MFMA)."""
+        """y = x . weight^T (+ resid).  Up to LINEAR_HIP_MAX_TOKENS tokens -- a query, a handful of queries --
+        msr_enc_linear: the HIP skinny product (weights streamed once, exact-f32 MFMA, K split over the waves).  Larger
+        batches are an ordinary GEMM whose operands want big shared tiles: the library (hipBLASLt through torch) is
+        1.4x faster there (profiles/r02_encoder_bench.json), so it keeps that case."""
         n_out, n_in = weight.shape
+        if x.shape[0] > LINEAR_HIP_MAX_TOKENS:
+            if resid is None:
+                torch.mm(x, weight.t(), out=y)
+            elif resid is y:
+                y.addmm_(x, weight.t())
+            else:
+                torch.addmm(resid, x, weight.t(), out=y)
+            return y
         self._check(self.lib.msr_enc_linear(_ptr(x), _ptr(weight), _ptr(resid), _ptr(y), int(x.shape[0]), int(n_out),
                                             int(n_in), self._stream()))
         return y

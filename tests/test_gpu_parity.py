@@ -102,6 +102,44 @@ def test_bm25_synthetic_vs_oracle(mods):
     eng.close()
 
 
+def test_bm25_sample_floor_keeps_the_exact_topk(mods):
+    """From 64 document tiles on, msr_bm25_topk runs a sample pass (every 8th / 16th tile) whose k-th score bounds what the
+    full pass emits.  The result must stay the exact top-k, bit for bit: 80 k documents (79 tiles, stride 8) and 300 k
+    (293 tiles, stride 16); queries with a common term (bound far above most scores), rare terms only (sample holds fewer
+    than k candidates: no bound), a term whose postings all tie, min_score above and below the bound, k = 10 and 1000."""
+    from msretr.synthetic import synthetic_corpus, synthetic_queries
+    for n_docs, seed in ((80_000, 21), (300_000, 22)):
+        ix = synthetic_corpus(n_docs, n_chunks=0, n_terms=50_000, seed=seed)
+        z = {k: (getattr(ix, k).cpu().numpy() if torch.is_tensor(getattr(ix, k)) else getattr(ix, k))
+             for k in ("doc_ids", "doc_len", "term_off", "post_doc", "post_tf", "idf")}
+        z["avgdl"] = ix.avgdl
+        df = np.diff(z["term_off"])
+        rare = [int(t) for t in np.nonzero((df > 0) & (df < 40))[0][:6]]
+        common = int(np.argmax(df))
+        terms, _ = synthetic_queries(ix, 12, seed=seed + 1)
+        terms[0] = [common]
+        terms[1] = rare[:3]                                  # a few dozen candidates in all
+        terms[2] = [common, common, rare[3]]
+        terms[3] = []
+        eng = mods["DeviceEngine"](ix, max_queries=8, max_k=1000)       # 12 queries -> 2 internal slices
+        for k, ms in ((1000, 0.0), (10, 0.0), (1000, 3.0), (100, -5.0)):
+            doc, score, n = [x.cpu().numpy() for x in eng.bm25_topk(terms, k=k, min_score=ms)]
+            for i, t in enumerate(terms):
+                oi, os_ = mods["bm25_ref"].topk(z, t, k, ms)
+                assert n[i] == len(oi), (n_docs, i, k, ms)
+                assert doc[i, :n[i]].tolist() == oi.tolist() and score[i, :n[i]].tolist() == os_.tolist(), (n_docs, i, k, ms)
+        eng.close()
+    # every posting of the only term ties: the bound equals the common score and nothing may be lost
+    N = 70_000
+    ix = mods["CorpusIndex"](doc_ids=np.arange(N, dtype=np.int64), doc_len=np.full(N, 7, np.int32),
+                             term_off=np.array([0, N], np.int64), post_doc=np.arange(N, dtype=np.int32),
+                             post_tf=np.full(N, 2, np.int32), idf=np.array([0.8], np.float32), avgdl=7.0, total_docs=N)
+    eng = mods["DeviceEngine"](ix, max_queries=2, max_k=1000)
+    doc, score, n = [x.cpu().numpy() for x in eng.bm25_topk([[0]], k=1000)]
+    assert n[0] == 1000 and doc[0].tolist() == list(range(1000)) and len(set(score[0].tolist())) == 1
+    eng.close()
+
+
 def test_bm25_massive_ties(mods):
     """All documents identical => every score equal: the k lowest doc indices must come back in order."""
     N = 20000
