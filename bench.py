@@ -507,7 +507,7 @@ def main():
             k_ms, k_n = scan_ms, scan_n
             kname = ("dense_ksplit_kernel" if wide_kernel else "dense_scan_v2_kernel") + ("<bf16>" if bf else "")
             if not bf and q_launch > 64:
-                kname = "gemm_f32_kernel<emit>"                 # 65..128 queries: one GEMM pass over the f32 rows
+                kname = "gemm_stream_kernel<emit>"              # 65..128 queries: one streaming pass over the f32 rows
             if gemm:
                 kname = "gemm_kernel<emit>"
                 alg_bytes = n_ch * 768 * 2 + min(Q, 1024) * 768 * 2     # E (bf16) once per 1024-query pass + the queries
@@ -545,7 +545,7 @@ def main():
             bm_gbs = bm_bytes / (roof["bm25_taat_ms_per_launch"] * 1e-3) / 1e9 if bm_n else 0.0
             roof["bm25_taat"] = {"achieved": bm_gbs, "unit": "GB/s", "frac": bm_gbs / HBM_PEAK_GBS,
                                  "algorithmic_bytes_per_launch": bm_bytes, "launches": bm_n}
-        dense_dt = {"f32": "f32", "f16x2": "f32 via f16x2-split products, f32 accumulate (|err| <= 8e-6)",
+        dense_dt = {"f32": "f32", "f16x2": "f32 (exact f32 cosines of every returned document; candidates filtered by one pass of f16 products with a measured margin; batches <= 64 queries: f16x2-split products, |err| <= 8e-6)",
                     "none": "-"}[eng.scan_arith()]
         names = {"hybrid": "two-stage retrieval top-100 (BM25 top-1000 + dense full scan + rerank/fuse)" +
                            (" [dense stage: bf16 candidates + f32 rescore]" if args.dense_mode == "bf16" else ""),

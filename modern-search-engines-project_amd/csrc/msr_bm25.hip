@@ -55,7 +55,13 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
                                                                   const double* __restrict__ floor_q,
                                                                   double* __restrict__ cand_score,
                                                                   int32_t* __restrict__ cand_doc,
-                                                                  int32_t* __restrict__ cand_n) {
+                                                                  int32_t* __restrict__ cand_n, int dbg_arg) {
+#ifdef MSR_DIAG
+    const int dbg = dbg_arg;   // timing experiments (wrong results): 1 no division, 2 no accumulator update, 4 no streaming
+                               // beyond the prefetch, 8 no prefetch, 16 no emission, 32 no term lookup
+#else
+    constexpr int dbg = 0;
+#endif
     __shared__ double acc_all[BM25_QPW][BM25_TILE];
     __shared__ double dn[BM25_TILE];                         // k1 * (1 - b + b * doc_length / avg_doc_length)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
     int64_t ps_v = 0, pe_v = 0;                      // [begin, end) of term j's postings to look at in this tile
     double idf_v = 0.0, qtf_v = 0.0;
     bool medium = false;
-    if (live) {
+    if (live && !(dbg & 32)) {
         const int t0 = q_term_off[q_first + q];
         nt = q_term_off[q_first + q + 1] - t0;
         if (nt > BM25_MAX_TERMS) nt = BM25_MAX_TERMS;        // the host never sends more
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
 #pragma unroll
     for (int j = 0; j < TPRE; ++j) {
         pd0[j] = -1; ptf0[j] = 0;
-        if (j < nt) {                                        // wave-uniform
+        if (j < nt && !(dbg & 8)) {                          // wave-uniform
             const int64_t i = lane_i64(ps_v, j) + lane;
             if (i < lane_i64(pe_v, j)) { pd0[j] = ix.post_doc[i]; ptf0[j] = ix.post_tf[i]; }
         }
@@ -174,15 +180,17 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
         if (d >= (uint32_t)n) return;                        // a posting of another tile (covering ranges), or none
         const double tf = (double)ptf;
         // tf_component = (tf * (k1 + 1)) / (tf + k1 * (1 - b + b * doc_length / avg_doc_length))
-        const double comp = (tf * k1p1) / (tf + dn[d]);
+        const double comp = (dbg & 1) ? (tf * k1p1) * (tf + dn[d]) : (tf * k1p1) / (tf + dn[d]);
         // term_score = idf * tf_component * query_term_freq[term]; bm25_score += term_score
         const double c = (idf * comp) * qtf;
+        if (dbg & 2) { if (c == 1.2345e-300) acc[d] = c; return; }
         const double a = acc[d];
         acc[d] = ((uint64_t)__double_as_longlong(a) == UNTOUCHED ? 0.0 : a) + c;
     };
     // The rest of a slice, U x 64 postings per round: all loads of a round are issued before the first is used.
     auto stream = [&](int64_t from, int64_t pe, double idf, double qtf) {
         constexpr int U = 4;
+        if (dbg & 4) return;
         for (int64_t base = from; base < pe; base += (int64_t)U * 64) {
             int32_t pd[U], ptf[U];
 #pragma unroll
@@ -209,7 +217,7 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
         if (pe <= ps) continue;
         stream(ps, pe, lane_f64(idf_v, j), lane_f64(qtf_v, j));
     }
-    if (!live) return;
+    if (!live || (dbg & 16)) return;
     // ---- 4. the tile's candidates (touched by a posting AND score >= min_score, :461,480) as (score, doc) pairs
     //         appended to the query's list: one reservation per wave.  Most documents of a tile are not candidates, so
     //         this replaces an 8 B/document dense row by 12 B per candidate. ----
@@ -293,7 +301,11 @@ __global__ __launch_bounds__(256) void build_skip_kernel(Bm25Index ix, const int
     }
 }
 
+int g_bm25_dbg = 0;
+
 }  // namespace
+
+void msr_bm25_set_dbg(int v) { g_bm25_dbg = v; }      // honoured by -DMSR_DIAG builds only
 
 hipError_t msr_bm25_build_skip(const Bm25Index& ix, const int32_t* heavy_terms, int n_heavy, uint32_t* tile_off,
                                hipStream_t stream) {
@@ -317,7 +329,7 @@ hipError_t msr_bm25_scores(const Bm25Index& ix, const int32_t* q_term_off, const
     const int n_pass = (ix.n_tiles - tile_first + tile_stride - 1) / tile_stride;
     dim3 grid((unsigned)((nq + BM25_QPW - 1) / BM25_QPW), (unsigned)n_pass);
     bm25_taat_kernel<<<grid, BM25_THREADS, 0, stream>>>(ix, q_term_off, q_terms, q_qtf, q_first, nq, min_score, tile_first,
-                                                        tile_stride, floor_q, cand_score, cand_doc, cand_n);
+                                                        tile_stride, floor_q, cand_score, cand_doc, cand_n, g_bm25_dbg);
     return hipGetLastError();
 }
 

@@ -59,6 +59,8 @@ struct msr_engine {
     int32_t* gf_top_doc = nullptr; float* gf_top_score = nullptr; int32_t* gf_top_n = nullptr;
     float* gf_thr = nullptr; float* gf_thr2 = nullptr; int32_t* gf_flag = nullptr; void* gf_wvbuf = nullptr;
     int32_t* gf_wv_count = nullptr; void* gf_pairs = nullptr; int32_t* gf_pair_n = nullptr; int32_t* gf_gate = nullptr;
+    uint32_t* gf_err = nullptr; float* gf_margin = nullptr; int32_t* gf_cand_doc = nullptr; float* gf_cand_score = nullptr;
+    int32_t* gf_cand_chunk = nullptr; int32_t* gf_cand_n = nullptr;
     // batched path as a tiled GEMM (msr_gemm.hip): unit-row bf16 image + tile table + scratch for GM_SLICE queries per pass
     GemmIndex gemm{};
     bool gemm_ok = false;
@@ -121,7 +123,10 @@ static void free_gf(msr_engine* e) {
     free_dev(e->tile_row); free_dev(e->gf_inv_pad); free_dev(e->gf_qimg); free_dev(e->gf_tmax_t); free_dev(e->gf_tmax);
     free_dev(e->gf_top_doc); free_dev(e->gf_top_score); free_dev(e->gf_top_n); free_dev(e->gf_thr); free_dev(e->gf_thr2);
     free_dev(e->gf_flag); free_dev(e->gf_wvbuf); free_dev(e->gf_wv_count); free_dev(e->gf_pairs); free_dev(e->gf_pair_n);
-    free_dev(e->gf_gate);
+    free_dev(e->gf_gate); free_dev(e->gf_err); free_dev(e->gf_margin); free_dev(e->gf_cand_doc); free_dev(e->gf_cand_score);
+    free_dev(e->gf_cand_chunk); free_dev(e->gf_cand_n);
+    e->gf_err = nullptr; e->gf_margin = nullptr; e->gf_cand_doc = nullptr; e->gf_cand_score = nullptr; e->gf_cand_chunk = nullptr;
+    e->gf_cand_n = nullptr;
     e->tile_row = nullptr; e->gf_inv_pad = nullptr; e->gf_qimg = nullptr; e->gf_tmax_t = nullptr; e->gf_tmax = nullptr;
     e->gf_top_doc = nullptr; e->gf_top_score = nullptr; e->gf_top_n = nullptr; e->gf_thr = e->gf_thr2 = nullptr;
     e->gf_flag = nullptr; e->gf_wvbuf = nullptr; e->gf_wv_count = nullptr; e->gf_pairs = nullptr; e->gf_pair_n = nullptr;
@@ -473,7 +478,8 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
             e->tiles_ok = true;
         }
     }
-    // the default (f16x2-split) scan of 65..128 queries runs as a GEMM over the f32 rows when the corpus allows it
+    // batches of 65..128 queries take ONE streaming pass over the f32 rows (f16 filter + exact f32 finish, msr_gemm_f32.hip)
+    // when the corpus allows it
     if (e->tiles_ok && variant == 14 && e->n_tiles >= 64) {
         const int n_tiles = e->n_tiles, nw = e->n_cus * 8, stride = (n_tiles + 31) / 32 * 32;
         constexpr int GF_WV_CAP = 4096;
@@ -492,14 +498,23 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
             (herr = alloc((void**)&e->gf_wv_count, (size_t)nw * 4)) != hipSuccess ||
             (herr = alloc(&e->gf_pairs, (size_t)128 * 4096 * 8)) != hipSuccess ||
             (herr = alloc((void**)&e->gf_pair_n, 128 * 4)) != hipSuccess ||
-            (herr = alloc((void**)&e->gf_gate, 4)) != hipSuccess)
+            (herr = alloc((void**)&e->gf_gate, 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gf_err, 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gf_margin, 128 * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gf_cand_doc, (size_t)128 * MSR_SEL_CAP * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gf_cand_score, (size_t)128 * MSR_SEL_CAP * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gf_cand_chunk, (size_t)128 * MSR_SEL_CAP * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gf_cand_n, 128 * 4)) != hipSuccess)
             return fail(e, MSR_ERR_NOMEM, "GEMM scan scratch: %s", hipGetErrorString(herr));
         HIP_TRY(e, msr_pad_inv_norm(inv_norm, n_chunks, n_chunks + 512, e->gf_inv_pad, st));
         HIP_TRY(e, hipMemsetAsync(e->gf_pair_n, 0, 128 * 4, st));
         HIP_TRY(e, hipMemsetAsync(e->gf_gate, 0, 4, st));
+        HIP_TRY(e, hipMemsetAsync(e->gf_cand_n, 0, 128 * 4, st));
+        HIP_TRY(e, msr_f16_row_error(emb, inv_norm, n_chunks, e->gf_err, st));   // measured once: the margin of the f16 filter
         e->gf = GemmF32Index{e->tile_row, n_tiles, e->n_cus, e->gf_inv_pad, e->gf_qimg, e->gf_tmax_t, e->gf_tmax, stride,
                              e->gf_top_doc, e->gf_top_score, e->gf_top_n, e->gf_thr, e->gf_thr2, e->gf_flag, e->gf_wvbuf,
-                             GF_WV_CAP, e->gf_wv_count, e->gf_pairs, e->gf_pair_n};
+                             GF_WV_CAP, e->gf_wv_count, e->gf_pairs, e->gf_pair_n, e->gf_err, e->gf_margin, e->gf_cand_doc,
+                             e->gf_cand_score, e->gf_cand_chunk, e->gf_cand_n};
         e->gf_ok = true;
     }
     e->have_chunks = true;
@@ -783,6 +798,7 @@ extern "C" int msr_tune(msr_engine* e, int32_t key, int32_t value) {
 #ifdef MSR_DIAG
     if (key == 100) { msr_gemm_set_dbg(value); return MSR_OK; }      // timing experiments of the diagnostic build
     if (key == 101) { msr_gemm_f32_set_dbg(value); return MSR_OK; }
+    if (key == 102) { msr_bm25_set_dbg(value); return MSR_OK; }
 #endif
     return fail(e, MSR_ERR_INVALID, "msr_tune: unknown key %d / value %d", key, value);
 }

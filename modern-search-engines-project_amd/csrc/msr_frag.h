@@ -28,3 +28,19 @@ __device__ __forceinline__ void split_f16(const f32x4& a, const f32x4& b, f16x8&
         lo[j] = l[0]; lo[j + 1] = l[1];
     }
 }
+
+// x (8 floats) -> 8 f16, round to nearest even (v_cvt_f16_f32).  The single-product mode of msr_gemm_f32.hip; its error
+// is MEASURED with f16_err2() below, element by element with this same conversion.
+__device__ __forceinline__ f16x8 cvt_f16_rtn(const f32x4& a, const f32x4& b) {
+    f16x8 h;
+    h[0] = (_Float16)a.x; h[1] = (_Float16)a.y; h[2] = (_Float16)a.z; h[3] = (_Float16)a.w;
+    h[4] = (_Float16)b.x; h[5] = (_Float16)b.y; h[6] = (_Float16)b.z; h[7] = (_Float16)b.w;
+    return h;
+}
+// squared error of one element under cvt_f16_rtn, conservative about the matrix cores' treatment of f16 subnormals: a
+// value that converts to a subnormal (or zero) is counted as lost entirely.
+__device__ __forceinline__ float f16_err2(float x) {
+    const float h = (float)(_Float16)x;
+    const float d = __builtin_fabsf(h) < 6.103515625e-05f ? x : h - x;
+    return d * d;
+}

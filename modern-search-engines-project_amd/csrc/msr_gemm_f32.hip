@@ -1,34 +1,36 @@
-// K2 + K3 + K4 for batches of 65 .. 128 queries: the dense scan as a tiled GEMM over the ORIGINAL f32 rows (gfx950).
+// K2 + K3 + K4 for batches of 65 .. 128 queries: the dense scan as ONE streaming pass over the ORIGINAL f32 rows (gfx950).
 //
 // Same cosine and per-document max as the sweeps (reference: reranker/reranker_api.py:285, :370; Retriever.quick_search,
-// search_api.py:60,87), same arithmetic as the default sweep -- every f32 row value is split on the fly into two f16 pieces
-// (x = hi + lo) and three v_mfma_f32_16x16x32_f16 (lo*hi + hi*lo + hi*hi) replace the f32 products, f32 accumulation;
-// error bound 8e-6 on the cosine for row norms in [0.5, 2], DESIGN.md section 3 -- but organised like the bf16 candidate
-// GEMM of msr_gemm.hip instead of the K-split sweep:
-//   * one pass over E serves 128 queries (the sweep: 64), so a 128-query step reads the 15.36 GB once instead of twice;
-//     3 x 2 x 768 flop per (row, query) on the f16 matrix pipe keep it about level with the HBM time of that one pass;
-//   * no cross-wave reduction, no LDS ring of per-document maxima, no score rows: the epilogue only (a) stores the
-//     tile maxima and (b) appends every (query, row, score) above a threshold to a per-wave buffer.  The threshold of a
-//     query is a LOWER BOUND of its k-th largest per-document score: tiles are cut at document boundaries, so the k-th
-//     largest tile maximum is attained by k different documents.  Pass 1 computes the maxima of every 16th tile (the bound
-//     used for emission), pass 2 all of them (a much tighter bound used to thin the emitted entries afterwards).
-//     The emitted scores ARE the final scores (no rescoring: they carry the default path's own arithmetic), so the bound
-//     needs no margin: a document of the top-k has score >= t >= bound and is emitted.
-//   * finish (gemm_f32_final_kernel, one workgroup per query): per-document maximum with its first arg-max row, exact sort by
-//     (score desc, document asc), top-k.  A query whose entries do not fit (huge tie groups) is flagged; the caller then
-//     runs the sweeps for the batch (msr_engine.hip gates them on that flag on the device, no host round trip).
+// search_api.py:60,87), for 128 queries per pass over E (the sweep: 64) -- a 128-query step reads the 15.36 GB once.
 //
-// Kernel shape: persistent workgroup per CU, tile 256 rows x 128 queries, K step 32; wave w owns rows 32 w .. +32 and ALL
-// 128 queries, so every f32 row fragment is split into its f16 pieces exactly once:
-//   LDS  4 x 32 KB of rows (256 x 128 B, LDS-DMA) + 2 x 16 KB of query pieces (hi | lo) = all 160 KB; 16 B chunks of a row
-//        XOR-swizzled so the 32 B fragment reads (two ds_read_b128) are conflict-free;
-//   DMA  waves 0-3 issue the rows (of the step after next-but-one: THREE steps of flight, ~80 KB per CU in flight -- the
-//        rows come from HBM and are read once), waves 4-7 the query pieces of the next step (L2-resident).  vmcnt is an
-//        in-order counter per wave: with one kind of DMA per wave, "all but the 16 youngest" retires exactly the rows of the
-//        next step, and the query waves simply wait for everything;
-//   per step and wave: 4 + 16 fragment reads, 2 splits (VALU), 48 MFMAs, one wait, ONE barrier;
-//   the inverse norms of a tile's rows (16 per lane) are fetched with plain loads two steps before the tile's last barrier
-//   (inline asm: the compiler must not see an ordinary load next to in-flight DMAs, it would drain them).
+// Arithmetic: a FILTER pass with one f16 product per element, then EXACT f32 cosines for the few documents that can
+// matter.  The pass multiplies f16(e) (round to nearest, converted in registers; E stays f32 in HBM, no second image)
+// by f16(q^), f32 accumulation on the matrix cores: v_mfma_f32_16x16x32_f16, 2 x 768 flop per (row, query) -- a third of
+// the f16x2-split arithmetic of the sweeps, which made this pass matrix-bound.  Its scores s^ are approximate with a
+// MEASURED bound: dE = max_r ||e_r - f16(e_r)|| / ||e_r|| (one pass at bind time, f16_row_error_kernel), dq = the same
+// for the normalised query (f16_margin_kernel); |s^ - s| <= eps_q = dE (1 + dq) + dq (Cauchy-Schwarz twice, the argument
+// of msr_batch.hip).  With t^ the k-th largest per-document s^, every document of the exact top-k has
+// s^ >= t^ - 2 eps_q, so keeping everything above (a lower bound of t^) - margin_q, margin_q = 2 eps_q + 1e-4, loses
+// nothing; the survivors' cosines are then recomputed in plain f32 from the f32 rows (msr_batch_rescore) and sorted
+// exactly.  Typical margin: 1.1e-3.  Every RETURNED score is an exact f32 cosine.
+//
+// No score matrix, no score rows: row tiles (<= 256 rows) are cut at document boundaries, so the k-th largest TILE
+// MAXIMUM is attained by k different documents -- a lower bound of t^.  Pass 1 (every ss-th tile) computes tile maxima
+// only and gives the emission threshold; pass 2 (all tiles) stores the maxima of ALL tiles (a tighter bound afterwards)
+// and appends every (row, query, score) at or above the threshold to a buffer private to the WAVE (scalar counter +
+// lane prefix count, plain 16 B stores: no atomics).  Finish: entries above the tighter bound are bucketed per query
+// (msr_gemm_bucket), reduced to distinct documents (gemm_f32_cand_kernel), rescored and sorted.  A query whose entries do
+// not fit anywhere on the way (huge tie groups) raises a device-side gate; the engine's sweeps, always enqueued behind
+// this path, run only when that gate is up (no host round trip).
+//
+// Kernel shape (gemm_stream_kernel; one persistent workgroup per CU, 8 waves, tile 256 rows x 128 queries, K step 32):
+// wave w owns rows 32 w .. +32 of the tile and ALL 128 queries, so it is the ONLY reader of its rows -- they never pass
+// through LDS: every wave loads its rows straight into a register ring, 4 K steps (16 KB per wave, 128 KB per CU) in
+// flight.  LDS holds only what the waves share, the f16 query image: blocks of 8 K steps (64 KB), double buffered, filled
+// by LDS-DMA one block ahead.  The workgroup meets at ONE barrier per block (3 per tile); in between the waves drift
+// freely, so one wave's memory wait hides behind the others' MFMAs.  (The first version staged the rows through LDS with
+// a barrier per K step: 3.6 ms per pass with the split arithmetic, 3.1 ms with one product; this form: 2.7 ms =
+// 5.7 TB/s on the same box, profiles/r02_gemm_knockout.md.)
 #include <type_traits>
 
 #include "msr_common.h"
@@ -41,23 +43,20 @@ namespace {
 constexpr int GF_THREADS = 512;
 constexpr int GF_KT = MSR_DIM / 32;             // 24 K steps per tile
 constexpr int GF_ROWB = MSR_DIM * 4;            // bytes per f32 row
-constexpr int GF_A = 32768, GF_B = 16384;       // bytes of one row buffer / one query buffer
-constexpr int GF_NA = 4;                        // row buffers
-constexpr int GF_LDS = GF_NA * GF_A + 2 * GF_B; // 160 KB
 constexpr int GF_PAIR_CAP = 4096;
 
 struct GemmF32Args {
     const char* E;             // f32 [n_rows][768] (caller's matrix: NOT padded, the last tile clamps its row index)
     const float* inv_pad;      // [n_rows + 512] inverse norms (engine-owned padded copy)
-    const char* qimg;          // [24 K steps][hi | lo][128 queries][64 B] f16 pieces, chunk-swizzled (build_qimg_kernel)
+    const char* qimg;          // [24 K steps][128 queries][64 B] f16, chunk-swizzled (build_qimg1_kernel)
     const int32_t* tile_row;   // [n_tiles + 1]
     int64_t n_rows;
     int t_first, t_stride, t_count;
     float* tmax_t;             // [t_count][8 waves][128]
     const float* thr;          // [128] emit threshold (+inf: never)                                   -- emit pass only
     int4* wvbuf; int wv_cap; int32_t* wv_count;   // per-wave emission buffers {row, query, score bits, tile}   -- emit pass only
-    int dbg;                   // -DMSR_DIAG builds only (timing experiments, wrong results): bit 2 no DMA after the prologue,
-                               // bit 3 no MFMA, bit 4 no fragment reads / splits
+    int dbg;                   // -DMSR_DIAG builds only (timing experiments, wrong results): bit 2 no row loads, bit 3 no MFMA,
+                               // bit 4 no query fragment reads, bit 5 no epilogue arithmetic, bit 6 no inverse norms
 };
 
 // a 64-bit value the compiler can prove wave-uniform (scalar registers): lets the DMA use the saddr + 32-bit voffset form
@@ -67,8 +66,23 @@ __device__ __forceinline__ const char* uniform_ptr(const char* p) {
     return (const char*)(((uint64_t)hi << 32) | lo);
 }
 
+constexpr int GS_NB = 8;                        // K steps per query block
+constexpr int GS_STEP = 8192;                   // bytes of one K step of the f16 query image: 128 queries x 64 B
+constexpr int GS_BLK = GS_NB * GS_STEP;         // 64 KB
+constexpr int GS_LDS = 2 * GS_BLK;              // 128 KB
+constexpr int GS_D = 4;                         // K steps of rows in flight per wave
+
+typedef const __attribute__((address_space(1))) char* gptr;       // (global, not flat: flat loads also count as LDS ops)
+// a 16-byte global load the compiler neither moves nor counts; the caller waits (s_waitcnt vmcnt) and pins before use
+template <int OFF>
+__device__ __forceinline__ void gload16(f32x4& r, gptr p) {
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(r) : "v"(p), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void pin4(f32x4& a, f32x4& b, f32x4& c, f32x4& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+__device__ __forceinline__ void pin2(f32x4& a, f32x4& b) { asm volatile("" : "+v"(a), "+v"(b)); }
+
 template <bool EMIT>
-__global__ __launch_bounds__(GF_THREADS) void gemm_f32_kernel(GemmF32Args a) {
+__global__ __launch_bounds__(GF_THREADS) void gemm_stream_kernel(GemmF32Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave w owns rows 32 w .. 32 w + 32 of the tile, ALL 128 queries
@@ -81,74 +95,25 @@ __global__ __launch_bounds__(GF_THREADS) void gemm_f32_kernel(GemmF32Args a) {
         return;
     }
     const int n_mine = (a.t_count - gid + G - 1) / G;
-
-    // ---- per-lane constants ----
-    // DMA of a row buffer (waves 0..3): instruction t (0..7) of wave w fills rows 8 (8 w + t) .. +8: lane -> (row R, physical
-    // chunk lane & 7), which holds logical chunk c = (lane & 7) ^ f(R & 15), f(r) = ((r >> 1) & 3) << 1 | (r >> 3).
-    // The per-lane part of the source address is the same for every tile: (R, chunk) -> a 32-bit offset from the tile's
-    // first row; the tile / K step part is wave-uniform (scalar registers), so a DMA costs no address arithmetic.
-    const int rowA0 = 64 * (w & 3) + (lane >> 3);      // + 8 t
-    uint32_t offA[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-        offA[t] = (uint32_t)((rowA0 + 8 * t) * GF_ROWB + (((lane & 7) ^ ((((lane >> 4) & 3) << 1) | (t & 1))) * 16));
-    // fragment reads: row li16 of a 16-row block, logical chunks 2 lg and 2 lg + 1 (32 B = 8 floats)
-    const int fr = (((li16 >> 1) & 3) << 1) | ((li16 >> 3) & 1);
-    uint32_t foffA[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) foffA[h] = (uint32_t)(li16 * 128 + (((2 * lg + h) ^ fr) << 4));
-    const uint32_t foffB = (uint32_t)(li16 * 64 + ((lg ^ (((li16 >> 3) & 1) << 1)) << 4));
-    const uint32_t a_base = (uint32_t)(w * 32 * 128);
-
-    auto a_slot = [](int j) { return j * GF_A; };
-    auto b_slot = [](int d) { return GF_NA * GF_A + d * GF_B; };
-    // rows of the tile that starts at `row0`, K step kt -> row buffer (waves 0..3, 8 x 1 KiB each); `clamp`: the tile
-    // sticks out of the matrix (only the last tile can): rows past the end re-read the last row (they are masked later)
-    auto stage_a = [&](int row0, int kt, int slot, bool clamp) {
-        const char* base = uniform_ptr(a.E + (size_t)row0 * GF_ROWB + (size_t)kt * 128);
-#ifdef MSR_DIAG
-        if (a.dbg & 128) {                              // timing experiment: the 32 KB of a K step as ONE contiguous block
-            const char* lin = uniform_ptr(a.E + ((size_t)row0 * GF_ROWB / 32768 * 32768) + (size_t)kt * 32768 + (size_t)(8 * (w & 3)) * 1024);
-#pragma unroll
-            for (int t = 0; t < 8; ++t)
-                __builtin_amdgcn_global_load_lds((glb_void*)(lin + (uint32_t)(t * 1024 + lane * 16)),
-                                                 (lds_void*)(smem + slot + (8 * (w & 3) + t) * 1024), 16, 0, 0);
-            return;
-        }
-#endif
-        if (!clamp) {
-#pragma unroll
-            for (int t = 0; t < 8; ++t)
-                __builtin_amdgcn_global_load_lds((glb_void*)(base + offA[t]), (lds_void*)(smem + slot + (8 * (w & 3) + t) * 1024), 16, 0, 0);
-        } else {
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                int64_t r = (int64_t)rowA0 + 8 * t;
-                if (row0 + r > a.n_rows - 1) r = a.n_rows - 1 - row0;
-                const uint32_t off = (uint32_t)(r * GF_ROWB) + (offA[t] - (uint32_t)((rowA0 + 8 * t) * GF_ROWB));
-                __builtin_amdgcn_global_load_lds((glb_void*)(base + off), (lds_void*)(smem + slot + (8 * (w & 3) + t) * 1024), 16, 0, 0);
-            }
-        }
-    };
-    auto stage_b = [&](int kt, int slot) {              // 16 KB, linear (waves 4..7, 4 x 1 KiB each)
-        const char* base = uniform_ptr(a.qimg + (size_t)kt * GF_B + (size_t)(4 * (w & 3)) * 1024);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((glb_void*)(base + (uint32_t)(i * 1024 + lane * 16)),
-                                             (lds_void*)(smem + slot + (4 * (w & 3) + i) * 1024), 16, 0, 0);
-    };
-    const bool row_wave = w < 4;                        // wave-uniform role: rows / query pieces
 #ifdef MSR_DIAG
     const int dbg = a.dbg;
 #else
     constexpr int dbg = 0;
 #endif
+    // query fragments: query 16 ni + li16, logical 16 B chunk lg of its 64 B, stored at physical chunk lg ^ (((q >> 3) & 1) << 1)
+    const uint32_t foffB = (uint32_t)(li16 * 64 + ((lg ^ (((li16 >> 3) & 1) << 1)) << 4));
+    // one query block: 64 KB, linear; wave w moves 8 KB of it
+    auto stage_b = [&](int blk, int pb) {
+        const char* base = uniform_ptr(a.qimg + (size_t)blk * GS_BLK + (size_t)w * 8192);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void*)(base + (uint32_t)(i * 1024 + lane * 16)),
+                                             (lds_void*)(smem + pb * GS_BLK + w * 8192 + i * 1024), 16, 0, 0);
+    };
 
     float thrv[8];
 #pragma unroll
     for (int ni = 0; ni < 8; ++ni) thrv[ni] = EMIT ? a.thr[ni * 16 + li16] : 0.f;
-    asm volatile("" :: "v"(thrv[0]), "v"(thrv[1]), "v"(thrv[2]), "v"(thrv[3]), "v"(thrv[4]), "v"(thrv[5]), "v"(thrv[6]),
-                 "v"(thrv[7]));                         // (retire these loads before any DMA is in flight)
 
     f32x4 acc[2][8];
 #pragma unroll
@@ -157,104 +122,132 @@ __global__ __launch_bounds__(GF_THREADS) void gemm_f32_kernel(GemmF32Args a) {
         for (int ni = 0; ni < 8; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     auto tile_of = [&](int j) { return a.t_first + j * a.t_stride; };
+    // the lane's two rows of a tile (fragment mi: row 32 w + 16 mi + li16; rows past the end of the matrix re-read the last
+    // row, they are masked in the epilogue), at its 32-byte piece lg of a K step
+    auto row_ptr = [&](int row0, int mi) -> gptr {
+        int64_t r = (int64_t)row0 + 32 * w + 16 * mi + li16;
+        if (r > a.n_rows - 1) r = a.n_rows - 1;
+        return (gptr)a.E + (size_t)r * GF_ROWB + lg * 32;
+    };
     int jt = gid;
     int row0 = a.tile_row[tile_of(jt)], row_end = a.tile_row[tile_of(jt) + 1];
     int jn = jt + G < a.t_count ? jt + G : jt;
     int row0n = a.tile_row[tile_of(jn)];
-    auto sticks_out = [&](int r0) { return (int64_t)r0 + 256 > a.n_rows; };
+    gptr rp0 = row_ptr(row0, 0), rp1 = row_ptr(row0, 1);
+    gptr rn0 = row_ptr(row0n, 0), rn1 = row_ptr(row0n, 1);
+    const __attribute__((address_space(1))) float* invp = (const __attribute__((address_space(1))) float*)a.inv_pad + w * 32 + 4 * lg;
 
-    // ---- prologue: rows of steps 0, 1, 2 and the queries of step 0 ----
-    if (row_wave) {
-        stage_a(row0, 0, a_slot(0), sticks_out(row0));
-        stage_a(row0, 1, a_slot(1), sticks_out(row0));
-        stage_a(row0, 2, a_slot(2), sticks_out(row0));
-    } else {
-        stage_b(0, b_slot(0));
-    }
+    // The row ring is driven by hand: the loads are inline asm (the compiler neither reorders them nor counts them) and
+    // every use is preceded by an explicit s_waitcnt.  vmcnt retires in order, so "all but the N youngest" is exact:
+    // per wave and query block the order is [8 DMAs of the next block] then per step [wait, convert, 4 row loads, compute].
+    // The rows of step s8 were loaded four steps earlier; younger than them are the loads of three steps (12) and, for the
+    // first four steps of a block, that block's 8 DMAs as well (20).  (The two inverse-norm loads of a tile's last block
+    // are not counted: leaving fewer in flight than strictly possible is always safe.)
+    f32x4 ring[GS_D][2][2];                              // [slot][fragment][16-byte half]
+    auto load_rows = [&](auto slot_c, gptr p0, gptr p1, auto off_c) {
+        constexpr int slot = decltype(slot_c)::value, off = decltype(off_c)::value;
+        if (dbg & 4) return;
+        gload16<off>(ring[slot][0][0], p0);
+        gload16<off + 16>(ring[slot][0][1], p0);
+        gload16<off>(ring[slot][1][0], p1);
+        gload16<off + 16>(ring[slot][1][1], p1);
+    };
+    auto pin_rows = [&](auto slot_c) {                   // after a wait: the slot's registers now hold the loaded rows
+        constexpr int slot = decltype(slot_c)::value;
+        pin4(ring[slot][0][0], ring[slot][0][1], ring[slot][1][0], ring[slot][1][1]);
+    };
+    // ---- prologue: query block 0, rows of steps 0 .. GS_D - 1 ----
+    stage_b(0, 0);
+#pragma unroll
+    for (int s = 0; s < GS_D; ++s)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) ring[s][mi][0] = ring[s][mi][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    load_rows(std::integral_constant<int, 0>{}, rp0, rp1, std::integral_constant<int, 0>{});
+    load_rows(std::integral_constant<int, 1>{}, rp0, rp1, std::integral_constant<int, 128>{});
+    load_rows(std::integral_constant<int, 2>{}, rp0, rp1, std::integral_constant<int, 256>{});
+    load_rows(std::integral_constant<int, 3>{}, rp0, rp1, std::integral_constant<int, 384>{});
     wait_vm0();
+    pin_rows(std::integral_constant<int, 0>{}); pin_rows(std::integral_constant<int, 1>{});
+    pin_rows(std::integral_constant<int, 2>{}); pin_rows(std::integral_constant<int, 3>{});
     wg_barrier();
+    int pb = 0;                                          // LDS buffer of the current query block
 
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
-    using I3 = std::integral_constant<int, 3>;
-    f32x4 inv4[2];                                      // inverse norms of the lane's 8 rows of the current tile
+    f32x4 inv4[2];
     inv4[0] = inv4[1] = (f32x4){1.f, 1.f, 1.f, 1.f};
-    // K step with row buffer j, query buffer d; issues the rows of step + 3 (waves 0..3) / the queries of step + 1 (4..7)
-    auto kstep = [&](auto j_c, auto d_c, int rowN, int ktN, bool clampN, int ktB, int inv_row) {
-        constexpr int j = decltype(j_c)::value, d = decltype(d_c)::value;
-        if (inv_row >= 0 && !(dbg & 64)) {              // (third step from the end of a tile: this tile's inverse norms)
+    const float NEG_INF = -__builtin_inff();
+    // one K step; S8: position in the query block (compile time), the ring slot is S8 % GS_D
+    auto step = [&](auto s8_c, int b3, bool last) {
+        constexpr int s8 = decltype(s8_c)::value, slot = s8 % GS_D;
+        using SL = std::integral_constant<int, slot>;
+        __builtin_amdgcn_sched_barrier(0);
+        if (s8 < GS_D) {
+            // (first block of a tile: the previous tile's epilogue put at least 8 stores -- they count too on gfx9 -- between
+            // the rows and this block's DMAs; on the very first tile the prologue has already waited for everything)
+            if (b3 == 0) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        }
+        pin_rows(SL{});
+        f16x8 af[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) af[mi] = cvt_f16_rtn(ring[slot][mi][0], ring[slot][mi][1]);
+        asm volatile("" :: "v"(af[0]), "v"(af[1]));      // (converted before the slot is reloaded)
+        if (s8 == GS_NB - 3 && last && !(dbg & 64)) {    // this tile's inverse norms (uniform branch), retired by later waits
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
-                const float* p = a.inv_pad + (size_t)inv_row + w * 32 + mi * 16 + 4 * lg;
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(inv4[mi]) : "v"(p) : "memory");
+                const __attribute__((address_space(1))) float* p = invp + (size_t)row0 + mi * 16;
+                gload16<0>(inv4[mi], (gptr)p);
             }
         }
-        if (!(dbg & 4)) {
-            if (row_wave) stage_a(rowN, ktN, a_slot((j + 3) % GF_NA), clampN);
-            else stage_b(ktB, b_slot(d ^ 1));
+        // rows of step + GS_D: of this block's tile, or (second half of a tile's last block) the first steps of the next tile
+        if (s8 < GS_NB - GS_D) {
+            load_rows(SL{}, rp0 + b3 * (GS_NB * 128), rp1 + b3 * (GS_NB * 128), std::integral_constant<int, (s8 + GS_D) * 128>{});
+        } else {
+            gptr q0 = last ? rn0 : rp0 + (b3 + 1) * (GS_NB * 128), q1 = last ? rn1 : rp1 + (b3 + 1) * (GS_NB * 128);
+            load_rows(SL{}, q0, q1, std::integral_constant<int, (s8 + GS_D - GS_NB) * 128>{});
         }
-        // the wave's 32 rows x this step's 32 dimensions: two fragments, split once into f16 hi / lo pieces
-        f16x8 ahi[2] = {}, alo[2] = {};
-        if (!(dbg & 16)) {
+        __builtin_amdgcn_sched_barrier(0);
+        const char* bq = smem + pb * GS_BLK + s8 * GS_STEP + foffB;
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                const char* p = smem + a_slot(j) + a_base + mi * 2048;
-                const f32x4 x0 = *(const f32x4*)(p + foffA[0]), x1 = *(const f32x4*)(p + foffA[1]);
-                split_f16(x0, x1, ahi[mi], alo[mi]);
-            }
-        }
-        // ... against all 128 queries, four 16-query blocks at a time
-#pragma unroll
-        for (int nq4 = 0; nq4 < 2; ++nq4) {
-            f16x8 bh[4] = {}, bl[4] = {};
+        for (int n4 = 0; n4 < 2; ++n4) {
+            f16x8 bh[4] = {};
             if (!(dbg & 16)) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const char* p = smem + b_slot(d) + (4 * nq4 + i) * 1024 + foffB;
-                    bh[i] = *(const f16x8*)p;
-                    bl[i] = *(const f16x8*)(p + 8192);
-                }
+                for (int i = 0; i < 4; ++i) bh[i] = *(const f16x8*)(bq + (4 * n4 + i) * 1024);
             }
             if (dbg & 8) continue;
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
+            for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[mi][4 * nq4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[mi], bh[i], acc[mi][4 * nq4 + i], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[mi][4 * nq4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[mi], bl[i], acc[mi][4 * nq4 + i], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[mi][4 * nq4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[mi], bh[i], acc[mi][4 * nq4 + i], 0, 0, 0);
-            }
+                for (int i = 0; i < 4; ++i)
+                    acc[mi][4 * n4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bh[i], acc[mi][4 * n4 + i], 0, 0, 0);
         }
-        // rows: all but the 16 youngest DMAs (the rows of steps + 2 and + 3 stay in flight); queries: everything
-        if (row_wave) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else wait_vm0();
-        wg_barrier();
     };
-
-    const float NEG_INF = -__builtin_inff();
     for (int it = 0; it < n_mine; ++it) {
-        const bool c0 = sticks_out(row0), c1 = sticks_out(row0n);
-        // step kt: rows of step kt + 3 (of the next tile once kt + 3 >= 24), queries of step kt + 1
 #pragma unroll 1
-        for (int k4 = 0; k4 < GF_KT / 4; ++k4) {
-            const int kt = 4 * k4;
-            auto rn = [&](int s) { return s < GF_KT ? row0 : row0n; };
-            auto kn = [&](int s) { return s < GF_KT ? s : s - GF_KT; };
-            auto cn = [&](int s) { return s < GF_KT ? c0 : c1; };
-            // the plain loads of the inverse norms are issued at the start of step 21: older than the DMAs of steps 21..23,
-            // so the ordinary waits of steps 22 and 23 retire them before the epilogue
-            kstep(I0{}, I0{}, rn(kt + 3), kn(kt + 3), cn(kt + 3), kn(kt + 1), -1);
-            kstep(I1{}, I1{}, rn(kt + 4), kn(kt + 4), cn(kt + 4), kn(kt + 2), kt == GF_KT - 4 ? row0 : -1);
-            kstep(I2{}, I0{}, rn(kt + 5), kn(kt + 5), cn(kt + 5), kn(kt + 3), -1);
-            kstep(I3{}, I1{}, rn(kt + 6), kn(kt + 6), cn(kt + 6), kn(kt + 4), -1);
+        for (int b3 = 0; b3 < GF_KT / GS_NB; ++b3) {
+            const bool last = b3 == GF_KT / GS_NB - 1;
+            stage_b(last ? 0 : b3 + 1, pb ^ 1);          // the next query block (the image repeats for every tile)
+            step(std::integral_constant<int, 0>{}, b3, last);
+            step(std::integral_constant<int, 1>{}, b3, last);
+            step(std::integral_constant<int, 2>{}, b3, last);
+            step(std::integral_constant<int, 3>{}, b3, last);
+            step(std::integral_constant<int, 4>{}, b3, last);
+            step(std::integral_constant<int, 5>{}, b3, last);
+            step(std::integral_constant<int, 6>{}, b3, last);
+            step(std::integral_constant<int, 7>{}, b3, last);
+            // end of a query block: everyone is done with it, and the next has landed (its DMAs are older than row loads
+            // this wave has already waited for)
+            wg_barrier();
+            pb ^= 1;
         }
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); // the inverse norms (older than the last three steps' row loads)
+        pin2(inv4[0], inv4[1]);
         // ---- epilogue: accumulator (mi, ni)[rr] = row 32 w + mi 16 + 4 lg + rr of the tile, query ni 16 + li16 ----
         const int n_valid = row_end - row0;
         int col_e = li16;
-        asm volatile("" : "+v"(col_e));                 // (keeps the address arithmetic below inside the tile loop: no spills)
-        asm volatile("" : "+v"(inv4[0]), "+v"(inv4[1])); // (read only here, after the waits that retired the loads)
+        asm volatile("" : "+v"(col_e));
         float cmax[8];
 #pragma unroll
         for (int ni = 0; ni < 8; ++ni) cmax[ni] = NEG_INF;
@@ -269,7 +262,6 @@ __global__ __launch_bounds__(GF_THREADS) void gemm_f32_kernel(GemmF32Args a) {
             for (int ni = 0; ni < 8; ++ni) {
                 f32x4 v = acc[mi][ni] * inv;            // cosine = <e, q^> / ||e||
                 if (part) {
-                    asm volatile("" ::: "memory");      // a real branch (at most one block per wave and tile)
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr)
                         if (rb + rr >= n_valid) v[rr] = NEG_INF;
@@ -279,9 +271,6 @@ __global__ __launch_bounds__(GF_THREADS) void gemm_f32_kernel(GemmF32Args a) {
             }
         }
         if (EMIT) {
-            // Emission, per 16-query block: only when some lane's maximum over its 8 rows reaches the threshold (about one
-            // block in three); every branch is wave-uniform, the position comes from a per-wave scalar counter and a prefix
-            // count over the emitting lanes (no atomics: an LDS atomic would wait for every pending LDS-DMA)
 #pragma unroll
             for (int ni = 0; ni < 8; ++ni) {
                 if (__ballot(cmax[ni] >= thrv[ni]) == 0) continue;
@@ -322,148 +311,130 @@ __global__ __launch_bounds__(GF_THREADS) void gemm_f32_kernel(GemmF32Args a) {
         row_end = a.tile_row[tile_of(jt) + 1];
         jn = jt + G < a.t_count ? jt + G : jt;
         row0n = a.tile_row[tile_of(jn)];
+        rp0 = rn0; rp1 = rn1;
+        rn0 = row_ptr(row0n, 0); rn1 = row_ptr(row0n, 1);
     }
-    wait_vm0();
+    wait_vm0();                                          // (the prefetched block and rows of a tile that does not exist)
     if (EMIT && lane == 0) a.wv_count[blockIdx.x * 8 + w] = wave_cnt;
 }
 
-// qimg[kt][piece][q][physical chunk c'] (16 B = 8 f16) = piece (hi | lo) of dims 32 kt + 8 c .. + 8 of normalised query q,
-// c = c' ^ (((q >> 3) & 1) << 1); queries >= nq are zero.  Same split as the row side (split_f16).
-__global__ __launch_bounds__(256) void build_qimg_kernel(const float* __restrict__ qn, int nq, f16x8* __restrict__ qimg) {
+// query image of the streaming kernel: [kt 24][q 128][physical chunk c' 4] x 16 B = f16 of dims 32 kt + 8 c .. + 8 of the
+// normalised query q, c = c' ^ (((q >> 3) & 1) << 1); queries >= nq are zero
+__global__ __launch_bounds__(256) void build_qimg1_kernel(const float* __restrict__ qn, int nq, f16x8* __restrict__ qimg) {
     const int i = blockIdx.x * 256 + threadIdx.x;       // (kt, q, c')
     if (i >= GF_KT * 128 * 4) return;
     const int cp = i & 3, q = (i >> 2) & 127, kt = i >> 9;
     const int c = cp ^ (((q >> 3) & 1) << 1);
-    f16x8 hi, lo;
+    f16x8 h;
     if (q < nq) {
         const float* src = qn + (size_t)q * MSR_DIM + 32 * kt + 8 * c;
-        split_f16(*(const f32x4*)src, *(const f32x4*)(src + 4), hi, lo);
+        h = cvt_f16_rtn(*(const f32x4*)src, *(const f32x4*)(src + 4));
     } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { hi[j] = (_Float16)0.f; lo[j] = (_Float16)0.f; }
+        for (int j = 0; j < 8; ++j) h[j] = (_Float16)0.f;
     }
-    qimg[((size_t)kt * 2 + 0) * 512 + q * 4 + cp] = hi;
-    qimg[((size_t)kt * 2 + 1) * 512 + q * 4 + cp] = lo;
+    qimg[i] = h;
 }
 
+// qimg[kt][piece][q][physical chunk c'] (16 B = 8 f16) = piece (hi | lo) of dims 32 kt + 8 c .. + 8 of normalised query q,
+// c = c' ^ (((q >> 3) & 1) << 1); queries >= nq are zero.  Same split as the row side (split_f16).
 __global__ __launch_bounds__(256) void pad_inv_kernel(const float* __restrict__ inv, int64_t n, int64_t n_pad, float* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n_pad) out[i] = i < n ? inv[i] : 1.0f;
 }
 
-__device__ __forceinline__ bool key_less2(uint64_t ah, uint32_t al, uint64_t bh, uint32_t bl) {
-    return ah < bh || (ah == bh && al < bl);
+__global__ __launch_bounds__(256) void f16_row_error_kernel(const float* __restrict__ src, const float* __restrict__ inv_norm,
+                                                             int64_t n_rows, uint32_t* __restrict__ err_max) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+    float worst = 0.f;
+    for (int64_t r = wave; r < n_rows; r += n_waves) {
+        const f32x4* p = (const f32x4*)(src + (size_t)r * MSR_DIM);
+        float ss = 0.f;
+#pragma unroll
+        for (int h = 0; h < 3; ++h) {
+            const f32x4 x = p[lane + 64 * h];
+            ss += f16_err2(x.x) + f16_err2(x.y) + f16_err2(x.z) + f16_err2(x.w);
+        }
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+        worst = fmaxf(worst, sqrtf(ss) * inv_norm[r]);
+    }
+    if (lane == 0) atomicMax(err_max, __float_as_uint(worst));
 }
 
-// One workgroup per query: entries (row, score) -> per-document maximum with its FIRST arg-max row -> exact order
-// (score desc, document asc) -> top-k.  Overflow (entries that did not fit anywhere on the way): out_n = -1 and *gate |= 1.
-__global__ __launch_bounds__(1024) void gemm_f32_final_kernel(const int2* __restrict__ pairs, int32_t* __restrict__ pair_n,
-                                                               const int32_t* __restrict__ chunk_doc,
-                                                               const int32_t* __restrict__ wv_count, int n_waves, int wv_cap,
-                                                               const int32_t* __restrict__ flag, int k,
-                                                               int32_t* __restrict__ out_doc, float* __restrict__ out_score,
-                                                               int32_t* __restrict__ out_chunk, int32_t* __restrict__ out_n,
-                                                               int32_t* __restrict__ gate) {
-    __shared__ uint64_t khi[GF_PAIR_CAP];
-    __shared__ uint32_t klo[GF_PAIR_CAP];
-    __shared__ int s_over, s_heads;
+// margin[q] = 2 eps_q + slack, eps_q = dE (1 + dq) + dq with dq = ||q^ - f16(q^)|| (q^: the normalised query); the slack
+// covers the f32 accumulation of 768 products on both sides of the argument (msr_batch.hip)
+__global__ __launch_bounds__(256) void f16_margin_kernel(const float* __restrict__ qn, int nq, const uint32_t* __restrict__ err_max,
+                                                          float* __restrict__ margin) {
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= nq) return;
+    float ss = 0.f;
+    for (int j = lane; j < MSR_DIM; j += 64) ss += f16_err2(qn[(size_t)q * MSR_DIM + j]);
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    if (lane == 0) {
+        const float dq = sqrtf(ss) * 1.0001f, dE = __uint_as_float(*err_max) * 1.0001f;
+        margin[q] = 2.0f * (dE * (1.0f + dq) + dq * 1.000001f) + 1.0e-4f;
+    }
+}
+
+// One workgroup per query: entries (row, approximate score) -> the distinct documents they belong to = the candidates
+// whose exact f32 cosines msr_batch_rescore computes.  Overflow anywhere on the way: no candidates and *gate |= 1 (the
+// caller's gated sweeps then redo the batch).
+__global__ __launch_bounds__(1024) void gemm_f32_cand_kernel(const int2* __restrict__ pairs, int32_t* __restrict__ pair_n,
+                                                              const int32_t* __restrict__ chunk_doc,
+                                                              const int32_t* __restrict__ wv_count, int n_waves, int wv_cap,
+                                                              const int32_t* __restrict__ flag, int32_t* __restrict__ cand_doc,
+                                                              int32_t* __restrict__ cand_n, int32_t* __restrict__ gate) {
+    __shared__ uint32_t key[GF_PAIR_CAP];
+    __shared__ int s_over, s_n;
     const int q = blockIdx.x, t = threadIdx.x;
     const int raw = pair_n[q];
-    // (all threads scan the per-wave counts: one thread walking 2048 words with a data-dependent exit took 0.12 ms)
     int over = raw > GF_PAIR_CAP || flag[q];
     for (int i = t; i < n_waves; i += 1024) over |= wv_count[i] > wv_cap;
-    if (t == 0) s_heads = 0;
-    s_over = 0;
+    if (t == 0) { s_n = 0; s_over = 0; }
     __syncthreads();
     if (over) s_over = 1;
     __syncthreads();
     if (s_over) {
-        for (int i = t; i < k; i += 1024) {
-            out_doc[(size_t)q * k + i] = -1;
-            out_score[(size_t)q * k + i] = -__builtin_inff();
-            if (out_chunk) out_chunk[(size_t)q * k + i] = -1;
-        }
-        if (t == 0) { out_n[q] = -1; pair_n[q] = 0; atomicOr(gate, 1); }
+        if (t == 0) { cand_n[q] = 0; pair_n[q] = 0; atomicOr(gate, 1); }
         return;
     }
     int P = 64;
     while (P < raw) P <<= 1;
-    auto sort_desc = [&]() {
-        for (int kk = 2; kk <= P; kk <<= 1)
-            for (int j = kk >> 1; j > 0; j >>= 1) {
-                for (int idx = t; idx < (P >> 1); idx += 1024) {
-                    const int i = ((idx & ~(j - 1)) << 1) | (idx & (j - 1));
-                    const int p = i | j;
-                    const bool desc = (i & kk) == 0;
-                    const uint64_t ah = khi[i], bh = khi[p];
-                    const uint32_t al = klo[i], bl = klo[p];
-                    if (desc ? key_less2(ah, al, bh, bl) : key_less2(bh, bl, ah, al)) {
-                        khi[i] = bh; klo[i] = bl; khi[p] = ah; klo[p] = al;
-                    }
-                }
-                __syncthreads();
+    for (int i = t; i < P; i += 1024) key[i] = i < raw ? (uint32_t)chunk_doc[pairs[(size_t)q * GF_PAIR_CAP + i].x] + 1u : 0u;
+    __syncthreads();
+    for (int kk = 2; kk <= P; kk <<= 1)
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int idx = t; idx < (P >> 1); idx += 1024) {
+                const int i = ((idx & ~(j - 1)) << 1) | (idx & (j - 1));
+                const int p = i | j;
+                const bool desc = (i & kk) == 0;
+                const uint32_t a = key[i], b = key[p];
+                if (desc ? a < b : a > b) { key[i] = b; key[p] = a; }
             }
-    };
-    // (1) by (document, score, ~row) descending: the first entry of a document's run is its maximum at its lowest row
-    for (int i = t; i < P; i += 1024) {
-        uint64_t h = 0; uint32_t l = 0;
-        if (i < raw) {
-            const int2 e = pairs[(size_t)q * GF_PAIR_CAP + i];
-            h = ((uint64_t)(uint32_t)(chunk_doc[e.x] + 1) << 32) | msr_ord32(__int_as_float(e.y));   // doc + 1: 0 is the pad key
-            l = ~(uint32_t)e.x;
+            __syncthreads();
         }
-        khi[i] = h; klo[i] = l;
-    }
+    for (int i = t; i < P; i += 1024)
+        if (key[i] != 0 && (i == 0 || key[i] != key[i - 1])) cand_doc[(size_t)q * MSR_SEL_CAP + atomicAdd(&s_n, 1)] = (int32_t)(key[i] - 1u);
     __syncthreads();
-    sort_desc();
-    // (2) heads re-keyed by (score, ~document) with the row as payload
-    uint64_t mh[GF_PAIR_CAP / 1024];
-    uint32_t ml[GF_PAIR_CAP / 1024];
-#pragma unroll
-    for (int u = 0; u < GF_PAIR_CAP / 1024; ++u) {
-        const int i = t + u * 1024;
-        uint64_t h = 0; uint32_t l = 0;
-        if (i < P && khi[i] != 0 && (i == 0 || (khi[i] >> 32) != (khi[i - 1] >> 32))) {
-            h = ((uint64_t)(uint32_t)khi[i] << 32) | (uint32_t)~(uint32_t)((khi[i] >> 32) - 1);
-            l = ~klo[i];                                 // the row
-        }
-        mh[u] = h; ml[u] = l;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < GF_PAIR_CAP / 1024; ++u) {
-        const int i = t + u * 1024;
-        if (i < P) {
-            khi[i] = mh[u]; klo[i] = ml[u];
-            if (mh[u]) atomicAdd(&s_heads, 1);
-        }
-    }
-    __syncthreads();
-    sort_desc();                                        // keys of heads are distinct (the document is part of them)
-    const int n_sel = s_heads < k ? s_heads : k;
-    for (int i = t; i < k; i += 1024) {
-        const bool ok = i < n_sel;
-        out_doc[(size_t)q * k + i] = ok ? (int32_t)~(uint32_t)khi[i] : -1;
-        out_score[(size_t)q * k + i] = ok ? msr_unord32((uint32_t)(khi[i] >> 32)) : -__builtin_inff();
-        if (out_chunk) out_chunk[(size_t)q * k + i] = ok ? (int32_t)klo[i] : -1;
-    }
-    if (t == 0) { out_n[q] = n_sel; pair_n[q] = 0; }
+    if (t == 0) { cand_n[q] = s_n; pair_n[q] = 0; }
 }
 
 int g_f32_dbg = 0;
 
-hipError_t launch_f32(bool emit, const GemmF32Args& a, int grid, hipStream_t stream) {
+template <bool EMIT>
+hipError_t launch_stream_t(const GemmF32Args& a, int grid, hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t err = hipFuncSetAttribute((const void*)gemm_f32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GF_LDS);
-        if (err != hipSuccess) return err;
-        err = hipFuncSetAttribute((const void*)gemm_f32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GF_LDS);
+        hipError_t err = hipFuncSetAttribute((const void*)gemm_stream_kernel<EMIT>, hipFuncAttributeMaxDynamicSharedMemorySize, GS_LDS);
         if (err != hipSuccess) return err;
         attr_done = true;
     }
-    if (emit) gemm_f32_kernel<true><<<grid, GF_THREADS, GF_LDS, stream>>>(a);
-    else gemm_f32_kernel<false><<<grid, GF_THREADS, GF_LDS, stream>>>(a);
+    gemm_stream_kernel<EMIT><<<grid, GF_THREADS, GS_LDS, stream>>>(a);
     return hipGetLastError();
+}
+hipError_t launch_f32(bool emit, const GemmF32Args& a, int grid, hipStream_t stream) {
+    return emit ? launch_stream_t<true>(a, grid, stream) : launch_stream_t<false>(a, grid, stream);
 }
 
 }  // namespace
@@ -476,14 +447,23 @@ hipError_t msr_pad_inv_norm(const float* inv, int64_t n, int64_t n_pad, float* o
     return hipGetLastError();
 }
 
-// Exact (f16x2-split arithmetic) top-k of up to 128 queries in one pass over the f32 rows; see the header of this file.
-// qn: [nq][768] normalised queries.  out_n[q] = -1 and *gate != 0 when a query overflowed (the caller falls back).
+hipError_t msr_f16_row_error(const float* emb, const float* inv_norm, int64_t n_rows, uint32_t* err_max, hipStream_t stream) {
+    hipError_t err = hipMemsetAsync(err_max, 0, 4, stream);
+    if (err != hipSuccess) return err;
+    f16_row_error_kernel<<<8192, 256, 0, stream>>>(emb, inv_norm, n_rows, err_max);
+    return hipGetLastError();
+}
+
+// Exact f32 top-k of up to 128 queries in one pass over the f32 rows; see the header of this file.
+// qn: [nq][768] normalised queries.  *gate != 0 when a query overflowed (the caller falls back).
 hipError_t msr_gemm_f32_topk(const GemmF32Index& g, const DenseIndex& ix, const float* qn, int nq, int k,
                              const SelScratch& sel, int32_t* out_doc, float* out_score, int32_t* out_chunk,
                              int32_t* out_n, int32_t* gate, hipEvent_t* ev, hipStream_t stream) {
     if (nq <= 0 || nq > 128 || k < 1 || g.n_tiles < 2 * k) return hipErrorInvalidValue;
     hipError_t err;
-    build_qimg_kernel<<<(GF_KT * 128 * 4 + 255) / 256, 256, 0, stream>>>(qn, nq, (f16x8*)g.qimg);
+    build_qimg1_kernel<<<(GF_KT * 128 * 4 + 255) / 256, 256, 0, stream>>>(qn, nq, (f16x8*)g.qimg);
+    f16_margin_kernel<<<(nq + 3) / 4, 256, 0, stream>>>(qn, nq, g.err_max, g.margin);
+    const float* margin = g.margin;
     int ss = g.n_tiles / (6 * k);                       // every ss-th tile bounds the k-th score from below: >= 6 k sampled tiles
     ss = ss < 1 ? 1 : (ss > 32 ? 32 : ss);
     const int n_s = (g.n_tiles - ss / 2 + ss - 1) / ss;
@@ -498,7 +478,7 @@ hipError_t msr_gemm_f32_topk(const GemmF32Index& g, const DenseIndex& ix, const 
     if (ev && (err = hipEventRecord(ev[1], stream)) != hipSuccess) return err;
     if ((err = msr_gemm_tmax(g.tmax_t, n_s, 8, 128, g.tmax, g.tmax_stride, stream)) != hipSuccess) return err;
     if ((err = msr_select_topk(32, g.tmax, n_s, g.tmax_stride, nq, k, sel, g.top_doc, g.top_score, g.top_n, stream)) != hipSuccess) return err;
-    if ((err = msr_gemm_thr(g.top_score, g.top_n, nq, 128, k, nullptr, g.thr, g.flag, stream)) != hipSuccess) return err;
+    if ((err = msr_gemm_thr(g.top_score, g.top_n, nq, 128, k, margin, g.thr, g.flag, stream)) != hipSuccess) return err;
     a.t_first = 0; a.t_stride = 1; a.t_count = g.n_tiles;
     a.thr = g.thr; a.wvbuf = (int4*)g.wvbuf; a.wv_cap = g.wv_cap; a.wv_count = g.wv_count;
     if (ev && (err = hipEventRecord(ev[2], stream)) != hipSuccess) return err;
@@ -506,9 +486,11 @@ hipError_t msr_gemm_f32_topk(const GemmF32Index& g, const DenseIndex& ix, const 
     if (ev && (err = hipEventRecord(ev[3], stream)) != hipSuccess) return err;
     if ((err = msr_gemm_tmax(g.tmax_t, g.n_tiles, 8, 128, g.tmax, g.tmax_stride, stream)) != hipSuccess) return err;
     if ((err = msr_select_topk(32, g.tmax, g.n_tiles, g.tmax_stride, nq, k, sel, g.top_doc, g.top_score, g.top_n, stream)) != hipSuccess) return err;
-    if ((err = msr_gemm_thr(g.top_score, g.top_n, nq, 128, k, nullptr, g.thr2, nullptr, stream)) != hipSuccess) return err;
+    if ((err = msr_gemm_thr(g.top_score, g.top_n, nq, 128, k, margin, g.thr2, nullptr, stream)) != hipSuccess) return err;
     if ((err = msr_gemm_bucket(g.wvbuf, g.wv_cap, g.wv_count, grid * 8, g.thr2, g.pairs, g.pair_n, stream)) != hipSuccess) return err;
-    gemm_f32_final_kernel<<<nq, 1024, 0, stream>>>((const int2*)g.pairs, g.pair_n, ix.chunk_doc, g.wv_count, grid * 8, g.wv_cap,
-                                                   g.flag, k, out_doc, out_score, out_chunk, out_n, gate);
-    return hipGetLastError();
+    gemm_f32_cand_kernel<<<nq, 1024, 0, stream>>>((const int2*)g.pairs, g.pair_n, ix.chunk_doc, g.wv_count, grid * 8, g.wv_cap,
+                                                  g.flag, g.cand_doc, g.cand_n, gate);
+    if ((err = hipGetLastError()) != hipSuccess) return err;
+    return msr_batch_rescore(ix, qn, nq, k, 0, g.cand_doc, g.cand_score, g.cand_chunk, g.cand_n, out_doc, out_score, out_chunk,
+                             out_n, stream);
 }

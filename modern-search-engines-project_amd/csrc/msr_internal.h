@@ -187,6 +187,7 @@ hipError_t msr_gemm_thr(const float* top_score, const int32_t* top_n, int nq, in
                         float* thr, int32_t* flag, hipStream_t stream);     // margin null: 0
 hipError_t msr_gemm_bucket(const void* wvbuf, int wv_cap, const int32_t* wv_count, int n_waves, const float* thr2,
                            void* pairs, int32_t* pair_n, hipStream_t stream);
+void msr_bm25_set_dbg(int v);       // honoured by -DMSR_DIAG builds only
 void msr_gemm_set_dbg(int v);       // honoured by -DMSR_DIAG builds only
 // dst[r] = bf16(src[r] * inv_norm[r]) (inv_norm null: 1), rows n_rows .. n_pad - 1 zero
 // err_max (device word, nullable) <- bits of max_r || bf16(u_r) - u_r ||, u_r the normalised row
@@ -201,13 +202,13 @@ hipError_t msr_gemm_candidates(const GemmIndex& g, const DenseIndex& ix, const f
                                const SelScratch& sel, int32_t* cand_doc, int32_t* cand_n, hipEvent_t* ev,
                                hipStream_t stream);
 
-// ---- K2 for 65 .. 128 queries: the default (f16x2-split) scan as a tiled GEMM over the f32 rows (msr_gemm_f32.hip) ----
+// ---- K2 for 65 .. 128 queries: one streaming pass over the f32 rows, f16 filter + exact f32 finish (msr_gemm_f32.hip) ----
 struct GemmF32Index {
     const int32_t* tile_row;   // [n_tiles + 1] (the tile table of the bf16 GEMM: whole documents, <= 256 rows)
     int32_t n_tiles;
     int32_t n_cus;
     const float* inv_pad;      // [n_chunks + 512] inverse row norms, padded with 1
-    void* qimg;                // 24 x 16 KB query image (f16 hi | lo pieces)
+    void* qimg;                // 24 x 8 KB query image (f16)
     float* tmax_t;             // [n_tiles][8 waves][128]
     float* tmax;               // [128][tmax_stride]
     int32_t tmax_stride;
@@ -215,7 +216,10 @@ struct GemmF32Index {
     float* thr; float* thr2; int32_t* flag;                 // [128]
     void* wvbuf; int32_t wv_cap; int32_t* wv_count;          // [n_cus * 8][wv_cap] x 16 B / [n_cus * 8]
     void* pairs; int32_t* pair_n;                            // [128][4096] x 8 B / [128], zero between calls
+    uint32_t* err_max; float* margin;                        // measured f16 rounding error of the rows (1 word) / margin [128]
+    int32_t* cand_doc; float* cand_score; int32_t* cand_chunk; int32_t* cand_n;   // [128][MSR_SEL_CAP] x 3 / [128] (zero between calls)
 };
+hipError_t msr_f16_row_error(const float* emb, const float* inv_norm, int64_t n_rows, uint32_t* err_max, hipStream_t stream);
 void msr_gemm_f32_set_dbg(int v);   // honoured by -DMSR_DIAG builds only
 hipError_t msr_pad_inv_norm(const float* inv, int64_t n, int64_t n_pad, float* out, hipStream_t stream);
 // Top-k of up to 128 normalised queries qn in one pass over the f32 rows; out_n[q] = -1 and *gate |= 1 for a query whose

@@ -34,7 +34,7 @@ def test_default_line_has_the_contract_fields():
     assert "f64" in d["dtype"] and d["outputs_sane"] is True and d["bm25_parity_vs_cpu"] is True
     r = d["roofline"]
     # 128 queries per step: ONE pass of the GEMM scan over the f32 rows (csrc/msr_gemm_f32.hip) per step
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "gemm_f32_kernel<emit>"
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "gemm_stream_kernel<emit>"
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "traffic" in r and r["launches"] == 3   # 1 pass x 3 steps
     assert r["bm25_taat"]["launches"] == 3
     c = d["cpu_baseline"]
