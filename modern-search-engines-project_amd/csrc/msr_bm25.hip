@@ -18,14 +18,8 @@
 // operation as Python evaluates it and this file is compiled with -ffp-contract=off, so scores are bit-identical to
 // the oracle.
 //
-// Two passes per call (msr_engine.hip msr_bm25_topk) when the index has enough tiles: a SAMPLE pass over every 16th tile
-// whose exact top-k gives a lower bound of the query's k-th largest score (the k-th largest of a subset), then the
-// pass over all tiles that emits only documents at or above that bound -- about 16 k instead of every touched document
-// (hundreds of thousands for a query with a common term), which removes most of the 12 B/candidate writes and most of
-// the select's input.  The result is the same exact top-k.
-//
 // HBM traffic per query: 8 B per posting of the query's terms + 1 B per document (doc_len, shared by four queries) +
-// 12 B per emitted candidate (the (score, doc) list consumed by the top-k select).
+// 12 B per candidate document (the (score, doc) list consumed by the top-k select).
 #include "msr_common.h"
 #include "msr_internal.h"
 
@@ -51,8 +45,6 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
                                                                   const int32_t* __restrict__ q_terms,
                                                                   const int32_t* __restrict__ q_qtf,
                                                                   int q_first, int nq, double min_score,
-                                                                  int tile_first, int tile_stride,
-                                                                  const double* __restrict__ floor_q,
                                                                   double* __restrict__ cand_score,
                                                                   int32_t* __restrict__ cand_doc,
                                                                   int32_t* __restrict__ cand_n, int dbg_arg) {
@@ -70,7 +62,7 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
     // are served by the L2 after the first of them
     const int q = blockIdx.x * BM25_QPW + wave;              // row of the candidate lists
     const bool live = q < nq;                                // (wave-uniform)
-    const int tile = tile_first + (int)blockIdx.y * tile_stride;
+    const int tile = blockIdx.y;
     const int64_t lo = (int64_t)tile * BM25_TILE;
     const int64_t hi = lo + BM25_TILE < ix.n_docs ? lo + BM25_TILE : ix.n_docs;
     const int n = (int)(hi - lo);
@@ -156,15 +148,24 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
             }
         }
     }
-    // ---- 3. prefetch: the first 64 postings of the first TPRE slices (for most terms: the whole slice) ----
-    constexpr int TPRE = 8;
-    int32_t pd0[TPRE], ptf0[TPRE];
+    // ---- 3. prefetch: the first PFC x 64 postings of the first TPRE slices (for nearly all terms: the whole slice), all
+    //         issued before anything is accumulated -- one memory round trip for the postings of all terms instead of one
+    //         per term (the kernel is bound by these chains of dependent loads, not by bandwidth or arithmetic) ----
+    constexpr int TPRE = 6, PFC = 4;
+    int32_t pd0[TPRE][PFC], ptf0[TPRE][PFC];
 #pragma unroll
     for (int j = 0; j < TPRE; ++j) {
-        pd0[j] = -1; ptf0[j] = 0;
+#pragma unroll
+        for (int c = 0; c < PFC; ++c) { pd0[j][c] = -1; ptf0[j][c] = 0; }
         if (j < nt && !(dbg & 8)) {                          // wave-uniform
-            const int64_t i = lane_i64(ps_v, j) + lane;
-            if (i < lane_i64(pe_v, j)) { pd0[j] = ix.post_doc[i]; ptf0[j] = ix.post_tf[i]; }
+            const int64_t ps = lane_i64(ps_v, j), pe = lane_i64(pe_v, j);
+#pragma unroll
+            for (int c = 0; c < PFC; ++c) {
+                if (ps + 64 * c < pe) {                      // wave-uniform: no instruction for chunks past the slice
+                    const int64_t i = ps + 64 * c + lane;
+                    if (i < pe) { pd0[j][c] = ix.post_doc[i]; ptf0[j][c] = ix.post_tf[i]; }
+                }
+            }
         }
     }
     // accumulators of this wave's query; the length norms of the tile (shared by the four waves)
@@ -209,8 +210,10 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
         const int64_t ps = lane_i64(ps_v, j), pe = lane_i64(pe_v, j);
         if (pe <= ps) continue;
         const double idf = lane_f64(idf_v, j), qtf = lane_f64(qtf_v, j);
-        apply(pd0[j], ptf0[j], idf, qtf);
-        if (pe - ps > 64) stream(ps + 64, pe, idf, qtf);
+#pragma unroll
+        for (int c = 0; c < PFC; ++c)
+            if (ps + 64 * c < pe) apply(pd0[j][c], ptf0[j][c], idf, qtf);
+        if (pe - ps > 64 * PFC) stream(ps + 64 * PFC, pe, idf, qtf);
     }
     for (int j = TPRE; j < nt; ++j) {
         const int64_t ps = lane_i64(ps_v, j), pe = lane_i64(pe_v, j);
@@ -221,12 +224,6 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
     // ---- 4. the tile's candidates (touched by a posting AND score >= min_score, :461,480) as (score, doc) pairs
     //         appended to the query's list: one reservation per wave.  Most documents of a tile are not candidates, so
     //         this replaces an 8 B/document dense row by 12 B per candidate. ----
-    // floor_q (full pass after a sample pass): a lower bound of the query's k-th largest score -- documents below it cannot
-    // be in the top-k and are not emitted (msr_engine.hip msr_bm25_topk)
-    if (floor_q) {
-        const double f = floor_q[q];
-        if (f > min_score) min_score = f;
-    }
     int total = 0;
     unsigned long long flags[BM25_TILE / 64];
 #pragma unroll
@@ -322,28 +319,11 @@ hipError_t msr_bm25_validate(const Bm25Index& ix, int32_t* flag, hipStream_t str
 }
 
 hipError_t msr_bm25_scores(const Bm25Index& ix, const int32_t* q_term_off, const int32_t* q_terms,
-                           const int32_t* q_qtf, int q_first, int nq, double min_score, int tile_first, int tile_stride,
-                           const double* floor_q, double* cand_score, int32_t* cand_doc, int32_t* cand_n,
-                           hipStream_t stream) {
-    if (nq <= 0 || ix.n_docs <= 0 || tile_stride < 1 || tile_first < 0 || tile_first >= ix.n_tiles) return hipSuccess;
-    const int n_pass = (ix.n_tiles - tile_first + tile_stride - 1) / tile_stride;
-    dim3 grid((unsigned)((nq + BM25_QPW - 1) / BM25_QPW), (unsigned)n_pass);
-    bm25_taat_kernel<<<grid, BM25_THREADS, 0, stream>>>(ix, q_term_off, q_terms, q_qtf, q_first, nq, min_score, tile_first,
-                                                        tile_stride, floor_q, cand_score, cand_doc, cand_n, g_bm25_dbg);
-    return hipGetLastError();
-}
-
-// floor_q[q] = the k-th largest score of the sample pass (row q of `score`, n[q] entries, descending), or -inf when the
-// sample holds fewer than k candidates; n[q] is reset for the full pass' select.
-__global__ void bm25_floor_kernel(const double* __restrict__ score, const int32_t* __restrict__ n, int nq, int k,
-                                  double* __restrict__ floor_q) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nq) return;
-    floor_q[q] = n[q] >= k ? score[(int64_t)q * k + (k - 1)] : -__builtin_inf();
-}
-
-hipError_t msr_bm25_floor(const double* top_score, const int32_t* top_n, int nq, int k, double* floor_q, hipStream_t stream) {
-    if (nq <= 0) return hipSuccess;
-    bm25_floor_kernel<<<(nq + 255) / 256, 256, 0, stream>>>(top_score, top_n, nq, k, floor_q);
+                           const int32_t* q_qtf, int q_first, int nq, double min_score, double* cand_score,
+                           int32_t* cand_doc, int32_t* cand_n, hipStream_t stream) {
+    if (nq <= 0 || ix.n_docs <= 0) return hipSuccess;
+    dim3 grid((unsigned)((nq + BM25_QPW - 1) / BM25_QPW), (unsigned)((ix.n_docs + BM25_TILE - 1) / BM25_TILE));
+    bm25_taat_kernel<<<grid, BM25_THREADS, 0, stream>>>(ix, q_term_off, q_terms, q_qtf, q_first, nq, min_score, cand_score,
+                                                        cand_doc, cand_n, g_bm25_dbg);
     return hipGetLastError();
 }

@@ -39,7 +39,6 @@ struct msr_engine {
     uint32_t* bm_tile_off = nullptr;
     int32_t* bm_cand_doc = nullptr;    // max_queries rows of n_docs i32: document of each BM25 candidate
     int32_t* bm_cand_n = nullptr;      // [max_queries] candidates per query (zero between calls)
-    double* bm_floor = nullptr;        // [max_queries] lower bound of the k-th largest score (sample pass)
     size_t bm_cand_bytes = 0;
     SelScratch sel{};
     float* rerank_cos = nullptr;
@@ -215,7 +214,7 @@ extern "C" int msr_create(const msr_config* cfg, msr_engine** out) {
 extern "C" int msr_destroy(msr_engine* e) {
     if (!e) return MSR_OK;
     free_dev(e->chunk_doc); free_dev(e->emb_presplit); free_dev(e->row_meta); free_dev(e->inv_norm_own); free_dev(e->span_doc); free_dev(e->wspan_doc); free_dev(e->wspan12_doc); free_dev(e->qn); free_dev(e->qimg); free_dev(e->emb_bf16);
-    free_dev(e->score_rows); free_dev(e->bm_heavy_id); free_dev(e->bm_tile_off); free_dev(e->bm_cand_doc); free_dev(e->bm_cand_n); free_dev(e->bm_floor); free_dev(e->sel.hist); free_dev(e->sel.state); free_dev(e->sel.cand_hi);
+    free_dev(e->score_rows); free_dev(e->bm_heavy_id); free_dev(e->bm_tile_off); free_dev(e->bm_cand_doc); free_dev(e->bm_cand_n); free_dev(e->sel.hist); free_dev(e->sel.state); free_dev(e->sel.cand_hi);
     free_dev(e->sel.cand_lo); free_dev(e->sel.cand_n); free_dev(e->rerank_cos); free_dev(e->rerank_meta);
     free_dev(e->bt_top_doc); free_dev(e->bt_top_score); free_dev(e->bt_top_n); free_dev(e->bt_cand_doc);
     free_dev(e->bt_cand_score); free_dev(e->bt_cand_chunk); free_dev(e->bt_cand_n);
@@ -271,10 +270,7 @@ extern "C" int msr_bind_postings(msr_engine* e, const int64_t* term_off, int64_t
             if ((herr = hipMalloc((void**)&e->bm_cand_n, (size_t)e->cfg.max_queries * sizeof(int32_t))) != hipSuccess)
                 return fail(e, MSR_ERR_NOMEM, "BM25 candidate counts: %s", hipGetErrorString(herr));
         }
-        if (!e->bm_floor) {
-            if ((herr = hipMalloc((void**)&e->bm_floor, (size_t)e->cfg.max_queries * sizeof(double))) != hipSuccess)
-                return fail(e, MSR_ERR_NOMEM, "BM25 score floors: %s", hipGetErrorString(herr));
-        }
+
     }
     Bm25Index cand{term_off, post_doc, post_tf, doc_len, idf, n_terms, n_postings, n_docs, (double)avgdl, k1, b,
                    nullptr, nullptr, (int32_t)((n_docs + MSR_BM25_TILE - 1) / MSR_BM25_TILE)};
@@ -597,28 +593,12 @@ extern "C" int msr_bm25_topk(msr_engine* e, const int32_t* q_term_off, const int
         const int nq = std::min(slice, n_queries - q0);
         int32_t* o_doc = out_doc + (int64_t)q0 * k;
         double* o_score = out_score + (int64_t)q0 * k;
-        // Sample pass: the exact top-k of every SS-th tile.  Its k-th score is a lower bound of the k-th largest score
-        // over all tiles (the k-th largest of a subset), so the full pass need not emit anything below it -- for a query
-        // with a common term that is the difference between every touched document and about SS x k of them.  Queries
-        // whose sample holds fewer than k candidates get no bound (-inf).  Worth it from 64 tiles on.
-        const int n_tiles = e->bm25.n_tiles;
-        const int ss = n_tiles >= 256 ? 16 : n_tiles >= 64 ? 8 : 0;
-        const double* floor_q = nullptr;
-        if (ss) {
-            HIP_TRY(e, hipMemsetAsync(e->bm_cand_n, 0, (size_t)nq * sizeof(int32_t), st));
-            HIP_TRY(e, msr_bm25_scores(e->bm25, q_term_off, q_terms, q_qtf, q0, nq, min_score, ss / 2, ss, nullptr,
-                                       (double*)e->score_rows, e->bm_cand_doc, e->bm_cand_n, st));
-            HIP_TRY(e, msr_select_topk_list((const double*)e->score_rows, e->bm_cand_doc, e->bm_cand_n, N, N, nq, k, e->sel,
-                                            o_doc, o_score, out_n + q0, st));
-            HIP_TRY(e, msr_bm25_floor(o_score, out_n + q0, nq, k, e->bm_floor, st));
-            floor_q = e->bm_floor;
-        }
-        // every launch of the full pass gets its own event pair (ring of EV_RING; later launches are not recorded)
+        // every launch gets its own event pair (ring of EV_RING; later launches are not recorded)
         const bool timed = e->timing && e->ev_count[1] < msr_engine::EV_RING;
         HIP_TRY(e, hipMemsetAsync(e->bm_cand_n, 0, (size_t)nq * sizeof(int32_t), st));
         if (timed) HIP_TRY(e, hipEventRecord(e->ev_start[1][e->ev_count[1]], st));
-        HIP_TRY(e, msr_bm25_scores(e->bm25, q_term_off, q_terms, q_qtf, q0, nq, min_score, 0, 1, floor_q,
-                                   (double*)e->score_rows, e->bm_cand_doc, e->bm_cand_n, st));
+        HIP_TRY(e, msr_bm25_scores(e->bm25, q_term_off, q_terms, q_qtf, q0, nq, min_score, (double*)e->score_rows, e->bm_cand_doc,
+                                   e->bm_cand_n, st));
         if (timed) {
             HIP_TRY(e, hipEventRecord(e->ev_stop[1][e->ev_count[1]], st));
             e->ev_count[1]++;

@@ -69,14 +69,11 @@ constexpr int MSR_BM25_HEAVY_DF = 2048;      // posting lists at least this long
 hipError_t msr_bm25_build_skip(const Bm25Index& ix, const int32_t* heavy_terms, int n_heavy, uint32_t* tile_off,
                                hipStream_t stream);
 // Candidate lists: for query q, cand_n[q] pairs (cand_score[q][i], cand_doc[q][i]) -- exactly the documents
-// touched by a posting whose score is >= max(min_score, floor_q[q]) (floor_q may be null), in no particular order (row
-// stride n_docs), over the tiles tile_first, tile_first + tile_stride, ...  cand_n must be zero on entry.
+// touched by a posting whose score is >= min_score, in no particular order (row stride n_docs).  cand_n must
+// be zero on entry.
 hipError_t msr_bm25_scores(const Bm25Index& ix, const int32_t* q_term_off, const int32_t* q_terms,
-                           const int32_t* q_qtf, int q_first, int nq, double min_score, int tile_first, int tile_stride,
-                           const double* floor_q, double* cand_score, int32_t* cand_doc, int32_t* cand_n,
-                           hipStream_t stream);
-// floor_q[q] = k-th entry of the (descending) top-k rows of a sample pass, -inf where a row has fewer than k entries.
-hipError_t msr_bm25_floor(const double* top_score, const int32_t* top_n, int nq, int k, double* floor_q, hipStream_t stream);
+                           const int32_t* q_qtf, int q_first, int nq, double min_score, double* cand_score,
+                           int32_t* cand_doc, int32_t* cand_n, hipStream_t stream);
 
 // *flag (device) <- 0x7F7F7F7F if the CSR is well formed, else the lowest violated rule number (msr_bm25.hip).
 hipError_t msr_bm25_validate(const Bm25Index& ix, int32_t* flag, hipStream_t stream);

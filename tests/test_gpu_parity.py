@@ -102,11 +102,11 @@ def test_bm25_synthetic_vs_oracle(mods):
     eng.close()
 
 
-def test_bm25_sample_floor_keeps_the_exact_topk(mods):
-    """From 64 document tiles on, msr_bm25_topk runs a sample pass (every 8th / 16th tile) whose k-th score bounds what the
-    full pass emits.  The result must stay the exact top-k, bit for bit: 80 k documents (79 tiles, stride 8) and 300 k
-    (293 tiles, stride 16); queries with a common term (bound far above most scores), rare terms only (sample holds fewer
-    than k candidates: no bound), a term whose postings all tie, min_score above and below the bound, k = 10 and 1000."""
+def test_bm25_many_tiles_common_rare_and_tied_terms(mods):
+    """80 k and 300 k documents (79 / 293 document tiles): queries with the most common term (long slices: the streaming
+    loop behind the prefetch), the rarest terms only (lists of <= 64 postings are read whole and masked; a few dozen
+    candidates in all), a repeated term, an empty query, min_score above and below most scores, k = 10 and 1000; then
+    70 000 postings that all tie.  Bit for bit against the oracle."""
     from msretr.synthetic import synthetic_corpus, synthetic_queries
     for n_docs, seed in ((80_000, 21), (300_000, 22)):
         ix = synthetic_corpus(n_docs, n_chunks=0, n_terms=50_000, seed=seed)
@@ -129,7 +129,7 @@ def test_bm25_sample_floor_keeps_the_exact_topk(mods):
                 assert n[i] == len(oi), (n_docs, i, k, ms)
                 assert doc[i, :n[i]].tolist() == oi.tolist() and score[i, :n[i]].tolist() == os_.tolist(), (n_docs, i, k, ms)
         eng.close()
-    # every posting of the only term ties: the bound equals the common score and nothing may be lost
+    # every posting of the only term ties
     N = 70_000
     ix = mods["CorpusIndex"](doc_ids=np.arange(N, dtype=np.int64), doc_len=np.full(N, 7, np.int32),
                              term_off=np.array([0, N], np.int64), post_doc=np.arange(N, dtype=np.int32),
