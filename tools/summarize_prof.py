@@ -17,6 +17,10 @@ import sys
 
 
 def short(name):
+    if name.startswith("_Z"):                       # a name the profiler could not demangle (f16 vector arguments)
+        m = re.search(r"\d+([a-z]\w*?_kernel)", name)
+        if m:
+            return m.group(1)
     m = re.search(r"(\w+_kernel\w*)(<[^>(]*>)?", name)
     return (m.group(1) + (m.group(2) or "")) if m else name[:60]
 
@@ -26,7 +30,7 @@ def stats(stats_csv, trace_csv, out):
     ours = [r for r in rows if any(k in r["Name"] for k in ("dense_scan", "dense_ksplit", "build_qimage", "thr_compact", "rescore", "bm25_taat", "sel_", "rerank_", "best_chunk",
                                                              "prep_queries", "merge_kernel", "interleave", "row_inv_norm",
                                                              "fill_chunk_doc", "gemm_", "build_qimg", "qmat_kernel", "batch_margin",
-                                                             "unit_bf16", "pad_inv"))]
+                                                             "unit_bf16", "pad_inv", "rescore", "f16_", "build_qimg1"))]
     lines = ["| kernel | calls | avg us | min us | max us | total ms |", "|---|---|---|---|---|---|"]
     for r in sorted(ours, key=lambda r: -float(r["TotalDurationNs"])):
         lines.append(f"| {short(r['Name'])} | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['MinNs']) / 1e3:.1f} | "
@@ -60,10 +64,10 @@ def pmc(fetch_csv, write_csv, out):
         for r in csv.DictReader(open(f)):
             agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
         for n, v in agg.items():
-            if any(k in n for k in ("dense_scan", "dense_ksplit", "bm25_taat", "sel_", "rerank_")):
+            if any(k in n for k in ("dense_scan", "dense_ksplit", "gemm_stream", "gemm_kernel", "bm25_taat", "sel_", "rerank_", "rescore")):
                 res[n][key] = {"per_launch_max": max(v), "per_launch_mean": sum(v) / len(v), "launches": len(v)}
     for n, d in res.items():
-        if ("dense_scan" in n or "dense_ksplit" in n) and "FETCH_SIZE_KiB" in d and "WRITE_SIZE_KiB" in d:
+        if any(k in n for k in ("dense_scan", "dense_ksplit", "gemm_stream", "gemm_kernel")) and "FETCH_SIZE_KiB" in d and "WRITE_SIZE_KiB" in d:
             d["hbm_bytes_per_launch"] = 2 * d["FETCH_SIZE_KiB"]["per_launch_max"] * 1024 + d["WRITE_SIZE_KiB"]["per_launch_max"] * 1024
             d["note"] = "read bytes = 2 x FETCH_SIZE (gfx950 wide-load correction), write bytes = WRITE_SIZE"
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
