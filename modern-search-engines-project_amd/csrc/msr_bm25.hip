@@ -28,6 +28,7 @@ namespace {
 constexpr int BM25_TILE = MSR_BM25_TILE;
 constexpr int BM25_THREADS = 256;
 constexpr int BM25_QPW = BM25_THREADS / 64;                   // queries per workgroup (one per wave)
+constexpr int BM25_TPW = 8;                                   // at most this many consecutive tiles per workgroup
 constexpr int BM25_MAX_TERMS = 64;                            // MSR_MAX_QUERY_TERMS: one lane per term
 constexpr uint64_t UNTOUCHED = 0x7FF8DEADBEEF0001ull;   // a quiet-NaN payload no computation produces
 
@@ -40,11 +41,11 @@ __device__ __forceinline__ double lane_f64(double v, int j) {
     return __longlong_as_double(lane_i64(__double_as_longlong(v), j));
 }
 
-__global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
+__global__ __launch_bounds__(BM25_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void bm25_taat_kernel(Bm25Index ix,
                                                                   const int32_t* __restrict__ q_term_off,
                                                                   const int32_t* __restrict__ q_terms,
                                                                   const int32_t* __restrict__ q_qtf,
-                                                                  int q_first, int nq, double min_score,
+                                                                  int q_first, int nq, double min_score, int tpw,
                                                                   double* __restrict__ cand_score,
                                                                   int32_t* __restrict__ cand_doc,
                                                                   int32_t* __restrict__ cand_n, int dbg_arg) {
@@ -57,31 +58,26 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
     __shared__ double acc_all[BM25_QPW][BM25_TILE];
     __shared__ double dn[BM25_TILE];                         // k1 * (1 - b + b * doc_length / avg_doc_length)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // grid = (query groups, tiles): consecutive workgroups score the SAME tile for other queries, so the tile's document
+    // grid = (query groups, tile spans): consecutive workgroups score the SAME tiles for other queries, so the tiles' document
     // lengths and the slices of the terms the queries share (the city term is in every query, search_api.py:155-166)
     // are served by the L2 after the first of them
     const int q = blockIdx.x * BM25_QPW + wave;              // row of the candidate lists
     const bool live = q < nq;                                // (wave-uniform)
-    const int tile = blockIdx.y;
-    const int64_t lo = (int64_t)tile * BM25_TILE;
-    const int64_t hi = lo + BM25_TILE < ix.n_docs ? lo + BM25_TILE : ix.n_docs;
-    const int n = (int)(hi - lo);
+    const int tile0 = (int)blockIdx.y * tpw;                 // this workgroup's tiles: tile0 .. tile0 + n_my - 1
+    const int n_my = tile0 + tpw <= ix.n_tiles ? tpw : ix.n_tiles - tile0;
     double* acc = acc_all[wave];
     const double k1 = ix.k1, b = ix.b, avgdl = ix.avgdl;
     const double k1p1 = k1 + 1.0;                    // self.k1 + 1
     const double omb = 1.0 - b;                      // 1 - self.b
-    // the tile's document lengths: issued first, parked in registers while the slices are located
-    int32_t dl_reg[BM25_TILE / BM25_THREADS];
-#pragma unroll
-    for (int u = 0; u < BM25_TILE / BM25_THREADS; ++u) {
-        const int i = tid + u * BM25_THREADS;
-        dl_reg[u] = i < n ? ix.doc_len[lo + i] : 0;
-    }
-    // ---- 1. the query's terms, lane j = term j ----
+    // ---- 1. the query's plan, ONCE for all tiles of the workgroup; lane j = term j ----
     int nt = 0;
-    int64_t ps_v = 0, pe_v = 0;                      // [begin, end) of term j's postings to look at in this tile
+    int64_t s_v = 0;                                 // long list: its first posting
+    uint32_t off_v[BM25_TPW + 1];                    // long list: where each of the workgroup's tiles starts inside it
+    int64_t r0_v = 0, r1_v = 0;                      // other lists: the postings to look at, for EVERY tile of the workgroup
     double idf_v = 0.0, qtf_v = 0.0;
-    bool medium = false;
+    bool heavy = false, medium = false;
+#pragma unroll
+    for (int i = 0; i <= BM25_TPW; ++i) off_v[i] = 0;
     if (live && !(dbg & 32)) {
         const int t0 = q_term_off[q_first + q];
         nt = q_term_off[q_first + q + 1] - t0;
@@ -94,22 +90,26 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
                     idf_v = (double)ix.idf[t];
                     qtf_v = (double)q_qtf[t0 + lane];
                     const int h = ix.heavy_id ? ix.heavy_id[t] : -1;
-                    if (h >= 0) {                            // long list: the slice comes from the skip table
-                        const uint32_t* row = ix.tile_off + (int64_t)h * (ix.n_tiles + 1) + tile;
-                        ps_v = s + row[0];
-                        pe_v = s + row[1];
+                    if (h >= 0) {                            // long list: the slices come from the skip table, one row
+                        heavy = true;                        // segment for all the workgroup's tiles
+                        s_v = s;
+                        const uint32_t* row = ix.tile_off + (int64_t)h * (ix.n_tiles + 1) + tile0;
+#pragma unroll
+                        for (int i = 0; i <= BM25_TPW; ++i) off_v[i] = row[i < n_my ? i : n_my];
                     } else {
-                        ps_v = s;                            // short list: all of it (postings of other tiles are masked)
-                        pe_v = e;
+                        r0_v = s;                            // short list: all of it (postings of other tiles are masked)
+                        r1_v = e;
                         medium = e - s > 64;
                     }
                 }
             }
         }
     }
-    // ---- 2. lists of 65 .. HEAVY_DF-1 postings: one round of 64 probes narrows [ps, pe) to the chunks that can hold
-    //         documents of this tile; MED lists side by side (the probes are independent loads) ----
+    // ---- 2. lists of 65 .. HEAVY_DF-1 postings: one round of 64 probes narrows [r0, r1) to the chunks that can hold
+    //         documents of the workgroup's tiles; MED lists side by side (the probes are independent loads) ----
     {
+        const int64_t lo8 = (int64_t)tile0 * BM25_TILE;
+        const int64_t hi8 = lo8 + (int64_t)n_my * BM25_TILE < ix.n_docs ? lo8 + (int64_t)n_my * BM25_TILE : ix.n_docs;
         constexpr int MED = 4;
         unsigned long long todo = __ballot(medium);
         while (todo) {
@@ -122,8 +122,8 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
                 if (todo) todo &= todo - 1;
                 probe[m] = 0; s_[m] = e_[m] = ch_[m] = 0;
                 if (jj[m] >= 0) {                            // wave-uniform
-                    s_[m] = lane_i64(ps_v, jj[m]);
-                    e_[m] = lane_i64(pe_v, jj[m]);
+                    s_[m] = lane_i64(r0_v, jj[m]);
+                    e_[m] = lane_i64(r1_v, jj[m]);
                     ch_[m] = (e_[m] - s_[m] + 63) >> 6;
                     int64_t idx = s_[m] + (int64_t)(lane + 1) * ch_[m] - 1;     // last posting of chunk `lane`
                     if (idx > e_[m] - 1) idx = e_[m] - 1;
@@ -133,8 +133,8 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
 #pragma unroll
             for (int m = 0; m < MED; ++m) {
                 if (jj[m] < 0) continue;                     // wave-uniform
-                const unsigned long long ge_lo = __ballot(probe[m] >= (int32_t)lo);
-                const unsigned long long ge_hi = __ballot((int64_t)probe[m] >= hi);
+                const unsigned long long ge_lo = __ballot((int64_t)probe[m] >= lo8);
+                const unsigned long long ge_hi = __ballot((int64_t)probe[m] >= hi8);
                 int64_t ps = e_[m], pe = e_[m];              // nothing >= lo: empty
                 if (ge_lo) {
                     ps = s_[m] + (int64_t)(__ffsll((long long)ge_lo) - 1) * ch_[m];
@@ -144,110 +144,133 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
                         if (pe > e_[m]) pe = e_[m];
                     }
                 }
-                if (lane == jj[m]) { ps_v = ps; pe_v = pe; }
+                if (lane == jj[m]) { r0_v = ps; r1_v = pe; }
             }
         }
     }
-    // ---- 3. prefetch: the first PFC x 64 postings of the first TPRE slices (for nearly all terms: the whole slice), all
-    //         issued before anything is accumulated -- one memory round trip for the postings of all terms instead of one
-    //         per term (the kernel is bound by these chains of dependent loads, not by bandwidth or arithmetic) ----
-    constexpr int TPRE = 6, PFC = 4;
-    int32_t pd0[TPRE][PFC], ptf0[TPRE][PFC];
+    for (int tt = 0; tt < n_my; ++tt) {
+        const int tile = tile0 + tt;
+        const int64_t lo = (int64_t)tile * BM25_TILE;
+        const int64_t hi = lo + BM25_TILE < ix.n_docs ? lo + BM25_TILE : ix.n_docs;
+        const int n = (int)(hi - lo);
+        // the tile's document lengths: issued first, parked in registers
+        int32_t dl_reg[BM25_TILE / BM25_THREADS];
 #pragma unroll
-    for (int j = 0; j < TPRE; ++j) {
+        for (int u = 0; u < BM25_TILE / BM25_THREADS; ++u) {
+            const int i = tid + u * BM25_THREADS;
+            dl_reg[u] = i < n ? ix.doc_len[lo + i] : 0;
+        }
+        // this tile's slice of every list (no memory access: the plan holds everything)
+        int64_t ps_v = r0_v, pe_v = r1_v;
+        if (heavy) {
+            uint32_t o0 = 0, o1 = 0;
 #pragma unroll
-        for (int c = 0; c < PFC; ++c) { pd0[j][c] = -1; ptf0[j][c] = 0; }
-        if (j < nt && !(dbg & 8)) {                          // wave-uniform
-            const int64_t ps = lane_i64(ps_v, j), pe = lane_i64(pe_v, j);
+            for (int i = 0; i < BM25_TPW; ++i)
+                if (i == tt) { o0 = off_v[i]; o1 = off_v[i + 1]; }
+            ps_v = s_v + o0;
+            pe_v = s_v + o1;
+        }
+        // ---- 3. prefetch: the first PFC x 64 postings of the first TPRE slices (for nearly all terms: the whole slice), all
+        //         issued before anything is accumulated -- one memory round trip for the postings of all terms ----
+        constexpr int TPRE = 5, PFC = 3;
+        int32_t pd0[TPRE][PFC], ptf0[TPRE][PFC];
 #pragma unroll
-            for (int c = 0; c < PFC; ++c) {
-                if (ps + 64 * c < pe) {                      // wave-uniform: no instruction for chunks past the slice
-                    const int64_t i = ps + 64 * c + lane;
-                    if (i < pe) { pd0[j][c] = ix.post_doc[i]; ptf0[j][c] = ix.post_tf[i]; }
+        for (int j = 0; j < TPRE; ++j) {
+#pragma unroll
+            for (int c = 0; c < PFC; ++c) { pd0[j][c] = -1; ptf0[j][c] = 0; }
+            if (j < nt && !(dbg & 8)) {                          // wave-uniform
+                const int64_t ps = lane_i64(ps_v, j), pe = lane_i64(pe_v, j);
+#pragma unroll
+                for (int c = 0; c < PFC; ++c) {
+                    if (ps + 64 * c < pe) {                      // wave-uniform: no instruction for chunks past the slice
+                        const int64_t i = ps + 64 * c + lane;
+                        if (i < pe) { pd0[j][c] = ix.post_doc[i]; ptf0[j][c] = ix.post_tf[i]; }
+                    }
                 }
             }
         }
-    }
-    // accumulators of this wave's query; the length norms of the tile (shared by the four waves)
+        // accumulators of this wave's query; the length norms of the tile (shared by the four waves)
 #pragma unroll
-    for (int u = 0; u < BM25_TILE / 64; ++u) acc[lane + 64 * u] = __longlong_as_double((long long)UNTOUCHED);
+        for (int u = 0; u < BM25_TILE / 64; ++u) acc[lane + 64 * u] = __longlong_as_double((long long)UNTOUCHED);
+        __syncthreads();                                         // every wave is done with the previous tile's norms
 #pragma unroll
-    for (int u = 0; u < BM25_TILE / BM25_THREADS; ++u)
-        dn[tid + u * BM25_THREADS] = k1 * (omb + (b * (double)dl_reg[u]) / avgdl);
-    __syncthreads();
-    // One posting: the reference's arithmetic, operation by operation (:472-478).
-    auto apply = [&](int32_t pdoc, int32_t ptf, double idf, double qtf) {
-        const uint32_t d = (uint32_t)(pdoc - (int32_t)lo);
-        if (d >= (uint32_t)n) return;                        // a posting of another tile (covering ranges), or none
-        const double tf = (double)ptf;
-        // tf_component = (tf * (k1 + 1)) / (tf + k1 * (1 - b + b * doc_length / avg_doc_length))
-        const double comp = (dbg & 1) ? (tf * k1p1) * (tf + dn[d]) : (tf * k1p1) / (tf + dn[d]);
-        // term_score = idf * tf_component * query_term_freq[term]; bm25_score += term_score
-        const double c = (idf * comp) * qtf;
-        if (dbg & 2) { if (c == 1.2345e-300) acc[d] = c; return; }
-        const double a = acc[d];
-        acc[d] = ((uint64_t)__double_as_longlong(a) == UNTOUCHED ? 0.0 : a) + c;
-    };
-    // The rest of a slice, U x 64 postings per round: all loads of a round are issued before the first is used.
-    auto stream = [&](int64_t from, int64_t pe, double idf, double qtf) {
-        constexpr int U = 4;
-        if (dbg & 4) return;
-        for (int64_t base = from; base < pe; base += (int64_t)U * 64) {
-            int32_t pd[U], ptf[U];
+        for (int u = 0; u < BM25_TILE / BM25_THREADS; ++u)
+            dn[tid + u * BM25_THREADS] = k1 * (omb + (b * (double)dl_reg[u]) / avgdl);
+        __syncthreads();
+        // One posting: the reference's arithmetic, operation by operation (:472-478).
+        auto apply = [&](int32_t pdoc, int32_t ptf, double idf, double qtf) {
+            const uint32_t d = (uint32_t)(pdoc - (int32_t)lo);
+            if (d >= (uint32_t)n) return;                        // a posting of another tile (covering ranges), or none
+            const double tf = (double)ptf;
+            // tf_component = (tf * (k1 + 1)) / (tf + k1 * (1 - b + b * doc_length / avg_doc_length))
+            const double comp = (dbg & 1) ? (tf * k1p1) * (tf + dn[d]) : (tf * k1p1) / (tf + dn[d]);
+            // term_score = idf * tf_component * query_term_freq[term]; bm25_score += term_score
+            const double c = (idf * comp) * qtf;
+            if (dbg & 2) { if (c == 1.2345e-300) acc[d] = c; return; }
+            const double a = acc[d];
+            acc[d] = ((uint64_t)__double_as_longlong(a) == UNTOUCHED ? 0.0 : a) + c;
+        };
+        // The rest of a slice, U x 64 postings per round: all loads of a round are issued before the first is used.
+        auto stream = [&](int64_t from, int64_t pe, double idf, double qtf) {
+            constexpr int U = 4;
+            if (dbg & 4) return;
+            for (int64_t base = from; base < pe; base += (int64_t)U * 64) {
+                int32_t pd[U], ptf[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int64_t i = base + lane + (int64_t)u * 64;
-                pd[u] = i < pe ? ix.post_doc[i] : -1;
-                ptf[u] = i < pe ? ix.post_tf[i] : 0;
+                for (int u = 0; u < U; ++u) {
+                    const int64_t i = base + lane + (int64_t)u * 64;
+                    pd[u] = i < pe ? ix.post_doc[i] : -1;
+                    ptf[u] = i < pe ? ix.post_tf[i] : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) apply(pd[u], ptf[u], idf, qtf);
             }
+        };
 #pragma unroll
-            for (int u = 0; u < U; ++u) apply(pd[u], ptf[u], idf, qtf);
+        for (int j = 0; j < TPRE; ++j) {
+            if (j >= nt) break;                                  // wave-uniform
+            const int64_t ps = lane_i64(ps_v, j), pe = lane_i64(pe_v, j);
+            if (pe <= ps) continue;
+            const double idf = lane_f64(idf_v, j), qtf = lane_f64(qtf_v, j);
+#pragma unroll
+            for (int c = 0; c < PFC; ++c)
+                if (ps + 64 * c < pe) apply(pd0[j][c], ptf0[j][c], idf, qtf);
+            if (pe - ps > 64 * PFC) stream(ps + 64 * PFC, pe, idf, qtf);
         }
-    };
+        for (int j = TPRE; j < nt; ++j) {
+            const int64_t ps = lane_i64(ps_v, j), pe = lane_i64(pe_v, j);
+            if (pe <= ps) continue;
+            stream(ps, pe, lane_f64(idf_v, j), lane_f64(qtf_v, j));
+        }
+        if (!live || (dbg & 16)) continue;                       // (wave-uniform; the barriers are at the top of the loop)
+        // ---- 4. the tile's candidates (touched by a posting AND score >= min_score, :461,480) as (score, doc) pairs
+        //         appended to the query's list: one reservation per wave.  Most documents of a tile are not candidates, so
+        //         this replaces an 8 B/document dense row by 12 B per candidate. ----
+        int total = 0;
+        unsigned long long flags[BM25_TILE / 64];
 #pragma unroll
-    for (int j = 0; j < TPRE; ++j) {
-        if (j >= nt) break;                                  // wave-uniform
-        const int64_t ps = lane_i64(ps_v, j), pe = lane_i64(pe_v, j);
-        if (pe <= ps) continue;
-        const double idf = lane_f64(idf_v, j), qtf = lane_f64(qtf_v, j);
-#pragma unroll
-        for (int c = 0; c < PFC; ++c)
-            if (ps + 64 * c < pe) apply(pd0[j][c], ptf0[j][c], idf, qtf);
-        if (pe - ps > 64 * PFC) stream(ps + 64 * PFC, pe, idf, qtf);
-    }
-    for (int j = TPRE; j < nt; ++j) {
-        const int64_t ps = lane_i64(ps_v, j), pe = lane_i64(pe_v, j);
-        if (pe <= ps) continue;
-        stream(ps, pe, lane_f64(idf_v, j), lane_f64(qtf_v, j));
-    }
-    if (!live || (dbg & 16)) return;
-    // ---- 4. the tile's candidates (touched by a posting AND score >= min_score, :461,480) as (score, doc) pairs
-    //         appended to the query's list: one reservation per wave.  Most documents of a tile are not candidates, so
-    //         this replaces an 8 B/document dense row by 12 B per candidate. ----
-    int total = 0;
-    unsigned long long flags[BM25_TILE / 64];
-#pragma unroll
-    for (int u = 0; u < BM25_TILE / 64; ++u) {
-        const int i = lane + 64 * u;
-        const double a = acc[i];
-        flags[u] = __ballot(i < n && (uint64_t)__double_as_longlong(a) != UNTOUCHED && a >= min_score);
-        total += __popcll(flags[u]);
-    }
-    if (total == 0) return;                                  // wave-uniform
-    int base = 0;
-    if (lane == 0) base = atomicAdd(&cand_n[q], total);
-    base = __builtin_amdgcn_readfirstlane(base);
-    const int64_t o = (int64_t)q * ix.n_docs + base;
-    int run = 0;
-#pragma unroll
-    for (int u = 0; u < BM25_TILE / 64; ++u) {
-        if ((flags[u] >> lane) & 1) {
+        for (int u = 0; u < BM25_TILE / 64; ++u) {
             const int i = lane + 64 * u;
-            const int w = run + __popcll(flags[u] & ((1ull << lane) - 1));
-            cand_score[o + w] = acc[i];
-            cand_doc[o + w] = (int32_t)(lo + i);
+            const double a = acc[i];
+            flags[u] = __ballot(i < n && (uint64_t)__double_as_longlong(a) != UNTOUCHED && a >= min_score);
+            total += __popcll(flags[u]);
         }
-        run += __popcll(flags[u]);
+        if (total == 0) continue;                                // wave-uniform
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&cand_n[q], total);
+        base = __builtin_amdgcn_readfirstlane(base);
+        const int64_t o = (int64_t)q * ix.n_docs + base;
+        int run = 0;
+#pragma unroll
+        for (int u = 0; u < BM25_TILE / 64; ++u) {
+            if ((flags[u] >> lane) & 1) {
+                const int i = lane + 64 * u;
+                const int w = run + __popcll(flags[u] & ((1ull << lane) - 1));
+                cand_score[o + w] = acc[i];
+                cand_doc[o + w] = (int32_t)(lo + i);
+            }
+            run += __popcll(flags[u]);
+        }
     }
 }
 
@@ -322,8 +345,14 @@ hipError_t msr_bm25_scores(const Bm25Index& ix, const int32_t* q_term_off, const
                            const int32_t* q_qtf, int q_first, int nq, double min_score, double* cand_score,
                            int32_t* cand_doc, int32_t* cand_n, hipStream_t stream) {
     if (nq <= 0 || ix.n_docs <= 0) return hipSuccess;
-    dim3 grid((unsigned)((nq + BM25_QPW - 1) / BM25_QPW), (unsigned)((ix.n_docs + BM25_TILE - 1) / BM25_TILE));
-    bm25_taat_kernel<<<grid, BM25_THREADS, 0, stream>>>(ix, q_term_off, q_terms, q_qtf, q_first, nq, min_score, cand_score,
+    // A workgroup looks a query's terms up once and then walks `tpw` consecutive tiles with that plan in registers.  More tiles
+    // per workgroup amortise the lookups (chains of dependent loads) but leave fewer workgroups: large batches take 8, a
+    // single query keeps one tile per workgroup (its ~1000 waves are all the parallelism it has).
+    const int groups = (nq + BM25_QPW - 1) / BM25_QPW;
+    int tpw = groups >= 16 ? 8 : groups >= 8 ? 4 : groups >= 4 ? 2 : 1;
+    while (tpw > 1 && (int64_t)groups * ((ix.n_tiles + tpw - 1) / tpw) < 2048) tpw >>= 1;
+    dim3 grid((unsigned)groups, (unsigned)((ix.n_tiles + tpw - 1) / tpw));
+    bm25_taat_kernel<<<grid, BM25_THREADS, 0, stream>>>(ix, q_term_off, q_terms, q_qtf, q_first, nq, min_score, tpw, cand_score,
                                                         cand_doc, cand_n, g_bm25_dbg);
     return hipGetLastError();
 }
