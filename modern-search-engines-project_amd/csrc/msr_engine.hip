@@ -59,7 +59,7 @@ struct msr_engine {
     float* gf_thr = nullptr; float* gf_thr2 = nullptr; int32_t* gf_flag = nullptr; void* gf_wvbuf = nullptr;
     int32_t* gf_wv_count = nullptr; void* gf_pairs = nullptr; int32_t* gf_pair_n = nullptr; int32_t* gf_gate = nullptr;
     uint32_t* gf_err = nullptr; float* gf_margin = nullptr; int32_t* gf_cand_doc = nullptr; float* gf_cand_score = nullptr;
-    int32_t* gf_cand_chunk = nullptr; int32_t* gf_cand_n = nullptr;
+    int32_t* gf_cand_chunk = nullptr; int32_t* gf_cand_n = nullptr; float* gf_qn = nullptr;
     // batched path as a tiled GEMM (msr_gemm.hip): unit-row bf16 image + tile table + scratch for GM_SLICE queries per pass
     GemmIndex gemm{};
     bool gemm_ok = false;
@@ -123,7 +123,7 @@ static void free_gf(msr_engine* e) {
     free_dev(e->gf_top_doc); free_dev(e->gf_top_score); free_dev(e->gf_top_n); free_dev(e->gf_thr); free_dev(e->gf_thr2);
     free_dev(e->gf_flag); free_dev(e->gf_wvbuf); free_dev(e->gf_wv_count); free_dev(e->gf_pairs); free_dev(e->gf_pair_n);
     free_dev(e->gf_gate); free_dev(e->gf_err); free_dev(e->gf_margin); free_dev(e->gf_cand_doc); free_dev(e->gf_cand_score);
-    free_dev(e->gf_cand_chunk); free_dev(e->gf_cand_n);
+    free_dev(e->gf_cand_chunk); free_dev(e->gf_cand_n); free_dev(e->gf_qn); e->gf_qn = nullptr;
     e->gf_err = nullptr; e->gf_margin = nullptr; e->gf_cand_doc = nullptr; e->gf_cand_score = nullptr; e->gf_cand_chunk = nullptr;
     e->gf_cand_n = nullptr;
     e->tile_row = nullptr; e->gf_inv_pad = nullptr; e->gf_qimg = nullptr; e->gf_tmax_t = nullptr; e->gf_tmax = nullptr;
@@ -479,35 +479,39 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
     if (e->tiles_ok && variant == 14 && e->n_tiles >= 64) {
         const int n_tiles = e->n_tiles, nw = e->n_cus * 8, stride = (n_tiles + 31) / 32 * 32;
         constexpr int GF_WV_CAP = 4096;
+        // one call holds up to 8 groups of 128 queries (bounded by the select scratch, which covers max(max_queries, 128) rows)
+        const int groups = std::min(8, std::max(e->cfg.max_queries, 128) / 128);
+        const size_t QM = (size_t)groups * 128;
         auto alloc = [&](void** p, size_t bytes) { return hipMalloc(p, bytes); };
         if ((herr = alloc((void**)&e->gf_inv_pad, (size_t)(n_chunks + 512) * 4)) != hipSuccess ||
-            (herr = alloc(&e->gf_qimg, (size_t)24 * 16384)) != hipSuccess ||
+            (herr = alloc(&e->gf_qimg, (size_t)groups * 24 * 8192)) != hipSuccess ||
+            (herr = alloc((void**)&e->gf_qn, QM * MSR_DIM * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gf_tmax_t, (size_t)n_tiles * 8 * 128 * 4)) != hipSuccess ||
-            (herr = alloc((void**)&e->gf_tmax, (size_t)128 * stride * 4)) != hipSuccess ||
-            (herr = alloc((void**)&e->gf_top_doc, (size_t)128 * MSR_MAX_K * 4)) != hipSuccess ||
-            (herr = alloc((void**)&e->gf_top_score, (size_t)128 * MSR_MAX_K * 4)) != hipSuccess ||
-            (herr = alloc((void**)&e->gf_top_n, 128 * 4)) != hipSuccess ||
-            (herr = alloc((void**)&e->gf_thr, 128 * 4)) != hipSuccess ||
-            (herr = alloc((void**)&e->gf_thr2, 128 * 4)) != hipSuccess ||
-            (herr = alloc((void**)&e->gf_flag, 128 * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gf_tmax, QM * stride * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gf_top_doc, QM * MSR_MAX_K * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gf_top_score, QM * MSR_MAX_K * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gf_top_n, QM * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gf_thr, QM * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gf_thr2, QM * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gf_flag, QM * 4)) != hipSuccess ||
             (herr = alloc(&e->gf_wvbuf, (size_t)nw * GF_WV_CAP * 16)) != hipSuccess ||
             (herr = alloc((void**)&e->gf_wv_count, (size_t)nw * 4)) != hipSuccess ||
-            (herr = alloc(&e->gf_pairs, (size_t)128 * 4096 * 8)) != hipSuccess ||
-            (herr = alloc((void**)&e->gf_pair_n, 128 * 4)) != hipSuccess ||
+            (herr = alloc(&e->gf_pairs, QM * 4096 * 8)) != hipSuccess ||
+            (herr = alloc((void**)&e->gf_pair_n, QM * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gf_gate, 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gf_err, 4)) != hipSuccess ||
-            (herr = alloc((void**)&e->gf_margin, 128 * 4)) != hipSuccess ||
-            (herr = alloc((void**)&e->gf_cand_doc, (size_t)128 * MSR_SEL_CAP * 4)) != hipSuccess ||
-            (herr = alloc((void**)&e->gf_cand_score, (size_t)128 * MSR_SEL_CAP * 4)) != hipSuccess ||
-            (herr = alloc((void**)&e->gf_cand_chunk, (size_t)128 * MSR_SEL_CAP * 4)) != hipSuccess ||
-            (herr = alloc((void**)&e->gf_cand_n, 128 * 4)) != hipSuccess)
+            (herr = alloc((void**)&e->gf_margin, QM * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gf_cand_doc, QM * MSR_SEL_CAP * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gf_cand_score, QM * MSR_SEL_CAP * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gf_cand_chunk, QM * MSR_SEL_CAP * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gf_cand_n, QM * 4)) != hipSuccess)
             return fail(e, MSR_ERR_NOMEM, "GEMM scan scratch: %s", hipGetErrorString(herr));
         HIP_TRY(e, msr_pad_inv_norm(inv_norm, n_chunks, n_chunks + 512, e->gf_inv_pad, st));
-        HIP_TRY(e, hipMemsetAsync(e->gf_pair_n, 0, 128 * 4, st));
+        HIP_TRY(e, hipMemsetAsync(e->gf_pair_n, 0, QM * 4, st));
         HIP_TRY(e, hipMemsetAsync(e->gf_gate, 0, 4, st));
-        HIP_TRY(e, hipMemsetAsync(e->gf_cand_n, 0, 128 * 4, st));
+        HIP_TRY(e, hipMemsetAsync(e->gf_cand_n, 0, QM * 4, st));
         HIP_TRY(e, msr_f16_row_error(emb, inv_norm, n_chunks, e->gf_err, st));   // measured once: the margin of the f16 filter
-        e->gf = GemmF32Index{e->tile_row, n_tiles, e->n_cus, e->gf_inv_pad, e->gf_qimg, e->gf_tmax_t, e->gf_tmax, stride,
+        e->gf = GemmF32Index{e->tile_row, n_tiles, e->n_cus, groups, e->gf_inv_pad, e->gf_qimg, e->gf_tmax_t, e->gf_tmax, stride,
                              e->gf_top_doc, e->gf_top_score, e->gf_top_n, e->gf_thr, e->gf_thr2, e->gf_flag, e->gf_wvbuf,
                              GF_WV_CAP, e->gf_wv_count, e->gf_pairs, e->gf_pair_n, e->gf_err, e->gf_margin, e->gf_cand_doc,
                              e->gf_cand_score, e->gf_cand_chunk, e->gf_cand_n};
@@ -655,8 +659,8 @@ extern "C" int msr_dense_topk(msr_engine* e, const float* q, int32_t n_queries, 
     while (q0 < n_queries) {
         const int left = n_queries - q0;
         if (gemm && left > 64) {
-            const int nq = std::min(128, left);
-            HIP_TRY(e, msr_prep_queries(q + (int64_t)q0 * MSR_DIM, nq, e->qn, nq, st));
+            const int nq = std::min(128 * e->gf.max_groups, left);
+            HIP_TRY(e, msr_prep_queries(q + (int64_t)q0 * MSR_DIM, nq, e->gf_qn, nq, st));
             HIP_TRY(e, hipMemsetAsync(e->gf_gate, 0, 4, st));
             hipEvent_t ev[4];
             const bool timed = e->timing && e->ev_count[0] < msr_engine::EV_RING && e->ev_count[3] < msr_engine::EV_RING;
@@ -664,7 +668,7 @@ extern "C" int msr_dense_topk(msr_engine* e, const float* q, int32_t n_queries, 
                 ev[0] = e->ev_start[3][e->ev_count[3]]; ev[1] = e->ev_stop[3][e->ev_count[3]];
                 ev[2] = e->ev_start[0][e->ev_count[0]]; ev[3] = e->ev_stop[0][e->ev_count[0]];
             }
-            HIP_TRY(e, msr_gemm_f32_topk(e->gf, e->dense, e->qn, nq, k, e->sel, out_doc + (int64_t)q0 * k,
+            HIP_TRY(e, msr_gemm_f32_topk(e->gf, e->dense, e->gf_qn, nq, k, e->sel, out_doc + (int64_t)q0 * k,
                                          out_score + (int64_t)q0 * k, out_chunk ? out_chunk + (int64_t)q0 * k : nullptr,
                                          out_n + q0, e->gf_gate, timed ? ev : nullptr, st));
             if (timed) { e->ev_count[0]++; e->ev_count[3]++; }

@@ -55,6 +55,8 @@ struct GemmF32Args {
     float* tmax_t;             // [t_count][8 waves][128]
     const float* thr;          // [128] emit threshold (+inf: never)                                   -- emit pass only
     int4* wvbuf; int wv_cap; int32_t* wv_count;   // per-wave emission buffers {row, query, score bits, tile}   -- emit pass only
+    int q_base;                // number of the group's first query within the call (the query field of an entry is global)
+    int append;                // emit pass: continue behind the entries earlier groups left in the wave buffers
     int dbg;                   // -DMSR_DIAG builds only (timing experiments, wrong results): bit 2 no row loads, bit 3 no MFMA,
                                // bit 4 no query fragment reads, bit 5 no epilogue arithmetic, bit 6 no inverse norms
 };
@@ -88,10 +90,10 @@ __global__ __launch_bounds__(GF_THREADS) void gemm_stream_kernel(GemmF32Args a) 
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave w owns rows 32 w .. 32 w + 32 of the tile, ALL 128 queries
     const int li16 = lane & 15, lg = lane >> 4;
     const int G = (int)gridDim.x, gid = (int)blockIdx.x;
-    int wave_cnt = 0;
+    int wave_cnt = EMIT && a.append ? __builtin_amdgcn_readfirstlane(a.wv_count[blockIdx.x * 8 + w]) : 0;
     int4* wvbuf = EMIT ? a.wvbuf + ((size_t)blockIdx.x * 8 + w) * a.wv_cap : nullptr;
     if (gid >= a.t_count) {                             // workgroup-uniform
-        if (EMIT && lane == 0) a.wv_count[blockIdx.x * 8 + w] = 0;
+        if (EMIT && lane == 0) a.wv_count[blockIdx.x * 8 + w] = wave_cnt;
         return;
     }
     const int n_mine = (a.t_count - gid + G - 1) / G;
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(GF_THREADS) void gemm_stream_kernel(GemmF32Args a) 
 #pragma unroll
             for (int ni = 0; ni < 8; ++ni) {
                 if (__ballot(cmax[ni] >= thrv[ni]) == 0) continue;
-                const int q = ni * 16 + col_e;
+                const int q = a.q_base + ni * 16 + col_e;
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi) {
                     const int rb = w * 32 + mi * 16 + 4 * lg;
@@ -321,10 +323,12 @@ __global__ __launch_bounds__(GF_THREADS) void gemm_stream_kernel(GemmF32Args a) 
 // query image of the streaming kernel: [kt 24][q 128][physical chunk c' 4] x 16 B = f16 of dims 32 kt + 8 c .. + 8 of the
 // normalised query q, c = c' ^ (((q >> 3) & 1) << 1); queries >= nq are zero
 __global__ __launch_bounds__(256) void build_qimg1_kernel(const float* __restrict__ qn, int nq, f16x8* __restrict__ qimg) {
-    const int i = blockIdx.x * 256 + threadIdx.x;       // (kt, q, c')
+    const int i = blockIdx.x * 256 + threadIdx.x;       // (kt, q, c') of group blockIdx.y (queries 128 g .. 128 g + 127)
     if (i >= GF_KT * 128 * 4) return;
-    const int cp = i & 3, q = (i >> 2) & 127, kt = i >> 9;
-    const int c = cp ^ (((q >> 3) & 1) << 1);
+    const int g = blockIdx.y;
+    const int cp = i & 3, ql = (i >> 2) & 127, kt = i >> 9;
+    const int q = 128 * g + ql;
+    const int c = cp ^ (((ql >> 3) & 1) << 1);
     f16x8 h;
     if (q < nq) {
         const float* src = qn + (size_t)q * MSR_DIM + 32 * kt + 8 * c;
@@ -333,11 +337,9 @@ __global__ __launch_bounds__(256) void build_qimg1_kernel(const float* __restric
 #pragma unroll
         for (int j = 0; j < 8; ++j) h[j] = (_Float16)0.f;
     }
-    qimg[i] = h;
+    qimg[(size_t)g * (GF_KT * 128 * 4) + i] = h;
 }
 
-// qimg[kt][piece][q][physical chunk c'] (16 B = 8 f16) = piece (hi | lo) of dims 32 kt + 8 c .. + 8 of normalised query q,
-// c = c' ^ (((q >> 3) & 1) << 1); queries >= nq are zero.  Same split as the row side (split_f16).
 __global__ __launch_bounds__(256) void pad_inv_kernel(const float* __restrict__ inv, int64_t n, int64_t n_pad, float* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n_pad) out[i] = i < n ? inv[i] : 1.0f;
@@ -454,39 +456,53 @@ hipError_t msr_f16_row_error(const float* emb, const float* inv_norm, int64_t n_
     return hipGetLastError();
 }
 
-// Exact f32 top-k of up to 128 queries in one pass over the f32 rows; see the header of this file.
-// qn: [nq][768] normalised queries.  *gate != 0 when a query overflowed (the caller falls back).
+// Exact f32 top-k of up to 128 x g.max_groups queries, one pass over the f32 rows per group of 128; see the header of this
+// file.  The passes of all groups are queued back to back; everything between and after them (the two selects over tile
+// maxima, thresholds, bucketing, candidate lists, rescoring, final sort) runs ONCE for all queries of the call.
+// qn: [nq][768] normalised queries.  *gate != 0 when a query overflowed (the caller falls back).  ev (nullable): events
+// around the sample pass (0, 1) and the emit pass (2, 3) of the first group.
 hipError_t msr_gemm_f32_topk(const GemmF32Index& g, const DenseIndex& ix, const float* qn, int nq, int k,
                              const SelScratch& sel, int32_t* out_doc, float* out_score, int32_t* out_chunk,
                              int32_t* out_n, int32_t* gate, hipEvent_t* ev, hipStream_t stream) {
-    if (nq <= 0 || nq > 128 || k < 1 || g.n_tiles < 2 * k) return hipErrorInvalidValue;
+    const int G = (nq + 127) / 128;
+    if (nq <= 0 || G > g.max_groups || k < 1 || g.n_tiles < 2 * k) return hipErrorInvalidValue;
     hipError_t err;
-    build_qimg1_kernel<<<(GF_KT * 128 * 4 + 255) / 256, 256, 0, stream>>>(qn, nq, (f16x8*)g.qimg);
+    build_qimg1_kernel<<<dim3((GF_KT * 128 * 4 + 255) / 256, G), 256, 0, stream>>>(qn, nq, (f16x8*)g.qimg);
     f16_margin_kernel<<<(nq + 3) / 4, 256, 0, stream>>>(qn, nq, g.err_max, g.margin);
     const float* margin = g.margin;
     int ss = g.n_tiles / (6 * k);                       // every ss-th tile bounds the k-th score from below: >= 6 k sampled tiles
     ss = ss < 1 ? 1 : (ss > 32 ? 32 : ss);
     const int n_s = (g.n_tiles - ss / 2 + ss - 1) / ss;
     const int grid = g.n_cus;
+    const size_t qimg_bytes = (size_t)GF_KT * GS_STEP;
     GemmF32Args a{};
     a.dbg = g_f32_dbg;
-    a.E = (const char*)ix.emb; a.inv_pad = g.inv_pad; a.qimg = (const char*)g.qimg; a.tile_row = g.tile_row;
+    a.E = (const char*)ix.emb; a.inv_pad = g.inv_pad; a.tile_row = g.tile_row;
     a.n_rows = ix.n_chunks; a.tmax_t = g.tmax_t;
+    // ---- pass 1 of every group: maxima of every ss-th tile -> emission thresholds ----
     a.t_first = ss / 2; a.t_stride = ss; a.t_count = n_s;
-    if (ev && (err = hipEventRecord(ev[0], stream)) != hipSuccess) return err;
-    if ((err = launch_f32(false, a, grid, stream)) != hipSuccess) return err;
-    if (ev && (err = hipEventRecord(ev[1], stream)) != hipSuccess) return err;
-    if ((err = msr_gemm_tmax(g.tmax_t, n_s, 8, 128, g.tmax, g.tmax_stride, stream)) != hipSuccess) return err;
+    for (int gi = 0; gi < G; ++gi) {
+        a.qimg = (const char*)g.qimg + gi * qimg_bytes;
+        if (ev && gi == 0 && (err = hipEventRecord(ev[0], stream)) != hipSuccess) return err;
+        if ((err = launch_f32(false, a, grid, stream)) != hipSuccess) return err;
+        if (ev && gi == 0 && (err = hipEventRecord(ev[1], stream)) != hipSuccess) return err;
+        if ((err = msr_gemm_tmax(g.tmax_t, n_s, 8, 128, g.tmax + (size_t)gi * 128 * g.tmax_stride, g.tmax_stride, stream)) != hipSuccess) return err;
+    }
     if ((err = msr_select_topk(32, g.tmax, n_s, g.tmax_stride, nq, k, sel, g.top_doc, g.top_score, g.top_n, stream)) != hipSuccess) return err;
-    if ((err = msr_gemm_thr(g.top_score, g.top_n, nq, 128, k, margin, g.thr, g.flag, stream)) != hipSuccess) return err;
+    if ((err = msr_gemm_thr(g.top_score, g.top_n, nq, 128 * G, k, margin, g.thr, g.flag, stream)) != hipSuccess) return err;
+    // ---- pass 2 of every group: maxima of all tiles + the entries at or above the threshold (one set of wave buffers) ----
     a.t_first = 0; a.t_stride = 1; a.t_count = g.n_tiles;
-    a.thr = g.thr; a.wvbuf = (int4*)g.wvbuf; a.wv_cap = g.wv_cap; a.wv_count = g.wv_count;
-    if (ev && (err = hipEventRecord(ev[2], stream)) != hipSuccess) return err;
-    if ((err = launch_f32(true, a, grid, stream)) != hipSuccess) return err;
-    if (ev && (err = hipEventRecord(ev[3], stream)) != hipSuccess) return err;
-    if ((err = msr_gemm_tmax(g.tmax_t, g.n_tiles, 8, 128, g.tmax, g.tmax_stride, stream)) != hipSuccess) return err;
+    a.wvbuf = (int4*)g.wvbuf; a.wv_cap = g.wv_cap; a.wv_count = g.wv_count;
+    for (int gi = 0; gi < G; ++gi) {
+        a.qimg = (const char*)g.qimg + gi * qimg_bytes;
+        a.thr = g.thr + gi * 128; a.q_base = gi * 128; a.append = gi > 0;
+        if (ev && gi == 0 && (err = hipEventRecord(ev[2], stream)) != hipSuccess) return err;
+        if ((err = launch_f32(true, a, grid, stream)) != hipSuccess) return err;
+        if (ev && gi == 0 && (err = hipEventRecord(ev[3], stream)) != hipSuccess) return err;
+        if ((err = msr_gemm_tmax(g.tmax_t, g.n_tiles, 8, 128, g.tmax + (size_t)gi * 128 * g.tmax_stride, g.tmax_stride, stream)) != hipSuccess) return err;
+    }
     if ((err = msr_select_topk(32, g.tmax, g.n_tiles, g.tmax_stride, nq, k, sel, g.top_doc, g.top_score, g.top_n, stream)) != hipSuccess) return err;
-    if ((err = msr_gemm_thr(g.top_score, g.top_n, nq, 128, k, margin, g.thr2, nullptr, stream)) != hipSuccess) return err;
+    if ((err = msr_gemm_thr(g.top_score, g.top_n, nq, 128 * G, k, margin, g.thr2, nullptr, stream)) != hipSuccess) return err;
     if ((err = msr_gemm_bucket(g.wvbuf, g.wv_cap, g.wv_count, grid * 8, g.thr2, g.pairs, g.pair_n, stream)) != hipSuccess) return err;
     gemm_f32_cand_kernel<<<nq, 1024, 0, stream>>>((const int2*)g.pairs, g.pair_n, ix.chunk_doc, g.wv_count, grid * 8, g.wv_cap,
                                                   g.flag, g.cand_doc, g.cand_n, gate);

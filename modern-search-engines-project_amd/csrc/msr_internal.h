@@ -204,8 +204,9 @@ struct GemmF32Index {
     const int32_t* tile_row;   // [n_tiles + 1] (the tile table of the bf16 GEMM: whole documents, <= 256 rows)
     int32_t n_tiles;
     int32_t n_cus;
+    int32_t max_groups;        // groups of 128 queries one call may hold (the per-query arrays below are sized 128 x this)
     const float* inv_pad;      // [n_chunks + 512] inverse row norms, padded with 1
-    void* qimg;                // 24 x 8 KB query image (f16)
+    void* qimg;                // [max_groups] x 24 x 8 KB query images (f16)
     float* tmax_t;             // [n_tiles][8 waves][128]
     float* tmax;               // [128][tmax_stride]
     int32_t tmax_stride;

@@ -423,6 +423,13 @@ def test_batched_gemm_path_equals_exact_scan(mods):
             agree = (got[2] == exact[2]) | ~same
             assert agree.mean() > 0.999
     assert eng.lib.msr_tune(eng.handle, 1, 3) < 0           # the product library has no tuning keys
+    # msr_dense_topk with room for several groups of 128 queries per call (max_queries = 512: the passes of up to 4 groups
+    # are queued back to back and finished together, 700 queries = 512 + 188) returns what one group per call returns
+    one = [x.cpu().numpy() for x in eng.dense_topk(q, k=100)]
+    eng4 = mods["DeviceEngine"](ix, max_queries=512, max_k=100, rerank_max_docs=0)
+    many = [x.cpu().numpy() for x in eng4.dense_topk(q, k=100)]
+    assert all(np.array_equal(a_, b_) for a_, b_ in zip(one, many))
+    eng4.close()
     # zero query: every cosine is exactly 0 -> the k lowest-indexed documents that have chunks, in order
     z = [x.cpu().numpy() for x in eng.dense_topk_batched(q[:200], k=100)]
     has = np.nonzero(n > 0)[0][:100]
