@@ -470,7 +470,7 @@ hipError_t msr_gemm_f32_topk(const GemmF32Index& g, const DenseIndex& ix, const 
     build_qimg1_kernel<<<dim3((GF_KT * 128 * 4 + 255) / 256, G), 256, 0, stream>>>(qn, nq, (f16x8*)g.qimg);
     f16_margin_kernel<<<(nq + 3) / 4, 256, 0, stream>>>(qn, nq, g.err_max, g.margin);
     const float* margin = g.margin;
-    int ss = g.n_tiles / (6 * k);                       // every ss-th tile bounds the k-th score from below: >= 6 k sampled tiles
+    int ss = g.n_tiles / (3 * k);                       // every ss-th tile bounds the k-th score from below: >= 3 k sampled tiles
     ss = ss < 1 ? 1 : (ss > 32 ? 32 : ss);
     const int n_s = (g.n_tiles - ss / 2 + ss - 1) / ss;
     const int grid = g.n_cus;
