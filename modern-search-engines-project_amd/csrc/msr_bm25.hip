@@ -1,20 +1,22 @@
 // K1 -- BM25 term-at-a-time scoring over HBM-resident CSR postings (gfx950).
 //
 // Replaces the per-query SQL fetch + Python grouping + scoring loop of the reference
-// (indexer/bm25_indexer.py:434-481).  The dense doc index is cut into tiles of TILE documents.  A workgroup owns one
-// tile and FOUR queries: its four waves score one query each, every wave with its own float64 accumulators in LDS,
-// sharing the tile's length norms k1 (1 - b + b dl / avgdl) (computed once per workgroup, also in LDS).  A wave
-//   1. looks its query's terms up lane-parallel (lane j = term j: offsets, idf, query frequency, skip-table row),
-//   2. finds the tile's slice of every posting list: two loads from the skip table for long lists, the whole list for
-//      lists of <= 64 postings, and ONE round of 64 probes for the lists in between (a covering range; postings outside
-//      the tile are masked when applied),
-//   3. fetches the first 64 postings of the first TPRE slices side by side, then accumulates IN QUERY ORDER.  A wave's
-//      LDS operations execute in order, so the float64 summation order of every document equals the reference's
+// (indexer/bm25_indexer.py:434-481).  The dense doc index is cut into tiles of TILE documents.  A workgroup owns a span
+// of up to 8 consecutive tiles and FOUR queries: its four waves score one query each, every wave with its own float64
+// accumulators in LDS, sharing the current tile's length norms k1 (1 - b + b dl / avgdl) (computed once per workgroup
+// and tile, also in LDS).  A wave
+//   1. builds its query's PLAN once for all tiles of the workgroup, lane-parallel (lane j = term j): offsets, idf, query
+//      frequency; for long lists the skip-table row segment (where each of the workgroup's tiles starts inside the list);
+//      for lists of <= 64 postings the whole list; for the lists in between ONE round of 64 probes (a covering range for
+//      the workgroup's document span; postings outside a tile are masked when applied);
+//   2. per tile: derives every term's slice from the plan (no memory access),
+//   3. fetches the first PFC x 64 postings of the first TPRE slices side by side, then accumulates IN QUERY ORDER.  A
+//      wave's LDS operations execute in order, so the float64 summation order of every document equals the reference's
 //      (:466-478) WITHOUT a barrier between terms; a document occurs at most once per posting list (PRIMARY KEY
 //      (doc_id, term), :100-104), so the read-modify-write of acc[doc] needs no atomics,
 //   4. appends the touched documents with score >= min_score to the query's candidate list (ballot prefix, one
-//      reservation per wave).
-// The only workgroup barrier is the one that publishes the length norms.  The arithmetic is written operation by
+//      reservation per wave and tile).
+// The only workgroup barriers (two per tile) publish the length norms.  The arithmetic is written operation by
 // operation as Python evaluates it and this file is compiled with -ffp-contract=off, so scores are bit-identical to
 // the oracle.
 //
