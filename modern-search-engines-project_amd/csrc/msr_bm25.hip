@@ -22,6 +22,8 @@
 //
 // HBM traffic per query: 8 B per posting of the query's terms + 1 B per document (doc_len, shared by four queries) +
 // 12 B per candidate document (the (score, doc) list consumed by the top-k select).
+#include <type_traits>
+
 #include "msr_common.h"
 #include "msr_internal.h"
 
@@ -199,18 +201,36 @@ __global__ __launch_bounds__(BM25_THREADS) __attribute__((amdgpu_waves_per_eu(4,
         for (int u = 0; u < BM25_TILE / BM25_THREADS; ++u)
             dn[tid + u * BM25_THREADS] = k1 * (omb + (b * (double)dl_reg[u]) / avgdl);
         __syncthreads();
-        // One posting: the reference's arithmetic, operation by operation (:472-478).
-        auto apply = [&](int32_t pdoc, int32_t ptf, double idf, double qtf) {
-            const uint32_t d = (uint32_t)(pdoc - (int32_t)lo);
-            if (d >= (uint32_t)n) return;                        // a posting of another tile (covering ranges), or none
-            const double tf = (double)ptf;
-            // tf_component = (tf * (k1 + 1)) / (tf + k1 * (1 - b + b * doc_length / avg_doc_length))
-            const double comp = (dbg & 1) ? (tf * k1p1) * (tf + dn[d]) : (tf * k1p1) / (tf + dn[d]);
-            // term_score = idf * tf_component * query_term_freq[term]; bm25_score += term_score
-            const double c = (idf * comp) * qtf;
-            if (dbg & 2) { if (c == 1.2345e-300) acc[d] = c; return; }
-            const double a = acc[d];
-            acc[d] = ((uint64_t)__double_as_longlong(a) == UNTOUCHED ? 0.0 : a) + c;
+        // U postings of ONE term per lane: the reference's arithmetic, operation by operation (:472-478), written so that the
+        // U chains (a float64 division is 11 dependent instructions) are independent and interleave: nothing is branched
+        // around -- a posting of another tile (covering ranges) or a missing one computes on document 0 and only its final
+        // store is masked.  A document occurs once per posting list, so the U read-modify-writes never touch the same slot.
+        auto apply = [&](auto u_c, const int32_t* pdoc, const int32_t* ptf, double idf, double qtf) {
+            constexpr int U = decltype(u_c)::value;
+            bool ok[U];
+            uint32_t d[U];
+            double c[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t dd = (uint32_t)(pdoc[u] - (int32_t)lo);
+                ok[u] = dd < (uint32_t)n;
+                d[u] = ok[u] ? dd : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double tf = (double)ptf[u];
+                // tf_component = (tf * (k1 + 1)) / (tf + k1 * (1 - b + b * doc_length / avg_doc_length))
+                const double comp = (dbg & 1) ? (tf * k1p1) * (tf + dn[d[u]]) : (tf * k1p1) / (tf + dn[d[u]]);
+                // term_score = idf * tf_component * query_term_freq[term]; bm25_score += term_score
+                c[u] = (idf * comp) * qtf;
+            }
+            if (dbg & 2) return;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double a = acc[d[u]];
+                const double x = ((uint64_t)__double_as_longlong(a) == UNTOUCHED ? 0.0 : a) + c[u];
+                if (ok[u]) acc[d[u]] = x;
+            }
         };
         // The rest of a slice, U x 64 postings per round: all loads of a round are issued before the first is used.
         auto stream = [&](int64_t from, int64_t pe, double idf, double qtf) {
@@ -224,8 +244,7 @@ __global__ __launch_bounds__(BM25_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                     pd[u] = i < pe ? ix.post_doc[i] : -1;
                     ptf[u] = i < pe ? ix.post_tf[i] : 0;
                 }
-#pragma unroll
-                for (int u = 0; u < U; ++u) apply(pd[u], ptf[u], idf, qtf);
+                apply(std::integral_constant<int, U>{}, pd, ptf, idf, qtf);
             }
         };
 #pragma unroll
@@ -234,9 +253,7 @@ __global__ __launch_bounds__(BM25_THREADS) __attribute__((amdgpu_waves_per_eu(4,
             const int64_t ps = lane_i64(ps_v, j), pe = lane_i64(pe_v, j);
             if (pe <= ps) continue;
             const double idf = lane_f64(idf_v, j), qtf = lane_f64(qtf_v, j);
-#pragma unroll
-            for (int c = 0; c < PFC; ++c)
-                if (ps + 64 * c < pe) apply(pd0[j][c], ptf0[j][c], idf, qtf);
+            apply(std::integral_constant<int, PFC>{}, pd0[j], ptf0[j], idf, qtf);     // (chunks past the slice hold doc -1)
             if (pe - ps > 64 * PFC) stream(ps + 64 * PFC, pe, idf, qtf);
         }
         for (int j = TPRE; j < nt; ++j) {
