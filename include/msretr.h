@@ -100,12 +100,15 @@ int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks, const int
  * the query string removed, or -1 when the document is not in urlsDB.   reranker_api.py:38-47 */
 int msr_bind_doc_meta(msr_engine* e, const int32_t* url_group, int64_t n_docs, void* stream);
 
-/* Arithmetic of the bound dense scan: 0 = exact f32 MFMA (bit-for-bit a k-ordered fmaf chain), 1 = f32 rows
- * split into two f16 pieces, three f16 MFMAs per k-step with f32 accumulation (|error| <= 8e-6 on the cosine
- * for row norms in [0.5, 2], proof in DESIGN.md); -1 = no chunks bound. */
+/* Arithmetic of the bound dense scan's SWEEPS (calls of <= 64 queries, and the fallback): 0 = exact f32 MFMA (bit-for-bit
+ * a k-ordered fmaf chain), 1 = f32 rows split into two f16 pieces, three f16 MFMAs per k-step with f32 accumulation
+ * (|error| <= 8e-6 on the cosine for row norms in [0.5, 2], proof in DESIGN.md); -1 = no chunks bound.  When
+ * msr_scan_width() says 128, calls of more than 64 queries take one streaming pass per 128 queries instead: an f16
+ * filter with a measured margin, then EXACT f32 cosines for every returned document. */
 int msr_scan_arith(const msr_engine* e);
 
-/* Most queries one sweep of the embedding matrix serves in msr_dense_topk: 64 when the K-split kernel is in use
+/* Most queries one pass over the embedding matrix serves in msr_dense_topk: 128 when the streaming pass is available
+ * (f16-split arithmetic bound, every document within one 256-row tile, enough tiles), 64 when only the K-split kernel is
  * (row-major layout, no per-document row limit, a corpus that meets its preconditions; both arithmetics), else 32;
  * -1 = no chunks bound. */
 int msr_scan_width(const msr_engine* e);
