@@ -22,6 +22,8 @@
 //
 // HBM traffic per query: 8 B per posting of the query's terms + 1 B per document (doc_len, shared by four queries) +
 // 12 B per candidate document (the (score, doc) list consumed by the top-k select).
+#include <stdio.h>
+
 #include <type_traits>
 
 #include "msr_common.h"
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(BM25_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                 for (int c = 0; c < PFC; ++c) {
                     if (ps + 64 * c < pe) {                      // wave-uniform: no instruction for chunks past the slice
                         const int64_t i = ps + 64 * c + lane;
-                        if (i < pe) { pd0[j][c] = ix.post_doc[i]; ptf0[j][c] = ix.post_tf[i]; }
+                        if (i < pe) { const int2 p = ix.post[i]; pd0[j][c] = p.x; ptf0[j][c] = p.y; }
                     }
                 }
             }
@@ -241,8 +243,9 @@ __global__ __launch_bounds__(BM25_THREADS) __attribute__((amdgpu_waves_per_eu(4,
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int64_t i = base + lane + (int64_t)u * 64;
-                    pd[u] = i < pe ? ix.post_doc[i] : -1;
-                    ptf[u] = i < pe ? ix.post_tf[i] : 0;
+                    const int2 p = i < pe ? ix.post[i] : make_int2(-1, 0);
+                    pd[u] = p.x;
+                    ptf[u] = p.y;
                 }
                 apply(std::integral_constant<int, U>{}, pd, ptf, idf, qtf);
             }
@@ -340,16 +343,31 @@ __global__ __launch_bounds__(256) void build_skip_kernel(Bm25Index ix, const int
     }
 }
 
+// post[i] = {post_doc[i], post_tf[i]}: the scoring kernel reads a posting with ONE 8-byte load (the engine-owned copy
+// costs 8 B per posting of HBM; with two 4-byte arrays the kernel issued twice the memory instructions, and their issue
+// rate -- not bandwidth -- is what the per-phase wave clocks showed to matter)
+__global__ __launch_bounds__(256) void interleave_postings_kernel(const int32_t* __restrict__ post_doc,
+                                                                   const int32_t* __restrict__ post_tf, int64_t n,
+                                                                   int2* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = make_int2(post_doc[i], post_tf[i]);
+}
+
 int g_bm25_dbg = 0;
 
 }  // namespace
 
 void msr_bm25_set_dbg(int v) { g_bm25_dbg = v; }      // honoured by -DMSR_DIAG builds only
-
 hipError_t msr_bm25_build_skip(const Bm25Index& ix, const int32_t* heavy_terms, int n_heavy, uint32_t* tile_off,
                                hipStream_t stream) {
     if (n_heavy <= 0) return hipSuccess;
     build_skip_kernel<<<n_heavy, 256, 0, stream>>>(ix, heavy_terms, tile_off);
+    return hipGetLastError();
+}
+
+hipError_t msr_bm25_interleave(const int32_t* post_doc, const int32_t* post_tf, int64_t n, void* out, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    interleave_postings_kernel<<<4096, 256, 0, stream>>>(post_doc, post_tf, n, (int2*)out);
     return hipGetLastError();
 }
 

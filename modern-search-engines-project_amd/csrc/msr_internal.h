@@ -63,7 +63,9 @@ struct Bm25Index {
     const int32_t* heavy_id;   // [n_terms]: row of tile_off, or -1
     const uint32_t* tile_off;  // [n_heavy][n_tiles + 1], relative to term_off[t]
     int32_t n_tiles;
+    const int2* post;          // [n_postings] {doc, tf}: engine-owned interleaved copy, what the scoring kernel streams
 };
+hipError_t msr_bm25_interleave(const int32_t* post_doc, const int32_t* post_tf, int64_t n, void* out, hipStream_t stream);
 constexpr int MSR_BM25_TILE = 1024;          // documents per BM25 tile
 constexpr int MSR_BM25_HEAVY_DF = 2048;      // posting lists at least this long get a skip-table row
 hipError_t msr_bm25_build_skip(const Bm25Index& ix, const int32_t* heavy_terms, int n_heavy, uint32_t* tile_off,
