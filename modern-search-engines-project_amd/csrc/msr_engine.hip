@@ -56,7 +56,6 @@ struct msr_engine {
     GemmF32Index gf{};
     bool gf_ok = false;
     float* gf_inv_pad = nullptr; void* gf_qimg = nullptr; float* gf_tmax_t = nullptr; float* gf_tmax = nullptr;
-    int32_t* gf_top_doc = nullptr; float* gf_top_score = nullptr; int32_t* gf_top_n = nullptr;
     float* gf_thr = nullptr; float* gf_thr2 = nullptr; int32_t* gf_flag = nullptr; void* gf_wvbuf = nullptr;
     int32_t* gf_wv_count = nullptr; void* gf_pairs = nullptr; int32_t* gf_pair_n = nullptr; int32_t* gf_gate = nullptr;
     uint32_t* gf_err = nullptr; float* gf_margin = nullptr; int32_t* gf_cand_doc = nullptr; float* gf_cand_score = nullptr;
@@ -65,10 +64,8 @@ struct msr_engine {
     GemmIndex gemm{};
     bool gemm_ok = false;
     void* gm_emb_n = nullptr; void* gm_qmat = nullptr; float* gm_tmax = nullptr; float* gm_tmax_t = nullptr;
-    int32_t* gm_top_doc = nullptr; float* gm_top_score = nullptr; int32_t* gm_top_n = nullptr;
     float* gm_thr = nullptr; float* gm_thr2 = nullptr; int32_t* gm_flag = nullptr; void* gm_wgbuf = nullptr;
     int32_t* gm_wv_count = nullptr; void* gm_pairs = nullptr; int32_t* gm_pair_n = nullptr; float* gm_qn = nullptr;
-    SelScratch gm_sel{};
     uint32_t* bf_err = nullptr;        // bits of the largest rounding-error norm of an image row (see msr_batch_margin)
     float* bf_margin = nullptr;        // [GM_SLICE] candidate margin of each query of the current slice
     float* bf_ones = nullptr;          // inverse norms of the unit-row image (all 1) for the <= 128-query bf16 sweeps
@@ -106,29 +103,28 @@ static void free_dev(void* p) {
 }
 
 static void free_gemm(msr_engine* e) {
-    free_dev(e->gm_emb_n); free_dev(e->gm_qmat); free_dev(e->gm_tmax); free_dev(e->gm_tmax_t); free_dev(e->gm_top_doc);
-    free_dev(e->gm_top_score); free_dev(e->gm_top_n); free_dev(e->gm_thr); free_dev(e->gm_thr2); free_dev(e->gm_flag);
+    free_dev(e->gm_emb_n); free_dev(e->gm_qmat); free_dev(e->gm_tmax); free_dev(e->gm_tmax_t);
+    free_dev(e->gm_thr); free_dev(e->gm_thr2); free_dev(e->gm_flag);
     free_dev(e->gm_wgbuf); free_dev(e->gm_wv_count); free_dev(e->gm_pairs); free_dev(e->gm_pair_n); free_dev(e->gm_qn);
-    free_dev(e->gm_sel.hist); free_dev(e->gm_sel.state); free_dev(e->gm_sel.cand_hi); free_dev(e->gm_sel.cand_lo);
-    free_dev(e->gm_sel.cand_n); free_dev(e->bf_ones); free_dev(e->bf_row_meta); free_dev(e->bf_err); free_dev(e->bf_margin);
+    free_dev(e->bf_ones); free_dev(e->bf_row_meta); free_dev(e->bf_err); free_dev(e->bf_margin);
     e->bf_err = nullptr; e->bf_margin = nullptr;
-    e->gm_emb_n = nullptr; e->gm_qmat = nullptr; e->gm_tmax = nullptr; e->gm_tmax_t = nullptr; e->gm_top_doc = nullptr;
-    e->gm_top_score = nullptr; e->gm_top_n = nullptr; e->gm_thr = e->gm_thr2 = nullptr; e->gm_flag = nullptr;
+    e->gm_emb_n = nullptr; e->gm_qmat = nullptr; e->gm_tmax = nullptr; e->gm_tmax_t = nullptr;
+    e->gm_thr = e->gm_thr2 = nullptr; e->gm_flag = nullptr;
     e->gm_wgbuf = nullptr; e->gm_wv_count = nullptr; e->gm_pairs = nullptr; e->gm_pair_n = nullptr; e->gm_qn = nullptr;
-    e->gm_sel = SelScratch{}; e->bf_ones = nullptr; e->bf_row_meta = nullptr;
+    e->bf_ones = nullptr; e->bf_row_meta = nullptr;
     e->gemm_ok = false;
 }
 
 static void free_gf(msr_engine* e) {
     free_dev(e->tile_row); free_dev(e->gf_inv_pad); free_dev(e->gf_qimg); free_dev(e->gf_tmax_t); free_dev(e->gf_tmax);
-    free_dev(e->gf_top_doc); free_dev(e->gf_top_score); free_dev(e->gf_top_n); free_dev(e->gf_thr); free_dev(e->gf_thr2);
+    free_dev(e->gf_thr); free_dev(e->gf_thr2);
     free_dev(e->gf_flag); free_dev(e->gf_wvbuf); free_dev(e->gf_wv_count); free_dev(e->gf_pairs); free_dev(e->gf_pair_n);
     free_dev(e->gf_gate); free_dev(e->gf_err); free_dev(e->gf_margin); free_dev(e->gf_cand_doc); free_dev(e->gf_cand_score);
     free_dev(e->gf_cand_chunk); free_dev(e->gf_cand_n); free_dev(e->gf_qn); e->gf_qn = nullptr;
     e->gf_err = nullptr; e->gf_margin = nullptr; e->gf_cand_doc = nullptr; e->gf_cand_score = nullptr; e->gf_cand_chunk = nullptr;
     e->gf_cand_n = nullptr;
     e->tile_row = nullptr; e->gf_inv_pad = nullptr; e->gf_qimg = nullptr; e->gf_tmax_t = nullptr; e->gf_tmax = nullptr;
-    e->gf_top_doc = nullptr; e->gf_top_score = nullptr; e->gf_top_n = nullptr; e->gf_thr = e->gf_thr2 = nullptr;
+    e->gf_thr = e->gf_thr2 = nullptr;
     e->gf_flag = nullptr; e->gf_wvbuf = nullptr; e->gf_wv_count = nullptr; e->gf_pairs = nullptr; e->gf_pair_n = nullptr;
     e->gf_gate = nullptr;
     e->n_tiles = 0; e->tiles_ok = false; e->gf_ok = false;
@@ -497,9 +493,6 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
             (herr = alloc((void**)&e->gf_qn, QM * MSR_DIM * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gf_tmax_t, (size_t)n_tiles * 8 * 128 * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gf_tmax, QM * stride * 4)) != hipSuccess ||
-            (herr = alloc((void**)&e->gf_top_doc, QM * MSR_MAX_K * 4)) != hipSuccess ||
-            (herr = alloc((void**)&e->gf_top_score, QM * MSR_MAX_K * 4)) != hipSuccess ||
-            (herr = alloc((void**)&e->gf_top_n, QM * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gf_thr, QM * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gf_thr2, QM * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gf_flag, QM * 4)) != hipSuccess ||
@@ -521,7 +514,7 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
         HIP_TRY(e, hipMemsetAsync(e->gf_cand_n, 0, QM * 4, st));
         HIP_TRY(e, msr_f16_row_error(emb, inv_norm, n_chunks, e->gf_err, st));   // measured once: the margin of the f16 filter
         e->gf = GemmF32Index{e->tile_row, n_tiles, e->n_cus, groups, e->gf_inv_pad, e->gf_qimg, e->gf_tmax_t, e->gf_tmax, stride,
-                             e->gf_top_doc, e->gf_top_score, e->gf_top_n, e->gf_thr, e->gf_thr2, e->gf_flag, e->gf_wvbuf,
+                             e->gf_thr, e->gf_thr2, e->gf_flag, e->gf_wvbuf,
                              GF_WV_CAP, e->gf_wv_count, e->gf_pairs, e->gf_pair_n, e->gf_err, e->gf_margin, e->gf_cand_doc,
                              e->gf_cand_score, e->gf_cand_chunk, e->gf_cand_n};
         e->gf_ok = true;
@@ -677,7 +670,7 @@ extern "C" int msr_dense_topk(msr_engine* e, const float* q, int32_t n_queries, 
                 ev[0] = e->ev_start[3][e->ev_count[3]]; ev[1] = e->ev_stop[3][e->ev_count[3]];
                 ev[2] = e->ev_start[0][e->ev_count[0]]; ev[3] = e->ev_stop[0][e->ev_count[0]];
             }
-            HIP_TRY(e, msr_gemm_f32_topk(e->gf, e->dense, e->gf_qn, nq, k, e->sel, out_doc + (int64_t)q0 * k,
+            HIP_TRY(e, msr_gemm_f32_topk(e->gf, e->dense, e->gf_qn, nq, k, out_doc + (int64_t)q0 * k,
                                          out_score + (int64_t)q0 * k, out_chunk ? out_chunk + (int64_t)q0 * k : nullptr,
                                          out_n + q0, e->gf_gate, timed ? ev : nullptr, st));
             if (timed) { e->ev_count[0]++; e->ev_count[3]++; }
@@ -754,32 +747,21 @@ extern "C" int msr_enable_bf16(msr_engine* e, void* stream) {
     const int grid = e->n_cus / 8 * 8;
     if (ok && n_tiles >= 64 && grid >= 32) {
         const int stride = (n_tiles + 31) / 32 * 32;
-        const size_t nsel = GM_SLICE;
         if ((herr = alloc(&e->gm_qmat, (size_t)GM_SLICE * MSR_DIM * 2)) != hipSuccess ||
             (herr = alloc((void**)&e->gm_qn, (size_t)GM_SLICE * MSR_DIM * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gm_tmax, (size_t)GM_SLICE * stride * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gm_tmax_t, (size_t)n_tiles * 2 * GM_SLICE * 4)) != hipSuccess ||
-            (herr = alloc((void**)&e->gm_top_doc, (size_t)GM_SLICE * MSR_MAX_K * 4)) != hipSuccess ||
-            (herr = alloc((void**)&e->gm_top_score, (size_t)GM_SLICE * MSR_MAX_K * 4)) != hipSuccess ||
-            (herr = alloc((void**)&e->gm_top_n, (size_t)GM_SLICE * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gm_thr, (size_t)GM_SLICE * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gm_thr2, (size_t)GM_SLICE * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gm_flag, (size_t)GM_SLICE * 4)) != hipSuccess ||
             (herr = alloc(&e->gm_wgbuf, (size_t)grid * 8 * GM_WV_CAP * 16)) != hipSuccess ||
             (herr = alloc((void**)&e->gm_wv_count, (size_t)grid * 8 * 4)) != hipSuccess ||
             (herr = alloc(&e->gm_pairs, (size_t)GM_SLICE * msr_gemm_pair_cap() * 8)) != hipSuccess ||
-            (herr = alloc((void**)&e->gm_pair_n, (size_t)GM_SLICE * 4)) != hipSuccess ||
-            (herr = alloc((void**)&e->gm_sel.hist, nsel * MSR_SEL_BINS * sizeof(uint32_t))) != hipSuccess ||
-            (herr = alloc((void**)&e->gm_sel.state, nsel * sizeof(SelState))) != hipSuccess ||
-            (herr = alloc((void**)&e->gm_sel.cand_hi, nsel * MSR_SEL_CAP * sizeof(uint64_t))) != hipSuccess ||
-            (herr = alloc((void**)&e->gm_sel.cand_lo, nsel * MSR_SEL_CAP * sizeof(uint32_t))) != hipSuccess ||
-            (herr = alloc((void**)&e->gm_sel.cand_n, nsel * sizeof(int32_t))) != hipSuccess)
+            (herr = alloc((void**)&e->gm_pair_n, (size_t)GM_SLICE * 4)) != hipSuccess)
             return fail(e, MSR_ERR_NOMEM, "GEMM path scratch: %s", hipGetErrorString(herr));
         HIP_TRY(e, hipMemsetAsync(e->gm_pair_n, 0, (size_t)GM_SLICE * 4, st));
-        HIP_TRY(e, hipMemsetAsync(e->gm_sel.hist, 0, nsel * MSR_SEL_BINS * sizeof(uint32_t), st));
-        HIP_TRY(e, hipMemsetAsync(e->gm_sel.cand_n, 0, nsel * sizeof(int32_t), st));
         e->gemm = GemmIndex{e->emb_bf16, e->tile_row, n_tiles, e->n_cus, GM_SLICE, e->gm_qmat, e->gm_tmax, stride,
-                            e->gm_tmax_t, e->gm_top_doc, e->gm_top_score, e->gm_top_n, e->gm_thr, e->gm_thr2, e->gm_flag, e->gm_wgbuf,
+                            e->gm_tmax_t, e->gm_thr, e->gm_thr2, e->gm_flag, e->gm_wgbuf,
                             GM_WV_CAP, e->gm_wv_count, e->gm_pairs, e->gm_pair_n};
         e->gemm_ok = true;
     }
@@ -823,7 +805,7 @@ extern "C" int msr_dense_topk_bf16(msr_engine* e, const float* q, int32_t n_quer
                 ev[0] = e->ev_start[3][e->ev_count[3]]; ev[1] = e->ev_stop[3][e->ev_count[3]];
                 ev[2] = e->ev_start[2][e->ev_count[2]]; ev[3] = e->ev_stop[2][e->ev_count[2]];
             }
-            HIP_TRY(e, msr_gemm_candidates(e->gemm, e->dense, e->gm_qn, nq, k, e->bf_margin, e->gm_sel, e->bt_cand_doc, e->bt_cand_n,
+            HIP_TRY(e, msr_gemm_candidates(e->gemm, e->dense, e->gm_qn, nq, k, e->bf_margin, e->bt_cand_doc, e->bt_cand_n,
                                            timed ? ev : nullptr, st));
             if (timed) { e->ev_count[2]++; e->ev_count[3]++; }
             HIP_TRY(e, msr_batch_rescore(e->dense, e->gm_qn, nq, k, 0, e->bt_cand_doc, e->bt_cand_score, e->bt_cand_chunk,

@@ -416,21 +416,70 @@ __global__ __launch_bounds__(256) void gemm_tmax_kernel(const float* __restrict_
 
 // thr[q] = (k-th largest tile maximum) - margin; fewer than k finite maxima (or a padding query): +inf, i.e. no emission,
 // and flag[q] = 1 so that the caller reports the query as "rerun on the exact path" (real queries only)
-__global__ __launch_bounds__(256) void gemm_thr_kernel(const float* __restrict__ top_score, const int32_t* __restrict__ top_n,
-                                                        int nq, int nq_pad, int k, const float* __restrict__ margin,
-                                                        float* __restrict__ thr,
-                                                        int32_t* __restrict__ flag) {
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= nq_pad) return;
-    float t = __builtin_inff();
-    int f = 0;
-    if (q < nq) {
-        if (top_n[q] >= k) t = top_score[(int64_t)q * k + (k - 1)] - (margin ? margin[q] : 0.0f);
-        else f = 1;
+// thr[q] = (k-th largest valid value of row q of tmax) - margin[q] -- the job of a full top-k select + a threshold kernel
+// (7 launches), done by ONE workgroup per query: a 3-pass radix select (11 + 11 + 10 bits of the orderable key) with an
+// LDS histogram; the row (<= a few 10^4 tile maxima) is re-read from the L2 in every pass.  Fewer than k valid values:
+// thr = +inf and flag[q] = 1 (the caller treats the query as overflowed).  Rows q >= nq (padding): +inf, flag 0.
+__global__ __launch_bounds__(1024) void gemm_kth_kernel(const float* __restrict__ tmax, int n, int stride, int nq, int k,
+                                                         const float* __restrict__ margin, float* __restrict__ thr,
+                                                         int32_t* __restrict__ flag) {
+    __shared__ uint32_t hist[2048];
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t s_bin, s_kk, s_hit;
+    const int q = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (q >= nq) {
+        if (t == 0) { thr[q] = __builtin_inff(); if (flag) flag[q] = 0; }
+        return;
     }
-    thr[q] = t;
-    if (flag) flag[q] = f;
+    const float* row = tmax + (size_t)q * stride;
+    uint32_t prefix = 0, mask = 0, kk = (uint32_t)k;
+    bool short_row = false;
+#pragma unroll 1
+    for (int pass = 0; pass < 3; ++pass) {
+        const int shift = pass == 0 ? 21 : pass == 1 ? 10 : 0;
+        const uint32_t nb = pass == 2 ? 1024u : 2048u;
+        hist[t] = 0; hist[t + 1024] = 0;
+        if (t == 0) s_hit = 0;
+        __syncthreads();
+        for (int i = t; i < n; i += 1024) {
+            const float x = row[i];
+            if (!msr_valid(x)) continue;
+            const uint32_t key = msr_ord32(x);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & (nb - 1)], 1u);
+        }
+        __syncthreads();
+        // the bin that holds the kk-th largest key: thread t owns bins 2t (low) and 2t + 1 (high); counts above a thread =
+        // higher lanes of its wave + higher waves
+        const uint32_t h0 = 2 * t < (int)nb ? hist[2 * t] : 0u, h1 = 2 * t + 1 < (int)nb ? hist[2 * t + 1] : 0u;
+        const uint32_t c2 = h0 + h1;
+        uint32_t inc = c2;                                   // inclusive suffix sum over lanes >= lane
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_down(inc, o);
+            if (lane + o < 64) inc += v;
+        }
+        if (lane == 0) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t above = inc - c2;
+        for (int w2 = wave + 1; w2 < 16; ++w2) above += wsum[w2];
+        if (above < kk && kk <= above + c2) {                // exactly one thread, if the row holds kk candidates at all
+            if (above + h1 >= kk) { s_bin = 2 * t + 1; s_kk = kk - above; }
+            else { s_bin = 2 * t; s_kk = kk - above - h1; }
+            s_hit = 1;
+        }
+        __syncthreads();
+        if (!s_hit) { short_row = true; break; }             // (block-uniform)
+        prefix |= s_bin << shift;
+        mask |= (nb - 1) << shift;
+        kk = s_kk;
+        __syncthreads();
+    }
+    if (t == 0) {
+        thr[q] = short_row ? __builtin_inff() : msr_unord32(prefix) - (margin ? margin[q] : 0.0f);
+        if (flag) flag[q] = short_row ? 1 : 0;
+    }
 }
+
 
 // Workgroup buffers -> per-query lists of (row, score) with score >= thr2[q].
 __global__ __launch_bounds__(256) void gemm_bucket_kernel(const int4* __restrict__ wgbuf, int wg_cap,
@@ -600,9 +649,10 @@ hipError_t msr_gemm_tmax(const float* tmax_t, int n_j, int parts, int nq_pad, fl
     gemm_tmax_kernel<<<dim3((n_j + 31) / 32, nq_pad / 32), 256, 0, stream>>>(tmax_t, n_j, parts, nq_pad, out, out_stride);
     return hipGetLastError();
 }
-hipError_t msr_gemm_thr(const float* top_score, const int32_t* top_n, int nq, int nq_pad, int k, const float* margin,
-                        float* thr, int32_t* flag, hipStream_t stream) {
-    gemm_thr_kernel<<<(nq_pad + 255) / 256, 256, 0, stream>>>(top_score, top_n, nq, nq_pad, k, margin, thr, flag);
+hipError_t msr_gemm_kth(const float* tmax, int n, int stride, int nq, int nq_pad, int k, const float* margin, float* thr,
+                        int32_t* flag, hipStream_t stream) {
+    if (nq_pad <= 0) return hipSuccess;
+    gemm_kth_kernel<<<nq_pad, 1024, 0, stream>>>(tmax, n, stride, nq, k, margin, thr, flag);
     return hipGetLastError();
 }
 hipError_t msr_gemm_bucket(const void* wvbuf, int wv_cap, const int32_t* wv_count, int n_waves, const float* thr2,
@@ -616,8 +666,7 @@ void msr_gemm_set_dbg(int v) { g_gemm_dbg = v; }
 // The whole batched candidate path for nq <= g.max_queries queries (see the header of this file); ends with cand_doc /
 // cand_n filled for msr_batch_rescore.  qn: normalised f32 queries [nq][768].
 hipError_t msr_gemm_candidates(const GemmIndex& g, const DenseIndex& ix, const float* qn, int nq, int k, const float* margin,
-                               const SelScratch& sel, int32_t* cand_doc, int32_t* cand_n, hipEvent_t* ev,
-                               hipStream_t stream) {
+                               int32_t* cand_doc, int32_t* cand_n, hipEvent_t* ev, hipStream_t stream) {
     const int nq_pad = (nq + 255) / 256 * 256;
     const int nt = nq_pad / 256;
     if (nq <= 0 || nq_pad > g.max_queries || k < 1 || g.n_tiles < 2 * k) return hipErrorInvalidValue;
@@ -640,8 +689,7 @@ hipError_t msr_gemm_candidates(const GemmIndex& g, const DenseIndex& ix, const f
     if ((err = launch_gemm(false, a, grid, stream)) != hipSuccess) return err;
     if (ev && (err = hipEventRecord(ev[1], stream)) != hipSuccess) return err;
     gemm_tmax_kernel<<<dim3((n_s + 31) / 32, nq_pad / 32), 256, 0, stream>>>(g.tmax_t, n_s, 2, nq_pad, (float*)g.tmax, g.tmax_stride);
-    if ((err = msr_select_topk(32, g.tmax, n_s, g.tmax_stride, nq, k, sel, g.top_doc, g.top_score, g.top_n, stream)) != hipSuccess) return err;
-    gemm_thr_kernel<<<(nq_pad + 255) / 256, 256, 0, stream>>>(g.top_score, g.top_n, nq, nq_pad, k, margin, g.thr, g.flag);
+    gemm_kth_kernel<<<nq_pad, 1024, 0, stream>>>((const float*)g.tmax, n_s, g.tmax_stride, nq, k, margin, g.thr, g.flag);
     // ---- pass 2: all tiles; maxima of all tiles + emission against the sample threshold ----
     a.t_first = 0; a.t_stride = 1; a.t_count = g.n_tiles;
     a.thr = g.thr; a.wgbuf = (int4*)g.wgbuf; a.wv_cap = g.wv_cap; a.wv_count = g.wv_count;
@@ -649,8 +697,7 @@ hipError_t msr_gemm_candidates(const GemmIndex& g, const DenseIndex& ix, const f
     if ((err = launch_gemm(true, a, grid, stream)) != hipSuccess) return err;
     if (ev && (err = hipEventRecord(ev[3], stream)) != hipSuccess) return err;
     gemm_tmax_kernel<<<dim3((g.n_tiles + 31) / 32, nq_pad / 32), 256, 0, stream>>>(g.tmax_t, g.n_tiles, 2, nq_pad, (float*)g.tmax, g.tmax_stride);
-    if ((err = msr_select_topk(32, g.tmax, g.n_tiles, g.tmax_stride, nq, k, sel, g.top_doc, g.top_score, g.top_n, stream)) != hipSuccess) return err;
-    gemm_thr_kernel<<<(nq_pad + 255) / 256, 256, 0, stream>>>(g.top_score, g.top_n, nq, nq_pad, k, margin, g.thr2, nullptr);
+    gemm_kth_kernel<<<nq_pad, 1024, 0, stream>>>((const float*)g.tmax, g.n_tiles, g.tmax_stride, nq, k, margin, g.thr2, nullptr);
     // ---- finish: bucket, per-document maxima, candidates ----
     gemm_bucket_kernel<<<dim3(2, (unsigned)grid * 8), 256, 0, stream>>>((const int4*)g.wgbuf, g.wv_cap, g.wv_count, g.thr2,
                                                                        (int2*)g.pairs, GM_PAIR_CAP, g.pair_n);

@@ -458,11 +458,12 @@ hipError_t msr_f16_row_error(const float* emb, const float* inv_norm, int64_t n_
 
 // Exact f32 top-k of up to 128 x g.max_groups queries, one pass over the f32 rows per group of 128; see the header of this
 // file.  The passes of all groups are queued back to back; everything between and after them (the two selects over tile
-// maxima, thresholds, bucketing, candidate lists, rescoring, final sort) runs ONCE for all queries of the call.
+// maxima (gemm_kth_kernel: one launch each), bucketing, candidate lists, rescoring, final sort) runs ONCE for all
+// queries of the call.
 // qn: [nq][768] normalised queries.  *gate != 0 when a query overflowed (the caller falls back).  ev (nullable): events
 // around the sample pass (0, 1) and the emit pass (2, 3) of the first group.
 hipError_t msr_gemm_f32_topk(const GemmF32Index& g, const DenseIndex& ix, const float* qn, int nq, int k,
-                             const SelScratch& sel, int32_t* out_doc, float* out_score, int32_t* out_chunk,
+                             int32_t* out_doc, float* out_score, int32_t* out_chunk,
                              int32_t* out_n, int32_t* gate, hipEvent_t* ev, hipStream_t stream) {
     const int G = (nq + 127) / 128;
     if (nq <= 0 || G > g.max_groups || k < 1 || g.n_tiles < 2 * k) return hipErrorInvalidValue;
@@ -488,8 +489,7 @@ hipError_t msr_gemm_f32_topk(const GemmF32Index& g, const DenseIndex& ix, const 
         if (ev && gi == 0 && (err = hipEventRecord(ev[1], stream)) != hipSuccess) return err;
         if ((err = msr_gemm_tmax(g.tmax_t, n_s, 8, 128, g.tmax + (size_t)gi * 128 * g.tmax_stride, g.tmax_stride, stream)) != hipSuccess) return err;
     }
-    if ((err = msr_select_topk(32, g.tmax, n_s, g.tmax_stride, nq, k, sel, g.top_doc, g.top_score, g.top_n, stream)) != hipSuccess) return err;
-    if ((err = msr_gemm_thr(g.top_score, g.top_n, nq, 128 * G, k, margin, g.thr, g.flag, stream)) != hipSuccess) return err;
+    if ((err = msr_gemm_kth(g.tmax, n_s, g.tmax_stride, nq, 128 * G, k, margin, g.thr, g.flag, stream)) != hipSuccess) return err;
     // ---- pass 2 of every group: maxima of all tiles + the entries at or above the threshold (one set of wave buffers) ----
     a.t_first = 0; a.t_stride = 1; a.t_count = g.n_tiles;
     a.wvbuf = (int4*)g.wvbuf; a.wv_cap = g.wv_cap; a.wv_count = g.wv_count;
@@ -501,8 +501,7 @@ hipError_t msr_gemm_f32_topk(const GemmF32Index& g, const DenseIndex& ix, const 
         if (ev && gi == 0 && (err = hipEventRecord(ev[3], stream)) != hipSuccess) return err;
         if ((err = msr_gemm_tmax(g.tmax_t, g.n_tiles, 8, 128, g.tmax + (size_t)gi * 128 * g.tmax_stride, g.tmax_stride, stream)) != hipSuccess) return err;
     }
-    if ((err = msr_select_topk(32, g.tmax, g.n_tiles, g.tmax_stride, nq, k, sel, g.top_doc, g.top_score, g.top_n, stream)) != hipSuccess) return err;
-    if ((err = msr_gemm_thr(g.top_score, g.top_n, nq, 128 * G, k, margin, g.thr2, nullptr, stream)) != hipSuccess) return err;
+    if ((err = msr_gemm_kth(g.tmax, g.n_tiles, g.tmax_stride, nq, 128 * G, k, margin, g.thr2, nullptr, stream)) != hipSuccess) return err;
     if ((err = msr_gemm_bucket(g.wvbuf, g.wv_cap, g.wv_count, grid * 8, g.thr2, g.pairs, g.pair_n, stream)) != hipSuccess) return err;
     gemm_f32_cand_kernel<<<nq, 1024, 0, stream>>>((const int2*)g.pairs, g.pair_n, ix.chunk_doc, g.wv_count, grid * 8, g.wv_cap,
                                                   g.flag, g.cand_doc, g.cand_n, gate);

@@ -170,7 +170,6 @@ struct GemmIndex {
     float* tmax;               // [max_queries][tmax_stride] tile maxima, one row per query (input of the top-k select)
     int32_t tmax_stride;
     float* tmax_t;             // [n_tiles][2][max_queries] as the GEMM epilogue stores them (see GemmArgs::tmax_t)
-    int32_t* top_doc; float* top_score; int32_t* top_n;     // [max_queries][MSR_MAX_K] / [max_queries]
     float* thr; float* thr2;   // [max_queries] emission threshold (sample bound) / final threshold (all tiles)
     int32_t* flag;             // [max_queries] 1: the sample could not bound this query (rerun on the exact path)
     void* wgbuf;               // [n_workgroups * 8 waves][wv_cap] x 16 B emitted (row, query, score, tile)
@@ -182,8 +181,9 @@ struct GemmIndex {
 int msr_gemm_pair_cap();
 // pieces of the candidate pipeline shared with the f32-class GEMM (msr_gemm_f32.hip)
 hipError_t msr_gemm_tmax(const float* tmax_t, int n_j, int parts, int nq_pad, float* out, int out_stride, hipStream_t stream);
-hipError_t msr_gemm_thr(const float* top_score, const int32_t* top_n, int nq, int nq_pad, int k, const float* margin,
-                        float* thr, int32_t* flag, hipStream_t stream);     // margin null: 0
+// thr[q] = k-th largest valid value of row q of tmax ([nq][stride], n values per row) - margin[q]; one launch
+hipError_t msr_gemm_kth(const float* tmax, int n, int stride, int nq, int nq_pad, int k, const float* margin, float* thr,
+                        int32_t* flag, hipStream_t stream);
 hipError_t msr_gemm_bucket(const void* wvbuf, int wv_cap, const int32_t* wv_count, int n_waves, const float* thr2,
                            void* pairs, int32_t* pair_n, hipStream_t stream);
 void msr_bm25_set_dbg(int v);       // honoured by -DMSR_DIAG builds only
@@ -198,7 +198,7 @@ hipError_t msr_batch_margin(const float* qn, int nq, const uint32_t* err_max, fl
 // MSR_SEL_CAP + 1: overflow, rerun that query on the exact path) for msr_batch_rescore.  ev (nullable): 4 events recorded
 // around the sample pass (0, 1) and the emit pass (2, 3).
 hipError_t msr_gemm_candidates(const GemmIndex& g, const DenseIndex& ix, const float* qn, int nq, int k, const float* margin,
-                               const SelScratch& sel, int32_t* cand_doc, int32_t* cand_n, hipEvent_t* ev,
+                               int32_t* cand_doc, int32_t* cand_n, hipEvent_t* ev,
                                hipStream_t stream);
 
 // ---- K2 for 65 .. 128 queries: one streaming pass over the f32 rows, f16 filter + exact f32 finish (msr_gemm_f32.hip) ----
@@ -212,7 +212,6 @@ struct GemmF32Index {
     float* tmax_t;             // [n_tiles][8 waves][128]
     float* tmax;               // [128][tmax_stride]
     int32_t tmax_stride;
-    int32_t* top_doc; float* top_score; int32_t* top_n;     // [128][MSR_MAX_K] / [128]
     float* thr; float* thr2; int32_t* flag;                 // [128]
     void* wvbuf; int32_t wv_cap; int32_t* wv_count;          // [n_cus * 8][wv_cap] x 16 B / [n_cus * 8]
     void* pairs; int32_t* pair_n;                            // [128][4096] x 8 B / [128], zero between calls
@@ -226,7 +225,7 @@ hipError_t msr_pad_inv_norm(const float* inv, int64_t n, int64_t n_pad, float* o
 // entries overflowed (caller: rerun the batch on the sweeps, gated on *gate).  ev (nullable): events around the sample
 // pass (0, 1) and the emit pass (2, 3).
 hipError_t msr_gemm_f32_topk(const GemmF32Index& g, const DenseIndex& ix, const float* qn, int nq, int k,
-                             const SelScratch& sel, int32_t* out_doc, float* out_score, int32_t* out_chunk,
+                             int32_t* out_doc, float* out_score, int32_t* out_chunk,
                              int32_t* out_n, int32_t* gate, hipEvent_t* ev, hipStream_t stream);
 
 // ---- K5: batched bf16 candidate scan finished exactly in f32 (msr_batch.hip) -----------------------
