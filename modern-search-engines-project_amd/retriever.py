@@ -45,9 +45,7 @@ class Retriever:
     def quick_search_batch(self, queries=None, top_k=10, return_unique_docs=True, query_embeddings=None,
                            max_chunks_per_doc=0):
         if not return_unique_docs:
-            raise NotImplementedError("chunk-level results (return_unique_docs=False) are not provided: the "
-                                      "reference's implementation is absent, only the unique-document call "
-                                      "shape survives (search_api.py:87)")
+            return self._chunk_search_batch(queries, top_k, query_embeddings)
         qv = np.stack([self._embed(q, None if query_embeddings is None else query_embeddings[i])
                        for i, q in enumerate(queries if queries is not None else [None] * len(query_embeddings))])
         doc, score, chunk, n = [x.cpu().numpy() for x in self.engine.dense_topk(qv, k=top_k, max_chunks_per_doc=max_chunks_per_doc)]
@@ -60,6 +58,41 @@ class Retriever:
                 i = int(doc[r, j])
                 rows.append({"rank": j + 1, "doc_id": int(self._ids[i]), "score": float(score[r, j]),
                              "best_chunk_id": int(cid[int(chunk[r, j])]),
+                             "url": ix.urls[i] if ix.urls is not None else None,
+                             "title": ix.titles[i] if ix.titles is not None else None})
+            out.append(rows)
+        return out
+
+    def _chunk_search_batch(self, queries, top_k, query_embeddings):
+        """return_unique_docs=False: the top_k CHUNKS by cosine, several per document allowed (the other half of the call
+        shape at search_api.py:87; retriever.py itself is absent from the reference, so the row format is ours: the
+        unique-document row plus `chunk_id`).  Runs the same scan kernels over a view of the corpus in which every chunk is
+        its own document (built once, on first use; the embedding matrix is shared, not copied)."""
+        from .engine import DeviceEngine
+        from .index import CorpusIndex
+        ix = self.index
+        if getattr(self, "_chunk_engine", None) is None:
+            C = int(ix.n_chunks)
+            # the engine's own device tensor when it holds the rows as they are (row-major layout): shared, not copied
+            emb = self.engine._t["emb"] if getattr(self.engine, "scan_layout", 0) == 0 else ix.emb
+            view = CorpusIndex(doc_ids=np.arange(C, dtype=np.int64), doc_off=np.arange(C + 1, dtype=np.int32),
+                               chunk_ids=ix.chunk_ids, emb=emb, total_docs=C)
+            self._chunk_engine = DeviceEngine(view, device=self.engine.device, max_queries=32,
+                                              max_k=self.engine.max_k, rerank_max_docs=0)
+            off = ix.doc_off.cpu().numpy() if hasattr(ix.doc_off, "cpu") else np.asarray(ix.doc_off)
+            self._chunk_doc_off = off.astype(np.int64)
+        qv = np.stack([self._embed(q, None if query_embeddings is None else query_embeddings[i])
+                       for i, q in enumerate(queries if queries is not None else [None] * len(query_embeddings))])
+        row, score, _, n = self._chunk_engine.dense_topk(qv, k=top_k, want_chunk=False)
+        row, score, n = row.cpu().numpy(), score.cpu().numpy(), n.cpu().numpy()
+        cid = ix.chunk_ids.cpu().numpy() if hasattr(ix.chunk_ids, "cpu") else np.asarray(ix.chunk_ids)
+        out = []
+        for r in range(len(qv)):
+            rows = []
+            for j in range(int(n[r])):
+                c = int(row[r, j])
+                i = int(np.searchsorted(self._chunk_doc_off, c, side="right") - 1)       # the chunk's document
+                rows.append({"rank": j + 1, "doc_id": int(self._ids[i]), "chunk_id": int(cid[c]), "score": float(score[r, j]),
                              "url": ix.urls[i] if ix.urls is not None else None,
                              "title": ix.titles[i] if ix.titles is not None else None})
             out.append(rows)

@@ -616,6 +616,19 @@ def test_retriever_two_stage_matches_oracle_chain(mods):
     qs = rt.quick_search(query_embedding=qvec[0].numpy(), top_k=10)
     oi, os_, oa = mods["dense_ref"].quick_search(ix.emb.numpy(), ix.doc_off.numpy(), qvec[0].numpy(), 10)
     assert [r["doc_id"] for r in qs] == [int(ids[i]) for i in oi]
+    # chunk-level results (return_unique_docs=False): the top chunks by cosine, several per document allowed
+    E, off = ix.emb.numpy(), ix.doc_off.numpy()
+    qn = qvec[0].numpy() / np.linalg.norm(qvec[0].numpy())
+    cos = (E @ qn) / np.linalg.norm(E, axis=1)
+    order = np.lexsort((np.arange(len(cos)), -cos))[:10]
+    cs = rt.quick_search(query_embedding=qvec[0].numpy(), top_k=10, return_unique_docs=False)
+    assert len(cs) == 10 and [r["rank"] for r in cs] == list(range(1, 11))
+    np.testing.assert_allclose([r["score"] for r in cs], cos[order], rtol=0, atol=1e-5)
+    cid = ix.chunk_ids.numpy()
+    for r, c in zip(cs, order):
+        if abs(r["score"] - cos[c]) < 1e-7:                  # (ties within rounding may swap neighbours)
+            assert r["chunk_id"] == int(cid[c]) and r["doc_id"] == int(ids[np.searchsorted(off, c, side="right") - 1])
+    rt._chunk_engine.close()
     rt.engine.close()
 
 
