@@ -3,8 +3,8 @@
 // Replaces the per-query SQL fetch + Python grouping + scoring loop of the reference
 // (indexer/bm25_indexer.py:434-481).  The dense doc index is cut into tiles of TILE documents.  A workgroup owns a span
 // of up to 8 consecutive tiles and FOUR queries: its four waves score one query each, every wave with its own float64
-// accumulators in LDS, sharing the current tile's length norms k1 (1 - b + b dl / avgdl) (computed once per workgroup
-// and tile, also in LDS).  A wave
+// accumulators in LDS, sharing the current tile's length norms k1 (1 - b + b dl / avgdl) (evaluated once per document
+// at bind time, bm25_dnorm_kernel; staged in LDS per tile).  A wave
 //   1. builds its query's PLAN once for all tiles of the workgroup, lane-parallel (lane j = term j): offsets, idf, query
 //      frequency; for long lists the skip-table row segment (where each of the workgroup's tiles starts inside the list);
 //      for lists of <= 64 postings the whole list; for the lists in between ONE round of 64 probes (a covering range for
@@ -72,9 +72,7 @@ __global__ __launch_bounds__(BM25_THREADS) __attribute__((amdgpu_waves_per_eu(4,
     const int tile0 = (int)blockIdx.y * tpw;                 // this workgroup's tiles: tile0 .. tile0 + n_my - 1
     const int n_my = tile0 + tpw <= ix.n_tiles ? tpw : ix.n_tiles - tile0;
     double* acc = acc_all[wave];
-    const double k1 = ix.k1, b = ix.b, avgdl = ix.avgdl;
-    const double k1p1 = k1 + 1.0;                    // self.k1 + 1
-    const double omb = 1.0 - b;                      // 1 - self.b
+    const double k1p1 = ix.k1 + 1.0;                 // self.k1 + 1
     // ---- 1. the query's plan, ONCE for all tiles of the workgroup; lane j = term j ----
     int nt = 0;
     int64_t s_v = 0;                                 // long list: its first posting
@@ -159,12 +157,13 @@ __global__ __launch_bounds__(BM25_THREADS) __attribute__((amdgpu_waves_per_eu(4,
         const int64_t lo = (int64_t)tile * BM25_TILE;
         const int64_t hi = lo + BM25_TILE < ix.n_docs ? lo + BM25_TILE : ix.n_docs;
         const int n = (int)(hi - lo);
-        // the tile's document lengths: issued first, parked in registers
-        int32_t dl_reg[BM25_TILE / BM25_THREADS];
-#pragma unroll
-        for (int u = 0; u < BM25_TILE / BM25_THREADS; ++u) {
-            const int i = tid + u * BM25_THREADS;
-            dl_reg[u] = i < n ? ix.doc_len[lo + i] : 0;
+        // the tile's length norms k1 (1 - b + b dl / avgdl) (computed at bind time with this very expression): issued first,
+        // parked in registers; thread t holds documents 4 t .. 4 t + 3 of the tile (the array is padded to whole tiles)
+        double dn_reg[BM25_TILE / BM25_THREADS];
+        {
+            const double2* p = (const double2*)(ix.dnorm + lo) + 2 * tid;
+            const double2 x = p[0], y = p[1];
+            dn_reg[0] = x.x; dn_reg[1] = x.y; dn_reg[2] = y.x; dn_reg[3] = y.y;
         }
         // this tile's slice of every list (no memory access: the plan holds everything)
         int64_t ps_v = r0_v, pe_v = r1_v;
@@ -196,12 +195,17 @@ __global__ __launch_bounds__(BM25_THREADS) __attribute__((amdgpu_waves_per_eu(4,
             }
         }
         // accumulators of this wave's query; the length norms of the tile (shared by the four waves)
+        {
+            const double un = __longlong_as_double((long long)UNTOUCHED);
 #pragma unroll
-        for (int u = 0; u < BM25_TILE / 64; ++u) acc[lane + 64 * u] = __longlong_as_double((long long)UNTOUCHED);
+            for (int u = 0; u < BM25_TILE / 128; ++u) ((double2*)acc)[lane + 64 * u] = make_double2(un, un);
+        }
         __syncthreads();                                         // every wave is done with the previous tile's norms
-#pragma unroll
-        for (int u = 0; u < BM25_TILE / BM25_THREADS; ++u)
-            dn[tid + u * BM25_THREADS] = k1 * (omb + (b * (double)dl_reg[u]) / avgdl);
+        {
+            double2* p = (double2*)dn + 2 * tid;
+            p[0] = make_double2(dn_reg[0], dn_reg[1]);
+            p[1] = make_double2(dn_reg[2], dn_reg[3]);
+        }
         __syncthreads();
         // U postings of ONE term per lane: the reference's arithmetic, operation by operation (:472-478), written so that the
         // U chains (a float64 division is 11 dependent instructions) are independent and interleave: nothing is branched
@@ -268,14 +272,16 @@ __global__ __launch_bounds__(BM25_THREADS) __attribute__((amdgpu_waves_per_eu(4,
         // ---- 4. the tile's candidates (touched by a posting AND score >= min_score, :461,480) as (score, doc) pairs
         //         appended to the query's list: one reservation per wave.  Most documents of a tile are not candidates, so
         //         this replaces an 8 B/document dense row by 12 B per candidate. ----
+        // lane l looks at documents 2 l + 128 u and 2 l + 128 u + 1 (one 16-byte LDS read per round)
         int total = 0;
-        unsigned long long flags[BM25_TILE / 64];
+        unsigned long long f0[BM25_TILE / 128], f1[BM25_TILE / 128];
 #pragma unroll
-        for (int u = 0; u < BM25_TILE / 64; ++u) {
-            const int i = lane + 64 * u;
-            const double a = acc[i];
-            flags[u] = __ballot(i < n && (uint64_t)__double_as_longlong(a) != UNTOUCHED && a >= min_score);
-            total += __popcll(flags[u]);
+        for (int u = 0; u < BM25_TILE / 128; ++u) {
+            const int i = 2 * lane + 128 * u;
+            const double2 a = ((const double2*)acc)[lane + 64 * u];
+            f0[u] = __ballot(i < n && (uint64_t)__double_as_longlong(a.x) != UNTOUCHED && a.x >= min_score);
+            f1[u] = __ballot(i + 1 < n && (uint64_t)__double_as_longlong(a.y) != UNTOUCHED && a.y >= min_score);
+            total += __popcll(f0[u]) + __popcll(f1[u]);
         }
         if (total == 0) continue;                                // wave-uniform
         int base = 0;
@@ -283,15 +289,22 @@ __global__ __launch_bounds__(BM25_THREADS) __attribute__((amdgpu_waves_per_eu(4,
         base = __builtin_amdgcn_readfirstlane(base);
         const int64_t o = (int64_t)q * ix.n_docs + base;
         int run = 0;
+        const unsigned long long below = (1ull << lane) - 1;
 #pragma unroll
-        for (int u = 0; u < BM25_TILE / 64; ++u) {
-            if ((flags[u] >> lane) & 1) {
-                const int i = lane + 64 * u;
-                const int w = run + __popcll(flags[u] & ((1ull << lane) - 1));
+        for (int u = 0; u < BM25_TILE / 128; ++u) {
+            const int i = 2 * lane + 128 * u;
+            if ((f0[u] >> lane) & 1) {
+                const int w = run + __popcll(f0[u] & below);
                 cand_score[o + w] = acc[i];
                 cand_doc[o + w] = (int32_t)(lo + i);
             }
-            run += __popcll(flags[u]);
+            run += __popcll(f0[u]);
+            if ((f1[u] >> lane) & 1) {
+                const int w = run + __popcll(f1[u] & below);
+                cand_score[o + w] = acc[i + 1];
+                cand_doc[o + w] = (int32_t)(lo + i + 1);
+            }
+            run += __popcll(f1[u]);
         }
     }
 }
@@ -353,6 +366,16 @@ __global__ __launch_bounds__(256) void interleave_postings_kernel(const int32_t*
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = make_int2(post_doc[i], post_tf[i]);
 }
 
+// dnorm[d] = k1 * (1 - b + b * doc_length / avg_doc_length) for every document, padded to whole tiles (1.0 beyond n_docs):
+// the scoring kernel's length norm, evaluated ONCE with the expression the reference evaluates per posting (:474)
+__global__ __launch_bounds__(256) void bm25_dnorm_kernel(const int32_t* __restrict__ doc_len, int64_t n_docs, int64_t n_pad,
+                                                          double k1, double b, double avgdl, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pad) return;
+    const double omb = 1.0 - b;
+    out[i] = i < n_docs ? k1 * (omb + (b * (double)doc_len[i]) / avgdl) : 1.0;
+}
+
 int g_bm25_dbg = 0;
 
 }  // namespace
@@ -368,6 +391,13 @@ hipError_t msr_bm25_build_skip(const Bm25Index& ix, const int32_t* heavy_terms, 
 hipError_t msr_bm25_interleave(const int32_t* post_doc, const int32_t* post_tf, int64_t n, void* out, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     interleave_postings_kernel<<<4096, 256, 0, stream>>>(post_doc, post_tf, n, (int2*)out);
+    return hipGetLastError();
+}
+
+hipError_t msr_bm25_dnorm(const int32_t* doc_len, int64_t n_docs, int64_t n_pad, double k1, double b, double avgdl, double* out,
+                          hipStream_t stream) {
+    if (n_pad <= 0) return hipSuccess;
+    bm25_dnorm_kernel<<<(unsigned)((n_pad + 255) / 256), 256, 0, stream>>>(doc_len, n_docs, n_pad, k1, b, avgdl, out);
     return hipGetLastError();
 }
 

@@ -37,6 +37,7 @@ struct msr_engine {
     size_t score_rows_bytes = 0;
     int32_t* bm_heavy_id = nullptr;    // skip table of the BM25 stage (see Bm25Index)
     void* bm_post = nullptr;           // interleaved {doc, tf} copy of the postings (see Bm25Index)
+    double* bm_dnorm = nullptr;        // per-document length norms (see Bm25Index)
     uint32_t* bm_tile_off = nullptr;
     int32_t* bm_cand_doc = nullptr;    // max_queries rows of n_docs i32: document of each BM25 candidate
     int32_t* bm_cand_n = nullptr;      // [max_queries] candidates per query (zero between calls)
@@ -211,7 +212,7 @@ extern "C" int msr_create(const msr_config* cfg, msr_engine** out) {
 extern "C" int msr_destroy(msr_engine* e) {
     if (!e) return MSR_OK;
     free_dev(e->chunk_doc); free_dev(e->emb_presplit); free_dev(e->row_meta); free_dev(e->inv_norm_own); free_dev(e->span_doc); free_dev(e->wspan_doc); free_dev(e->wspan12_doc); free_dev(e->qn); free_dev(e->qimg); free_dev(e->emb_bf16);
-    free_dev(e->score_rows); free_dev(e->bm_heavy_id); free_dev(e->bm_post); free_dev(e->bm_tile_off); free_dev(e->bm_cand_doc); free_dev(e->bm_cand_n); free_dev(e->sel.hist); free_dev(e->sel.state); free_dev(e->sel.cand_hi);
+    free_dev(e->score_rows); free_dev(e->bm_heavy_id); free_dev(e->bm_post); free_dev(e->bm_dnorm); free_dev(e->bm_tile_off); free_dev(e->bm_cand_doc); free_dev(e->bm_cand_n); free_dev(e->sel.hist); free_dev(e->sel.state); free_dev(e->sel.cand_hi);
     free_dev(e->sel.cand_lo); free_dev(e->sel.cand_n); free_dev(e->rerank_cos); free_dev(e->rerank_meta);
     free_dev(e->bt_top_doc); free_dev(e->bt_top_score); free_dev(e->bt_top_n); free_dev(e->bt_cand_doc);
     free_dev(e->bt_cand_score); free_dev(e->bt_cand_chunk); free_dev(e->bt_cand_n);
@@ -270,7 +271,7 @@ extern "C" int msr_bind_postings(msr_engine* e, const int64_t* term_off, int64_t
 
     }
     Bm25Index cand{term_off, post_doc, post_tf, doc_len, idf, n_terms, n_postings, n_docs, (double)avgdl, k1, b,
-                   nullptr, nullptr, (int32_t)((n_docs + MSR_BM25_TILE - 1) / MSR_BM25_TILE), nullptr};
+                   nullptr, nullptr, (int32_t)((n_docs + MSR_BM25_TILE - 1) / MSR_BM25_TILE), nullptr, nullptr};
     // the scoring kernel indexes LDS with (post_doc - tile start): validate the CSR once, on the device
     hipStream_t st = (hipStream_t)stream;
     int32_t h_flag = 0;
@@ -327,6 +328,14 @@ extern "C" int msr_bind_postings(msr_engine* e, const int64_t* term_off, int64_t
         HIP_TRY(e, msr_bm25_interleave(post_doc, post_tf, n_postings, e->bm_post, st));
     }
     cand.post = (const int2*)e->bm_post;
+    free_dev(e->bm_dnorm); e->bm_dnorm = nullptr;
+    {
+        const int64_t n_pad = (int64_t)cand.n_tiles * MSR_BM25_TILE;
+        hipError_t herr = hipMalloc((void**)&e->bm_dnorm, (size_t)n_pad * sizeof(double));
+        if (herr != hipSuccess) return fail(e, MSR_ERR_NOMEM, "length norms: %s", hipGetErrorString(herr));
+        HIP_TRY(e, msr_bm25_dnorm(doc_len, n_docs, n_pad, k1, b, (double)avgdl, e->bm_dnorm, st));
+    }
+    cand.dnorm = e->bm_dnorm;
     e->bm25 = cand;
     e->have_postings = true;
     return MSR_OK;

@@ -64,7 +64,10 @@ struct Bm25Index {
     const uint32_t* tile_off;  // [n_heavy][n_tiles + 1], relative to term_off[t]
     int32_t n_tiles;
     const int2* post;          // [n_postings] {doc, tf}: engine-owned interleaved copy, what the scoring kernel streams
+    const double* dnorm;       // [n_tiles * TILE] k1 (1 - b + b dl / avgdl) per document (engine-owned, built at bind)
 };
+hipError_t msr_bm25_dnorm(const int32_t* doc_len, int64_t n_docs, int64_t n_pad, double k1, double b, double avgdl, double* out,
+                          hipStream_t stream);
 hipError_t msr_bm25_interleave(const int32_t* post_doc, const int32_t* post_tf, int64_t n, void* out, hipStream_t stream);
 constexpr int MSR_BM25_TILE = 1024;          // documents per BM25 tile
 constexpr int MSR_BM25_HEAVY_DF = 2048;      // posting lists at least this long get a skip-table row
