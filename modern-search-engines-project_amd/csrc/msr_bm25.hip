@@ -34,6 +34,9 @@ namespace {
 constexpr int BM25_TILE = MSR_BM25_TILE;
 constexpr int BM25_THREADS = 256;
 constexpr int BM25_QPW = BM25_THREADS / 64;                   // queries per workgroup (one per wave)
+#ifndef BM25_WPE
+#define BM25_WPE 4                                             // waves per SIMD the register budget is cut for
+#endif
 constexpr int BM25_TPW = 8;                                   // at most this many consecutive tiles per workgroup
 constexpr int BM25_MAX_TERMS = 64;                            // MSR_MAX_QUERY_TERMS: one lane per term
 constexpr uint64_t UNTOUCHED = 0x7FF8DEADBEEF0001ull;   // a quiet-NaN payload no computation produces
@@ -47,7 +50,7 @@ __device__ __forceinline__ double lane_f64(double v, int j) {
     return __longlong_as_double(lane_i64(__double_as_longlong(v), j));
 }
 
-__global__ __launch_bounds__(BM25_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void bm25_taat_kernel(Bm25Index ix,
+__global__ __launch_bounds__(BM25_THREADS) __attribute__((amdgpu_waves_per_eu(BM25_WPE, BM25_WPE))) void bm25_taat_kernel(Bm25Index ix,
                                                                   const int32_t* __restrict__ q_term_off,
                                                                   const int32_t* __restrict__ q_terms,
                                                                   const int32_t* __restrict__ q_qtf,
@@ -159,12 +162,10 @@ __global__ __launch_bounds__(BM25_THREADS) __attribute__((amdgpu_waves_per_eu(4,
         const int n = (int)(hi - lo);
         // the tile's length norms k1 (1 - b + b dl / avgdl) (computed at bind time with this very expression): issued first,
         // parked in registers; thread t holds documents 4 t .. 4 t + 3 of the tile (the array is padded to whole tiles)
-        double dn_reg[BM25_TILE / BM25_THREADS];
-        {
-            const double2* p = (const double2*)(ix.dnorm + lo) + 2 * tid;
-            const double2 x = p[0], y = p[1];
-            dn_reg[0] = x.x; dn_reg[1] = x.y; dn_reg[2] = y.x; dn_reg[3] = y.y;
-        }
+        constexpr int DPT2 = BM25_TILE / BM25_THREADS / 2;       // 16-byte pieces per thread
+        double2 dn_reg[DPT2];
+#pragma unroll
+        for (int u = 0; u < DPT2; ++u) dn_reg[u] = ((const double2*)(ix.dnorm + lo))[DPT2 * tid + u];
         // this tile's slice of every list (no memory access: the plan holds everything)
         int64_t ps_v = r0_v, pe_v = r1_v;
         if (heavy) {
@@ -201,11 +202,8 @@ __global__ __launch_bounds__(BM25_THREADS) __attribute__((amdgpu_waves_per_eu(4,
             for (int u = 0; u < BM25_TILE / 128; ++u) ((double2*)acc)[lane + 64 * u] = make_double2(un, un);
         }
         __syncthreads();                                         // every wave is done with the previous tile's norms
-        {
-            double2* p = (double2*)dn + 2 * tid;
-            p[0] = make_double2(dn_reg[0], dn_reg[1]);
-            p[1] = make_double2(dn_reg[2], dn_reg[3]);
-        }
+#pragma unroll
+        for (int u = 0; u < DPT2; ++u) ((double2*)dn)[DPT2 * tid + u] = dn_reg[u];
         __syncthreads();
         // U postings of ONE term per lane: the reference's arithmetic, operation by operation (:472-478), written so that the
         // U chains (a float64 division is 11 dependent instructions) are independent and interleave: nothing is branched
@@ -419,7 +417,9 @@ hipError_t msr_bm25_scores(const Bm25Index& ix, const int32_t* q_term_off, const
     int tpw = groups >= 16 ? 8 : groups >= 8 ? 4 : groups >= 4 ? 2 : 1;
     while (tpw > 1 && (int64_t)groups * ((ix.n_tiles + tpw - 1) / tpw) < 2048) tpw >>= 1;
     dim3 grid((unsigned)groups, (unsigned)((ix.n_tiles + tpw - 1) / tpw));
-    bm25_taat_kernel<<<grid, BM25_THREADS, 0, stream>>>(ix, q_term_off, q_terms, q_qtf, q_first, nq, min_score, tpw, cand_score,
+    // (diagnostic build: bit 6 of the knock-out mask pads every workgroup with 41 KB of unused LDS -> 2 instead of 4 per CU)
+    const size_t pad_lds = (g_bm25_dbg & 64) ? 41 * 1024 : 0;
+    bm25_taat_kernel<<<grid, BM25_THREADS, pad_lds, stream>>>(ix, q_term_off, q_terms, q_qtf, q_first, nq, min_score, tpw, cand_score,
                                                         cand_doc, cand_n, g_bm25_dbg);
     return hipGetLastError();
 }
