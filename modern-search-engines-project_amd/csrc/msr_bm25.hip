@@ -35,7 +35,7 @@ constexpr int BM25_TILE = MSR_BM25_TILE;
 constexpr int BM25_THREADS = 256;
 constexpr int BM25_QPW = BM25_THREADS / 64;                   // queries per workgroup (one per wave)
 #ifndef BM25_WPE
-#define BM25_WPE 4                                             // waves per SIMD the register budget is cut for
+#define BM25_WPE 3                                             // waves per SIMD the register budget is cut for
 #endif
 constexpr int BM25_TPW = 8;                                   // at most this many consecutive tiles per workgroup
 constexpr int BM25_MAX_TERMS = 64;                            // MSR_MAX_QUERY_TERMS: one lane per term
@@ -155,46 +155,54 @@ __global__ __launch_bounds__(BM25_THREADS) __attribute__((amdgpu_waves_per_eu(BM
             }
         }
     }
-    for (int tt = 0; tt < n_my; ++tt) {
-        const int tile = tile0 + tt;
-        const int64_t lo = (int64_t)tile * BM25_TILE;
-        const int64_t hi = lo + BM25_TILE < ix.n_docs ? lo + BM25_TILE : ix.n_docs;
-        const int n = (int)(hi - lo);
-        // the tile's length norms k1 (1 - b + b dl / avgdl) (computed at bind time with this very expression): issued first,
-        // parked in registers; thread t holds documents 4 t .. 4 t + 3 of the tile (the array is padded to whole tiles)
-        constexpr int DPT2 = BM25_TILE / BM25_THREADS / 2;       // 16-byte pieces per thread
-        double2 dn_reg[DPT2];
+    // Two tiles are in flight per wave: the loads of tile t + 1 (length norms, the first postings of every slice) are issued
+    // BEFORE tile t is accumulated and emitted, into a second register set -- the pass is latency-bound (its time follows
+    // the number of resident waves), so every wave hides its own memory latency behind its own arithmetic.
+    constexpr int TPRE = 5, PFC = 3;
+    constexpr int DPT2 = BM25_TILE / BM25_THREADS / 2;       // 16-byte pieces of the length norms per thread
+    struct TileRegs {
+        int32_t pd[TPRE][PFC], tf[TPRE][PFC];                // the first PFC x 64 postings of the first TPRE slices
+        double2 dn[DPT2];                                    // length norms: thread t holds documents 2 DPT2 t .. of the tile
+        int64_t ps, pe;                                      // lane j: this tile's slice of term j
+    };
+    auto issue = [&](int tt, TileRegs& r) {
+        const int64_t lo = (int64_t)(tile0 + tt) * BM25_TILE;
 #pragma unroll
-        for (int u = 0; u < DPT2; ++u) dn_reg[u] = ((const double2*)(ix.dnorm + lo))[DPT2 * tid + u];
-        // this tile's slice of every list (no memory access: the plan holds everything)
-        int64_t ps_v = r0_v, pe_v = r1_v;
+        for (int u = 0; u < DPT2; ++u) r.dn[u] = ((const double2*)(ix.dnorm + lo))[DPT2 * tid + u];      // (padded to whole tiles)
+        // the tile's slice of every list (no memory access: the plan holds everything)
+        r.ps = r0_v; r.pe = r1_v;
         if (heavy) {
             uint32_t o0 = 0, o1 = 0;
 #pragma unroll
             for (int i = 0; i < BM25_TPW; ++i)
                 if (i == tt) { o0 = off_v[i]; o1 = off_v[i + 1]; }
-            ps_v = s_v + o0;
-            pe_v = s_v + o1;
+            r.ps = s_v + o0;
+            r.pe = s_v + o1;
         }
-        // ---- 3. prefetch: the first PFC x 64 postings of the first TPRE slices (for nearly all terms: the whole slice), all
-        //         issued before anything is accumulated -- one memory round trip for the postings of all terms ----
-        constexpr int TPRE = 5, PFC = 3;
-        int32_t pd0[TPRE][PFC], ptf0[TPRE][PFC];
+        // the first PFC x 64 postings of the first TPRE slices (for nearly all terms: the whole slice): one memory round
+        // trip for the postings of all terms
 #pragma unroll
         for (int j = 0; j < TPRE; ++j) {
 #pragma unroll
-            for (int c = 0; c < PFC; ++c) { pd0[j][c] = -1; ptf0[j][c] = 0; }
+            for (int c = 0; c < PFC; ++c) { r.pd[j][c] = -1; r.tf[j][c] = 0; }
             if (j < nt && !(dbg & 8)) {                          // wave-uniform
-                const int64_t ps = lane_i64(ps_v, j), pe = lane_i64(pe_v, j);
+                const int64_t ps = lane_i64(r.ps, j), pe = lane_i64(r.pe, j);
 #pragma unroll
                 for (int c = 0; c < PFC; ++c) {
                     if (ps + 64 * c < pe) {                      // wave-uniform: no instruction for chunks past the slice
                         const int64_t i = ps + 64 * c + lane;
-                        if (i < pe) { const int2 p = ix.post[i]; pd0[j][c] = p.x; ptf0[j][c] = p.y; }
+                        if (i < pe) { const int2 p = ix.post[i]; r.pd[j][c] = p.x; r.tf[j][c] = p.y; }
                     }
                 }
             }
         }
+    };
+    auto process = [&](int tt, TileRegs& r) {
+        const int tile = tile0 + tt;
+        const int64_t lo = (int64_t)tile * BM25_TILE;
+        const int64_t hi = lo + BM25_TILE < ix.n_docs ? lo + BM25_TILE : ix.n_docs;
+        const int n = (int)(hi - lo);
+        const int64_t ps_v = r.ps, pe_v = r.pe;
         // accumulators of this wave's query; the length norms of the tile (shared by the four waves)
         {
             const double un = __longlong_as_double((long long)UNTOUCHED);
@@ -203,7 +211,7 @@ __global__ __launch_bounds__(BM25_THREADS) __attribute__((amdgpu_waves_per_eu(BM
         }
         __syncthreads();                                         // every wave is done with the previous tile's norms
 #pragma unroll
-        for (int u = 0; u < DPT2; ++u) ((double2*)dn)[DPT2 * tid + u] = dn_reg[u];
+        for (int u = 0; u < DPT2; ++u) ((double2*)dn)[DPT2 * tid + u] = r.dn[u];
         __syncthreads();
         // U postings of ONE term per lane: the reference's arithmetic, operation by operation (:472-478), written so that the
         // U chains (a float64 division is 11 dependent instructions) are independent and interleave: nothing is branched
@@ -258,7 +266,7 @@ __global__ __launch_bounds__(BM25_THREADS) __attribute__((amdgpu_waves_per_eu(BM
             const int64_t ps = lane_i64(ps_v, j), pe = lane_i64(pe_v, j);
             if (pe <= ps) continue;
             const double idf = lane_f64(idf_v, j), qtf = lane_f64(qtf_v, j);
-            apply(std::integral_constant<int, PFC>{}, pd0[j], ptf0[j], idf, qtf);     // (chunks past the slice hold doc -1)
+            apply(std::integral_constant<int, PFC>{}, r.pd[j], r.tf[j], idf, qtf);     // (chunks past the slice hold doc -1)
             if (pe - ps > 64 * PFC) stream(ps + 64 * PFC, pe, idf, qtf);
         }
         for (int j = TPRE; j < nt; ++j) {
@@ -266,7 +274,7 @@ __global__ __launch_bounds__(BM25_THREADS) __attribute__((amdgpu_waves_per_eu(BM
             if (pe <= ps) continue;
             stream(ps, pe, lane_f64(idf_v, j), lane_f64(qtf_v, j));
         }
-        if (!live || (dbg & 16)) continue;                       // (wave-uniform; the barriers are at the top of the loop)
+        if (!live || (dbg & 16)) return;                       // (wave-uniform; the barriers are at the top of the loop)
         // ---- 4. the tile's candidates (touched by a posting AND score >= min_score, :461,480) as (score, doc) pairs
         //         appended to the query's list: one reservation per wave.  Most documents of a tile are not candidates, so
         //         this replaces an 8 B/document dense row by 12 B per candidate. ----
@@ -281,7 +289,7 @@ __global__ __launch_bounds__(BM25_THREADS) __attribute__((amdgpu_waves_per_eu(BM
             f1[u] = __ballot(i + 1 < n && (uint64_t)__double_as_longlong(a.y) != UNTOUCHED && a.y >= min_score);
             total += __popcll(f0[u]) + __popcll(f1[u]);
         }
-        if (total == 0) continue;                                // wave-uniform
+        if (total == 0) return;                                // wave-uniform
         int base = 0;
         if (lane == 0) base = atomicAdd(&cand_n[q], total);
         base = __builtin_amdgcn_readfirstlane(base);
@@ -303,6 +311,16 @@ __global__ __launch_bounds__(BM25_THREADS) __attribute__((amdgpu_waves_per_eu(BM
                 cand_doc[o + w] = (int32_t)(lo + i + 1);
             }
             run += __popcll(f1[u]);
+        }
+    };
+    TileRegs ra, rb;
+    issue(0, ra);
+    for (int tt = 0; tt < n_my; tt += 2) {
+        if (tt + 1 < n_my) issue(tt + 1, rb);
+        process(tt, ra);
+        if (tt + 1 < n_my) {
+            if (tt + 2 < n_my) issue(tt + 2, ra);
+            process(tt + 1, rb);
         }
     }
 }
