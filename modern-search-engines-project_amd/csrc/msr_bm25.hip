@@ -9,7 +9,8 @@
 //      frequency; for long lists the skip-table row segment (where each of the workgroup's tiles starts inside the list);
 //      for lists of <= 64 postings the whole list; for the lists in between ONE round of 64 probes (a covering range for
 //      the workgroup's document span; postings outside a tile are masked when applied);
-//   2. per tile: derives every term's slice from the plan (no memory access),
+//   2. per tile: derives every term's slice from the plan (no memory access) -- one tile AHEAD of the tile it is
+//      accumulating (two register sets: the kernel is latency-bound, a wave hides its own loads behind its arithmetic),
 //   3. fetches the first PFC x 64 postings of the first TPRE slices side by side, then accumulates IN QUERY ORDER.  A
 //      wave's LDS operations execute in order, so the float64 summation order of every document equals the reference's
 //      (:466-478) WITHOUT a barrier between terms; a document occurs at most once per posting list (PRIMARY KEY
