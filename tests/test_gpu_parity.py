@@ -364,6 +364,36 @@ def test_dense_massive_ties(mods):
     eng.close()
 
 
+def test_dense_streaming_pass_overflow_takes_the_gated_sweeps(mods):
+    """More than 64 queries on a corpus the streaming pass accepts, one of them with a tie group of 9000 documents (more
+    entries than a query's candidate list holds): the pass raises its device-side gate and the sweeps queued behind it
+    redo the batch -- the call returns what the sweeps return (bit for bit what two <= 64-query calls give), with the tie
+    rule intact; a batch without such a query, on the same engine afterwards, takes the pass again."""
+    rng = np.random.default_rng(8)
+    n = 60_000
+    E = rng.standard_normal((n, 768)).astype(np.float32)
+    E /= np.linalg.norm(E, axis=1, keepdims=True)
+    v = rng.standard_normal(768).astype(np.float32); v /= np.linalg.norm(v)
+    tied = np.sort(rng.choice(n, size=9000, replace=False))
+    E[tied] = v
+    ix = mods["CorpusIndex"](doc_ids=np.arange(n, dtype=np.int64), doc_off=np.arange(n + 1, dtype=np.int32),
+                             chunk_ids=np.arange(n, dtype=np.int64), emb=E, total_docs=n)
+    eng = mods["DeviceEngine"](ix, max_queries=128, max_k=100, rerank_max_docs=0)
+    assert eng.scan_width() == 128
+    q = rng.standard_normal((100, 768)).astype(np.float32)
+    q[7] = 2.5 * v
+    got = [x.cpu().numpy() for x in eng.dense_topk(q, k=100)]
+    ref = [np.concatenate(p) for p in zip(*[[x.cpu().numpy() for x in eng.dense_topk(q[s:s + 50], k=100)] for s in (0, 50)])]
+    assert all(np.array_equal(a, b) for a, b in zip(got, ref))
+    assert got[3][7] == 100 and got[0][7].tolist() == tied[:100].tolist() and np.all(np.abs(got[1][7] - 1.0) < 1e-5)
+    q[7] = rng.standard_normal(768).astype(np.float32)                        # no tie group any more: the pass itself answers
+    again = [x.cpu().numpy() for x in eng.dense_topk(q, k=100)]
+    ref2 = [np.concatenate(p) for p in zip(*[[x.cpu().numpy() for x in eng.dense_topk(q[s:s + 50], k=100)] for s in (0, 50)])]
+    assert np.array_equal(again[3], ref2[3]) and np.abs(again[1] - ref2[1]).max() <= 1e-5
+    assert (again[0] == ref2[0]).mean() > 0.99
+    eng.close()
+
+
 def test_dense_cosine_golden(mods):
     """One chunk per document: the engine's scores are the reference's cosine_similarity values."""
     z = np.load(os.path.join(G, "cosine.npz"))
