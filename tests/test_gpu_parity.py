@@ -394,6 +394,52 @@ def test_dense_streaming_pass_overflow_takes_the_gated_sweeps(mods):
     eng.close()
 
 
+def test_streaming_pass_vs_oracle_and_query_groups(mods):
+    """msr_dense_topk with more than 64 queries on a corpus the streaming pass accepts (60 k documents of 0..8 chunks, one of
+    200; ~950 row tiles): (a) against the ORACLE for a few queries of a 100-query call -- an exact hit, near-duplicates of
+    rows, random ones, a non-unit row in the corpus -- at k = 100 and k = 10; (b) an engine with room for 4 groups of 128
+    queries per call (700 queries = 512 + 188: passes queued back to back, one finish) returns bit for bit what one group
+    per call returns; (c) a batch with a ZERO query (every cosine 0: a tie group of the whole corpus) overflows the pass and
+    comes back from the gated sweeps -- still the oracle's answer."""
+    rng = np.random.default_rng(91)
+    n_docs = 60000
+    n = rng.integers(0, 9, size=n_docs)
+    n[5] = 200
+    doc_off = np.zeros(n_docs + 1, np.int64); doc_off[1:] = np.cumsum(n)
+    C = int(doc_off[-1])
+    emb_t = torch.randn((C, 768), generator=torch.Generator().manual_seed(4))
+    emb_t /= emb_t.norm(dim=1, keepdim=True)
+    emb_t[321] *= 1.6
+    emb = emb_t.numpy()
+    ix = mods["CorpusIndex"](doc_ids=np.arange(n_docs, dtype=np.int64), doc_off=doc_off.astype(np.int32),
+                             chunk_ids=np.arange(C, dtype=np.int64), emb=emb, total_docs=n_docs)
+    eng = mods["DeviceEngine"](ix, max_queries=64, max_k=100, rerank_max_docs=0)
+    assert eng.scan_width() == 128
+    q = rng.standard_normal((700, 768)).astype(np.float32) * rng.uniform(0.5, 12, size=(700, 1)).astype(np.float32)
+    q[0] = emb[4567] * 3.0
+    q[2:40] = emb[rng.integers(0, C, 38)] + 0.4 * q[2:40] / np.linalg.norm(q[2:40], axis=1, keepdims=True)
+    pick = [0, 1, 2, 3, 40, 99]
+    for k in (100, 10):
+        got = eng.dense_topk(q[:100], k=k)
+        _check_dense(mods, eng, doc_off, emb, q[pick], k, 0, [x[pick] for x in got])
+    # the pass returns exact f32 cosines: they differ from the sweeps' f16x2-split scores in the last bits (a sweep-served
+    # answer would be bit-equal to a 50-query call), so this also shows that the pass itself answered
+    sweep = eng.dense_topk(q[:50], k=100)[1].cpu().numpy()
+    assert not np.array_equal(eng.dense_topk(q[:100], k=100)[1].cpu().numpy()[:50], sweep)
+    one = [x.cpu().numpy() for x in eng.dense_topk(q, k=100)]
+    eng4 = mods["DeviceEngine"](ix, max_queries=512, max_k=100, rerank_max_docs=0)
+    many = [x.cpu().numpy() for x in eng4.dense_topk(q, k=100)]
+    for r in range(0, 640, 128):                             # (the last 60 queries of `one` are a sweep call: compared below)
+        assert all(np.array_equal(a_[r:r + 128], b_[r:r + 128]) for a_, b_ in zip(one, many)), r
+    assert np.array_equal(one[3], many[3]) and np.abs(one[1] - many[1]).max() <= 1e-6
+    eng4.close()
+    # (c) the zero query
+    qz = q[:100].copy(); qz[1] = 0.0
+    got = eng.dense_topk(qz, k=100)
+    _check_dense(mods, eng, doc_off, emb, qz[[0, 1, 2]], 100, 0, [x[[0, 1, 2]] for x in got])
+    eng.close()
+
+
 def test_dense_cosine_golden(mods):
     """One chunk per document: the engine's scores are the reference's cosine_similarity values."""
     z = np.load(os.path.join(G, "cosine.npz"))
