@@ -509,7 +509,7 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
             (herr = alloc((void**)&e->gf_wv_count, (size_t)nw * 4)) != hipSuccess ||
             (herr = alloc(&e->gf_pairs, QM * 4096 * 8)) != hipSuccess ||
             (herr = alloc((void**)&e->gf_pair_n, QM * 4)) != hipSuccess ||
-            (herr = alloc((void**)&e->gf_gate, 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gf_gate, 16 * 4)) != hipSuccess ||       // one gate word per slice of 64 queries
             (herr = alloc((void**)&e->gf_err, 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gf_margin, QM * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gf_cand_doc, QM * MSR_SEL_CAP * 4)) != hipSuccess ||
@@ -519,7 +519,7 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
             return fail(e, MSR_ERR_NOMEM, "GEMM scan scratch: %s", hipGetErrorString(herr));
         HIP_TRY(e, msr_pad_inv_norm(inv_norm, n_chunks, n_chunks + 512, e->gf_inv_pad, st));
         HIP_TRY(e, hipMemsetAsync(e->gf_pair_n, 0, QM * 4, st));
-        HIP_TRY(e, hipMemsetAsync(e->gf_gate, 0, 4, st));
+        HIP_TRY(e, hipMemsetAsync(e->gf_gate, 0, 16 * 4, st));
         HIP_TRY(e, hipMemsetAsync(e->gf_cand_n, 0, QM * 4, st));
         HIP_TRY(e, msr_f16_row_error(emb, inv_norm, n_chunks, e->gf_err, st));   // measured once: the margin of the f16 filter
         e->gf = GemmF32Index{e->tile_row, n_tiles, e->n_cus, groups, e->gf_inv_pad, e->gf_qimg, e->gf_tmax_t, e->gf_tmax, stride,
@@ -643,11 +643,12 @@ extern "C" int msr_dense_topk(msr_engine* e, const float* q, int32_t n_queries, 
     auto sweeps = [&](int q0, int cnt, const int32_t* gate) -> int {
         const int slice = wide ? 64 : 32;
         DenseIndex ix = e->dense;
-        ix.gate = gate;
         SelScratch sel = e->sel;
-        sel.gate = gate;
         for (int s0 = q0; s0 < q0 + cnt; s0 += slice) {
             const int nq = std::min(slice, q0 + cnt - s0);
+            // gated fallback: one gate word per slice of 64 queries (the streaming path raises the gates of the slices that
+            // hold an overflowed query)
+            ix.gate = sel.gate = gate ? gate + (s0 - q0) / 64 : nullptr;
             // zero rows up to the query-block count of the kernel that runs (1, 2 or 4 blocks of 16)
             const int nq_pad = nq > 32 ? 64 : (nq > 16 || (wide && e->dense.variant >= 14)) ? 32 : 16;
             const bool timed = !gate && e->timing && e->ev_count[0] < msr_engine::EV_RING;
@@ -672,7 +673,7 @@ extern "C" int msr_dense_topk(msr_engine* e, const float* q, int32_t n_queries, 
         if (gemm && left > 64) {
             const int nq = std::min(128 * e->gf.max_groups, left);
             HIP_TRY(e, msr_prep_queries(q + (int64_t)q0 * MSR_DIM, nq, e->gf_qn, nq, st));
-            HIP_TRY(e, hipMemsetAsync(e->gf_gate, 0, 4, st));
+            HIP_TRY(e, hipMemsetAsync(e->gf_gate, 0, 16 * 4, st));
             hipEvent_t ev[4];
             const bool timed = e->timing && e->ev_count[0] < msr_engine::EV_RING && e->ev_count[3] < msr_engine::EV_RING;
             if (timed) {

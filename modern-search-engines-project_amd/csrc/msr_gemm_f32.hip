@@ -380,8 +380,9 @@ __global__ __launch_bounds__(256) void f16_margin_kernel(const float* __restrict
 }
 
 // One workgroup per query: entries (row, approximate score) -> the distinct documents they belong to = the candidates
-// whose exact f32 cosines msr_batch_rescore computes.  Overflow anywhere on the way: no candidates and *gate |= 1 (the
-// caller's gated sweeps then redo the batch).
+// whose exact f32 cosines msr_batch_rescore computes.  Overflow on the way: no candidates and gate[q / 64] |= 1 -- one
+// gate word per slice of 64 queries, the unit of the caller's gated sweeps, so a query with a huge tie group sends its own
+// slice back to the sweeps, not the whole call (an overflowing wave buffer concerns every query: all slices).
 __global__ __launch_bounds__(1024) void gemm_f32_cand_kernel(const int2* __restrict__ pairs, int32_t* __restrict__ pair_n,
                                                               const int32_t* __restrict__ chunk_doc,
                                                               const int32_t* __restrict__ wv_count, int n_waves, int wv_cap,
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(1024) void gemm_f32_cand_kernel(const int2* __restr
     if (over) s_over = 1;
     __syncthreads();
     if (s_over) {
-        if (t == 0) { cand_n[q] = 0; pair_n[q] = 0; atomicOr(gate, 1); }
+        if (t == 0) { cand_n[q] = 0; pair_n[q] = 0; atomicOr(gate + (q >> 6), 1); }   // the gate of the query's 64-query slice
         return;
     }
     int P = 64;
@@ -460,7 +461,8 @@ hipError_t msr_f16_row_error(const float* emb, const float* inv_norm, int64_t n_
 // file.  The passes of all groups are queued back to back; everything between and after them (the two selects over tile
 // maxima (gemm_kth_kernel: one launch each), bucketing, candidate lists, rescoring, final sort) runs ONCE for all
 // queries of the call.
-// qn: [nq][768] normalised queries.  *gate != 0 when a query overflowed (the caller falls back).  ev (nullable): events
+// qn: [nq][768] normalised queries.  gate[s] != 0 (one word per 64 queries, zero on entry) when a query of slice s overflowed
+// (the caller falls back for that slice).  ev (nullable): events
 // around the sample pass (0, 1) and the emit pass (2, 3) of the first group.
 hipError_t msr_gemm_f32_topk(const GemmF32Index& g, const DenseIndex& ix, const float* qn, int nq, int k,
                              int32_t* out_doc, float* out_score, int32_t* out_chunk,

@@ -366,9 +366,9 @@ def test_dense_massive_ties(mods):
 
 def test_dense_streaming_pass_overflow_takes_the_gated_sweeps(mods):
     """More than 64 queries on a corpus the streaming pass accepts, one of them with a tie group of 9000 documents (more
-    entries than a query's candidate list holds): the pass raises its device-side gate and the sweeps queued behind it
-    redo the batch -- the call returns what the sweeps return (bit for bit what two <= 64-query calls give), with the tie
-    rule intact; a batch without such a query, on the same engine afterwards, takes the pass again."""
+    entries than a query's candidate list holds): the pass raises the device-side gate of that query's 64-query slice and
+    the sweeps queued behind it redo the slice -- bit for bit what a 64-query call gives, with the tie rule intact; the
+    other slice keeps the pass' answer; a batch without such a query, on the same engine afterwards, takes the pass again."""
     rng = np.random.default_rng(8)
     n = 60_000
     E = rng.standard_normal((n, 768)).astype(np.float32)
@@ -383,8 +383,13 @@ def test_dense_streaming_pass_overflow_takes_the_gated_sweeps(mods):
     q = rng.standard_normal((100, 768)).astype(np.float32)
     q[7] = 2.5 * v
     got = [x.cpu().numpy() for x in eng.dense_topk(q, k=100)]
-    ref = [np.concatenate(p) for p in zip(*[[x.cpu().numpy() for x in eng.dense_topk(q[s:s + 50], k=100)] for s in (0, 50)])]
-    assert all(np.array_equal(a, b) for a, b in zip(got, ref))
+    # the tie query sits in the first 64-query slice: that slice comes back from the sweeps (bit for bit a 64-query call),
+    # the other slice from the pass (exact f32 cosines: within rounding of the sweeps' f16x2-split scores)
+    lo = [x.cpu().numpy() for x in eng.dense_topk(q[:64], k=100)]
+    hi = [x.cpu().numpy() for x in eng.dense_topk(q[64:], k=100)]
+    assert all(np.array_equal(a[:64], b) for a, b in zip(got, lo))
+    assert np.array_equal(got[3][64:], hi[3]) and np.abs(got[1][64:] - hi[1]).max() <= 1e-5
+    assert (got[0][64:] == hi[0]).mean() > 0.99
     assert got[3][7] == 100 and got[0][7].tolist() == tied[:100].tolist() and np.all(np.abs(got[1][7] - 1.0) < 1e-5)
     q[7] = rng.standard_normal(768).astype(np.float32)                        # no tie group any more: the pass itself answers
     again = [x.cpu().numpy() for x in eng.dense_topk(q, k=100)]
@@ -400,7 +405,7 @@ def test_streaming_pass_vs_oracle_and_query_groups(mods):
     rows, random ones, a non-unit row in the corpus -- at k = 100 and k = 10; (b) an engine with room for 4 groups of 128
     queries per call (700 queries = 512 + 188: passes queued back to back, one finish) returns bit for bit what one group
     per call returns; (c) a batch with a ZERO query (every cosine 0: a tie group of the whole corpus) overflows the pass and
-    comes back from the gated sweeps -- still the oracle's answer."""
+    comes back from the gated sweeps -- still the oracle's answer, and only for its own 64-query slice."""
     rng = np.random.default_rng(91)
     n_docs = 60000
     n = rng.integers(0, 9, size=n_docs)
@@ -437,6 +442,13 @@ def test_streaming_pass_vs_oracle_and_query_groups(mods):
     qz = q[:100].copy(); qz[1] = 0.0
     got = eng.dense_topk(qz, k=100)
     _check_dense(mods, eng, doc_off, emb, qz[[0, 1, 2]], 100, 0, [x[[0, 1, 2]] for x in got])
+    # only the zero query's 64-query slice went back to the sweeps (one gate word per slice): rows 0..63 are what a 64-query
+    # sweep call returns, rows 64..99 what the pass returned for the batch without the zero query
+    gz = [x.cpu().numpy() for x in got]
+    sw = [x.cpu().numpy() for x in eng.dense_topk(qz[:64], k=100)]
+    ps = [x.cpu().numpy() for x in eng.dense_topk(q[:100], k=100)]
+    assert all(np.array_equal(a_[:64], b_) for a_, b_ in zip(gz, sw))
+    assert all(np.array_equal(a_[64:], b_[64:]) for a_, b_ in zip(gz, ps))
     eng.close()
 
 
