@@ -1,28 +1,38 @@
 // K1 -- BM25 term-at-a-time scoring over HBM-resident CSR postings (gfx950).
 //
 // Replaces the per-query SQL fetch + Python grouping + scoring loop of the reference
-// (indexer/bm25_indexer.py:434-481).  The dense doc index is cut into tiles of TILE documents.  A workgroup owns a span
-// of up to 8 consecutive tiles and FOUR queries: its four waves score one query each, every wave with its own float64
-// accumulators in LDS, sharing the current tile's length norms k1 (1 - b + b dl / avgdl) (evaluated once per document
-// at bind time, bm25_dnorm_kernel; staged in LDS per tile).  A wave
-//   1. builds its query's PLAN once for all tiles of the workgroup, lane-parallel (lane j = term j): offsets, idf, query
-//      frequency; for long lists the skip-table row segment (where each of the workgroup's tiles starts inside the list);
-//      for lists of <= 64 postings the whole list; for the lists in between ONE round of 64 probes (a covering range for
-//      the workgroup's document span; postings outside a tile are masked when applied);
-//   2. per tile: derives every term's slice from the plan (no memory access) -- one tile AHEAD of the tile it is
-//      accumulating (two register sets: the kernel is latency-bound, a wave hides its own loads behind its arithmetic),
-//   3. fetches the first PFC x 64 postings of the first TPRE slices side by side, then accumulates IN QUERY ORDER.  A
-//      wave's LDS operations execute in order, so the float64 summation order of every document equals the reference's
-//      (:466-478) WITHOUT a barrier between terms; a document occurs at most once per posting list (PRIMARY KEY
-//      (doc_id, term), :100-104), so the read-modify-write of acc[doc] needs no atomics,
-//   4. appends the touched documents with score >= min_score to the query's candidate list (ballot prefix, one
-//      reservation per wave and tile).
-// The only workgroup barriers (two per tile) publish the length norms.  The arithmetic is written operation by
-// operation as Python evaluates it and this file is compiled with -ffp-contract=off, so scores are bit-identical to
-// the oracle.
+// (indexer/bm25_indexer.py:434-481).  The dense doc index is cut into tiles of TILE documents; a WAVE scores one query
+// over a span of up to 8 consecutive tiles, with its own float64 accumulators (one per document of the current tile) and
+// the list of the documents it has touched in LDS.  Waves are independent: no workgroup barrier anywhere.
 //
-// HBM traffic per query: 8 B per posting of the query's terms + 1 B per document (doc_len, shared by four queries) +
-// 12 B per candidate document (the (score, doc) list consumed by the top-k select).
+// What is streamed and what is looked up.  A posting is read as {doc, tf, tf_component}: the tf_component
+// (tf (k1 + 1)) / (tf + k1 (1 - b + b dl / avgdl)) (:473-475) depends on (tf, document) only and is evaluated ONCE at bind
+// time with the reference's own operations (bm25_post_comp_kernel), so the kernel neither divides nor looks a length up.
+// A term whose idf is NEGATIVE (document frequency above half the corpus: the city term that search_api.py:160-164 puts
+// into every query) can only lower a score: every one of its contributions (idf * tf_component) * qtf is < 0.  With
+// min_score >= 0 (:480) a document matched by such terms alone is never a candidate, so their lists -- 96 % of the
+// postings a benchmark query names -- are not streamed at all: the candidates are the documents touched by the OTHER terms
+// ("streamed" terms), and a negative term's contribution to one of them is looked up in a dense per-document table of its
+// tf_components (built at bind for the long negative lists, 8 B per document).  With min_score < 0, or for a negative
+// term without a table, every list is streamed; the result is the same either way, bit for bit.
+//
+// Summation order.  The reference adds the contributions of a document's terms in the query's first-occurrence order
+// (:466-478) in float64.  A wave walks its query's terms in that order:
+//   streamed term j: for each posting of the tile, acc[doc] += (idf * tfc) * qtf as an LDS read-modify-write (a wave's LDS
+//     operations execute in order; a document occurs at most once per list, PRIMARY KEY (doc_id, term) :100-104, so no
+//     atomics).  A document touched for the FIRST time starts from 0.0 plus the looked-up contributions of the negative
+//     terms BEFORE j, in order, and is appended to the wave's list;
+//   looked-up term i: for each document on the list so far, acc[doc] += (idf * table_i[doc]) * qtf if the table has it.
+// So every candidate's sum is the reference's sum operation by operation; this file is compiled with -ffp-contract=off.
+// At the end of a tile the list is what is emitted (score >= min_score, :480) and what is reset -- there is no pass over
+// all TILE accumulators.
+//
+// The plan (where each term's slices are: skip-table row segment for long lists, the whole list for <= 64 postings, ONE
+// round of 64 probes for the lists in between) is built once per span, lane-parallel (lane j = term j); the loads of
+// tile t + 1 are issued before tile t is accumulated (two register sets).
+//
+// HBM traffic per query: 16 B per posting of its streamed terms + 8 B per (touched document, looked-up term) from tables
+// that stay in the L2 / Infinity Cache + 12 B per candidate (the (score, doc) list consumed by the top-k select).
 #include <stdio.h>
 
 #include <type_traits>
@@ -34,11 +44,8 @@ namespace {
 
 constexpr int BM25_TILE = MSR_BM25_TILE;
 constexpr int BM25_THREADS = 256;
-constexpr int BM25_QPW = BM25_THREADS / 64;                   // queries per workgroup (one per wave)
-#ifndef BM25_WPE
-#define BM25_WPE 3                                             // waves per SIMD the register budget is cut for
-#endif
-constexpr int BM25_TPW = 8;                                   // at most this many consecutive tiles per workgroup
+constexpr int BM25_WAVES = BM25_THREADS / 64;                 // independent waves per workgroup (one work item each)
+constexpr int BM25_TPW = 8;                                   // at most this many consecutive tiles per work item
 constexpr int BM25_MAX_TERMS = 64;                            // MSR_MAX_QUERY_TERMS: one lane per term
 constexpr uint64_t UNTOUCHED = 0x7FF8DEADBEEF0001ull;   // a quiet-NaN payload no computation produces
 
@@ -50,43 +57,56 @@ __device__ __forceinline__ int64_t lane_i64(int64_t v, int j) {          // v of
 __device__ __forceinline__ double lane_f64(double v, int j) {
     return __longlong_as_double(lane_i64(__double_as_longlong(v), j));
 }
+__device__ __forceinline__ int lane_rank(unsigned long long m) {         // number of set bits of m below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
 
-__global__ __launch_bounds__(BM25_THREADS) __attribute__((amdgpu_waves_per_eu(BM25_WPE, BM25_WPE))) void bm25_taat_kernel(Bm25Index ix,
+enum : int { K_DEAD = 0, K_LOOKUP = 1, K_HEAVY = 2, K_RANGE = 3 };
+
+__global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
                                                                   const int32_t* __restrict__ q_term_off,
                                                                   const int32_t* __restrict__ q_terms,
                                                                   const int32_t* __restrict__ q_qtf,
-                                                                  int q_first, int nq, double min_score, int tpw,
+                                                                  int q_first, int nq, double min_score, int tpw, int n_spans,
                                                                   double* __restrict__ cand_score,
                                                                   int32_t* __restrict__ cand_doc,
                                                                   int32_t* __restrict__ cand_n, int dbg_arg) {
 #ifdef MSR_DIAG
-    const int dbg = dbg_arg;   // timing experiments (wrong results): 1 no division, 2 no accumulator update, 4 no streaming
-                               // beyond the prefetch, 8 no prefetch, 16 no emission, 32 no term lookup
+    const int dbg = dbg_arg;   // timing experiments (wrong results): 1 no table lookups, 2 no accumulator update, 4 no streaming
+                               // beyond the prefetch, 8 no prefetch, 16 no emission, 64 stream every list (no pruning)
 #else
     constexpr int dbg = 0;
 #endif
-    __shared__ double acc_all[BM25_QPW][BM25_TILE];
-    __shared__ double dn[BM25_TILE];                         // k1 * (1 - b + b * doc_length / avg_doc_length)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // grid = (query groups, tile spans): consecutive workgroups score the SAME tiles for other queries, so the tiles' document
-    // lengths and the slices of the terms the queries share (the city term is in every query, search_api.py:155-166)
-    // are served by the L2 after the first of them
-    const int q = blockIdx.x * BM25_QPW + wave;              // row of the candidate lists
-    const bool live = q < nq;                                // (wave-uniform)
-    const int tile0 = (int)blockIdx.y * tpw;                 // this workgroup's tiles: tile0 .. tile0 + n_my - 1
+    __shared__ double acc_all[BM25_WAVES][BM25_TILE];
+    __shared__ uint16_t list_all[BM25_WAVES][BM25_TILE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // work item = (query, span of tiles), the query running fastest: the waves of a workgroup and of its neighbours score the
+    // SAME tiles for different queries, so the table lines and the slices of terms the queries share come from the L2
+    const int item = (int)blockIdx.x * BM25_WAVES + wave;
+    const int span = item / nq, q = item - span * nq;          // q: row of the candidate lists
+    if (span >= n_spans) return;                               // (wave-uniform; there is no barrier in this kernel)
+    const int tile0 = span * tpw;                              // this wave's tiles: tile0 .. tile0 + n_my - 1
     const int n_my = tile0 + tpw <= ix.n_tiles ? tpw : ix.n_tiles - tile0;
     double* acc = acc_all[wave];
-    const double k1p1 = ix.k1 + 1.0;                 // self.k1 + 1
-    // ---- 1. the query's plan, ONCE for all tiles of the workgroup; lane j = term j ----
-    int nt = 0;
-    int64_t s_v = 0;                                 // long list: its first posting
-    uint32_t off_v[BM25_TPW + 1];                    // long list: where each of the workgroup's tiles starts inside it
-    int64_t r0_v = 0, r1_v = 0;                      // other lists: the postings to look at, for EVERY tile of the workgroup
+    uint16_t* list = list_all[wave];
+    {   // every accumulator starts untouched; a tile resets exactly the ones it touched
+        const double un = __longlong_as_double((long long)UNTOUCHED);
+#pragma unroll
+        for (int u = 0; u < BM25_TILE / 128; ++u) ((double2*)acc)[lane + 64 * u] = make_double2(un, un);
+    }
+    // a negative term's list need not be streamed when nothing below 0 can be a candidate (:480)
+    const bool prune = min_score >= 0.0 && ix.dense_id != nullptr && !(dbg & 64);
+    // ---- 1. the query's plan, ONCE for all tiles of the span; lane j = term j ----
+    int nt = 0, klass = K_DEAD;
+    int64_t s_v = 0;                                 // long list: its first posting; looked-up term: its table row
+    uint32_t off_v[BM25_TPW + 1];                    // long list: where each of the span's tiles starts inside it
+    int64_t r0_v = 0, r1_v = 0;                      // other lists: the postings to look at, for EVERY tile of the span
     double idf_v = 0.0, qtf_v = 0.0;
-    bool heavy = false, medium = false;
+    bool medium = false;
 #pragma unroll
     for (int i = 0; i <= BM25_TPW; ++i) off_v[i] = 0;
-    if (live && !(dbg & 32)) {
+    {
         const int t0 = q_term_off[q_first + q];
         nt = q_term_off[q_first + q + 1] - t0;
         if (nt > BM25_MAX_TERMS) nt = BM25_MAX_TERMS;        // the host never sends more
@@ -97,14 +117,19 @@ __global__ __launch_bounds__(BM25_THREADS) __attribute__((amdgpu_waves_per_eu(BM
                 if (e > s) {
                     idf_v = (double)ix.idf[t];
                     qtf_v = (double)q_qtf[t0 + lane];
+                    const int dh = prune ? ix.dense_id[t] : -1;
                     const int h = ix.heavy_id ? ix.heavy_id[t] : -1;
-                    if (h >= 0) {                            // long list: the slices come from the skip table, one row
-                        heavy = true;                        // segment for all the workgroup's tiles
+                    if (dh >= 0 && idf_v < 0.0 && qtf_v > 0.0) {   // every contribution < 0: looked up, never streamed
+                        klass = K_LOOKUP;
+                        s_v = (int64_t)(ix.dense_comp + (int64_t)dh * ix.dense_stride);
+                    } else if (h >= 0) {                     // long list: the slices come from the skip table, one row
+                        klass = K_HEAVY;                     // segment for all the span's tiles
                         s_v = s;
                         const uint32_t* row = ix.tile_off + (int64_t)h * (ix.n_tiles + 1) + tile0;
 #pragma unroll
                         for (int i = 0; i <= BM25_TPW; ++i) off_v[i] = row[i < n_my ? i : n_my];
                     } else {
+                        klass = K_RANGE;
                         r0_v = s;                            // short list: all of it (postings of other tiles are masked)
                         r1_v = e;
                         medium = e - s > 64;
@@ -113,8 +138,11 @@ __global__ __launch_bounds__(BM25_THREADS) __attribute__((amdgpu_waves_per_eu(BM
             }
         }
     }
+    const unsigned long long look_mask = __ballot(klass == K_LOOKUP);
+    const unsigned long long stream_mask = __ballot(klass >= K_HEAVY);
+    if (stream_mask == 0) return;                    // no streamed term: no document can reach min_score (or no known term)
     // ---- 2. lists of 65 .. HEAVY_DF-1 postings: one round of 64 probes narrows [r0, r1) to the chunks that can hold
-    //         documents of the workgroup's tiles; MED lists side by side (the probes are independent loads) ----
+    //         documents of the span's tiles; MED lists side by side (the probes are independent loads) ----
     {
         const int64_t lo8 = (int64_t)tile0 * BM25_TILE;
         const int64_t hi8 = lo8 + (int64_t)n_my * BM25_TILE < ix.n_docs ? lo8 + (int64_t)n_my * BM25_TILE : ix.n_docs;
@@ -135,7 +163,7 @@ __global__ __launch_bounds__(BM25_THREADS) __attribute__((amdgpu_waves_per_eu(BM
                     ch_[m] = (e_[m] - s_[m] + 63) >> 6;
                     int64_t idx = s_[m] + (int64_t)(lane + 1) * ch_[m] - 1;     // last posting of chunk `lane`
                     if (idx > e_[m] - 1) idx = e_[m] - 1;
-                    probe[m] = ix.post_doc[idx];
+                    probe[m] = ix.post[idx].doc;
                 }
             }
 #pragma unroll
@@ -156,23 +184,29 @@ __global__ __launch_bounds__(BM25_THREADS) __attribute__((amdgpu_waves_per_eu(BM
             }
         }
     }
-    // Two tiles are in flight per wave: the loads of tile t + 1 (length norms, the first postings of every slice) are issued
-    // BEFORE tile t is accumulated and emitted, into a second register set -- the pass is latency-bound (its time follows
-    // the number of resident waves), so every wave hides its own memory latency behind its own arithmetic.
-    constexpr int TPRE = 5, PFC = 3;
-    constexpr int DPT2 = BM25_TILE / BM25_THREADS / 2;       // 16-byte pieces of the length norms per thread
+    // the first TPRE streamed terms get their first PFC x 64 postings of a tile prefetched (for nearly all terms: the whole slice)
+    constexpr int TPRE = 4, PFC = 2;
+    int sj[TPRE];
+    {
+        unsigned long long m = stream_mask;
+#pragma unroll
+        for (int k = 0; k < TPRE; ++k) {
+            sj[k] = m ? __ffsll((long long)m) - 1 : -1;
+            if (m) m &= m - 1;
+        }
+    }
+    const int j_rest = sj[TPRE - 1] >= 0 ? sj[TPRE - 1] + 1 : nt;       // terms from here on are not prefetched
+    // Two tiles are in flight per wave: the loads of tile t + 1 are issued BEFORE tile t is accumulated and emitted, into a
+    // second register set -- the pass is latency-bound, every wave hides its own memory latency behind its own arithmetic.
     struct TileRegs {
-        int32_t pd[TPRE][PFC], tf[TPRE][PFC];                // the first PFC x 64 postings of the first TPRE slices
-        double2 dn[DPT2];                                    // length norms: thread t holds documents 2 DPT2 t .. of the tile
+        int32_t pd[TPRE][PFC];                               // the first PFC x 64 postings of the first TPRE streamed slices
+        double pc[TPRE][PFC];
         int64_t ps, pe;                                      // lane j: this tile's slice of term j
     };
     auto issue = [&](int tt, TileRegs& r) {
-        const int64_t lo = (int64_t)(tile0 + tt) * BM25_TILE;
-#pragma unroll
-        for (int u = 0; u < DPT2; ++u) r.dn[u] = ((const double2*)(ix.dnorm + lo))[DPT2 * tid + u];      // (padded to whole tiles)
         // the tile's slice of every list (no memory access: the plan holds everything)
         r.ps = r0_v; r.pe = r1_v;
-        if (heavy) {
+        if (klass == K_HEAVY) {
             uint32_t o0 = 0, o1 = 0;
 #pragma unroll
             for (int i = 0; i < BM25_TPW; ++i)
@@ -180,19 +214,17 @@ __global__ __launch_bounds__(BM25_THREADS) __attribute__((amdgpu_waves_per_eu(BM
             r.ps = s_v + o0;
             r.pe = s_v + o1;
         }
-        // the first PFC x 64 postings of the first TPRE slices (for nearly all terms: the whole slice): one memory round
-        // trip for the postings of all terms
 #pragma unroll
-        for (int j = 0; j < TPRE; ++j) {
+        for (int k = 0; k < TPRE; ++k) {
 #pragma unroll
-            for (int c = 0; c < PFC; ++c) { r.pd[j][c] = -1; r.tf[j][c] = 0; }
-            if (j < nt && !(dbg & 8)) {                          // wave-uniform
-                const int64_t ps = lane_i64(r.ps, j), pe = lane_i64(r.pe, j);
+            for (int c = 0; c < PFC; ++c) { r.pd[k][c] = -1; r.pc[k][c] = 0.0; }
+            if (sj[k] >= 0 && !(dbg & 8)) {                  // wave-uniform
+                const int64_t ps = lane_i64(r.ps, sj[k]), pe = lane_i64(r.pe, sj[k]);
 #pragma unroll
                 for (int c = 0; c < PFC; ++c) {
-                    if (ps + 64 * c < pe) {                      // wave-uniform: no instruction for chunks past the slice
+                    if (ps + 64 * c < pe) {                  // wave-uniform: no instruction for chunks past the slice
                         const int64_t i = ps + 64 * c + lane;
-                        if (i < pe) { const int2 p = ix.post[i]; r.pd[j][c] = p.x; r.tf[j][c] = p.y; }
+                        if (i < pe) { const Bm25Post p = ix.post[i]; r.pd[k][c] = p.doc; r.pc[k][c] = p.comp; }
                     }
                 }
             }
@@ -204,21 +236,11 @@ __global__ __launch_bounds__(BM25_THREADS) __attribute__((amdgpu_waves_per_eu(BM
         const int64_t hi = lo + BM25_TILE < ix.n_docs ? lo + BM25_TILE : ix.n_docs;
         const int n = (int)(hi - lo);
         const int64_t ps_v = r.ps, pe_v = r.pe;
-        // accumulators of this wave's query; the length norms of the tile (shared by the four waves)
-        {
-            const double un = __longlong_as_double((long long)UNTOUCHED);
-#pragma unroll
-            for (int u = 0; u < BM25_TILE / 128; ++u) ((double2*)acc)[lane + 64 * u] = make_double2(un, un);
-        }
-        __syncthreads();                                         // every wave is done with the previous tile's norms
-#pragma unroll
-        for (int u = 0; u < DPT2; ++u) ((double2*)dn)[DPT2 * tid + u] = r.dn[u];
-        __syncthreads();
-        // U postings of ONE term per lane: the reference's arithmetic, operation by operation (:472-478), written so that the
-        // U chains (a float64 division is 11 dependent instructions) are independent and interleave: nothing is branched
-        // around -- a posting of another tile (covering ranges) or a missing one computes on document 0 and only its final
-        // store is masked.  A document occurs once per posting list, so the U read-modify-writes never touch the same slot.
-        auto apply = [&](auto u_c, const int32_t* pdoc, const int32_t* ptf, double idf, double qtf) {
+        int list_n = 0;                                      // documents touched so far in this tile (wave-uniform)
+        // U postings of streamed term j per lane.  Nothing is branched around per lane: a posting of another tile (covering
+        // ranges) or a missing one computes on document 0 and only its stores are masked.  A document occurs once per
+        // posting list, so the lanes of one step never touch the same slot.
+        auto apply = [&](auto u_c, const int32_t* pdoc, const double* pcomp, double idf, double qtf, int j) {
             constexpr int U = decltype(u_c)::value;
             bool ok[U];
             uint32_t d[U];
@@ -228,90 +250,127 @@ __global__ __launch_bounds__(BM25_THREADS) __attribute__((amdgpu_waves_per_eu(BM
                 const uint32_t dd = (uint32_t)(pdoc[u] - (int32_t)lo);
                 ok[u] = dd < (uint32_t)n;
                 d[u] = ok[u] ? dd : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const double tf = (double)ptf[u];
-                // tf_component = (tf * (k1 + 1)) / (tf + k1 * (1 - b + b * doc_length / avg_doc_length))
-                const double comp = (dbg & 1) ? (tf * k1p1) * (tf + dn[d[u]]) : (tf * k1p1) / (tf + dn[d[u]]);
-                // term_score = idf * tf_component * query_term_freq[term]; bm25_score += term_score
-                c[u] = (idf * comp) * qtf;
+                // term_score = idf * tf_component * query_term_freq[term]  (:478)
+                c[u] = (idf * pcomp[u]) * qtf;
             }
             if (dbg & 2) return;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const double a = acc[d[u]];
-                const double x = ((uint64_t)__double_as_longlong(a) == UNTOUCHED ? 0.0 : a) + c[u];
+                double a = acc[d[u]];
+                const bool first = ok[u] && (uint64_t)__double_as_longlong(a) == UNTOUCHED;
+                const unsigned long long fm = __ballot(first);
+                if (fm) {                                    // (wave-uniform) first touch: bm25_score = 0.0 (:466), then the
+                    double a0 = 0.0;                         // negative terms that precede term j in the query, in order
+                    unsigned long long lm = (dbg & 1) ? 0ull : look_mask & ((1ull << j) - 1ull);
+                    while (lm) {
+                        const int i = __ffsll((long long)lm) - 1;
+                        lm &= lm - 1;
+                        const double* tbl = (const double*)lane_i64(s_v, i) + lo;
+                        const double tc = first ? tbl[d[u]] : 0.0;
+                        const double ci = (lane_f64(idf_v, i) * tc) * lane_f64(qtf_v, i);
+                        if (tc != 0.0) a0 = a0 + ci;         // (0.0: the document lacks term i)
+                    }
+                    if (first) { list[list_n + lane_rank(fm)] = (uint16_t)d[u]; a = a0; }
+                    list_n += __popcll(fm);
+                }
+                const double x = a + c[u];                   // bm25_score += term_score
                 if (ok[u]) acc[d[u]] = x;
             }
         };
         // The rest of a slice, U x 64 postings per round: all loads of a round are issued before the first is used.
-        auto stream = [&](int64_t from, int64_t pe, double idf, double qtf) {
+        auto stream = [&](int64_t from, int64_t pe, double idf, double qtf, int j) {
             constexpr int U = 4;
             if (dbg & 4) return;
             for (int64_t base = from; base < pe; base += (int64_t)U * 64) {
-                int32_t pd[U], ptf[U];
+                int32_t pd[U];
+                double pc[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int64_t i = base + lane + (int64_t)u * 64;
-                    const int2 p = i < pe ? ix.post[i] : make_int2(-1, 0);
-                    pd[u] = p.x;
-                    ptf[u] = p.y;
+                    pd[u] = -1; pc[u] = 0.0;
+                    if (i < pe) { const Bm25Post p = ix.post[i]; pd[u] = p.doc; pc[u] = p.comp; }
                 }
-                apply(std::integral_constant<int, U>{}, pd, ptf, idf, qtf);
+                apply(std::integral_constant<int, U>{}, pd, pc, idf, qtf, j);
             }
         };
+        // looked-up term i: its contribution to every document touched so far
+        auto walk = [&](int i) {
+            if (list_n == 0 || (dbg & 1)) return;
+            const double* tbl = (const double*)lane_i64(s_v, i) + lo;
+            const double idf = lane_f64(idf_v, i), qtf = lane_f64(qtf_v, i);
+            for (int b = 0; b < list_n; b += 64) {
+                const int e = b + lane;
+                if (e < list_n) {
+                    const uint32_t d = list[e];
+                    const double tc = tbl[d];
+                    if (tc != 0.0) acc[d] = acc[d] + (idf * tc) * qtf;
+                }
+            }
+        };
+        auto walks = [&](int from, int to) {                 // the looked-up terms at positions [from, to)
+            unsigned long long lm = look_mask & ~((1ull << from) - 1ull);
+            if (to < 64) lm &= (1ull << to) - 1ull;
+            while (lm) {
+                const int i = __ffsll((long long)lm) - 1;
+                lm &= lm - 1;
+                walk(i);
+            }
+        };
+        // ---- the terms in query order: the first TPRE streamed ones from the prefetched registers ----
+        int jprev = 0;
 #pragma unroll
-        for (int j = 0; j < TPRE; ++j) {
-            if (j >= nt) break;                                  // wave-uniform
+        for (int k = 0; k < TPRE; ++k) {
+            const int j = sj[k];
+            if (j < 0) break;                                // wave-uniform
+            walks(jprev, j);
+            jprev = j + 1;
             const int64_t ps = lane_i64(ps_v, j), pe = lane_i64(pe_v, j);
             if (pe <= ps) continue;
             const double idf = lane_f64(idf_v, j), qtf = lane_f64(qtf_v, j);
-            apply(std::integral_constant<int, PFC>{}, r.pd[j], r.tf[j], idf, qtf);     // (chunks past the slice hold doc -1)
-            if (pe - ps > 64 * PFC) stream(ps + 64 * PFC, pe, idf, qtf);
+            apply(std::integral_constant<int, PFC>{}, r.pd[k], r.pc[k], idf, qtf, j);   // (chunks past the slice hold doc -1)
+            if (pe - ps > 64 * PFC) stream(ps + 64 * PFC, pe, idf, qtf, j);
         }
-        for (int j = TPRE; j < nt; ++j) {
+        for (int j = j_rest; j < nt; ++j) {
+            const int kj = __builtin_amdgcn_readlane(klass, j);
+            if (kj == K_LOOKUP) { walk(j); continue; }
+            if (kj == K_DEAD) continue;
             const int64_t ps = lane_i64(ps_v, j), pe = lane_i64(pe_v, j);
             if (pe <= ps) continue;
-            stream(ps, pe, lane_f64(idf_v, j), lane_f64(qtf_v, j));
+            stream(ps, pe, lane_f64(idf_v, j), lane_f64(qtf_v, j), j);
         }
-        if (!live || (dbg & 16)) return;                       // (wave-uniform; the barriers are at the top of the loop)
-        // ---- 4. the tile's candidates (touched by a posting AND score >= min_score, :461,480) as (score, doc) pairs
-        //         appended to the query's list: one reservation per wave.  Most documents of a tile are not candidates, so
-        //         this replaces an 8 B/document dense row by 12 B per candidate. ----
-        // lane l looks at documents 2 l + 128 u and 2 l + 128 u + 1 (one 16-byte LDS read per round)
+        if (jprev < j_rest) walks(jprev, j_rest);            // (fewer than TPRE streamed terms: the looked-up ones behind the last)
+        if (list_n == 0) return;
+        // ---- the tile's candidates: the touched documents with score >= min_score (:461,480) as (score, doc) pairs appended
+        //      to the query's list, one reservation per wave and tile; every touched accumulator goes back to "untouched" ----
+        const double un = __longlong_as_double((long long)UNTOUCHED);
         int total = 0;
-        unsigned long long f0[BM25_TILE / 128], f1[BM25_TILE / 128];
-#pragma unroll
-        for (int u = 0; u < BM25_TILE / 128; ++u) {
-            const int i = 2 * lane + 128 * u;
-            const double2 a = ((const double2*)acc)[lane + 64 * u];
-            f0[u] = __ballot(i < n && (uint64_t)__double_as_longlong(a.x) != UNTOUCHED && a.x >= min_score);
-            f1[u] = __ballot(i + 1 < n && (uint64_t)__double_as_longlong(a.y) != UNTOUCHED && a.y >= min_score);
-            total += __popcll(f0[u]) + __popcll(f1[u]);
+        if (!(dbg & 16)) {
+            for (int b = 0; b < list_n; b += 64) {
+                const int e = b + lane;
+                const bool keep = e < list_n && acc[list[e < list_n ? e : 0]] >= min_score;
+                total += __popcll(__ballot(keep));
+            }
         }
-        if (total == 0) return;                                // wave-uniform
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&cand_n[q], total);
-        base = __builtin_amdgcn_readfirstlane(base);
-        const int64_t o = (int64_t)q * ix.n_docs + base;
-        int run = 0;
-        const unsigned long long below = (1ull << lane) - 1;
-#pragma unroll
-        for (int u = 0; u < BM25_TILE / 128; ++u) {
-            const int i = 2 * lane + 128 * u;
-            if ((f0[u] >> lane) & 1) {
-                const int w = run + __popcll(f0[u] & below);
-                cand_score[o + w] = acc[i];
-                cand_doc[o + w] = (int32_t)(lo + i);
+        int64_t o = 0;
+        if (total) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&cand_n[q], total);
+            o = (int64_t)q * ix.n_docs + __builtin_amdgcn_readfirstlane(base);
+        }
+        for (int b = 0; b < list_n; b += 64) {
+            const int e = b + lane;
+            const bool in = e < list_n;
+            const uint32_t d = list[in ? e : 0];
+            const double sc = acc[d];
+            const bool keep = total && in && sc >= min_score;
+            const unsigned long long km = __ballot(keep);
+            if (keep) {
+                const int64_t w = o + lane_rank(km);
+                cand_score[w] = sc;
+                cand_doc[w] = (int32_t)(lo + d);
             }
-            run += __popcll(f0[u]);
-            if ((f1[u] >> lane) & 1) {
-                const int w = run + __popcll(f1[u] & below);
-                cand_score[o + w] = acc[i + 1];
-                cand_doc[o + w] = (int32_t)(lo + i + 1);
-            }
-            run += __popcll(f1[u]);
+            o += __popcll(km);
+            if (in) acc[d] = un;
         }
     };
     TileRegs ra, rb;
@@ -373,14 +432,37 @@ __global__ __launch_bounds__(256) void build_skip_kernel(Bm25Index ix, const int
     }
 }
 
-// post[i] = {post_doc[i], post_tf[i]}: the scoring kernel reads a posting with ONE 8-byte load (the engine-owned copy
-// costs 8 B per posting of HBM; with two 4-byte arrays the kernel issued twice the memory instructions, and their issue
-// rate -- not bandwidth -- is what the per-phase wave clocks showed to matter)
-__global__ __launch_bounds__(256) void interleave_postings_kernel(const int32_t* __restrict__ post_doc,
-                                                                   const int32_t* __restrict__ post_tf, int64_t n,
-                                                                   int2* __restrict__ out) {
+// post[i] = {post_doc[i], post_tf[i], tf_component}: what the scoring kernel streams, one 16-byte load per posting.
+// tf_component = (tf * (k1 + 1)) / (tf + k1 * (1 - b + b * doc_length / avg_doc_length))  (:473-475), evaluated here ONCE
+// per posting, operation by operation as Python evaluates it (tf is a Python int: it is converted, not truncated)
+__global__ __launch_bounds__(256) void bm25_post_comp_kernel(const int32_t* __restrict__ post_doc,
+                                                              const int32_t* __restrict__ post_tf,
+                                                              const double* __restrict__ dnorm, double k1p1, int64_t n,
+                                                              Bm25Post* __restrict__ out) {
     const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = make_int2(post_doc[i], post_tf[i]);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const int32_t d = post_doc[i], f = post_tf[i];
+        const double tf = (double)f;
+        Bm25Post p;
+        p.doc = d; p.tf = f;
+        p.comp = (tf * k1p1) / (tf + dnorm[d]);
+        out[i] = p;
+    }
+}
+
+// row h of the dense tables <- the tf_components of term dense_terms[h], by document (the rows are zero on entry: 0.0 marks
+// a document without the term; a tf_component itself is never 0: tf >= 1, finite positive denominator)
+__global__ __launch_bounds__(256) void bm25_dense_kernel(Bm25Index ix, const int32_t* __restrict__ dense_terms,
+                                                          double* __restrict__ dense_comp, int64_t dense_stride) {
+    const int h = blockIdx.y;
+    const int32_t t = dense_terms[h];
+    const int64_t s = ix.term_off[t], e = ix.term_off[t + 1];
+    double* row = dense_comp + (int64_t)h * dense_stride;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = s + (int64_t)blockIdx.x * 256 + threadIdx.x; i < e; i += stride) {
+        const Bm25Post p = ix.post[i];
+        row[p.doc] = p.comp;
+    }
 }
 
 // dnorm[d] = k1 * (1 - b + b * doc_length / avg_doc_length) for every document, padded to whole tiles (1.0 beyond n_docs):
@@ -405,9 +487,17 @@ hipError_t msr_bm25_build_skip(const Bm25Index& ix, const int32_t* heavy_terms, 
     return hipGetLastError();
 }
 
-hipError_t msr_bm25_interleave(const int32_t* post_doc, const int32_t* post_tf, int64_t n, void* out, hipStream_t stream) {
+hipError_t msr_bm25_post_comp(const int32_t* post_doc, const int32_t* post_tf, const double* dnorm, double k1, int64_t n,
+                              Bm25Post* out, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    interleave_postings_kernel<<<4096, 256, 0, stream>>>(post_doc, post_tf, n, (int2*)out);
+    bm25_post_comp_kernel<<<4096, 256, 0, stream>>>(post_doc, post_tf, dnorm, k1 + 1.0, n, out);   // self.k1 + 1
+    return hipGetLastError();
+}
+
+hipError_t msr_bm25_build_dense(const Bm25Index& ix, const int32_t* dense_terms, int n_dense, double* dense_comp,
+                                int64_t dense_stride, hipStream_t stream) {
+    if (n_dense <= 0) return hipSuccess;
+    bm25_dense_kernel<<<dim3(256, (unsigned)n_dense), 256, 0, stream>>>(ix, dense_terms, dense_comp, dense_stride);
     return hipGetLastError();
 }
 
@@ -429,16 +519,15 @@ hipError_t msr_bm25_scores(const Bm25Index& ix, const int32_t* q_term_off, const
                            const int32_t* q_qtf, int q_first, int nq, double min_score, double* cand_score,
                            int32_t* cand_doc, int32_t* cand_n, hipStream_t stream) {
     if (nq <= 0 || ix.n_docs <= 0) return hipSuccess;
-    // A workgroup looks a query's terms up once and then walks `tpw` consecutive tiles with that plan in registers.  More tiles
-    // per workgroup amortise the lookups (chains of dependent loads) but leave fewer workgroups: large batches take 8, a
-    // single query keeps one tile per workgroup (its ~1000 waves are all the parallelism it has).
-    const int groups = (nq + BM25_QPW - 1) / BM25_QPW;
-    int tpw = groups >= 16 ? 8 : groups >= 8 ? 4 : groups >= 4 ? 2 : 1;
-    while (tpw > 1 && (int64_t)groups * ((ix.n_tiles + tpw - 1) / tpw) < 2048) tpw >>= 1;
-    dim3 grid((unsigned)groups, (unsigned)((ix.n_tiles + tpw - 1) / tpw));
-    // (diagnostic build: bit 6 of the knock-out mask pads every workgroup with 41 KB of unused LDS -> 2 instead of 4 per CU)
-    const size_t pad_lds = (g_bm25_dbg & 64) ? 41 * 1024 : 0;
-    bm25_taat_kernel<<<grid, BM25_THREADS, pad_lds, stream>>>(ix, q_term_off, q_terms, q_qtf, q_first, nq, min_score, tpw, cand_score,
-                                                        cand_doc, cand_n, g_bm25_dbg);
+    // A wave looks its query's terms up once and then walks `tpw` consecutive tiles with that plan in registers.  More tiles
+    // per wave amortise the lookups (chains of dependent loads) but leave fewer work items: large batches take 8, a single
+    // query one tile per wave (its ~1000 waves are all the parallelism it has).
+    int tpw = BM25_TPW;
+    while (tpw > 1 && (int64_t)nq * ((ix.n_tiles + tpw - 1) / tpw) < 8192) tpw >>= 1;
+    const int n_spans = (ix.n_tiles + tpw - 1) / tpw;
+    const int64_t items = (int64_t)nq * n_spans;
+    if (items >= (1ll << 31)) return hipErrorInvalidValue;
+    bm25_taat_kernel<<<(unsigned)((items + BM25_WAVES - 1) / BM25_WAVES), BM25_THREADS, 0, stream>>>(
+        ix, q_term_off, q_terms, q_qtf, q_first, nq, min_score, tpw, n_spans, cand_score, cand_doc, cand_n, g_bm25_dbg);
     return hipGetLastError();
 }

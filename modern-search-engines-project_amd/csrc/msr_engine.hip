@@ -36,8 +36,9 @@ struct msr_engine {
     void* score_rows = nullptr;       // max_queries rows of n_docs float64 (reused as float32 rows)
     size_t score_rows_bytes = 0;
     int32_t* bm_heavy_id = nullptr;    // skip table of the BM25 stage (see Bm25Index)
-    void* bm_post = nullptr;           // interleaved {doc, tf} copy of the postings (see Bm25Index)
-    double* bm_dnorm = nullptr;        // per-document length norms (see Bm25Index)
+    void* bm_post = nullptr;           // {doc, tf, tf_component} copy of the postings (see Bm25Index)
+    int32_t* bm_dense_id = nullptr;    // dense tf_component tables of the long negative-idf lists (see Bm25Index)
+    double* bm_dense = nullptr;
     uint32_t* bm_tile_off = nullptr;
     int32_t* bm_cand_doc = nullptr;    // max_queries rows of n_docs i32: document of each BM25 candidate
     int32_t* bm_cand_n = nullptr;      // [max_queries] candidates per query (zero between calls)
@@ -212,7 +213,7 @@ extern "C" int msr_create(const msr_config* cfg, msr_engine** out) {
 extern "C" int msr_destroy(msr_engine* e) {
     if (!e) return MSR_OK;
     free_dev(e->chunk_doc); free_dev(e->emb_presplit); free_dev(e->row_meta); free_dev(e->inv_norm_own); free_dev(e->span_doc); free_dev(e->wspan_doc); free_dev(e->wspan12_doc); free_dev(e->qn); free_dev(e->qimg); free_dev(e->emb_bf16);
-    free_dev(e->score_rows); free_dev(e->bm_heavy_id); free_dev(e->bm_post); free_dev(e->bm_dnorm); free_dev(e->bm_tile_off); free_dev(e->bm_cand_doc); free_dev(e->bm_cand_n); free_dev(e->sel.hist); free_dev(e->sel.state); free_dev(e->sel.cand_hi);
+    free_dev(e->score_rows); free_dev(e->bm_heavy_id); free_dev(e->bm_post); free_dev(e->bm_dense_id); free_dev(e->bm_dense); free_dev(e->bm_tile_off); free_dev(e->bm_cand_doc); free_dev(e->bm_cand_n); free_dev(e->sel.hist); free_dev(e->sel.state); free_dev(e->sel.cand_hi);
     free_dev(e->sel.cand_lo); free_dev(e->sel.cand_n); free_dev(e->rerank_cos); free_dev(e->rerank_meta);
     free_dev(e->bt_top_doc); free_dev(e->bt_top_score); free_dev(e->bt_top_n); free_dev(e->bt_cand_doc);
     free_dev(e->bt_cand_score); free_dev(e->bt_cand_chunk); free_dev(e->bt_cand_n);
@@ -271,7 +272,7 @@ extern "C" int msr_bind_postings(msr_engine* e, const int64_t* term_off, int64_t
 
     }
     Bm25Index cand{term_off, post_doc, post_tf, doc_len, idf, n_terms, n_postings, n_docs, (double)avgdl, k1, b,
-                   nullptr, nullptr, (int32_t)((n_docs + MSR_BM25_TILE - 1) / MSR_BM25_TILE), nullptr, nullptr};
+                   nullptr, nullptr, (int32_t)((n_docs + MSR_BM25_TILE - 1) / MSR_BM25_TILE), nullptr, nullptr, nullptr, 0};
     // the scoring kernel indexes LDS with (post_doc - tile start): validate the CSR once, on the device
     hipStream_t st = (hipStream_t)stream;
     int32_t h_flag = 0;
@@ -291,15 +292,21 @@ extern "C" int msr_bind_postings(msr_engine* e, const int64_t* term_off, int64_t
     // skip table for the long posting lists (one-time; the offsets come to the host once for this)
     free_dev(e->bm_heavy_id); e->bm_heavy_id = nullptr;
     free_dev(e->bm_tile_off); e->bm_tile_off = nullptr;
+    free_dev(e->bm_dense_id); e->bm_dense_id = nullptr;
+    free_dev(e->bm_dense); e->bm_dense = nullptr;
+    std::vector<int32_t> dense_terms;                         // long lists with negative idf, longest first (tables below)
     if (n_terms > 0) {
         std::vector<int64_t> h_toff((size_t)n_terms + 1);
+        std::vector<float> h_idf((size_t)n_terms);
         HIP_TRY(e, hipMemcpyAsync(h_toff.data(), term_off, h_toff.size() * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(e, hipMemcpyAsync(h_idf.data(), idf, h_idf.size() * sizeof(float), hipMemcpyDeviceToHost, st));
         HIP_TRY(e, hipStreamSynchronize(st));
         std::vector<int32_t> heavy_id((size_t)n_terms, -1), heavy_terms;
         for (int64_t t = 0; t < n_terms; ++t)
             if (h_toff[t + 1] - h_toff[t] >= MSR_BM25_HEAVY_DF && h_toff[t + 1] - h_toff[t] < (1ll << 32)) {
                 heavy_id[t] = (int32_t)heavy_terms.size();
                 heavy_terms.push_back((int32_t)t);
+                if (h_idf[t] < 0.0f) dense_terms.push_back((int32_t)t);
             }
         if (!heavy_terms.empty()) {
             hipError_t herr;
@@ -319,23 +326,55 @@ extern "C" int msr_bind_postings(msr_engine* e, const int64_t* term_off, int64_t
             cand.heavy_id = e->bm_heavy_id;
             cand.tile_off = e->bm_tile_off;
         }
+        // the longest negative-idf lists get a dense table: at most MSR_BM25_MAX_DENSE of them and 4 GiB in all
+        std::stable_sort(dense_terms.begin(), dense_terms.end(), [&](int32_t a, int32_t b2) {
+            return h_toff[a + 1] - h_toff[a] > h_toff[b2 + 1] - h_toff[b2];
+        });
+        const size_t row_bytes = (size_t)cand.n_tiles * MSR_BM25_TILE * sizeof(double);
+        const size_t cap = std::min<size_t>(MSR_BM25_MAX_DENSE, (size_t)(4ull << 30) / row_bytes);
+        if (dense_terms.size() > cap) dense_terms.resize(cap);
     }
-    // the interleaved copy the scoring kernel streams (after the validation above: the copy is of a well-formed index)
+    // the copy the scoring kernel streams (after the validation above: the copy is of a well-formed index): every posting with
+    // its tf_component, from the per-document length norms k1 (1 - b + b dl / avgdl)
     free_dev(e->bm_post); e->bm_post = nullptr;
     if (n_postings > 0) {
-        hipError_t herr = hipMalloc(&e->bm_post, (size_t)n_postings * 8);
-        if (herr != hipSuccess) return fail(e, MSR_ERR_NOMEM, "interleaved postings (%zu bytes): %s", (size_t)n_postings * 8, hipGetErrorString(herr));
-        HIP_TRY(e, msr_bm25_interleave(post_doc, post_tf, n_postings, e->bm_post, st));
-    }
-    cand.post = (const int2*)e->bm_post;
-    free_dev(e->bm_dnorm); e->bm_dnorm = nullptr;
-    {
         const int64_t n_pad = (int64_t)cand.n_tiles * MSR_BM25_TILE;
-        hipError_t herr = hipMalloc((void**)&e->bm_dnorm, (size_t)n_pad * sizeof(double));
-        if (herr != hipSuccess) return fail(e, MSR_ERR_NOMEM, "length norms: %s", hipGetErrorString(herr));
-        HIP_TRY(e, msr_bm25_dnorm(doc_len, n_docs, n_pad, k1, b, (double)avgdl, e->bm_dnorm, st));
+        double* dnorm = nullptr;
+        hipError_t herr = hipMalloc(&e->bm_post, (size_t)n_postings * sizeof(Bm25Post));
+        if (herr != hipSuccess)
+            return fail(e, MSR_ERR_NOMEM, "postings with tf components (%zu bytes): %s", (size_t)n_postings * sizeof(Bm25Post), hipGetErrorString(herr));
+        if ((herr = hipMalloc((void**)&dnorm, (size_t)n_pad * sizeof(double))) != hipSuccess)
+            return fail(e, MSR_ERR_NOMEM, "length norms: %s", hipGetErrorString(herr));
+        hipError_t h1 = msr_bm25_dnorm(doc_len, n_docs, n_pad, k1, b, (double)avgdl, dnorm, st);
+        hipError_t h2 = h1 == hipSuccess ? msr_bm25_post_comp(post_doc, post_tf, dnorm, k1, n_postings, (Bm25Post*)e->bm_post, st) : h1;
+        hipError_t h3 = hipStreamSynchronize(st);
+        free_dev(dnorm);
+        if (h2 != hipSuccess || h3 != hipSuccess)
+            return fail(e, MSR_ERR_HIP, "tf components: %s", hipGetErrorString(h2 != hipSuccess ? h2 : h3));
     }
-    cand.dnorm = e->bm_dnorm;
+    cand.post = (const Bm25Post*)e->bm_post;
+    if (!dense_terms.empty()) {
+        const int64_t stride = (int64_t)cand.n_tiles * MSR_BM25_TILE;
+        std::vector<int32_t> dense_id((size_t)n_terms, -1);
+        for (size_t h = 0; h < dense_terms.size(); ++h) dense_id[dense_terms[h]] = (int32_t)h;
+        hipError_t herr;
+        int32_t* d_terms = nullptr;
+        if ((herr = hipMalloc((void**)&e->bm_dense_id, dense_id.size() * sizeof(int32_t))) != hipSuccess ||
+            (herr = hipMalloc((void**)&e->bm_dense, dense_terms.size() * (size_t)stride * sizeof(double))) != hipSuccess ||
+            (herr = hipMalloc((void**)&d_terms, dense_terms.size() * sizeof(int32_t))) != hipSuccess) {
+            free_dev(d_terms);
+            return fail(e, MSR_ERR_NOMEM, "BM25 dense tables: %s", hipGetErrorString(herr));
+        }
+        HIP_TRY(e, hipMemcpyAsync(e->bm_dense_id, dense_id.data(), dense_id.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(e, hipMemcpyAsync(d_terms, dense_terms.data(), dense_terms.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(e, hipMemsetAsync(e->bm_dense, 0, dense_terms.size() * (size_t)stride * sizeof(double), st));
+        HIP_TRY(e, msr_bm25_build_dense(cand, d_terms, (int)dense_terms.size(), e->bm_dense, stride, st));
+        HIP_TRY(e, hipStreamSynchronize(st));
+        free_dev(d_terms);
+        cand.dense_id = e->bm_dense_id;
+        cand.dense_comp = e->bm_dense;
+        cand.dense_stride = stride;
+    }
     e->bm25 = cand;
     e->have_postings = true;
     return MSR_OK;

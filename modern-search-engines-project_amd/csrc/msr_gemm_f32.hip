@@ -256,7 +256,12 @@ __global__ __launch_bounds__(GF_THREADS) void gemm_stream_kernel(GemmF32Args a) 
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
             const int blk = w * 32 + mi * 16;
-            if (blk >= n_valid || (dbg & 32)) continue; // wave-uniform
+            if (blk >= n_valid || (dbg & 32)) {         // wave-uniform: a fragment wholly behind the tile.  Its accumulators hold
+#pragma unroll                                          // dot products of the NEXT tile's rows (or of the clamped last row):
+                for (int ni = 0; ni < 8; ++ni)          // mask them, the emission loop below looks at both fragments
+                    acc[mi][ni] = (f32x4){NEG_INF, NEG_INF, NEG_INF, NEG_INF};
+                continue;
+            }
             const int rb = blk + 4 * lg;
             const bool part = blk + 16 > n_valid;       // wave-uniform
             const f32x4 inv = inv4[mi];
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(GF_THREADS) void gemm_stream_kernel(GemmF32Args a) 
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) {
                         const float x = acc[mi][ni][rr];
-                        const bool hit = x >= thrv[ni];                       // (masked and skipped rows hold -inf / 0 < thr)
+                        const bool hit = x >= thrv[ni];                       // (rows behind the tile hold -inf: masked in the epilogue)
                         const unsigned long long hm = __ballot(hit);
                         if (hm != 0) {
                             const int pos = wave_cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
@@ -384,7 +389,7 @@ __global__ __launch_bounds__(256) void f16_margin_kernel(const float* __restrict
 // gate word per slice of 64 queries, the unit of the caller's gated sweeps, so a query with a huge tie group sends its own
 // slice back to the sweeps, not the whole call (an overflowing wave buffer concerns every query: all slices).
 __global__ __launch_bounds__(1024) void gemm_f32_cand_kernel(const int2* __restrict__ pairs, int32_t* __restrict__ pair_n,
-                                                              const int32_t* __restrict__ chunk_doc,
+                                                              const int32_t* __restrict__ chunk_doc, int64_t n_rows,
                                                               const int32_t* __restrict__ wv_count, int n_waves, int wv_cap,
                                                               const int32_t* __restrict__ flag, int32_t* __restrict__ cand_doc,
                                                               int32_t* __restrict__ cand_n, int32_t* __restrict__ gate) {
@@ -404,7 +409,14 @@ __global__ __launch_bounds__(1024) void gemm_f32_cand_kernel(const int2* __restr
     }
     int P = 64;
     while (P < raw) P <<= 1;
-    for (int i = t; i < P; i += 1024) key[i] = i < raw ? (uint32_t)chunk_doc[pairs[(size_t)q * GF_PAIR_CAP + i].x] + 1u : 0u;
+    for (int i = t; i < P; i += 1024) {
+        uint32_t kk = 0u;                               // (pad key)
+        if (i < raw) {
+            const int64_t row = pairs[(size_t)q * GF_PAIR_CAP + i].x;
+            if (row >= 0 && row < n_rows) kk = (uint32_t)chunk_doc[row] + 1u;   // (a row index is never trusted as an address)
+        }
+        key[i] = kk;
+    }
     __syncthreads();
     for (int kk = 2; kk <= P; kk <<= 1)
         for (int j = kk >> 1; j > 0; j >>= 1) {
@@ -505,8 +517,8 @@ hipError_t msr_gemm_f32_topk(const GemmF32Index& g, const DenseIndex& ix, const 
     }
     if ((err = msr_gemm_kth(g.tmax, g.n_tiles, g.tmax_stride, nq, 128 * G, k, margin, g.thr2, nullptr, stream)) != hipSuccess) return err;
     if ((err = msr_gemm_bucket(g.wvbuf, g.wv_cap, g.wv_count, grid * 8, g.thr2, g.pairs, g.pair_n, stream)) != hipSuccess) return err;
-    gemm_f32_cand_kernel<<<nq, 1024, 0, stream>>>((const int2*)g.pairs, g.pair_n, ix.chunk_doc, g.wv_count, grid * 8, g.wv_cap,
-                                                  g.flag, g.cand_doc, g.cand_n, gate);
+    gemm_f32_cand_kernel<<<nq, 1024, 0, stream>>>((const int2*)g.pairs, g.pair_n, ix.chunk_doc, ix.n_chunks, g.wv_count, grid * 8,
+                                                  g.wv_cap, g.flag, g.cand_doc, g.cand_n, gate);
     if ((err = hipGetLastError()) != hipSuccess) return err;
     return msr_batch_rescore(ix, qn, nq, k, 0, g.cand_doc, g.cand_score, g.cand_chunk, g.cand_n, out_doc, out_score, out_chunk,
                              out_n, stream);

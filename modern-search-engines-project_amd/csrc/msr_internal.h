@@ -50,6 +50,15 @@ hipError_t msr_merge_lists(int score_bits, const int32_t* in_doc, const void* in
 int msr_fail_global(int code, const char* fmt, ...);
 
 // ---- K1: BM25 term-at-a-time ----------------------------------------------------------------------
+// One posting as the scoring kernel streams it (engine-owned copy, built at bind): the document and the posting's
+// tf_component = (tf (k1 + 1)) / (tf + k1 (1 - b + b dl / avgdl)) (indexer/bm25_indexer.py:473-475), which depends on
+// (tf, document) only -- evaluated ONCE with the reference's own operations, so the kernel neither divides nor looks the
+// document length up.
+struct Bm25Post {
+    int32_t doc;
+    int32_t tf;
+    double comp;
+};
 struct Bm25Index {
     const int64_t* term_off;
     const int32_t* post_doc;
@@ -59,18 +68,29 @@ struct Bm25Index {
     int64_t n_terms, n_postings, n_docs;
     double avgdl, k1, b;
     // skip table (engine-owned, built at bind): for the terms with long posting lists, where each document
-    // tile starts inside the list, so a workgroup finds its slice with two loads instead of a search
+    // tile starts inside the list, so a wave finds its slice with two loads instead of a search
     const int32_t* heavy_id;   // [n_terms]: row of tile_off, or -1
     const uint32_t* tile_off;  // [n_heavy][n_tiles + 1], relative to term_off[t]
     int32_t n_tiles;
-    const int2* post;          // [n_postings] {doc, tf}: engine-owned interleaved copy, what the scoring kernel streams
-    const double* dnorm;       // [n_tiles * TILE] k1 (1 - b + b dl / avgdl) per document (engine-owned, built at bind)
+    const Bm25Post* post;      // [n_postings] {doc, tf, tf_component}: what the scoring kernel streams
+    // dense tf_component tables of the long lists with NEGATIVE idf (document frequency above half the corpus): such a
+    // term can only lower a score, so with min_score >= 0 a document it alone matches is never a candidate; its list is not
+    // streamed at all, its contribution is looked up for the documents the other terms touch (msr_bm25.hip)
+    const int32_t* dense_id;   // [n_terms]: row of dense_comp, or -1 (null: no table)
+    const double* dense_comp;  // [n_dense][dense_stride]: tf_component of (term, document), 0.0 = the document lacks the term
+    int64_t dense_stride;
 };
 hipError_t msr_bm25_dnorm(const int32_t* doc_len, int64_t n_docs, int64_t n_pad, double k1, double b, double avgdl, double* out,
                           hipStream_t stream);
-hipError_t msr_bm25_interleave(const int32_t* post_doc, const int32_t* post_tf, int64_t n, void* out, hipStream_t stream);
+// out[i] = {post_doc[i], post_tf[i], tf_component(post_tf[i], dnorm[post_doc[i]])}
+hipError_t msr_bm25_post_comp(const int32_t* post_doc, const int32_t* post_tf, const double* dnorm, double k1, int64_t n,
+                              Bm25Post* out, hipStream_t stream);
+// dense_comp row h <- the tf_components of term dense_terms[h] scattered by document (rows zeroed by the caller)
+hipError_t msr_bm25_build_dense(const Bm25Index& ix, const int32_t* dense_terms, int n_dense, double* dense_comp,
+                                int64_t dense_stride, hipStream_t stream);
 constexpr int MSR_BM25_TILE = 1024;          // documents per BM25 tile
 constexpr int MSR_BM25_HEAVY_DF = 2048;      // posting lists at least this long get a skip-table row
+constexpr int MSR_BM25_MAX_DENSE = 64;       // at most this many dense tf_component tables
 hipError_t msr_bm25_build_skip(const Bm25Index& ix, const int32_t* heavy_terms, int n_heavy, uint32_t* tile_off,
                                hipStream_t stream);
 // Candidate lists: for query q, cand_n[q] pairs (cand_score[q][i], cand_doc[q][i]) -- exactly the documents

@@ -213,6 +213,70 @@ def load_bm25_methods():
     return ns["search"], ns["_get_corpus_stats"]
 
 
+def load_bm25_build_method():
+    """BM25._process_document_batch (bm25_indexer.py:196-243): the per-batch table builder of build_index, sequential
+    branch (< 50 documents).  Same AST route as `search`; the tokeniser is the only stand-in (spaCy is absent)."""
+    src = _read("indexer/bm25_indexer.py")
+    lines = src.split("\n")
+    bad = [i for i, l in enumerate(lines) if "f'{title or 'N/A'}" in l]
+    if len(bad) != 1:
+        raise RuntimeError("expected exactly one 3.12-only f-string in bm25_indexer.py")
+    lines[bad[0]] = lines[bad[0]].replace("'N/A'", '"N/A"')
+    tree = ast.parse("\n".join(lines))
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "BM25")
+    methods = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "_process_document_batch"]
+    if len(methods) != 1:
+        raise RuntimeError("BM25._process_document_batch not found")
+    mod = ast.Module(body=methods, type_ignores=[])
+    ast.fix_missing_locations(mod)
+    ns = {"defaultdict": defaultdict, "List": List, "Dict": Dict, "Tuple": Tuple, "Optional": Optional}
+    _exec(mod, ns, "<reference bm25_indexer.py>")
+    return ns["_process_document_batch"]
+
+
+def bm25_build_fixture(build_fn):
+    """Three small crawls through the reference's own batch builder.  Tokeniser stand-in: str.split on the text the
+    reference hands to it (lower-cased, city spellings unified, bm25_indexer.py:216-219) -- tokenisation itself (spaCy)
+    stays unpinned.  Stored: the documents and the three tables the method returns."""
+    def parallel(*_a, **_k):
+        raise AssertionError("the fixture must stay below the 50-document switch to the multiprocessing branch")
+    self = types.SimpleNamespace(_tokenize=lambda text: text.split(), _process_document_batch_parallel=parallel)
+    rng = np.random.default_rng(77)
+    words = ["schloss", "neckar", "tübingen", "castle", "market", "bridge", "museum", "garden", "tower", "boat", "river",
+             "uni", "old", "town", "hall", "food", "beer", "walk", "hill", "view"]
+    cases = []
+    # (1) hand-made: a NULL title, a token-less document (only white space), both ASCII spellings of the city (also inside a
+    #     longer word), upper case, a repeated term, ids not in insertion order
+    docs1 = [(42, "Hohentubingen Castle", "The castle of Tuebingen above the Neckar castle"),
+             (7, None, "TUBINGEN market MARKET Market"),
+             (19, "   ", "  \t \n "),
+             (3, "Boat", None),
+             (100, "tübingen tuebingen tubingen", "x")]
+    cases.append(("hand_made", docs1))
+    # (2) random: 30 documents of 0..40 words from a 20-word vocabulary, ids with gaps, every fifth title NULL, two empty ones
+    docs2 = []
+    for i, doc_id in enumerate(sorted(rng.choice(5000, size=30, replace=False).tolist())):
+        n = 0 if i in (4, 17) else int(rng.integers(1, 41))
+        text = " ".join(rng.choice(words, size=n).tolist())
+        title = None if i % 5 == 0 else " ".join(rng.choice(words, size=int(rng.integers(0, 4))).tolist())
+        docs2.append((int(doc_id), title, text))
+    cases.append(("random_30", docs2))
+    # (3) 49 documents (the largest batch of the sequential branch), longer texts, ids descending
+    docs3 = []
+    for doc_id in sorted(rng.choice(100000, size=49, replace=False).tolist(), reverse=True):
+        text = " ".join(rng.choice(words, size=int(rng.integers(20, 200))).tolist())
+        docs3.append((int(doc_id), "Tuebingen " + str(doc_id % 7), text))
+    cases.append(("batch_49_descending_ids", docs3))
+    out = []
+    for name, docs in cases:
+        doc_stats, term_freq, term_updates = build_fn(self, docs)
+        out.append({"name": name, "documents": [[d, t, x] for d, t, x in docs],
+                    "doc_stats": [[int(d), int(l)] for d, l in doc_stats],
+                    "term_freq": [[int(d), t, int(f)] for d, t, f in term_freq],
+                    "term_updates": {t: [int(u["new_docs"]), int(u["freq_increase"])] for t, u in term_updates.items()}})
+    dump_json("bm25_build.json", out)
+
+
 def f32(x):
     return float(np.float32(x))
 
@@ -578,6 +642,7 @@ def main():
     bm25_kat(search_fn, stats_fn)
     bm25_random(search_fn, stats_fn, "bm25_random_a", seed=101, N=600, V=400, mean_len=30, nq=14)
     bm25_random(search_fn, stats_fn, "bm25_random_b", seed=202, N=2500, V=1500, mean_len=45, nq=20)
+    bm25_build_fixture(load_bm25_build_method())
     ns = load_reranker_namespace()
     cosine_fixture(ns)
     cosine_unit_fixture(ns)

@@ -42,6 +42,11 @@ def test_default_line_has_the_contract_fields():
     for leg in ("port", "vectorised", "literal"):          # three legs, p50 per query, cores stated
         assert c[leg]["p50_ms"] > 0 and c[leg]["value"] > 0 and c[leg]["cores"] >= 1 and c[leg]["queries"] == 2, leg
     assert c["literal"]["cores"] == 1 and c["p50_ms"] == c["port"]["p50_ms"]
+    # dense parity against the CPU restatement is reported with every benchmark line
+    p = d["dense_parity_vs_cpu"]
+    assert p["queries"] == 2 and p["k"] == 100 and p["within_1e-5"] is True and p["max_abs_score_diff"] <= 1e-5
+    assert p["top_k_doc_sets_equal_up_to_boundary_near_ties"] is True and p["same_doc_at_same_rank"] > 0.95
+    assert abs(d["vs_cpu_baseline"] - d["value"] / c["value"]) <= 1e-9 * d["vs_cpu_baseline"]
     v = d["variant_bf16_candidates"]
     assert v["value"] > 0 and v["top100_equals_default_path_within_2e-6"] is True
 

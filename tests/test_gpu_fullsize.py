@@ -98,6 +98,69 @@ def test_dense_fullsize_vs_torch_f32(world):
     assert float(score[:, 0].min()) > 0.8
 
 
+def test_stream_pass_fullsize_vs_torch_f32(world):
+    """The kernel behind bench.py's `value` -- gemm_stream_kernel, ONE pass over the f32 rows for 128 queries, ~20 k row
+    tiles at this size -- against the plain torch f32 reference at the full size: an exact hit, a
+    near-duplicate, planted and random queries, at k = 100 and k = 10; a NaN query returns nothing and leaves every other
+    64-query slice of the call bit for bit alone; the rerank of a 128-query ShardedEngine step equals that of the same
+    queries served 64 at a time (the sweeps)."""
+    from msretr.distributed import ShardedEngine
+    from msretr.synthetic import synthetic_queries
+    ix, dev = world["ix"], world["dev"]
+    eng = world["DeviceEngine"](ix, max_queries=128, max_k=1000, rerank_max_docs=1000)
+    assert eng.scan_width() == 128
+    terms, qvec = synthetic_queries(ix, 128, seed=123)
+    q = qvec.clone()
+    g = torch.Generator(device="cpu"); g.manual_seed(5)
+    q[0] = ix.emb[4_321_987] * 3.0                                                 # exact hit: cosine 1
+    noise = torch.nn.functional.normalize(torch.randn(768, generator=g), dim=0).to(dev)
+    q[1] = (ix.emb[77] + 0.05 * noise) * 0.3                                       # near-duplicate of a row in the first tile
+    q[2] = torch.randn(768, generator=g).to(dev) * 11.0                            # random direction: a flat score landscape
+    q[127] = (ix.emb[N_CHUNKS - 1] + 0.2 * noise) * 6.0                            # near the LAST row of the matrix (last tile)
+    picks = (0, 1, 2, 40, 64, 127)
+    for k in (100, 10):
+        doc, score, chunk, n = eng.dense_topk(q, k=k)
+        assert bool((n == k).all())
+        for i in picks:
+            best, ti, tv = _dense_torch(ix, q[i], k)
+            assert float((score[i] - best[doc[i].long()]).abs().max()) <= 1e-5    # every reported score is right
+            assert float((score[i] - tv).abs().max()) <= 1e-5                      # and the list is the top-k
+            missing = set(ti.tolist()) ^ set(doc[i].tolist())
+            assert all(abs(float(best[d]) - float(tv[-1])) <= 2e-5 for d in missing)   # only boundary near-ties may swap
+            lo = ix.doc_off[doc[i].long()].long(); hi = ix.doc_off[doc[i].long() + 1].long()
+            assert bool(((chunk[i] >= lo) & (chunk[i] < hi)).all())
+        assert abs(float(score[0, 0]) - 1.0) <= 1e-5 and int(chunk[0, 0]) == 4_321_987
+        assert int(chunk[127, 0]) == N_CHUNKS - 1
+    # the pass itself answered: its scores are exact f32 cosines, those of a 64-query call (K-split sweep, f16x2-split
+    # products) differ from them in the last bits
+    full = eng.dense_topk(q, k=100)
+    sweep = eng.dense_topk(q[:64], k=100)
+    assert not torch.equal(full[1][:64], sweep[1]) and float((full[1][:64] - sweep[1]).abs().max()) <= 1e-5
+    # a NaN query: n == 0 for it; its own 64-query slice comes back from the gated sweeps (= a 64-query call, bit for bit),
+    # the other slice keeps the pass' answer bit for bit
+    qn = q.clone(); qn[100, 5] = float("nan")
+    got = eng.dense_topk(qn, k=100)
+    assert int(got[3][100]) == 0 and bool((got[3][torch.arange(128, device=dev) != 100] == 100).all())
+    for a, b in zip(got, full):
+        assert torch.equal(a[:64], b[:64])
+    sw = eng.dense_topk(qn[64:], k=100)
+    for a, b in zip(got, sw):
+        assert torch.equal(a[64:], b)
+    # one step of the whole path, 128 queries: the rerank equals that of the same queries served 64 at a time
+    se = ShardedEngine(eng, 0, 0)
+    tl = [ix.term_ids(t) for t in terms]
+    one = se.search(tl, q, k1=1000, k2=100)
+    halves = [se.search(tl[s:s + 64], q[s:s + 64], k1=1000, k2=100) for s in (0, 64)]
+    for j in range(6):
+        assert torch.equal(one["rerank"][j], torch.cat([h["rerank"][j] for h in halves]))
+    for j in range(3):
+        assert torch.equal(one["bm25"][j], torch.cat([h["bm25"][j] for h in halves]))
+    hd = [torch.cat([h["dense"][j] for h in halves]) for j in range(4)]
+    assert torch.equal(one["dense"][3], hd[3]) and float((one["dense"][1] - hd[1]).abs().max()) <= 1e-5
+    assert float((one["dense"][0] == hd[0]).float().mean()) > 0.99
+    eng.close()
+
+
 def test_dense_fullsize_f16split_vs_exact(world):
     """The default (f16-split) scan against the exact f32 MFMA scan on the full corpus: same top-100 up to
     near-ties, scores within the proven bound."""

@@ -140,6 +140,62 @@ def test_bm25_many_tiles_common_rare_and_tied_terms(mods):
     eng.close()
 
 
+def test_bm25_negative_idf_terms_are_looked_up_in_query_order(mods):
+    """The scoring kernel does not stream the long lists with negative idf (min_score >= 0): their contributions are looked up
+    in dense tables for the documents the other terms touch, and must enter every sum at the term's position in the query.
+    70 such terms (only 64 get a table: the others are streamed), one dense term with idf exactly 0 (not prunable: its documents
+    score 0.0 >= 0.0), a dense positive term, a SHORT list with a negative idf (no table), medium and short positive lists;
+    queries put the negative terms first, last, in between, repeated (query frequency 2), alone, and beyond the four
+    prefetched streamed terms; min_score on both sides of 0.  Bit for bit against the oracle."""
+    rng = np.random.default_rng(2024)
+    N, lists, idf = 5000, [], []
+    def add(p_in, value):
+        docs = np.nonzero(rng.random(N) < p_in)[0].astype(np.int32)
+        lists.append(docs); idf.append(value)
+    for _ in range(70):
+        add(0.6, -rng.uniform(0.05, 0.9))                    # 0..69: ~3000 postings each, idf < 0
+    add(0.7, 0.0)                                            # 70: dense, idf exactly 0
+    add(0.55, 0.3)                                           # 71: dense, idf > 0
+    for _ in range(8):
+        add(0.05, rng.uniform(0.5, 3.0))                     # 72..79: ~250 postings (probed ranges)
+    add(0.006, -0.4)                                         # 80: ~30 postings with a NEGATIVE idf: streamed, no table
+    for _ in range(9):
+        add(0.006, rng.uniform(1.0, 4.0))                    # 81..89: ~30 postings
+    term_off = np.zeros(len(lists) + 1, np.int64); term_off[1:] = np.cumsum([len(x) for x in lists])
+    post_doc = np.concatenate(lists)
+    post_tf = rng.integers(1, 6, size=len(post_doc)).astype(np.int32)
+    doc_len = rng.integers(5, 900, size=N).astype(np.int32)
+    avgdl = float(np.float32(doc_len.mean()))
+    z = dict(doc_ids=np.arange(N, dtype=np.int64) * 2 + 1, doc_len=doc_len, term_off=term_off, post_doc=post_doc, post_tf=post_tf,
+             idf=np.asarray(idf, np.float32), avgdl=avgdl)
+    ix = mods["CorpusIndex"](total_docs=N, **z)
+    eng = mods["DeviceEngine"](ix, max_queries=16, max_k=1000)
+    queries = [
+        [3, 72, 81],                       # negative first
+        [72, 81, 3],                       # ... last (what preprocess_query's appended city term looks like)
+        [72, 3, 81, 5, 82],                # ... in between, two of them
+        [3, 3, 72],                        # query frequency 2 on a looked-up term
+        [3], [3, 5, 7],                    # negative terms only: no candidate at min_score >= 0
+        [69, 68, 67, 66, 65, 64, 72],      # (some of) the negative terms without a table: streamed
+        [70, 3], [3, 70, 72],              # idf == 0: every document of term 70 is a candidate
+        [71, 3, 72], [80, 81], [80, 3], [80],
+        [72, 1, 73, 2, 74, 3, 75, 4, 76, 5, 77, 6, 81, 7],          # lookups beyond the four prefetched streamed terms
+        [int(t) for t in rng.permutation(90)[:50]],               # 50 terms of every kind
+        [int(t) for t in rng.permutation(90)[:64]],               # MSR_MAX_QUERY_TERMS
+        [81, 82, 83],                      # no negative term at all
+        [200, -3, 3, 72],                  # unknown ids around a looked-up term
+    ]
+    for k, ms in ((1000, 0.0), (10, 0.0), (1000, 0.75), (1000, -0.5), (100, -100.0)):
+        for s0 in range(0, len(queries), 16):
+            qs = queries[s0:s0 + 16]
+            doc, score, n = [x.cpu().numpy() for x in eng.bm25_topk(qs, k=k, min_score=ms)]
+            for i, t in enumerate(qs):
+                oi, os_ = mods["bm25_ref"].topk(z, t, k, ms)
+                assert n[i] == len(oi), (s0 + i, k, ms)
+                assert doc[i, :n[i]].tolist() == oi.tolist() and score[i, :n[i]].tolist() == os_.tolist(), (s0 + i, k, ms)
+    eng.close()
+
+
 def test_bm25_massive_ties(mods):
     """All documents identical => every score equal: the k lowest doc indices must come back in order."""
     N = 20000
@@ -397,6 +453,40 @@ def test_dense_streaming_pass_overflow_takes_the_gated_sweeps(mods):
     assert np.array_equal(again[3], ref2[3]) and np.abs(again[1] - ref2[1]).max() <= 1e-5
     assert (again[0] == ref2[0]).mean() > 0.99
     eng.close()
+
+
+def test_streaming_pass_last_tile_with_a_partly_filled_fragment(mods):
+    """the last row tile ends inside a wave's FIRST 16-row fragment ((rows mod 32) in 1..16), so that wave's
+    second fragment lies wholly behind the matrix and accumulates products of the clamped last row.  A query equal to the last
+    row makes those phantom rows pass the emission threshold: they must be masked (an emitted row index >= n_rows is an
+    out-of-bounds read of chunk_doc further down).  Also an INNER tile of that shape (a 200-chunk document forces short
+    tiles): the rows behind it belong to the next tile and must not be emitted twice."""
+    rng = np.random.default_rng(17)
+    for tail in (9, 16, 1):
+        n_docs = 256 * 250 + tail                                # one chunk per document: tiles of exactly 256 rows + the tail
+        n = np.ones(n_docs, np.int64)
+        n[1000] = 200; n[1001] = 73                              # ... and short inner tiles (73 = 2 x 32 + 9 rows)
+        doc_off = np.zeros(n_docs + 1, np.int64); doc_off[1:] = np.cumsum(n)
+        C = int(doc_off[-1])
+        emb_t = torch.randn((C, 768), generator=torch.Generator().manual_seed(tail))
+        emb_t /= emb_t.norm(dim=1, keepdim=True)
+        emb_t[C - 1] *= 1.9                                      # un-normalised products of the phantom rows would be larger still
+        emb = emb_t.numpy()
+        ix = mods["CorpusIndex"](doc_ids=np.arange(n_docs, dtype=np.int64), doc_off=doc_off.astype(np.int32),
+                                 chunk_ids=np.arange(C, dtype=np.int64), emb=emb, total_docs=n_docs)
+        eng = mods["DeviceEngine"](ix, max_queries=128, max_k=100, rerank_max_docs=0)
+        assert eng.scan_width() == 128
+        q = rng.standard_normal((100, 768)).astype(np.float32)
+        q[3] = emb[C - 1] * 2.0                                  # the last row of the matrix
+        q[70] = emb[C - 1] + 0.1 * q[70] / np.linalg.norm(q[70])
+        q[5] = emb[doc_off[1001] + 72] * 0.7                     # the last row of the short inner tile
+        got = eng.dense_topk(q, k=100)
+        _check_dense(mods, eng, doc_off, emb, q[[3, 5, 70, 99]], 100, 0, [x[[3, 5, 70, 99]] for x in got])
+        g = [x.cpu().numpy() for x in got]
+        assert g[0][3, 0] == n_docs - 1 and g[2][3, 0] == C - 1 and abs(g[1][3, 0] - 1.0) <= 1e-5
+        sw = [np.concatenate(p) for p in zip(*[[x.cpu().numpy() for x in eng.dense_topk(q[s:s + 50], k=100)] for s in (0, 50)])]
+        assert np.array_equal(g[3], sw[3]) and np.abs(g[1] - sw[1]).max() <= 1e-5 and (g[0] == sw[0]).mean() > 0.99
+        eng.close()
 
 
 def test_streaming_pass_vs_oracle_and_query_groups(mods):
