@@ -59,9 +59,9 @@ typedef struct msr_config {
     int32_t rerank_max_docs;  /* largest candidate list per query for msr_rerank, <= 1024 */
     int32_t scan_layout;      /* 0 = row-major embeddings; 1 = 16-row interleaved */
     int32_t scan_variant;     /* 0 = default: f16-split products when every row norm is in [0.5, 2], else exact f32;
-                                 2 = always the exact-f32 MFMA kernel; 7 = f16-split on the 32-query kernel; 15 = the default kernel over a
-                                 pre-split f16 hi/lo copy of the rows (+4 bytes per value of HBM, ~4 % faster); other values (<= 15):
-                                 A/B variants (msr_dense.hip, msr_dense_ks.hip) */
+                                 2 = always the exact-f32 MFMA kernel; 7 = f16-split on the 32-query kernel; 14 = the K-split kernel
+                                 (what 0 resolves to on unit-norm rows); 15 = the K-split kernel over a pre-split f16 hi/lo copy of
+                                 the rows (+4 bytes per value of HBM, ~4 % faster).  Any other value: msr_create fails */
 } msr_config;
 
 /* BM25 parameters travel with the postings (bm25_indexer.py:57 k1=1.2, b=0.75). */
@@ -179,6 +179,16 @@ int msr_rerank_fuse(msr_engine* e, int32_t n_queries, const int32_t* cand_doc, c
                     const int32_t* cand_n, int32_t max_cand, const float* cos, const int32_t* meta,
                     const msr_rerank_params* params, int32_t* out_doc, double* out_score, double* out_orig,
                     int32_t* out_chunk, int32_t* out_n, int32_t* out_rows, void* stream);
+
+/* Join of the per-shard halves of msr_rerank_gather after they have been exchanged (msretr/distributed.py sends every
+ * shard's half of a query to the rank that fuses that query: one all-to-all).  Part p holds cos [n_queries][max_cand][10] at
+ * cos_parts + p * part_stride_bytes and meta [n_queries][max_cand][3] at meta_parts + p * part_stride_bytes (4-byte aligned;
+ * 16-byte aligned pointers and stride take the wide path).  out = bitwise OR over the parts: exactly one shard owns a
+ * candidate's document and wrote non-zero words for it, so the OR is that shard's entry.  No reference counterpart
+ * (reranker_api.py:27-63 fetches all rows from one database). */
+int msr_rerank_combine(msr_engine* e, const float* cos_parts, const int32_t* meta_parts, int32_t n_parts,
+                       int64_t part_stride_bytes, int32_t n_queries, int32_t max_cand, float* out_cos,
+                       int32_t* out_meta, void* stream);
 
 /* Merge n_parts per-shard top-k lists (the payload of the RCCL all-gather) into the global top-k.
  * in_doc [n_parts][n_queries][k] i32 GLOBAL doc indices, in_score same shape (score_bits = 32: f32,

@@ -60,6 +60,7 @@ _SIGNATURES = {
     "msr_rerank_gather": (C.c_int, [_P, _P, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     "msr_rerank_fuse": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_int32, _P, _P, C.POINTER(MsrRerankParams), _P, _P,
                                   _P, _P, _P, _P, _P]),
+    "msr_rerank_combine": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P]),
     "msr_merge_topk": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "msr_merge_topk_payload": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P,
                                          _P, _P]),

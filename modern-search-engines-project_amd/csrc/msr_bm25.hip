@@ -31,6 +31,9 @@
 // round of 64 probes for the lists in between) is built once per span, lane-parallel (lane j = term j); the loads of
 // tile t + 1 are issued before tile t is accumulated (two register sets).
 //
+// Output: the candidates of a (query, span) go to a segment of the query's candidate row that belongs to that wave alone
+// -- no atomics, no counters to clear; the top-k select (msr_topk.hip) walks the segments.
+//
 // HBM traffic per query: 16 B per posting of its streamed terms + 8 B per (touched document, looked-up term) from tables
 // that stay in the L2 / Infinity Cache + 12 B per candidate (the (score, doc) list consumed by the top-k select).
 #include <stdio.h>
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
                                                                   int q_first, int nq, double min_score, int tpw, int n_spans,
                                                                   double* __restrict__ cand_score,
                                                                   int32_t* __restrict__ cand_doc,
-                                                                  int32_t* __restrict__ cand_n, int dbg_arg) {
+                                                                  int32_t* __restrict__ seg_n, int dbg_arg) {
 #ifdef MSR_DIAG
     const int dbg = dbg_arg;   // timing experiments (wrong results): 1 no table lookups, 2 no accumulator update, 4 no streaming
                                // beyond the prefetch, 8 no prefetch, 16 no emission, 64 stream every list (no pruning)
@@ -86,6 +89,11 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
     const int item = (int)blockIdx.x * BM25_WAVES + wave;
     const int span = item / nq, q = item - span * nq;          // q: row of the candidate lists
     if (span >= n_spans) return;                               // (wave-uniform; there is no barrier in this kernel)
+    // The candidates of this item go to segment `span` of row q of the candidate arrays: positions [span tpw TILE, ...) of
+    // the row belong to this wave alone (a span cannot yield more candidates than it has documents), so nothing is reserved
+    // with an atomic; the segment's length is written once, at the end.
+    int32_t* seg_len = seg_n + (int64_t)q * n_spans + span;
+    int seg_cnt = 0;
     const int tile0 = span * tpw;                              // this wave's tiles: tile0 .. tile0 + n_my - 1
     const int n_my = tile0 + tpw <= ix.n_tiles ? tpw : ix.n_tiles - tile0;
     double* acc = acc_all[wave];
@@ -140,7 +148,11 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
     }
     const unsigned long long look_mask = __ballot(klass == K_LOOKUP);
     const unsigned long long stream_mask = __ballot(klass >= K_HEAVY);
-    if (stream_mask == 0) return;                    // no streamed term: no document can reach min_score (or no known term)
+    if (stream_mask == 0) {                          // no streamed term: no document can reach min_score (or no known term)
+        if (lane == 0) *seg_len = 0;
+        return;
+    }
+    const int64_t seg_base = (int64_t)q * ix.n_docs + (int64_t)tile0 * BM25_TILE;
     // ---- 2. lists of 65 .. HEAVY_DF-1 postings: one round of 64 probes narrows [r0, r1) to the chunks that can hold
     //         documents of the span's tiles; MED lists side by side (the probes are independent loads) ----
     {
@@ -341,35 +353,21 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
         if (jprev < j_rest) walks(jprev, j_rest);            // (fewer than TPRE streamed terms: the looked-up ones behind the last)
         if (list_n == 0) return;
         // ---- the tile's candidates: the touched documents with score >= min_score (:461,480) as (score, doc) pairs appended
-        //      to the query's list, one reservation per wave and tile; every touched accumulator goes back to "untouched" ----
+        //      to the item's segment; every touched accumulator goes back to "untouched" ----
         const double un = __longlong_as_double((long long)UNTOUCHED);
-        int total = 0;
-        if (!(dbg & 16)) {
-            for (int b = 0; b < list_n; b += 64) {
-                const int e = b + lane;
-                const bool keep = e < list_n && acc[list[e < list_n ? e : 0]] >= min_score;
-                total += __popcll(__ballot(keep));
-            }
-        }
-        int64_t o = 0;
-        if (total) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&cand_n[q], total);
-            o = (int64_t)q * ix.n_docs + __builtin_amdgcn_readfirstlane(base);
-        }
         for (int b = 0; b < list_n; b += 64) {
             const int e = b + lane;
             const bool in = e < list_n;
             const uint32_t d = list[in ? e : 0];
             const double sc = acc[d];
-            const bool keep = total && in && sc >= min_score;
+            const bool keep = in && sc >= min_score && !(dbg & 16);
             const unsigned long long km = __ballot(keep);
             if (keep) {
-                const int64_t w = o + lane_rank(km);
+                const int64_t w = seg_base + seg_cnt + lane_rank(km);
                 cand_score[w] = sc;
                 cand_doc[w] = (int32_t)(lo + d);
             }
-            o += __popcll(km);
+            seg_cnt += __popcll(km);
             if (in) acc[d] = un;
         }
     };
@@ -383,6 +381,7 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
             process(tt + 1, rb);
         }
     }
+    if (lane == 0) *seg_len = seg_cnt;
 }
 
 // Bind-time validation of the CSR the scoring kernel trusts: offsets monotone and complete, document indices
@@ -515,9 +514,12 @@ hipError_t msr_bm25_validate(const Bm25Index& ix, int32_t* flag, hipStream_t str
     return hipGetLastError();
 }
 
+int msr_bm25_max_segments(int64_t n_docs) { return (int)((n_docs + BM25_TILE - 1) / BM25_TILE); }
+
 hipError_t msr_bm25_scores(const Bm25Index& ix, const int32_t* q_term_off, const int32_t* q_terms,
                            const int32_t* q_qtf, int q_first, int nq, double min_score, double* cand_score,
-                           int32_t* cand_doc, int32_t* cand_n, hipStream_t stream) {
+                           int32_t* cand_doc, int32_t* seg_n, int* n_seg, int64_t* seg_stride, hipStream_t stream) {
+    *n_seg = 0; *seg_stride = 0;
     if (nq <= 0 || ix.n_docs <= 0) return hipSuccess;
     // A wave looks its query's terms up once and then walks `tpw` consecutive tiles with that plan in registers.  More tiles
     // per wave amortise the lookups (chains of dependent loads) but leave fewer work items: large batches take 8, a single
@@ -527,7 +529,9 @@ hipError_t msr_bm25_scores(const Bm25Index& ix, const int32_t* q_term_off, const
     const int n_spans = (ix.n_tiles + tpw - 1) / tpw;
     const int64_t items = (int64_t)nq * n_spans;
     if (items >= (1ll << 31)) return hipErrorInvalidValue;
+    *n_seg = n_spans;
+    *seg_stride = (int64_t)tpw * BM25_TILE;
     bm25_taat_kernel<<<(unsigned)((items + BM25_WAVES - 1) / BM25_WAVES), BM25_THREADS, 0, stream>>>(
-        ix, q_term_off, q_terms, q_qtf, q_first, nq, min_score, tpw, n_spans, cand_score, cand_doc, cand_n, g_bm25_dbg);
+        ix, q_term_off, q_terms, q_qtf, q_first, nq, min_score, tpw, n_spans, cand_score, cand_doc, seg_n, g_bm25_dbg);
     return hipGetLastError();
 }

@@ -41,7 +41,7 @@ struct msr_engine {
     double* bm_dense = nullptr;
     uint32_t* bm_tile_off = nullptr;
     int32_t* bm_cand_doc = nullptr;    // max_queries rows of n_docs i32: document of each BM25 candidate
-    int32_t* bm_cand_n = nullptr;      // [max_queries] candidates per query (zero between calls)
+    int32_t* bm_cand_n = nullptr;      // [max_queries][tiles] candidates per (query, segment) of the candidate rows
     size_t bm_cand_bytes = 0;
     SelScratch sel{};
     float* rerank_cos = nullptr;
@@ -265,10 +265,9 @@ extern "C" int msr_bind_postings(msr_engine* e, const int64_t* term_off, int64_t
                 return fail(e, MSR_ERR_NOMEM, "BM25 candidate lists (%zu bytes): %s", need, hipGetErrorString(herr));
             e->bm_cand_bytes = need;
         }
-        if (!e->bm_cand_n) {
-            if ((herr = hipMalloc((void**)&e->bm_cand_n, (size_t)e->cfg.max_queries * sizeof(int32_t))) != hipSuccess)
-                return fail(e, MSR_ERR_NOMEM, "BM25 candidate counts: %s", hipGetErrorString(herr));
-        }
+        free_dev(e->bm_cand_n); e->bm_cand_n = nullptr;
+        if ((herr = hipMalloc((void**)&e->bm_cand_n, (size_t)e->cfg.max_queries * msr_bm25_max_segments(n_docs) * sizeof(int32_t))) != hipSuccess)
+            return fail(e, MSR_ERR_NOMEM, "BM25 candidate counts: %s", hipGetErrorString(herr));
 
     }
     Bm25Index cand{term_off, post_doc, post_tf, doc_len, idf, n_terms, n_postings, n_docs, (double)avgdl, k1, b,
@@ -649,16 +648,17 @@ extern "C" int msr_bm25_topk(msr_engine* e, const int32_t* q_term_off, const int
         double* o_score = out_score + (int64_t)q0 * k;
         // every launch gets its own event pair (ring of EV_RING; later launches are not recorded)
         const bool timed = e->timing && e->ev_count[1] < msr_engine::EV_RING;
-        HIP_TRY(e, hipMemsetAsync(e->bm_cand_n, 0, (size_t)nq * sizeof(int32_t), st));
+        int n_seg = 0;
+        int64_t seg_stride = 0;
         if (timed) HIP_TRY(e, hipEventRecord(e->ev_start[1][e->ev_count[1]], st));
         HIP_TRY(e, msr_bm25_scores(e->bm25, q_term_off, q_terms, q_qtf, q0, nq, min_score, (double*)e->score_rows, e->bm_cand_doc,
-                                   e->bm_cand_n, st));
+                                   e->bm_cand_n, &n_seg, &seg_stride, st));
         if (timed) {
             HIP_TRY(e, hipEventRecord(e->ev_stop[1][e->ev_count[1]], st));
             e->ev_count[1]++;
         }
-        HIP_TRY(e, msr_select_topk_list((const double*)e->score_rows, e->bm_cand_doc, e->bm_cand_n, N, N, nq, k, e->sel,
-                                        o_doc, o_score, out_n + q0, st));
+        HIP_TRY(e, msr_select_topk_list((const double*)e->score_rows, e->bm_cand_doc, e->bm_cand_n, n_seg, seg_stride, N, nq, k,
+                                        e->sel, o_doc, o_score, out_n + q0, st));
     }
     return MSR_OK;
 }
@@ -938,6 +938,21 @@ extern "C" int msr_rerank_fuse(msr_engine* e, int32_t n_queries, const int32_t* 
     const RerankParams p{params->smoothing, params->max_boost, params->max_decay, params->max_chunks};
     HIP_TRY(e, msr_rerank_fuse_run(n_queries, cand_doc, cand_bm25, cand_n, max_cand, p, cos, meta, out_doc, out_score,
                                    out_orig, out_chunk, out_n, out_rows, (hipStream_t)stream));
+    return MSR_OK;
+}
+
+extern "C" int msr_rerank_combine(msr_engine* e, const float* cos_parts, const int32_t* meta_parts, int32_t n_parts,
+                                  int64_t part_stride_bytes, int32_t n_queries, int32_t max_cand, float* out_cos,
+                                  int32_t* out_meta, void* stream) {
+    if (!e) return MSR_ERR_INVALID;
+    if (!cos_parts || !meta_parts || !out_cos || !out_meta || n_parts < 1 || n_parts > 64 || n_queries < 0 || max_cand < 1 ||
+        max_cand > 1024 || part_stride_bytes < 0 || (part_stride_bytes & 3) || (n_parts > 1 && part_stride_bytes == 0))
+        return fail(e, MSR_ERR_INVALID, "msr_rerank_combine: bad argument (n_parts=%d, max_cand=%d)", n_parts, max_cand);
+    if (n_queries == 0) return MSR_OK;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    const int64_t rows = (int64_t)n_queries * max_cand;
+    HIP_TRY(e, msr_or_parts(cos_parts, n_parts, part_stride_bytes, rows * MSR_RERANK_MAX_CHUNKS, out_cos, (hipStream_t)stream));
+    HIP_TRY(e, msr_or_parts(meta_parts, n_parts, part_stride_bytes, rows * 3, out_meta, (hipStream_t)stream));
     return MSR_OK;
 }
 

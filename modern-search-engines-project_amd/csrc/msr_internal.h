@@ -34,8 +34,9 @@ hipError_t msr_select_topk(int score_bits, const void* scores, int64_t n, int64_
                            const SelScratch& sc, int32_t* out_doc, void* out_score, int32_t* out_n,
                            hipStream_t stream);
 
-// The same over LISTS: row q holds counts[q] (<= n_max) pairs (scores[q][i], idx[q][i]) in any order.
-hipError_t msr_select_topk_list(const double* scores, const int32_t* idx, const int32_t* counts, int64_t n_max,
+// The same over segmented LISTS: row q (stride elements apart) is cut into n_seg segments seg_stride elements apart; segment s
+// holds counts[q * n_seg + s] pairs (scores, idx) in any order, from its first position on.
+hipError_t msr_select_topk_list(const double* scores, const int32_t* idx, const int32_t* counts, int n_seg, int64_t seg_stride,
                                 int64_t stride, int nq, int k, const SelScratch& sc, int32_t* out_doc,
                                 double* out_score, int32_t* out_n, hipStream_t stream);
 
@@ -93,12 +94,14 @@ constexpr int MSR_BM25_HEAVY_DF = 2048;      // posting lists at least this long
 constexpr int MSR_BM25_MAX_DENSE = 64;       // at most this many dense tf_component tables
 hipError_t msr_bm25_build_skip(const Bm25Index& ix, const int32_t* heavy_terms, int n_heavy, uint32_t* tile_off,
                                hipStream_t stream);
-// Candidate lists: for query q, cand_n[q] pairs (cand_score[q][i], cand_doc[q][i]) -- exactly the documents
-// touched by a posting whose score is >= min_score, in no particular order (row stride n_docs).  cand_n must
-// be zero on entry.
+// Candidate lists: exactly the documents touched by a posting whose score is >= min_score, as pairs (cand_score, cand_doc)
+// in SEGMENTS: row q (stride n_docs) is cut into *n_seg segments of *seg_stride documents (one per work item of the kernel:
+// a span of tiles); segment s holds seg_n[q * n_seg + s] pairs from position s * seg_stride on, in no particular order.
+// Every count is written by the kernel (no initialisation, no atomics).  seg_n: msr_bm25_max_segments(n_docs) words per query.
+int msr_bm25_max_segments(int64_t n_docs);
 hipError_t msr_bm25_scores(const Bm25Index& ix, const int32_t* q_term_off, const int32_t* q_terms,
                            const int32_t* q_qtf, int q_first, int nq, double min_score, double* cand_score,
-                           int32_t* cand_doc, int32_t* cand_n, hipStream_t stream);
+                           int32_t* cand_doc, int32_t* seg_n, int* n_seg, int64_t* seg_stride, hipStream_t stream);
 
 // *flag (device) <- 0x7F7F7F7F if the CSR is well formed, else the lowest violated rule number (msr_bm25.hip).
 hipError_t msr_bm25_validate(const Bm25Index& ix, int32_t* flag, hipStream_t stream);
@@ -181,6 +184,9 @@ hipError_t msr_rerank_fuse_run(int nq, const int32_t* cand_doc, const double* ca
                                int max_cand, const RerankParams& p, const float* cos_in, const int32_t* meta,
                                int32_t* out_doc, double* out_score, double* out_orig, int32_t* out_chunk,
                                int32_t* out_n, int32_t* out_rows, hipStream_t stream);
+
+// out[0 .. n_words) = OR over the n_parts arrays in + p * part_stride_bytes (32-bit words)
+hipError_t msr_or_parts(const void* in, int n_parts, int64_t part_stride_bytes, int64_t n_words, void* out, hipStream_t stream);
 
 // ---- K5 as a tiled GEMM (msr_gemm.hip): candidates for hundreds to thousands of queries per call ------------------
 struct GemmIndex {

@@ -11,8 +11,9 @@
 // cosines (HBM-bound gather of <= 10 x 3 KiB rows) plus three integers per candidate (rows, URL group,
 // first row); (B) one workgroup per query runs the float64 chain on <= 1024 candidates entirely in LDS,
 // reading ONLY the arrays (A) produced.  That split is what lets a doc-sharded index rerank a global
-// candidate list: each shard runs (A) for the documents it owns, the arrays are summed across shards
-// (all other shards contribute zeros), and every rank runs (B) on identical inputs.
+// candidate list: each shard runs (A) for the documents it owns, the halves of a query travel to the rank that fuses that
+// query (one all-to-all, msretr/distributed.py) and are joined there (or_parts_kernel: all other shards contributed
+// zeros), and that rank runs (B) for its share of the queries.
 #include "msr_common.h"
 #include "msr_internal.h"
 
@@ -252,6 +253,30 @@ hipError_t msr_rerank_gather(const DenseIndex& ix, const int32_t* url_group, con
     return hipGetLastError();
 }
 
+// out[i] = OR over parts p of in[p][i]: the join of the per-shard halves of msr_rerank_gather.  Exactly one shard wrote a
+// non-zero word for a candidate (the owner of its document), every other shard wrote 0, so the OR -- like the integer sum the
+// all-reduce form used -- IS that shard's word.  16 bytes per thread and step.
+__global__ __launch_bounds__(256) void or_parts_kernel(const uint4* __restrict__ in, int n_parts, int64_t part_stride16,
+                                                        int64_t n16, uint4* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) {
+        uint4 v = in[i];
+        for (int p = 1; p < n_parts; ++p) {
+            const uint4 u = in[p * part_stride16 + i];
+            v.x |= u.x; v.y |= u.y; v.z |= u.z; v.w |= u.w;
+        }
+        out[i] = v;
+    }
+}
+__global__ __launch_bounds__(256) void or_parts_tail_kernel(const uint32_t* __restrict__ in, int n_parts, int64_t part_stride,
+                                                             int64_t first, int64_t n, uint32_t* __restrict__ out) {
+    const int64_t i = first + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t v = in[i];
+    for (int p = 1; p < n_parts; ++p) v |= in[p * part_stride + i];
+    out[i] = v;
+}
+
 hipError_t msr_rerank_fuse_run(int nq, const int32_t* cand_doc, const double* cand_bm25, const int32_t* cand_n,
                                int max_cand, const RerankParams& p, const float* cos_in, const int32_t* meta,
                                int32_t* out_doc, double* out_score, double* out_orig, int32_t* out_chunk,
@@ -260,5 +285,22 @@ hipError_t msr_rerank_fuse_run(int nq, const int32_t* cand_doc, const double* ca
     if (max_cand <= 0 || max_cand > RR_MAXM || p.max_chunks <= 0 || p.max_chunks > RR_MAXC) return hipErrorInvalidValue;
     rerank_fuse_kernel<<<nq, RR_THREADS, 0, stream>>>(cand_doc, cand_bm25, cand_n, max_cand, p, cos_in, meta, out_doc,
                                                       out_score, out_orig, out_chunk, out_n, out_rows);
+    return hipGetLastError();
+}
+
+// out[0 .. n_words) = OR over the n_parts arrays in + p * part_stride_bytes (32-bit words; every pointer and the stride
+// 4-byte aligned, 16-byte aligned ones take the wide path)
+hipError_t msr_or_parts(const void* in, int n_parts, int64_t part_stride_bytes, int64_t n_words, void* out, hipStream_t stream) {
+    if (n_words <= 0) return hipSuccess;
+    const bool wide = (((uintptr_t)in | (uintptr_t)out | (uint64_t)part_stride_bytes) & 15) == 0;
+    const int64_t n16 = wide ? n_words / 4 : 0;
+    if (n16 > 0) {
+        const unsigned grid = (unsigned)((n16 + 255) / 256 < 4096 ? (n16 + 255) / 256 : 4096);
+        or_parts_kernel<<<grid, 256, 0, stream>>>((const uint4*)in, n_parts, part_stride_bytes / 16, n16, (uint4*)out);
+    }
+    const int64_t rest = n_words - 4 * n16;
+    if (rest > 0)
+        or_parts_tail_kernel<<<(unsigned)((rest + 255) / 256), 256, 0, stream>>>((const uint32_t*)in, n_parts, part_stride_bytes / 4,
+                                                                              4 * n16, n_words, (uint32_t*)out);
     return hipGetLastError();
 }

@@ -109,15 +109,35 @@ __device__ __forceinline__ bool key_of(const T s, int64_t i, uint64_t& khi, uint
     return true;
 }
 
-// A row is either dense (element i belongs to index i, n elements) or a LIST (element i belongs to index
-// idx[i]; the row holds counts[q] elements in no particular order).  Lists are what the BM25 kernel emits:
-// only the documents that are candidates at all.
+// A row is either dense (element i belongs to index i, n elements) or a LIST (element i belongs to index idx[i]) cut into
+// n_seg SEGMENTS: segment s of row q holds counts[q * n_seg + s] elements, in no particular order, from position
+// s * seg_stride of the row.  Lists are what the BM25 kernel emits -- only the documents that are candidates at all, one
+// segment per span of document tiles, written without any atomic (every segment has exactly one writer).
 struct RowView {
     const int32_t* idx;      // null: dense
     const int32_t* counts;   // null: every row has n elements
+    int32_t n_seg;           // lists: segments per row (dense: unused)
+    int64_t seg_stride;      // lists: elements between the starts of consecutive segments
 };
-__device__ __forceinline__ int64_t row_len(const RowView& v, int q, int64_t n) { return v.counts ? v.counts[q] : n; }
 __device__ __forceinline__ int64_t row_index(const int32_t* idx_row, int64_t i) { return idx_row ? idx_row[i] : i; }
+// Work split: part `part` of `parts` takes a contiguous range of a dense row, or whole segments of a list.
+__device__ __forceinline__ void part_segments(const RowView& v, int part, int parts, int& s_first, int& s_last) {
+    if (!v.counts) { s_first = 0; s_last = 1; return; }
+    const int per = (v.n_seg + parts - 1) / parts;
+    s_first = part * per;
+    s_last = s_first + per < v.n_seg ? s_first + per : v.n_seg;
+}
+__device__ __forceinline__ void segment_range(const RowView& v, int q, int64_t n_dense, int s, int part, int parts,
+                                              int64_t& lo, int64_t& hi) {
+    if (!v.counts) {
+        const int64_t per = (n_dense + parts - 1) / parts;
+        lo = (int64_t)part * per;
+        hi = lo + per < n_dense ? lo + per : n_dense;
+    } else {
+        lo = (int64_t)s * v.seg_stride;
+        hi = lo + v.counts[(int64_t)q * v.n_seg + s];
+    }
+}
 
 // Histogram of digit `digit` over the elements that match the resolved prefix.  digit 0 needs no state.
 template <typename T>
@@ -140,29 +160,31 @@ __global__ __launch_bounds__(SEL_THREADS) void sel_hist_kernel(const T* __restri
     int part, shift, width;
     digit_pos<SB>(digit, part, shift, width);
     const uint32_t wmask = (1u << width) - 1u;
-    const int64_t n = row_len(view, q, n_dense);
-    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
-    const int64_t lo = (int64_t)blockIdx.x * per;
-    const int64_t hi = lo + per < n ? lo + per : n;
     const T* row = scores + (int64_t)q * stride;
     const int32_t* irow = view.idx ? view.idx + (int64_t)q * stride : nullptr;
-    // four independent loads in flight per thread (one per iteration left the pass latency-bound)
-    for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += 4 * SEL_THREADS) {
-        T v[4];
-        int64_t ix[4];
+    int s_first, s_last;
+    part_segments(view, (int)blockIdx.x, (int)gridDim.x, s_first, s_last);
+    for (int sg = s_first; sg < s_last; ++sg) {
+        int64_t lo, hi;
+        segment_range(view, q, n_dense, sg, (int)blockIdx.x, (int)gridDim.x, lo, hi);
+        // four independent loads in flight per thread (one per iteration left the pass latency-bound)
+        for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += 4 * SEL_THREADS) {
+            T v[4];
+            int64_t ix[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t i = i0 + (int64_t)u * SEL_THREADS;
-            v[u] = i < hi ? row[i] : ScoreTraits<T>::neg_inf();
-            ix[u] = i < hi ? row_index(irow, i) : 0;
-        }
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = i0 + (int64_t)u * SEL_THREADS;
+                v[u] = i < hi ? row[i] : ScoreTraits<T>::neg_inf();
+                ix[u] = i < hi ? row_index(irow, i) : 0;
+            }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            uint64_t khi; uint32_t klo;
-            if (!key_of(v[u], ix[u], khi, klo)) continue;
-            if ((khi & S.mask_hi) != S.pref_hi || (klo & S.mask_lo) != S.pref_lo) continue;
-            const uint32_t dg = part == 0 ? (uint32_t)(khi >> shift) & wmask : (klo >> shift) & wmask;
-            atomicAdd(&h[dg], 1u);
+            for (int u = 0; u < 4; ++u) {
+                uint64_t khi; uint32_t klo;
+                if (!key_of(v[u], ix[u], khi, klo)) continue;
+                if ((khi & S.mask_hi) != S.pref_hi || (klo & S.mask_lo) != S.pref_lo) continue;
+                const uint32_t dg = part == 0 ? (uint32_t)(khi >> shift) & wmask : (klo >> shift) & wmask;
+                atomicAdd(&h[dg], 1u);
+            }
         }
     }
     __syncthreads();
@@ -225,36 +247,38 @@ __global__ __launch_bounds__(SEL_THREADS) void sel_compact_kernel(const T* __res
     if (!S.done) return;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    const int64_t n = row_len(view, q, n_dense);
-    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
-    const int64_t lo = (int64_t)blockIdx.x * per;
-    const int64_t hi = lo + per < n ? lo + per : n;
     const T* row = scores + (int64_t)q * stride;
     const int32_t* irow = view.idx ? view.idx + (int64_t)q * stride : nullptr;
-    for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += 4 * SEL_THREADS) {
-        T v[4];
-        int64_t ix[4];
+    int s_first, s_last;
+    part_segments(view, (int)blockIdx.x, (int)gridDim.x, s_first, s_last);
+    for (int sg = s_first; sg < s_last; ++sg) {
+        int64_t lo, hi;
+        segment_range(view, q, n_dense, sg, (int)blockIdx.x, (int)gridDim.x, lo, hi);
+        for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += 4 * SEL_THREADS) {
+            T v[4];
+            int64_t ix[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t i = i0 + (int64_t)u * SEL_THREADS;
-            v[u] = i < hi ? row[i] : ScoreTraits<T>::neg_inf();
-            ix[u] = i < hi ? row_index(irow, i) : 0;
-        }
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = i0 + (int64_t)u * SEL_THREADS;
+                v[u] = i < hi ? row[i] : ScoreTraits<T>::neg_inf();
+                ix[u] = i < hi ? row_index(irow, i) : 0;
+            }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            uint64_t khi; uint32_t klo;
-            if (!key_of(v[u], ix[u], khi, klo)) continue;
-            const uint64_t mh = khi & S.mask_hi;
-            const bool ge = mh > S.pref_hi || (mh == S.pref_hi && (klo & S.mask_lo) >= S.pref_lo);
-            if (!ge) continue;
-            const int pos = atomicAdd(&s_n, 1);                  // LDS atomic
-            if (pos < STAGE) {
-                s_hi[pos] = khi; s_lo[pos] = klo;
-            } else {                                             // more matches than the stage holds: append directly
-                const int g = atomicAdd(&cand_n[q], 1);
-                if (g < MSR_SEL_CAP) {
-                    cand_hi[(int64_t)q * MSR_SEL_CAP + g] = khi;
-                    cand_lo[(int64_t)q * MSR_SEL_CAP + g] = klo;
+            for (int u = 0; u < 4; ++u) {
+                uint64_t khi; uint32_t klo;
+                if (!key_of(v[u], ix[u], khi, klo)) continue;
+                const uint64_t mh = khi & S.mask_hi;
+                const bool ge = mh > S.pref_hi || (mh == S.pref_hi && (klo & S.mask_lo) >= S.pref_lo);
+                if (!ge) continue;
+                const int pos = atomicAdd(&s_n, 1);              // LDS atomic
+                if (pos < STAGE) {
+                    s_hi[pos] = khi; s_lo[pos] = klo;
+                } else {                                         // more matches than the stage holds: append directly
+                    const int g = atomicAdd(&cand_n[q], 1);
+                    if (g < MSR_SEL_CAP) {
+                        cand_hi[(int64_t)q * MSR_SEL_CAP + g] = khi;
+                        cand_lo[(int64_t)q * MSR_SEL_CAP + g] = klo;
+                    }
                 }
             }
         }
@@ -325,7 +349,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void sel_final_kernel(const T* __rest
     const int q = blockIdx.x, t = threadIdx.x;
     const T* row = scores + (int64_t)q * stride;
     const int32_t* irow = view.idx ? view.idx + (int64_t)q * stride : nullptr;
-    const int64_t n = row_len(view, q, n_dense);
+    int n_sg = 1, sg0 = 0;
+    part_segments(view, 0, 1, sg0, n_sg);                        // (this workgroup walks every segment of the row)
     if (t == 0) S_sh = st[q];
     __syncthreads();
     int cnt;
@@ -345,11 +370,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void sel_final_kernel(const T* __rest
             int part, shift, width;
             digit_pos<SB>(d, part, shift, width);
             const uint32_t wmask = (1u << width) - 1u;
-            for (int64_t i = t; i < n; i += SCAN_THREADS) {
-                uint64_t a; uint32_t b;
-                if (!key_of(row[i], row_index(irow, i), a, b)) continue;
-                if ((a & S.mask_hi) != S.pref_hi || (b & S.mask_lo) != S.pref_lo) continue;
-                atomicAdd(&h[part == 0 ? (uint32_t)(a >> shift) & wmask : (b >> shift) & wmask], 1u);
+            for (int sg = 0; sg < n_sg; ++sg) {
+                int64_t lo, hi;
+                segment_range(view, q, n_dense, sg, 0, 1, lo, hi);
+                for (int64_t i = lo + t; i < hi; i += SCAN_THREADS) {
+                    uint64_t a; uint32_t b;
+                    if (!key_of(row[i], row_index(irow, i), a, b)) continue;
+                    if ((a & S.mask_hi) != S.pref_hi || (b & S.mask_lo) != S.pref_lo) continue;
+                    atomicAdd(&h[part == 0 ? (uint32_t)(a >> shift) & wmask : (b >> shift) & wmask], 1u);
+                }
             }
             __syncthreads();
             select_step<SB>(h, suf, &S_sh, d, k);
@@ -358,13 +387,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void sel_final_kernel(const T* __rest
         if (t == 0) s_cnt = 0;
         __syncthreads();
         const SelState S = S_sh;
-        for (int64_t i = t; i < n; i += SCAN_THREADS) {
-            uint64_t a; uint32_t b;
-            if (!key_of(row[i], row_index(irow, i), a, b)) continue;
-            const uint64_t mh = a & S.mask_hi;
-            if (mh > S.pref_hi || (mh == S.pref_hi && (b & S.mask_lo) >= S.pref_lo)) {
-                const int pos = atomicAdd(&s_cnt, 1);
-                if (pos < MSR_SEL_CAP) { khi[pos] = a; klo[pos] = b; }   // h is dead: safe to overwrite
+        for (int sg = 0; sg < n_sg; ++sg) {
+            int64_t lo, hi;
+            segment_range(view, q, n_dense, sg, 0, 1, lo, hi);
+            for (int64_t i = lo + t; i < hi; i += SCAN_THREADS) {
+                uint64_t a; uint32_t b;
+                if (!key_of(row[i], row_index(irow, i), a, b)) continue;
+                const uint64_t mh = a & S.mask_hi;
+                if (mh > S.pref_hi || (mh == S.pref_hi && (b & S.mask_lo) >= S.pref_lo)) {
+                    const int pos = atomicAdd(&s_cnt, 1);
+                    if (pos < MSR_SEL_CAP) { khi[pos] = a; klo[pos] = b; }   // h is dead: safe to overwrite
+                }
             }
         }
         __syncthreads();
@@ -394,7 +427,7 @@ hipError_t select_impl(const T* scores, int64_t n, int64_t stride, RowView view,
                        int32_t* out_doc, T* out_score, int32_t* out_n, hipStream_t stream) {
     constexpr int SB = ScoreTraits<T>::SB;
     if (nq <= 0) return hipSuccess;
-    int64_t parts = (n + 8191) / 8192;
+    int64_t parts = view.counts ? view.n_seg : (n + 8191) / 8192;     // lists: whole segments per workgroup
     const int64_t max_parts = 2048 / nq > 0 ? 2048 / nq : 1;
     if (parts > max_parts) parts = max_parts;
     if (parts < 1) parts = 1;
@@ -500,17 +533,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void merge_kernel(const int32_t* __re
 hipError_t msr_select_topk(int score_bits, const void* scores, int64_t n, int64_t stride, int nq, int k,
                            const SelScratch& sc, int32_t* out_doc, void* out_score, int32_t* out_n,
                            hipStream_t stream) {
-    const RowView dense{nullptr, nullptr};
+    const RowView dense{nullptr, nullptr, 1, 0};
     if (score_bits == 32)
         return select_impl<float>((const float*)scores, n, stride, dense, nq, k, sc, out_doc, (float*)out_score, out_n, stream);
     return select_impl<double>((const double*)scores, n, stride, dense, nq, k, sc, out_doc, (double*)out_score, out_n, stream);
 }
 
-hipError_t msr_select_topk_list(const double* scores, const int32_t* idx, const int32_t* counts, int64_t n_max,
+hipError_t msr_select_topk_list(const double* scores, const int32_t* idx, const int32_t* counts, int n_seg, int64_t seg_stride,
                                 int64_t stride, int nq, int k, const SelScratch& sc, int32_t* out_doc,
                                 double* out_score, int32_t* out_n, hipStream_t stream) {
-    const RowView list{idx, counts};
-    return select_impl<double>(scores, n_max, stride, list, nq, k, sc, out_doc, out_score, out_n, stream);
+    if (n_seg < 1 || !counts || !idx) return hipErrorInvalidValue;
+    const RowView list{idx, counts, n_seg, seg_stride};
+    return select_impl<double>(scores, stride, stride, list, nq, k, sc, out_doc, out_score, out_n, stream);
 }
 
 hipError_t msr_merge_lists(int score_bits, const int32_t* in_doc, const void* in_score, const int32_t* in_n,

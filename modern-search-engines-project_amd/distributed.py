@@ -9,9 +9,16 @@ to the unsharded ones.  Per query batch:
      allocated once per batch shape
   3. every rank: the same deterministic merge (score desc, doc index asc), reading the gathered records in place; the
      arg-max chunk row of a dense entry rides along as the merge payload          (msr_merge_topk_payload)
-  4. reference-exact rerank of the GLOBAL stage-1 candidates: each rank computes the cosines of the
-     candidates it owns (msr_rerank_gather), one all-reduce (integer SUM over the raw bits: exactly one rank
-     contributes non-zero bits per candidate, so the sum is a select), and every rank runs the float64 chain (msr_rerank_fuse).
+  4. reference-exact rerank of the GLOBAL stage-1 candidates, sharded BY QUERY for everything that is not tied to the
+     documents: rank r owns queries [r Qs, (r + 1) Qs), Qs = ceil(Q / world).
+       a. every rank computes the cosines / meta of the candidates it owns, for all queries (msr_rerank_gather), straight
+          into the send buffer of
+       b. ONE all-to-all: the half of query q goes to the rank that owns q (xGMI is point to point: every link carries
+          1 / world of a rank's buffer at the same time -- an all-reduce of the same words moved twice the bytes around a
+          ring and left every rank with all queries);
+       c. the owner joins the `world` halves (bitwise OR: exactly one rank wrote non-zero words per candidate,
+          msr_rerank_combine) and runs the float64 chain for ITS queries only (msr_rerank_fuse: 1 / world of the work);
+       d. ONE all-gather of the fused lists (rerank_keep entries per query) gives every rank the result.
 
 No embedding or posting ever crosses a link: only k records per query do.  The reference has no counterpart
 (it is a single process talking HTTP to itself).
@@ -40,7 +47,7 @@ class _Exchange:
         self.world, self.Q, self.k1, self.k2 = world, Q, k1, k2
         self.send = torch.zeros(o, dtype=torch.uint8, device=device)
         self.recv = torch.zeros(world * o, dtype=torch.uint8, device=device) if world > 1 else self.send
-        self.rerank = {}                                  # M -> int32 buffer of the all-reduce
+        self.rerank = {}                                  # (M, keep) -> _RerankExchange
 
     def _view(self, buf, base, name):
         o, n, dt = self.off[name]
@@ -54,6 +61,58 @@ class _Exchange:
 
     def part(self, g, name):                              # rank g's segment of the gathered buffer
         return self._view(self.recv, g * self.record, name)
+
+
+_FUSED = (("doc", torch.int32, True), ("score", torch.float64, True), ("orig", torch.float64, True),
+          ("chunk", torch.int32, True), ("n", torch.int32, False), ("rows", torch.int32, False))
+
+
+class _RerankExchange:
+    """Buffers of the query-sharded rerank, allocated once per (Q, M, keep, device).
+    a2a_send / a2a_recv: int32 [world][block]; block o of the send buffer holds this rank's halves of the queries rank o owns,
+    cos [Qs][M][10] (float bits) followed by meta [Qs][M][3]; block g of the receive buffer is rank g's half of MY queries.
+    out_send / out_recv: the fused lists of my queries, [doc | score | orig | chunk | n | rows] with `keep` entries per query,
+    every segment 8-byte aligned, and the gathered records of all ranks."""
+
+    def __init__(self, world, Q, M, keep, device):
+        self.world, self.Q, self.M, self.keep = world, Q, M, keep
+        self.Qs = (Q + world - 1) // world
+        self.cos_words = self.Qs * M * 10
+        self.block = (self.Qs * M * 13 + 3) // 4 * 4      # whole 16-byte units: the join takes its wide path
+        self.a2a_send = torch.zeros(world * self.block, dtype=torch.int32, device=device)
+        self.a2a_recv = torch.zeros(world * self.block, dtype=torch.int32, device=device)
+        self.off, o = {}, 0
+        for name, dt, per_k in _FUSED:
+            n = self.Qs * (keep if per_k else 1)
+            self.off[name] = (o, n, dt)
+            o += (n * torch.empty(0, dtype=dt).element_size() + 7) // 8 * 8
+        self.record = o
+        self.out_send = torch.zeros(o, dtype=torch.uint8, device=device)
+        self.out_recv = torch.zeros(world * o, dtype=torch.uint8, device=device)
+
+    def send_views(self, o):
+        """(cos float32 [Qs, M, 10], meta int32 [Qs, M, 3]) of block o of the send buffer."""
+        b = self.a2a_send[o * self.block:(o + 1) * self.block]
+        return (b[:self.cos_words].view(torch.float32).view(self.Qs, self.M, 10),
+                b[self.cos_words:self.Qs * self.M * 13].view(self.Qs, self.M, 3))
+
+    def recv_parts(self):
+        """(cos float32 [world, Qs, M, 10], meta int32 [world, Qs, M, 3]): strided views of the receive buffer."""
+        r = self.a2a_recv.view(self.world, self.block)
+        return (r[:, :self.cos_words].view(torch.float32).view(self.world, self.Qs, self.M, 10),
+                r[:, self.cos_words:self.Qs * self.M * 13].view(self.world, self.Qs, self.M, 3))
+
+    def out_view(self, name):
+        o, n, dt = self.off[name]
+        v = self.out_send[o:o + n * torch.empty(0, dtype=dt).element_size()].view(dt)
+        return v.view(self.Qs, self.keep) if dict((a, c) for a, _, c in _FUSED)[name] else v
+
+    def gathered(self, name):
+        """Field `name` of all ranks in query order: [world * Qs, keep] (or [world * Qs]); rows >= Q are padding."""
+        o, n, dt = self.off[name]
+        es = torch.empty(0, dtype=dt).element_size()
+        v = self.out_recv.view(self.world, self.record)[:, o:o + n * es].contiguous().view(dt)
+        return v.view(self.world * self.Qs, self.keep) if dict((a, c) for a, _, c in _FUSED)[name] else v.view(-1)
 
 
 class ShardedEngine:
@@ -114,13 +173,16 @@ class ShardedEngine:
 
     # ------------------------------------------------------------------ the sharded hot path
     def search(self, term_lists, qvec, k1=1000, k2=100, min_score=0.0, max_chunks_per_doc=0, rerank=True,
-               packed=None, dense_batched=False, **rerank_params):
+               packed=None, dense_batched=False, rerank_keep=None, **rerank_params):
+        """-> dict(bm25=(doc, score, n), dense=(doc, score, chunk, n), rerank=(doc, score, orig, chunk, n, rows)); documents
+        and chunk rows are GLOBAL indices; every rank returns the same tensors.  rerank_keep: entries per query of the fused
+        lists to return (None: all k1; the reranker facade's diversification wants them all, a top-100 service k2)."""
         e = self.engine
         b_doc, b_score, b_n = e.bm25_topk(term_lists, k=k1, min_score=min_score, packed=packed)
         dense = e.dense_topk_batched if dense_batched else e.dense_topk
         d_doc, d_score, d_chunk, d_n = dense(qvec, k=k2, max_chunks_per_doc=max_chunks_per_doc)
+        Q = int(b_doc.shape[0])
         if self.world > 1:
-            Q = int(b_doc.shape[0])
             ex = self._exchange(Q, k1, k2, b_doc.device)
             # this rank's record: local indices -> global, written straight into the preallocated send buffer
             self._globalise_into(ex.out("b_doc"), b_doc, self.doc_base)
@@ -140,20 +202,38 @@ class ShardedEngine:
             d_doc = self._globalise(d_doc, self.doc_base)
             d_chunk = self._globalise(d_chunk, self.row_base)
         out = dict(bm25=(b_doc, b_score, b_n), dense=(d_doc, d_score, d_chunk, d_n))
-        if rerank:
-            cos, meta = e.rerank_gather(qvec, b_doc, b_n, doc_base=self.doc_base, row_base=self.row_base,
-                                        max_chunks=rerank_params.get("max_chunks", 10))
-            if self.world > 1:
-                nc, nm = cos.numel(), meta.numel()
-                buf = ex.rerank.get((nc, nm))
-                if buf is None:
-                    buf = ex.rerank[(nc, nm)] = torch.empty(nc + nm, dtype=torch.int32, device=cos.device)
-                buf[:nc].copy_(cos.view(torch.int32).reshape(-1))
-                buf[nc:].copy_(meta.reshape(-1))
-                # integer SUM of the raw bits: exactly one rank holds non-zero bits per word, so the sum IS that word
-                # (RCCL/NCCL has no bitwise reduce op; float SUM would also be exact here but -0.0 + 0.0 is not)
-                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
-                cos = buf[:nc].view(torch.float32).reshape(cos.shape)
-                meta = buf[nc:].reshape(meta.shape)
-            out["rerank"] = e.rerank_fuse(b_doc, b_score, b_n, cos, meta, **rerank_params)
+        if not rerank:
+            return out
+        keep = k1 if rerank_keep is None else min(int(rerank_keep), k1)
+        max_chunks = rerank_params.get("max_chunks", 10)
+        if self.world == 1:
+            cos, meta = e.rerank_gather(qvec, b_doc, b_n, doc_base=self.doc_base, row_base=self.row_base, max_chunks=max_chunks)
+            r = e.rerank_fuse(b_doc, b_score, b_n, cos, meta, **rerank_params)
+            out["rerank"] = r if keep == k1 else tuple(x[:, :keep] if x.dim() == 2 else x for x in r)
+            return out
+        rx = ex.rerank.get((k1, keep))
+        if rx is None:
+            rx = ex.rerank[(k1, keep)] = _RerankExchange(self.world, Q, k1, keep, b_doc.device)
+        Qs = rx.Qs
+        # a. my documents' halves of every query, written into the block of the rank that owns the query (the rows of a
+        #    short last block stay zero)
+        for o in range(self.world):
+            lo, hi = min(Q, o * Qs), min(Q, (o + 1) * Qs)
+            if hi > lo:
+                cv, mv = rx.send_views(o)
+                e.rerank_gather(qvec[lo:hi], b_doc[lo:hi], b_n[lo:hi], doc_base=self.doc_base, row_base=self.row_base,
+                                max_chunks=max_chunks, out=(cv[:hi - lo], mv[:hi - lo]))
+        # b. every half to the owner of its query
+        dist.all_to_all_single(rx.a2a_recv, rx.a2a_send, group=self.group)
+        # c. join + the float64 chain, for my queries only
+        lo, hi = min(Q, self.rank * Qs), min(Q, (self.rank + 1) * Qs)
+        if hi > lo:
+            cp, mp = rx.recv_parts()
+            cos, meta = e.rerank_combine(cp, mp, hi - lo)
+            fused = e.rerank_fuse(b_doc[lo:hi], b_score[lo:hi], b_n[lo:hi], cos, meta, **rerank_params)
+            for (name, _, per_k), x in zip(_FUSED, fused):
+                rx.out_view(name)[:hi - lo].copy_(x[:, :keep] if per_k else x)
+        # d. the fused lists of all queries to every rank
+        dist.all_gather_into_tensor(rx.out_recv, rx.out_send, group=self.group)
+        out["rerank"] = tuple(rx.gathered(name)[:Q] for name, _, _ in _FUSED)
         return out

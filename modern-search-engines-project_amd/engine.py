@@ -242,16 +242,36 @@ class DeviceEngine:
                                         _ptr(out_chunk), _ptr(out_n), _ptr(out_rows), self._stream()))
         return out_doc, out_score, out_orig, out_chunk, out_n, out_rows
 
-    def rerank_gather(self, qvec, cand_doc_global, cand_n, doc_base=0, row_base=0, max_chunks=10):
-        """Shard-local half of rerank: (cos float32 [Q, M, 10], meta int32 [Q, M, 3]); zeros for foreign docs."""
+    def rerank_gather(self, qvec, cand_doc_global, cand_n, doc_base=0, row_base=0, max_chunks=10, out=None):
+        """Shard-local half of rerank: (cos float32 [Q, M, 10], meta int32 [Q, M, 3]); zeros for foreign docs.
+        out: optional (cos, meta) contiguous tensors of those shapes to write into (views of an exchange buffer)."""
         q = self._dev(qvec, torch.float32).reshape(-1, DIM)
         cand = self._dev(cand_doc_global, torch.int32)
         cn = self._dev(cand_n, torch.int32)
         Q, M = int(cand.shape[0]), int(cand.shape[1])
-        cos = torch.empty((Q, M, _abi.MSR_RERANK_MAX_CHUNKS), dtype=torch.float32, device=self.device)
-        meta = torch.empty((Q, M, 3), dtype=torch.int32, device=self.device)
+        if out is not None:
+            cos, meta = out
+            assert cos.is_contiguous() and meta.is_contiguous() and cos.dtype == torch.float32 and meta.dtype == torch.int32
+            assert tuple(cos.shape) == (Q, M, _abi.MSR_RERANK_MAX_CHUNKS) and tuple(meta.shape) == (Q, M, 3)
+        else:
+            cos = torch.empty((Q, M, _abi.MSR_RERANK_MAX_CHUNKS), dtype=torch.float32, device=self.device)
+            meta = torch.empty((Q, M, 3), dtype=torch.int32, device=self.device)
         self._check(self.lib.msr_rerank_gather(self.handle, _ptr(q), Q, _ptr(cand), _ptr(cn), M, int(doc_base),
                                                int(row_base), int(max_chunks), _ptr(cos), _ptr(meta), self._stream()))
+        return cos, meta
+
+    def rerank_combine(self, cos_parts, meta_parts, nq):
+        """Join of the gathered halves: cos_parts float32 [G, Qs, M, 10] and meta_parts int32 [G, Qs, M, 3] are views of ONE
+        receive buffer (the same stride between parts, each part contiguous); -> (cos [nq, M, 10], meta [nq, M, 3]) of the
+        first nq queries, the bitwise OR over the G parts (msr_rerank_combine)."""
+        G, M = int(cos_parts.shape[0]), int(cos_parts.shape[2])
+        stride = cos_parts.stride(0) * 4 if G > 1 else 0
+        assert G == 1 or meta_parts.stride(0) * 4 == stride
+        assert cos_parts[0].is_contiguous() and meta_parts[0].is_contiguous()
+        cos = torch.empty((nq, M, _abi.MSR_RERANK_MAX_CHUNKS), dtype=torch.float32, device=self.device)
+        meta = torch.empty((nq, M, 3), dtype=torch.int32, device=self.device)
+        self._check(self.lib.msr_rerank_combine(self.handle, _ptr(cos_parts), _ptr(meta_parts), G, int(stride), int(nq), M,
+                                                _ptr(cos), _ptr(meta), self._stream()))
         return cos, meta
 
     def rerank_fuse(self, cand_doc_global, cand_bm25, cand_n, cos, meta, **params):

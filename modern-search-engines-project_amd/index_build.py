@@ -8,7 +8,6 @@ already-tokenised documents -- the spaCy lemmatiser stays external:
   * idf = LOG((N - df + 0.5) / (df + 0.5)) evaluated by DuckDB (LOG = log10) and stored REAL
 The result is a CorpusIndex in the engine's layout (CSR by term, documents ascending inside a term).
 """
-import math
 from collections import Counter
 
 import numpy as np
@@ -22,6 +21,14 @@ def normalise_document_text(title, text):
     1 M characters (bm25_indexer.py:30-32)."""
     s = f"{title or ''} {text or ''}".lower().replace("tuebingen", CITY).replace("tubingen", CITY)
     return s[:1_000_000]
+
+
+def idf_real(total_docs, doc_freq):
+    """idf_score of every term at once: LOG((N - df + 0.5) / (df + 0.5)) (bm25_indexer.py:138; DuckDB's LOG is log10) in
+    float64, stored REAL (float32); N itself round-trips through a REAL column (:361-364, :133).  doc_freq: integer array."""
+    n_real = float(np.float32(total_docs))
+    df = np.asarray(doc_freq, np.float64)
+    return np.log10((n_real - df + 0.5) / (df + 0.5)).astype(np.float32)
 
 
 def bm25_index_from_tokens(doc_ids, token_lists, k1=1.2, b=0.75):
@@ -44,8 +51,7 @@ def bm25_index_from_tokens(doc_ids, token_lists, k1=1.2, b=0.75):
     term_off[1:] = np.cumsum([len(p) for p in postings])
     post_doc = np.fromiter((d for p in postings for d, _ in p), np.int32, count=int(term_off[-1]))
     post_tf = np.fromiter((tf for p in postings for _, tf in p), np.int32, count=int(term_off[-1]))
-    n_real = float(np.float32(N))                  # total_docs round-trips through a REAL column (:361-364, :133)
-    idf = np.array([np.float32(math.log10((n_real - len(p) + 0.5) / (len(p) + 0.5))) for p in postings], np.float32)
+    idf = idf_real(N, np.diff(term_off))
     avgdl = float(np.float32(doc_len.astype(np.float64).mean())) if N else 0.0
     ix = CorpusIndex(doc_ids=ids, doc_len=doc_len, term_off=term_off, post_doc=post_doc, post_tf=post_tf, idf=idf,
                      avgdl=avgdl, total_docs=N, k1=k1, b=b, vocab=vocab)
@@ -90,9 +96,7 @@ def bm25_index_from_token_ids(doc_ids, tok_off, tok_ids, n_terms, device="cpu", 
     term_off = torch.zeros(n_terms + 1, dtype=torch.int64, device=dev)
     term_off[1:] = torch.cumsum(df, 0)
     doc_len = lens[keep].to(torch.int32)
-    n_real = float(np.float32(N))
-    df_h = df.cpu().numpy()
-    idf = np.array([np.float32(math.log10((n_real - int(c) + 0.5) / (int(c) + 0.5))) for c in df_h], np.float32)
+    idf = idf_real(N, df.cpu().numpy())
     avgdl = float(np.float32(doc_len.to(torch.float64).mean().item())) if N else 0.0
     ix = CorpusIndex(doc_ids=ids[keep.cpu()].numpy(), doc_len=doc_len, term_off=term_off, post_doc=p_doc.to(torch.int32),
                      post_tf=tf.to(torch.int32), idf=torch.as_tensor(idf).to(dev), avgdl=avgdl, total_docs=N, k1=k1, b=b,
@@ -141,9 +145,7 @@ def _bm25_index_from_token_ids_hip(doc_ids, tok_off, tok_ids, n_terms, dev, k1, 
         post_tf = torch.empty(max(P, 1), dtype=torch.int32, device=dev)
         _abi.check(None, lib.msr_build_postings(ptr(d_off), ptr(k_tok), N, int(n_terms), ptr(term_off), ptr(post_doc), ptr(post_tf), max(P, 1),
                                                 C.byref(n_post), stream))
-    df_h = np.diff(term_off.cpu().numpy())
-    n_real = float(np.float32(N))
-    idf = np.array([np.float32(math.log10((n_real - int(c) + 0.5) / (int(c) + 0.5))) for c in df_h], np.float32)
+    idf = idf_real(N, np.diff(term_off.cpu().numpy()))
     doc_len = torch.as_tensor(lens[keep].astype(np.int32)).to(dev)
     avgdl = float(np.float32(lens[keep].astype(np.float64).mean())) if N else 0.0
     ix = CorpusIndex(doc_ids=ids[keep], doc_len=doc_len, term_off=term_off, post_doc=post_doc[:P], post_tf=post_tf[:P],

@@ -65,7 +65,12 @@ class OracleEngine:
             op = torch.as_tensor(op)
         return torch.as_tensor(od), torch.as_tensor(os_), torch.as_tensor(on), op
 
-    def rerank_gather(self, qvec, cand_doc_global, cand_n, doc_base=0, row_base=0, max_chunks=10):
+    def rerank_combine(self, cos_parts, meta_parts, nq):
+        c = np.bitwise_or.reduce(_np(cos_parts).view(np.uint32), axis=0)[:nq]
+        m = np.bitwise_or.reduce(_np(meta_parts), axis=0)[:nq]
+        return torch.as_tensor(np.ascontiguousarray(c).view(np.float32)), torch.as_tensor(np.ascontiguousarray(m))
+
+    def rerank_gather(self, qvec, cand_doc_global, cand_n, doc_base=0, row_base=0, max_chunks=10, out=None):
         q, cand, cn = _np(qvec), _np(cand_doc_global), _np(cand_n)
         Q, M = cand.shape
         cos = np.zeros((Q, M, 10), np.float32); meta = np.zeros((Q, M, 3), np.int32)
@@ -79,6 +84,9 @@ class OracleEngine:
                 if hi > lo:
                     cos[i, m, :hi - lo] = rerank_ref.cosine_f32(q[i], self.emb[lo:hi])
                 meta[i, m] = (hi - lo, self.url_group[d] + 2, lo + row_base)
+        if out is not None:
+            out[0].copy_(torch.as_tensor(cos)); out[1].copy_(torch.as_tensor(meta))
+            return out
         return torch.as_tensor(cos), torch.as_tensor(meta)
 
     def rerank_fuse(self, cand_doc_global, cand_bm25, cand_n, cos, meta, smoothing=0.15, max_boost=0.1,

@@ -1067,13 +1067,42 @@ def test_http_routes_on_the_gpu_retriever(mods, tmp_path):
     rt.engine.close()
 
 
+def test_index_build_kernels_on_the_reference_fixture(mods):
+    """msr_build_postings on the crawls of tests/golden/bm25_build.json: the tables equal what the reference's own
+    BM25._process_document_batch returned for them (doc_stats, term_freq rows, doc_freq / total_freq per term)."""
+    from msretr.index_build import bm25_index_from_token_ids, normalise_document_text
+    for case in _load("bm25_build.json"):
+        docs = [tuple(d) for d in case["documents"]]
+        toks = [normalise_document_text(t, x).split() for _, t, x in docs]
+        vocab = {}
+        for tl in toks:
+            for w in tl:
+                vocab.setdefault(w, len(vocab))
+        tok_off = np.zeros(len(docs) + 1, np.int64); tok_off[1:] = np.cumsum([len(t) for t in toks])
+        tok_ids = np.array([vocab[w] for t in toks for w in t], np.int32)
+        ix = bm25_index_from_token_ids([d for d, _, _ in docs], tok_off, tok_ids, len(vocab), device="cuda")
+        ids, lens = ix.doc_ids.tolist(), ix.doc_len.cpu().numpy().tolist()
+        assert dict(zip(ids, lens)) == {d: l for d, l in case["doc_stats"]} and ids == sorted(ids)
+        toff, pd_, ptf = [x.cpu().numpy() for x in (ix.term_off, ix.post_doc, ix.post_tf)]
+        got = {(ids[d], w): int(f) for w, i in vocab.items() for d, f in zip(pd_[toff[i]:toff[i + 1]], ptf[toff[i]:toff[i + 1]])}
+        assert got == {(d, t): f for d, t, f in case["term_freq"]}, case["name"]
+        for w, i in vocab.items():
+            assert [int(toff[i + 1] - toff[i]), int(ptf[toff[i]:toff[i + 1]].sum())] == case["term_updates"][w]
+            assert np.all(np.diff(pd_[toff[i]:toff[i + 1]]) > 0)
+        assert set(vocab) == set(case["term_updates"]) and ix.total_docs == len(case["doc_stats"])
+
+
 def test_index_build_kernels_equal_the_reference_tables(mods):
     """msr_build_postings (per-document sort + run lengths, stable radix sort by term, boundary doc_freq --
-    csrc/msr_build.hip) against the dict-based builder that is pinned to the reference's tables (bm25_indexer.py:16-54,
-    203-250, 130-147): postings, lengths, offsets, idf bits and avgdl identical.  Covers unsorted doc ids, token-less
+    csrc/msr_build.hip) against the oracle's builder (oracle/build_ref.py, pinned to the output of the reference's own
+    BM25._process_document_batch by tests/golden/bm25_build.json; bm25_indexer.py:196-243, 130-147, 346-369): postings,
+    lengths, offsets, idf bits and avgdl identical.  Covers unsorted doc ids, token-less
     documents (no row), documents longer than one 4096-token chunk (their chunks' counts are merged), a term present
     in every document, and vocabularies that need 1, 2 and 3 radix passes."""
-    from msretr.index_build import bm25_index_from_token_ids, bm25_index_from_tokens
+    from types import SimpleNamespace
+
+    from msretr.index_build import bm25_index_from_token_ids
+    from oracle import build_ref
     rng = np.random.default_rng(19)
     for n, V, long_docs, p_uni in ((300, 200, (), 0.3), (700, 40_000, (5, 77), 0.3),
                                    (400, 300_000, tuple(range(9, 400, 30)), 0.9)):
@@ -1090,8 +1119,8 @@ def test_index_build_kernels_equal_the_reference_tables(mods):
             if l:
                 t[0] = 0                                                          # term 0 in every document
             toks.append(t.tolist())
-        ref = bm25_index_from_tokens(doc_ids, [[f"w{t}" for t in tl] for tl in toks])
-        ids_of = {k: v for k, v in ref.vocab.items()}                             # the dict builder's numbering
+        ref = SimpleNamespace(**build_ref.index_from_tokens(doc_ids, [[f"w{t}" for t in tl] for tl in toks]))
+        ids_of = {k: v for k, v in ref.vocab.items()}                             # the oracle's numbering
         assert (len(ref.vocab) > 65536) == (V == 300_000)                         # the last case needs a third radix pass
         tok_off = np.zeros(n + 1, np.int64); tok_off[1:] = np.cumsum(lens)
         tok_ids = np.array([ids_of[f"w{t}"] for tl in toks for t in tl], np.int32)

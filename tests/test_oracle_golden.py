@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from oracle import bm25_ref, dense_ref, rerank_ref
+from oracle import bm25_ref, build_ref, dense_ref, rerank_ref
 
 G = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -229,3 +229,76 @@ def test_c_port_equals_the_numpy_restatement():
         a, b, c_ = c_oracle.dense_topk(emb, off, qv[i].numpy(), 50)
         oi, os_, oc = dense_ref.quick_search(emb, off, qv[i].numpy(), 50)
         assert np.abs(b - os_).max() <= 2e-6 and (a == oi).mean() > 0.95
+
+
+# ------------------------------------------------------------------------------------------------ index build
+def _golden_tables(case):
+    """The reference's tables of one fixture case as order-free maps."""
+    lens = {d: l for d, l in case["doc_stats"]}
+    tf = {(d, t): f for d, t, f in case["term_freq"]}
+    df = {t: u[0] for t, u in case["term_updates"].items()}
+    total = {t: u[1] for t, u in case["term_updates"].items()}
+    return lens, tf, df, total
+
+
+@pytest.mark.parametrize("case", _load("bm25_build.json"), ids=lambda c: c["name"])
+def test_index_build_restatement_equals_the_reference_tables(case):
+    """oracle/build_ref.process_document_batch against the output of the reference's own BM25._process_document_batch
+    (tests/golden/make_goldens.py::bm25_build_fixture): the three tables, row for row and in the reference's row order."""
+    docs = [tuple(d) for d in case["documents"]]
+    stats, tf, upd = build_ref.process_document_batch(docs, lambda text: text.split())
+    assert [list(x) for x in stats] == case["doc_stats"]
+    assert [list(x) for x in tf] == case["term_freq"]
+    assert {t: list(u) for t, u in upd.items()} == case["term_updates"] and list(upd) == list(case["term_updates"])
+    # and laid out for the engine: ascending doc ids, postings ascending inside a term, df = new_docs, sum tf = freq_increase
+    z = build_ref.index_from_batches(stats, tf)
+    lens, tfm, df, total = _golden_tables(case)
+    assert z["doc_ids"].tolist() == sorted(lens) and z["doc_len"].tolist() == [lens[d] for d in sorted(lens)]
+    assert set(z["vocab"]) == set(df)
+    for t, i in z["vocab"].items():
+        lo, hi = int(z["term_off"][i]), int(z["term_off"][i + 1])
+        assert hi - lo == df[t] and int(z["post_tf"][lo:hi].sum()) == total[t]
+        assert np.all(np.diff(z["post_doc"][lo:hi]) > 0)
+        assert {(int(z["doc_ids"][d]), t): int(f) for d, f in zip(z["post_doc"][lo:hi], z["post_tf"][lo:hi])} == \
+            {k: v for k, v in tfm.items() if k[1] == t}
+    assert z["avgdl"] == float(np.float32(np.mean([l for l in lens.values()])))
+
+
+@pytest.mark.parametrize("case", _load("bm25_build.json"), ids=lambda c: c["name"])
+def test_product_host_builder_equals_the_reference_tables(case):
+    """The product's host-side builders (index_build.py: the dict builder and the sort-based one on the CPU device) produce
+    the reference's tables for the fixture crawls: same rows as BM25._process_document_batch returned, idf / avgdl as the
+    restatement stores them, bit for bit."""
+    from msretr.index_build import bm25_index_from_token_ids, bm25_index_from_tokens, normalise_document_text
+    docs = [tuple(d) for d in case["documents"]]
+    toks = [normalise_document_text(t, x).split() for _, t, x in docs]
+    ix = bm25_index_from_tokens([d for d, _, _ in docs], toks)
+    stats, tf, _ = build_ref.process_document_batch(docs, lambda text: text.split())
+    z = build_ref.index_from_batches(stats, tf, vocab=ix.vocab)
+    for name in ("doc_ids", "doc_len", "term_off", "post_doc", "post_tf"):
+        assert np.array_equal(np.asarray(getattr(ix, name)), z[name]), name
+    assert np.array_equal(np.asarray(ix.idf).view(np.uint32), z["idf"].view(np.uint32)) and ix.avgdl == z["avgdl"]
+    assert ix.total_docs == z["total_docs"] == len(case["doc_stats"])
+    lens, tfm, df, total = _golden_tables(case)
+    got = {(int(ix.doc_ids[d]), t): int(f) for t, i in ix.vocab.items()
+           for d, f in zip(ix.post_doc[ix.term_off[i]:ix.term_off[i + 1]], ix.post_tf[ix.term_off[i]:ix.term_off[i + 1]])}
+    assert got == tfm and {int(d): int(l) for d, l in zip(ix.doc_ids, ix.doc_len)} == lens
+    # the sort-based builder from token ids (the form msr_build_postings implements on the GPU), CPU device
+    tok_off = np.zeros(len(docs) + 1, np.int64); tok_off[1:] = np.cumsum([len(t) for t in toks])
+    tok_ids = np.array([ix.vocab[w] for t in toks for w in t], np.int32)
+    sx = bm25_index_from_token_ids([d for d, _, _ in docs], tok_off, tok_ids, len(ix.vocab), device="cpu")
+    for name in ("doc_ids", "doc_len", "term_off", "post_doc", "post_tf"):
+        assert np.array_equal(np.asarray(getattr(sx, name)), z[name]), name
+    assert np.array_equal(np.asarray(sx.idf).view(np.uint32), z["idf"].view(np.uint32)) and sx.avgdl == z["avgdl"]
+
+
+def test_vectorised_idf_equals_the_scalar_formula():
+    """index_build evaluates idf for the whole vocabulary at once (numpy float64 log10 -> float32); the restatement's
+    scalar math.log10 form must give the same bits for every document frequency."""
+    from msretr.index_build import idf_real
+    for N in (1, 2, 7, 4999, 1_000_000, 16_777_217):
+        top = int(np.float32(N))                      # (N round-trips through a REAL column; df <= N)
+        df = np.unique(np.concatenate([np.arange(0, min(top, 3000) + 1), np.linspace(0, top, 2000).astype(np.int64)]))
+        got = idf_real(N, df)
+        exp = np.array([build_ref.idf_real(N, int(c)) for c in df], np.float32)
+        assert got.dtype == np.float32 and np.array_equal(got.view(np.uint32), exp.view(np.uint32)), N
