@@ -5,7 +5,7 @@
 // over a span of up to 8 consecutive tiles, with its own float64 accumulators (one per document of the current tile) and
 // the list of the documents it has touched in LDS.  Waves are independent: no workgroup barrier anywhere.
 //
-// What is streamed and what is looked up.  A posting is read as {doc, tf, tf_component}: the tf_component
+// What is streamed and what is looked up.  A posting is read as {doc, tf_component} (12 bytes): the tf_component
 // (tf (k1 + 1)) / (tf + k1 (1 - b + b dl / avgdl)) (:473-475) depends on (tf, document) only and is evaluated ONCE at bind
 // time with the reference's own operations (bm25_post_comp_kernel), so the kernel neither divides nor looks a length up.
 // A term whose idf is NEGATIVE (document frequency above half the corpus: the city term that search_api.py:160-164 puts
@@ -34,7 +34,7 @@
 // Output: the candidates of a (query, span) go to a segment of the query's candidate row that belongs to that wave alone
 // -- no atomics, no counters to clear; the top-k select (msr_topk.hip) walks the segments.
 //
-// HBM traffic per query: 16 B per posting of its streamed terms + 8 B per (touched document, looked-up term) from tables
+// HBM traffic per query: 12 B per posting of its streamed terms + 8 B per (touched document, looked-up term) from tables
 // that stay in the L2 / Infinity Cache + 12 B per candidate (the (score, doc) list consumed by the top-k select).
 #include <stdio.h>
 
@@ -46,8 +46,11 @@
 namespace {
 
 constexpr int BM25_TILE = MSR_BM25_TILE;
-constexpr int BM25_THREADS = 256;
-constexpr int BM25_WAVES = BM25_THREADS / 64;                 // independent waves per workgroup (one work item each)
+#ifndef BM25_WPW
+#define BM25_WPW 1                                             // one-wave workgroups: work items differ by an order of magnitude (a long
+#endif                                                         // positive list or not) and a workgroup holds its LDS until its slowest
+constexpr int BM25_WAVES = BM25_WPW;                          // wave is done (measured: 1 wave 0.18 ms, 2 waves 0.21, 4 waves 0.23)
+constexpr int BM25_THREADS = 64 * BM25_WAVES;
 constexpr int BM25_TPW = 8;                                   // at most this many consecutive tiles per work item
 constexpr int BM25_MAX_TERMS = 64;                            // MSR_MAX_QUERY_TERMS: one lane per term
 constexpr uint64_t UNTOUCHED = 0x7FF8DEADBEEF0001ull;   // a quiet-NaN payload no computation produces
@@ -64,9 +67,19 @@ __device__ __forceinline__ int lane_rank(unsigned long long m) {         // numb
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
+// one posting = one 12-byte load
+__device__ __forceinline__ double post_comp(const Bm25Post& x) { return __hiloint2double((int)x.comp_hi, (int)x.comp_lo); }
+// a table row as a GLOBAL pointer: rebuilt from the integer a lane carries it would be a flat pointer, and flat loads return
+// out of order -- every one of them makes the wave wait for ALL its outstanding memory operations (vmcnt(0) + lgkmcnt(0))
+typedef const __attribute__((address_space(1))) double* gtable;
+__device__ __forceinline__ gtable table_of(int64_t bits) { return (gtable)(uint64_t)bits; }
+
 enum : int { K_DEAD = 0, K_LOOKUP = 1, K_HEAVY = 2, K_RANGE = 3 };
 
-__global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
+#ifndef BM25_WPE
+#define BM25_WPE 4                                             // waves per SIMD the register budget is cut for
+#endif
+__global__ __launch_bounds__(BM25_THREADS) __attribute__((amdgpu_waves_per_eu(BM25_WPE, BM25_WPE))) void bm25_taat_kernel(Bm25Index ix,
                                                                   const int32_t* __restrict__ q_term_off,
                                                                   const int32_t* __restrict__ q_terms,
                                                                   const int32_t* __restrict__ q_qtf,
@@ -210,9 +223,11 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
     const int j_rest = sj[TPRE - 1] >= 0 ? sj[TPRE - 1] + 1 : nt;       // terms from here on are not prefetched
     // Two tiles are in flight per wave: the loads of tile t + 1 are issued BEFORE tile t is accumulated and emitted, into a
     // second register set -- the pass is latency-bound, every wave hides its own memory latency behind its own arithmetic.
+    // Inside a chunk a lane without a posting loads the sentinel {doc -1, 0.0} the bind step put behind the last posting: no
+    // load sits in a divergent branch, and the loaded words are not touched before they are used.
+    const int64_t null_post = ix.n_postings;
     struct TileRegs {
-        int32_t pd[TPRE][PFC];                               // the first PFC x 64 postings of the first TPRE streamed slices
-        double pc[TPRE][PFC];
+        Bm25Post p[TPRE][PFC];                               // the first PFC x 64 postings of the first TPRE streamed slices
         int64_t ps, pe;                                      // lane j: this tile's slice of term j
     };
     auto issue = [&](int tt, TileRegs& r) {
@@ -229,14 +244,14 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
 #pragma unroll
         for (int k = 0; k < TPRE; ++k) {
 #pragma unroll
-            for (int c = 0; c < PFC; ++c) { r.pd[k][c] = -1; r.pc[k][c] = 0.0; }
+            for (int c = 0; c < PFC; ++c) r.p[k][c].doc = -1;
             if (sj[k] >= 0 && !(dbg & 8)) {                  // wave-uniform
                 const int64_t ps = lane_i64(r.ps, sj[k]), pe = lane_i64(r.pe, sj[k]);
 #pragma unroll
                 for (int c = 0; c < PFC; ++c) {
                     if (ps + 64 * c < pe) {                  // wave-uniform: no instruction for chunks past the slice
                         const int64_t i = ps + 64 * c + lane;
-                        if (i < pe) { const Bm25Post p = ix.post[i]; r.pd[k][c] = p.doc; r.pc[k][c] = p.comp; }
+                        r.p[k][c] = ix.post[i < pe ? i : null_post];
                     }
                 }
             }
@@ -277,7 +292,7 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
                     while (lm) {
                         const int i = __ffsll((long long)lm) - 1;
                         lm &= lm - 1;
-                        const double* tbl = (const double*)lane_i64(s_v, i) + lo;
+                        const gtable tbl = table_of(lane_i64(s_v, i)) + lo;
                         const double tc = first ? tbl[d[u]] : 0.0;
                         const double ci = (lane_f64(idf_v, i) * tc) * lane_f64(qtf_v, i);
                         if (tc != 0.0) a0 = a0 + ci;         // (0.0: the document lacks term i)
@@ -299,8 +314,8 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int64_t i = base + lane + (int64_t)u * 64;
-                    pd[u] = -1; pc[u] = 0.0;
-                    if (i < pe) { const Bm25Post p = ix.post[i]; pd[u] = p.doc; pc[u] = p.comp; }
+                    const Bm25Post x = ix.post[i < pe ? i : null_post];
+                    pd[u] = x.doc; pc[u] = post_comp(x);
                 }
                 apply(std::integral_constant<int, U>{}, pd, pc, idf, qtf, j);
             }
@@ -308,15 +323,14 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
         // looked-up term i: its contribution to every document touched so far
         auto walk = [&](int i) {
             if (list_n == 0 || (dbg & 1)) return;
-            const double* tbl = (const double*)lane_i64(s_v, i) + lo;
+            const gtable tbl = table_of(lane_i64(s_v, i)) + lo;
             const double idf = lane_f64(idf_v, i), qtf = lane_f64(qtf_v, i);
-            for (int b = 0; b < list_n; b += 64) {
-                const int e = b + lane;
-                if (e < list_n) {
-                    const uint32_t d = list[e];
-                    const double tc = tbl[d];
-                    if (tc != 0.0) acc[d] = acc[d] + (idf * tc) * qtf;
-                }
+            for (int b = 0; b < list_n; b += 128) {          // two batches of gathers in flight
+                const int e0 = b + lane, e1 = b + 64 + lane;
+                const uint32_t d0 = list[e0 < list_n ? e0 : 0], d1 = list[e1 < list_n ? e1 : 0];
+                const double t0 = e0 < list_n ? tbl[d0] : 0.0, t1 = e1 < list_n ? tbl[d1] : 0.0;
+                if (t0 != 0.0) acc[d0] = acc[d0] + (idf * t0) * qtf;
+                if (t1 != 0.0) acc[d1] = acc[d1] + (idf * t1) * qtf;
             }
         };
         auto walks = [&](int from, int to) {                 // the looked-up terms at positions [from, to)
@@ -339,7 +353,12 @@ __global__ __launch_bounds__(BM25_THREADS) void bm25_taat_kernel(Bm25Index ix,
             const int64_t ps = lane_i64(ps_v, j), pe = lane_i64(pe_v, j);
             if (pe <= ps) continue;
             const double idf = lane_f64(idf_v, j), qtf = lane_f64(qtf_v, j);
-            apply(std::integral_constant<int, PFC>{}, r.pd[k], r.pc[k], idf, qtf, j);   // (chunks past the slice hold doc -1)
+            int32_t pd[PFC];
+            double pc[PFC];
+#pragma unroll
+            for (int c = 0; c < PFC; ++c) { pd[c] = r.p[k][c].doc; pc[c] = post_comp(r.p[k][c]); }   // (no posting: doc -1)
+            if (pe - ps <= 64) apply(std::integral_constant<int, 1>{}, pd, pc, idf, qtf, j);
+            else apply(std::integral_constant<int, PFC>{}, pd, pc, idf, qtf, j);
             if (pe - ps > 64 * PFC) stream(ps + 64 * PFC, pe, idf, qtf, j);
         }
         for (int j = j_rest; j < nt; ++j) {
@@ -431,7 +450,7 @@ __global__ __launch_bounds__(256) void build_skip_kernel(Bm25Index ix, const int
     }
 }
 
-// post[i] = {post_doc[i], post_tf[i], tf_component}: what the scoring kernel streams, one 16-byte load per posting.
+// post[i] = {post_doc[i], tf_component}: what the scoring kernel streams, one 12-byte load per posting; post[n] = {-1, 0.0}.
 // tf_component = (tf * (k1 + 1)) / (tf + k1 * (1 - b + b * doc_length / avg_doc_length))  (:473-475), evaluated here ONCE
 // per posting, operation by operation as Python evaluates it (tf is a Python int: it is converted, not truncated)
 __global__ __launch_bounds__(256) void bm25_post_comp_kernel(const int32_t* __restrict__ post_doc,
@@ -439,12 +458,19 @@ __global__ __launch_bounds__(256) void bm25_post_comp_kernel(const int32_t* __re
                                                               const double* __restrict__ dnorm, double k1p1, int64_t n,
                                                               Bm25Post* __restrict__ out) {
     const int64_t stride = (int64_t)gridDim.x * 256;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                   // the sentinel behind the last posting: "no posting here"
+        Bm25Post z;
+        z.doc = -1; z.comp_lo = 0u; z.comp_hi = 0u;
+        out[n] = z;
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         const int32_t d = post_doc[i], f = post_tf[i];
         const double tf = (double)f;
+        const double comp = (tf * k1p1) / (tf + dnorm[d]);
         Bm25Post p;
-        p.doc = d; p.tf = f;
-        p.comp = (tf * k1p1) / (tf + dnorm[d]);
+        p.doc = d;
+        p.comp_lo = (uint32_t)__double2loint(comp);
+        p.comp_hi = (uint32_t)__double2hiint(comp);
         out[i] = p;
     }
 }
@@ -460,7 +486,7 @@ __global__ __launch_bounds__(256) void bm25_dense_kernel(Bm25Index ix, const int
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = s + (int64_t)blockIdx.x * 256 + threadIdx.x; i < e; i += stride) {
         const Bm25Post p = ix.post[i];
-        row[p.doc] = p.comp;
+        row[p.doc] = post_comp(p);
     }
 }
 
@@ -488,7 +514,7 @@ hipError_t msr_bm25_build_skip(const Bm25Index& ix, const int32_t* heavy_terms, 
 
 hipError_t msr_bm25_post_comp(const int32_t* post_doc, const int32_t* post_tf, const double* dnorm, double k1, int64_t n,
                               Bm25Post* out, hipStream_t stream) {
-    if (n <= 0) return hipSuccess;
+    if (n < 0) return hipSuccess;
     bm25_post_comp_kernel<<<4096, 256, 0, stream>>>(post_doc, post_tf, dnorm, k1 + 1.0, n, out);   // self.k1 + 1
     return hipGetLastError();
 }

@@ -329,19 +329,20 @@ extern "C" int msr_bind_postings(msr_engine* e, const int64_t* term_off, int64_t
         std::stable_sort(dense_terms.begin(), dense_terms.end(), [&](int32_t a, int32_t b2) {
             return h_toff[a + 1] - h_toff[a] > h_toff[b2 + 1] - h_toff[b2];
         });
-        const size_t row_bytes = (size_t)cand.n_tiles * MSR_BM25_TILE * sizeof(double);
+        const size_t row_bytes = ((size_t)cand.n_tiles * MSR_BM25_TILE + 8) * sizeof(double);
         const size_t cap = std::min<size_t>(MSR_BM25_MAX_DENSE, (size_t)(4ull << 30) / row_bytes);
         if (dense_terms.size() > cap) dense_terms.resize(cap);
     }
     // the copy the scoring kernel streams (after the validation above: the copy is of a well-formed index): every posting with
     // its tf_component, from the per-document length norms k1 (1 - b + b dl / avgdl)
     free_dev(e->bm_post); e->bm_post = nullptr;
-    if (n_postings > 0) {
+    {
         const int64_t n_pad = (int64_t)cand.n_tiles * MSR_BM25_TILE;
         double* dnorm = nullptr;
-        hipError_t herr = hipMalloc(&e->bm_post, (size_t)n_postings * sizeof(Bm25Post));
+        const size_t bytes = (size_t)(n_postings + 1) * sizeof(Bm25Post);      // + the sentinel posting
+        hipError_t herr = hipMalloc(&e->bm_post, bytes);
         if (herr != hipSuccess)
-            return fail(e, MSR_ERR_NOMEM, "postings with tf components (%zu bytes): %s", (size_t)n_postings * sizeof(Bm25Post), hipGetErrorString(herr));
+            return fail(e, MSR_ERR_NOMEM, "postings with tf components (%zu bytes): %s", bytes, hipGetErrorString(herr));
         if ((herr = hipMalloc((void**)&dnorm, (size_t)n_pad * sizeof(double))) != hipSuccess)
             return fail(e, MSR_ERR_NOMEM, "length norms: %s", hipGetErrorString(herr));
         hipError_t h1 = msr_bm25_dnorm(doc_len, n_docs, n_pad, k1, b, (double)avgdl, dnorm, st);
@@ -353,7 +354,7 @@ extern "C" int msr_bind_postings(msr_engine* e, const int64_t* term_off, int64_t
     }
     cand.post = (const Bm25Post*)e->bm_post;
     if (!dense_terms.empty()) {
-        const int64_t stride = (int64_t)cand.n_tiles * MSR_BM25_TILE;
+        const int64_t stride = (int64_t)cand.n_tiles * MSR_BM25_TILE + 8;      // the tail of a row stays 0.0 (the kernel's "no value")
         std::vector<int32_t> dense_id((size_t)n_terms, -1);
         for (size_t h = 0; h < dense_terms.size(); ++h) dense_id[dense_terms[h]] = (int32_t)h;
         hipError_t herr;

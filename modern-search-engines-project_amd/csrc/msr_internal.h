@@ -55,10 +55,9 @@ int msr_fail_global(int code, const char* fmt, ...);
 // tf_component = (tf (k1 + 1)) / (tf + k1 (1 - b + b dl / avgdl)) (indexer/bm25_indexer.py:473-475), which depends on
 // (tf, document) only -- evaluated ONCE with the reference's own operations, so the kernel neither divides nor looks the
 // document length up.
-struct Bm25Post {
+struct Bm25Post {              // 12 bytes, 4-byte aligned: one global_load_dwordx3 per posting
     int32_t doc;
-    int32_t tf;
-    double comp;
+    uint32_t comp_lo, comp_hi; // the float64 tf_component
 };
 struct Bm25Index {
     const int64_t* term_off;
@@ -73,17 +72,19 @@ struct Bm25Index {
     const int32_t* heavy_id;   // [n_terms]: row of tile_off, or -1
     const uint32_t* tile_off;  // [n_heavy][n_tiles + 1], relative to term_off[t]
     int32_t n_tiles;
-    const Bm25Post* post;      // [n_postings] {doc, tf, tf_component}: what the scoring kernel streams
+    const Bm25Post* post;      // [n_postings + 1] {doc, tf_component}: what the scoring kernel streams; the last entry is the
+                               // sentinel {-1, 0.0} that lanes without a posting load
     // dense tf_component tables of the long lists with NEGATIVE idf (document frequency above half the corpus): such a
     // term can only lower a score, so with min_score >= 0 a document it alone matches is never a candidate; its list is not
     // streamed at all, its contribution is looked up for the documents the other terms touch (msr_bm25.hip)
     const int32_t* dense_id;   // [n_terms]: row of dense_comp, or -1 (null: no table)
-    const double* dense_comp;  // [n_dense][dense_stride]: tf_component of (term, document), 0.0 = the document lacks the term
+    const double* dense_comp;  // [n_dense][dense_stride]: tf_component of (term, document), 0.0 = the document lacks the term;
+                               // dense_stride > the padded document count: the last entry of a row is always 0.0
     int64_t dense_stride;
 };
 hipError_t msr_bm25_dnorm(const int32_t* doc_len, int64_t n_docs, int64_t n_pad, double k1, double b, double avgdl, double* out,
                           hipStream_t stream);
-// out[i] = {post_doc[i], post_tf[i], tf_component(post_tf[i], dnorm[post_doc[i]])}
+// out[i] = {post_doc[i], tf_component(post_tf[i], dnorm[post_doc[i]])} for i < n, out[n] = {-1, 0.0}
 hipError_t msr_bm25_post_comp(const int32_t* post_doc, const int32_t* post_tf, const double* dnorm, double k1, int64_t n,
                               Bm25Post* out, hipStream_t stream);
 // dense_comp row h <- the tf_components of term dense_terms[h] scattered by document (rows zeroed by the caller)

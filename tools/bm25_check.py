@@ -14,7 +14,9 @@ from msretr import _abi  # noqa: E402
 from msretr.build import build_library  # noqa: E402
 from msretr.engine import DeviceEngine  # noqa: E402
 
-if os.environ.get("MSR_DIAG_LIB"):       # timing experiments (--dbg) only exist in the -DMSR_DIAG build
+if os.environ.get("MSR_LIB"):            # a variant library built by hand (timing experiments)
+    _abi.LIB_PATH = os.environ["MSR_LIB"]
+elif os.environ.get("MSR_DIAG_LIB"):       # timing experiments (--dbg) only exist in the -DMSR_DIAG build
     _abi.LIB_PATH = build_library(diag=True)
 from msretr.synthetic import synthetic_corpus, synthetic_queries  # noqa: E402
 
