@@ -2,14 +2,15 @@
 """Headline benchmark: queries/sec (and single-query p50 latency) of the two-stage retriever, top-100 on a
 synthetic 1 M-document / 5 M x 768 f32-chunk corpus resident in HBM (BASELINE.json metric / configs[2]).
 
-A STEP = one pass of the whole hot path over one batch of `--queries-per-step` (default 128) queries:
+A STEP = one pass of the whole hot path over one batch of `--queries-per-step` (default 256) queries:
     stage 1  BM25 term-at-a-time + top-1000                        (msr_bm25_topk)
-    stage 2  dense full scan: q x chunk cosine, per-doc max-pool, top-100   (msr_dense_topk; ONE pass over E per 128 queries)
+    stage 2  dense full scan: q x chunk cosine, per-doc max-pool, top-100   (msr_dense_topk; ONE pass over E per 256 queries)
     fuse     reference rerank chain on the stage-1 candidates -> top-100     (msr_rerank_gather + _fuse)
-With N > 1 GPUs the corpus is doc-sharded and, by default, the batch is 128 queries PER GPU: every GPU sweeps 1/N of
+With N > 1 GPUs the corpus is doc-sharded and, by default, the batch is 256 queries PER GPU: every GPU sweeps 1/N of
 the rows for N times the queries, i.e. the same work per GPU and step at every N -- reported as "scaling": "weak"
 (an explicit --queries-per-step fixes the batch instead: "strong").  Per step one all-gather of the per-shard top-k
-lists and one integer-SUM all-reduce of the raw bits of the candidates' cosines cross xGMI.
+lists, one all-to-all of the candidates' cosines (every query's halves to the rank that fuses it) and one all-gather of the
+fused lists cross xGMI.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -269,7 +270,7 @@ def dense_parity(gpu, cpu, k):
     return {"queries": len(cpu), "k": k, "max_abs_score_diff": worst, "within_1e-5": worst <= 1e-5 and n_ok,
             "top_k_doc_sets_equal_up_to_boundary_near_ties": bool(sets_ok),
             "same_doc_at_same_rank": same_rank / max(1, total),
-            "kernel": "the 128-query batch of the timed steps (gemm_stream_kernel + exact f32 rescoring), rows of the CPU sample"}
+            "kernel": "the batch of the timed steps in one msr_dense_topk call (streaming pass + exact f32 rescoring), rows of the CPU sample"}
 
 
 def main():
@@ -281,7 +282,7 @@ def main():
     ap.add_argument("--chunks", type=int, default=5_000_000)
     ap.add_argument("--terms", type=int, default=1_000_000)
     ap.add_argument("--queries-per-step", type=int, default=0,
-                    help="queries per step (the dense stage reads E once per 128 of them); 0 = 128 per GPU: with the "
+                    help="queries per step (the dense stage reads E once per 256 of them); 0 = 256 per GPU: with the "
                          "corpus sharded N ways and the batch N times larger, every GPU does the same work per step "
                          "at every N (weak scaling); an explicit value keeps the batch fixed (strong scaling)")
     ap.add_argument("--k1", type=int, default=1000, help="stage-1 candidates (config.py:13)")
@@ -314,7 +315,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     auto_batch = args.queries_per_step <= 0
     if auto_batch:
-        args.queries_per_step = 128 * world
+        args.queries_per_step = 256 * world
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
@@ -388,6 +389,7 @@ def main():
     else:
         scan_ms, scan_n = eng.kernel_time_ms(0) if args.workload != "bm25" else (0.0, 0)
     bm_ms, bm_n = eng.kernel_time_ms(1) if args.workload != "dense" else (0.0, 0)
+    dense_width = eng.dense_path() if args.workload != "bm25" and args.dense_mode == "f32" else 0   # of the TIMED calls' kernel
     eng.set_timing(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -407,7 +409,7 @@ def main():
                 lat.append(time.perf_counter() - t1)
     p50_ms = 1e3 * float(np.median(lat)) if lat else None
 
-    # The same steps with the dense stage on the batched path (bf16 candidate sweep, 128 queries per pass, + exact f32
+    # The same steps with the dense stage on the batched path (bf16 candidates: a sweep per 128 queries, the tiled GEMM for more, + exact f32
     # rescoring; final scores and top-100 are those of the default path up to f32 rounding).  Reported NEXT TO the
     # headline, never as `value`.
     variant = None
@@ -531,14 +533,15 @@ def main():
             k_ms, k_n, kname = bm_ms, bm_n, "bm25_taat_kernel"
         else:
             bf = args.dense_mode == "bf16"
-            width = eng.batch_width() if bf else eng.scan_width()   # queries served by one sweep
+            # queries served by one pass over the matrix: of the kernel the timed calls actually ran (msr_dense_path)
+            width = eng.batch_width() if bf else (dense_width or eng.scan_width())
             q_launch = min(Q, width)
             alg_bytes = n_ch * 768 * (2 if bf else 4) + (shard.n_docs + 1) * 4 + q_launch * 768 * 4
             wide_kernel = q_launch > 32                         # 33..64 queries per sweep run on the K-split kernel
             k_ms, k_n = scan_ms, scan_n
             kname = ("dense_ksplit_kernel" if wide_kernel else "dense_scan_v2_kernel") + ("<bf16>" if bf else "")
-            if not bf and q_launch > 64:
-                kname = "gemm_stream_kernel<emit>"              # 65..128 queries: one streaming pass over the f32 rows
+            if not bf and q_launch > 64:                        # more than 64 queries: one streaming pass over the f32 rows
+                kname = "gemm_stream256_kernel<emit>" if width == 256 else "gemm_stream_kernel<emit>"
             if gemm:
                 kname = "gemm_kernel<emit>"
                 alg_bytes = n_ch * 768 * 2 + min(Q, 1024) * 768 * 2     # E (bf16) once per 1024-query pass + the queries

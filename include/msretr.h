@@ -103,15 +103,19 @@ int msr_bind_doc_meta(msr_engine* e, const int32_t* url_group, int64_t n_docs, v
 /* Arithmetic of the bound dense scan's SWEEPS (calls of <= 64 queries, and the fallback): 0 = exact f32 MFMA (bit-for-bit
  * a k-ordered fmaf chain), 1 = f32 rows split into two f16 pieces, three f16 MFMAs per k-step with f32 accumulation
  * (|error| <= 8e-6 on the cosine for row norms in [0.5, 2], proof in DESIGN.md); -1 = no chunks bound.  When
- * msr_scan_width() says 128, calls of more than 64 queries take one streaming pass per 128 queries instead: an f16
- * filter with a measured margin, then EXACT f32 cosines for every returned document. */
+ * msr_scan_width() says 128 or 256, calls of more than 64 queries take one streaming pass per 128 (256) queries instead:
+ * an f16 filter with a measured margin, then EXACT f32 cosines for every returned document. */
 int msr_scan_arith(const msr_engine* e);
 
-/* Most queries one pass over the embedding matrix serves in msr_dense_topk: 128 when the streaming pass is available
- * (f16-split arithmetic bound, every document within one 256-row tile, enough tiles), 64 when only the K-split kernel is
- * (row-major layout, no per-document row limit, a corpus that meets its preconditions; both arithmetics), else 32;
- * -1 = no chunks bound. */
+/* Most queries one pass over the embedding matrix serves in msr_dense_topk: 256 / 128 when the streaming pass is available
+ * (f16-split arithmetic bound, every document within one 256-row tile, enough tiles; 256 needs max_queries >= 256 and a
+ * call of more than 128 queries), 64 when only the K-split kernel is (row-major layout, no per-document row limit, a
+ * corpus that meets its preconditions; both arithmetics), else 32; -1 = no chunks bound. */
 int msr_scan_width(const msr_engine* e);
+/* Queries per pass over the matrix of the kernel the MOST RECENT msr_dense_topk call ran (256 / 128: the streaming pass;
+ * 64 / 32: the sweeps -- also what a call takes whose k or max_chunks_per_doc the streaming pass does not serve); 0 before
+ * the first call.  For whoever attributes a measured kernel time to a kernel (bench.py). */
+int msr_dense_path(const msr_engine* e);
 /* The same for the <= 128-query sweeps of msr_dense_topk_bf16 (after msr_enable_bf16): 128, 64, or -1. */
 int msr_batch_width(const msr_engine* e);
 /* 1 if calls of msr_dense_topk_bf16 with more than 128 queries run as the tiled matrix-core GEMM (every document fits a

@@ -42,6 +42,7 @@ _SIGNATURES = {
     "msr_bind_doc_meta": (C.c_int, [_P, _P, C.c_int64, _P]),
     "msr_scan_arith": (C.c_int, [_P]),
     "msr_scan_width": (C.c_int, [_P]),
+    "msr_dense_path": (C.c_int, [_P]),
     # include/msretr_encoder.h
     "msr_enc_layernorm": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
     "msr_enc_attention": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P]),

@@ -74,6 +74,7 @@ struct msr_engine {
     void* bf_row_meta = nullptr;       // {document, 1.0f} per row for the K-split bf16 sweeps
     DenseIndex dense_bf16{};           // `dense` with the unit-row image, its inverse norms and row meta
     int n_cus = 256;
+    int last_dense_width = 0;          // queries per pass over the matrix of the most recent msr_dense_topk call (msr_dense_path)
     // timing
     bool timing = false;
     static constexpr int EV_RING = 256;
@@ -531,15 +532,16 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
     // when the corpus allows it
     if (e->tiles_ok && variant == 14 && e->n_tiles >= 64) {
         const int n_tiles = e->n_tiles, nw = e->n_cus * 8, stride = (n_tiles + 31) / 32 * 32;
-        constexpr int GF_WV_CAP = 4096;
         // one call holds up to 8 groups of 128 queries (bounded by the select scratch, which covers max(max_queries, 128) rows)
         const int groups = std::min(8, std::max(e->cfg.max_queries, 128) / 128);
+        // emitted entries per wave and call: ~600 per 128 queries at 5 M rows (150 x sample stride per query over 2048 waves)
+        const int GF_WV_CAP = 4096 * std::max(1, groups / 2);
         const size_t QM = (size_t)groups * 128;
         auto alloc = [&](void** p, size_t bytes) { return hipMalloc(p, bytes); };
         if ((herr = alloc((void**)&e->gf_inv_pad, (size_t)(n_chunks + 512) * 4)) != hipSuccess ||
             (herr = alloc(&e->gf_qimg, (size_t)groups * 24 * 8192)) != hipSuccess ||
             (herr = alloc((void**)&e->gf_qn, QM * MSR_DIM * 4)) != hipSuccess ||
-            (herr = alloc((void**)&e->gf_tmax_t, (size_t)n_tiles * 8 * 128 * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gf_tmax_t, (size_t)n_tiles * 8 * (groups >= 2 ? 256 : 128) * 4)) != hipSuccess ||   // [tile][wave][queries of a pass]
             (herr = alloc((void**)&e->gf_tmax, QM * stride * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gf_thr, QM * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gf_thr2, QM * 4)) != hipSuccess ||
@@ -599,9 +601,13 @@ extern "C" int msr_scan_width(const msr_engine* e) {
     if (!e || !e->have_chunks) return -1;
     const int v = e->dense.variant;
     const bool wide = (v == 2 || v == 14 || v == 15) && e->dense.layout == 0 && e->dense.wide_ok;
-    if (e->gf_ok && wide) return 128;                       // GEMM over the f32 rows for batches of more than 64 queries
+    // streaming pass over the f32 rows for batches of more than 64 queries: 128 queries per pass, 256 for batches of more
+    // than 128 (when the engine was created for that many queries per call)
+    if (e->gf_ok && wide && v == 14) return e->gf.max_groups >= 2 ? 256 : 128;
     return wide ? 64 : 32;
 }
+
+extern "C" int msr_dense_path(const msr_engine* e) { return e ? e->last_dense_width : -1; }
 
 extern "C" int msr_batch_width(const msr_engine* e) {
     if (!e || !e->have_chunks || !e->emb_bf16) return -1;
@@ -679,6 +685,7 @@ extern "C" int msr_dense_topk(msr_engine* e, const float* q, int32_t n_queries, 
                       e->dense.wide_ok && max_chunks_per_doc == 0;
     const bool gemm = wide && e->gf_ok && e->dense.variant == 14 && e->gf.n_tiles >= 2 * k;
     const int64_t N = e->dense.n_docs;
+    e->last_dense_width = gemm && n_queries > 64 ? 0 : (wide ? 64 : 32);       // (the streaming path reports its own width below)
     // sweeps for queries [q0, q0 + cnt): `gate` non-null = fallback launches that only do work when *gate != 0
     auto sweeps = [&](int q0, int cnt, const int32_t* gate) -> int {
         const int slice = wide ? 64 : 32;
@@ -720,9 +727,11 @@ extern "C" int msr_dense_topk(msr_engine* e, const float* q, int32_t n_queries, 
                 ev[0] = e->ev_start[3][e->ev_count[3]]; ev[1] = e->ev_stop[3][e->ev_count[3]];
                 ev[2] = e->ev_start[0][e->ev_count[0]]; ev[3] = e->ev_stop[0][e->ev_count[0]];
             }
+            int width = 0;
             HIP_TRY(e, msr_gemm_f32_topk(e->gf, e->dense, e->gf_qn, nq, k, out_doc + (int64_t)q0 * k,
                                          out_score + (int64_t)q0 * k, out_chunk ? out_chunk + (int64_t)q0 * k : nullptr,
-                                         out_n + q0, e->gf_gate, timed ? ev : nullptr, st));
+                                         out_n + q0, e->gf_gate, timed ? ev : nullptr, &width, st));
+            e->last_dense_width = std::max(e->last_dense_width, width);
             if (timed) { e->ev_count[0]++; e->ev_count[3]++; }
             // A query whose entries overflowed (huge tie groups) raised the gate: the same batch once more on the sweeps,
             // which handle any input; when the gate is down (the normal case) these launches return at once.

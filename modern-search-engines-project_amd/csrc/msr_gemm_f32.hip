@@ -325,6 +325,253 @@ __global__ __launch_bounds__(GF_THREADS) void gemm_stream_kernel(GemmF32Args a) 
     if (EMIT && lane == 0) a.wv_count[blockIdx.x * 8 + w] = wave_cnt;
 }
 
+// ---- 256 queries per pass --------------------------------------------------------------------------------------------------
+// The pass above moves 15.36 GB for 128 queries at ~0.9 of what a copy achieves: the bytes per query are the only lever left.
+// This kernel serves 256 queries with the same bytes and the same shape -- 8 waves, wave w owns rows 32 w .. +32 of the tile
+// and ALL queries, its rows never pass through LDS (ring of 4 K steps, 128 KB per CU in flight).  What changes: 128
+// accumulator registers per wave instead of 64 (they take the accumulation half of the wave's 256 registers; the row
+// ring, the fragments and the addresses the other half: thresholds and inverse row norms therefore live in LDS and rows are
+// addressed scalar base + one 32-bit offset register); the f16 query image of a K step is 16 KB, so a block is 4 K steps
+// (64 KB), double buffered, LDS-DMA one block ahead, ONE barrier per block (6 per tile).  The matrix cores see twice the
+// work per byte (2 x 768 x 256 flop per row: ~1 PFLOP/s at the pass' byte rate, well under the f16 peak); the fragment
+// reads are 128 KB of LDS per K step and CU (half of what the LDS delivers in the time HBM needs for the step's rows).
+constexpr int G2_THREADS = 512;
+constexpr int G2_NB = 4;                        // K steps per query block (= the depth of the row ring)
+constexpr int G2_STEP = 16384;                  // bytes of one K step of the image: 256 queries x 64 B
+constexpr int G2_BLK = G2_NB * G2_STEP;         // 64 KB
+constexpr int G2_LDS = 2 * G2_BLK + 1024 + 8 * 256;   // + the 256 emission thresholds + 64 inverse row norms per wave
+
+// a 16-byte global load in the scalar-base + 32-bit lane-offset form: one register per row pointer instead of two
+template <int OFF>
+__device__ __forceinline__ void gload16s(f32x4& r, uint32_t voff, uint64_t sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(r) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t u) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave w owns rows 32 w .. 32 w + 32 of the tile, ALL 256 queries
+    const int li16 = lane & 15, lg = lane >> 4;
+    const int G = (int)gridDim.x, gid = (int)blockIdx.x;
+    int wave_cnt = EMIT && a.append ? __builtin_amdgcn_readfirstlane(a.wv_count[blockIdx.x * 8 + w]) : 0;
+    int4* wvbuf = EMIT ? a.wvbuf + ((size_t)blockIdx.x * 8 + w) * a.wv_cap : nullptr;
+    if (gid >= a.t_count) {                             // workgroup-uniform
+        if (EMIT && lane == 0) a.wv_count[blockIdx.x * 8 + w] = wave_cnt;
+        return;
+    }
+    const int n_mine = (a.t_count - gid + G - 1) / G;
+    float* thr_lds = (float*)(smem + 2 * G2_BLK);
+    if (EMIT && tid < 256) thr_lds[tid] = a.thr[tid];
+    // the wave's 32 inverse row norms of a tile go through LDS: one DMA in the tile's last block (all 64 lanes take part: 64
+    // floats, the upper half belongs to the next wave's rows and is not used; inv_pad is padded by 512 entries)
+    float* inv_lds = (float*)(smem + 2 * G2_BLK + 1024) + w * 64;
+    // query fragments: query 16 ni + li16, logical 16 B chunk lg of its 64 B, stored at physical chunk lg ^ (((q >> 3) & 1) << 1)
+    const uint32_t foffB = (uint32_t)(li16 * 64 + ((lg ^ (((li16 >> 3) & 1) << 1)) << 4));
+    // one query block: 64 KB, linear; wave w moves 8 KB of it
+    auto stage_b = [&](int blk, int pb) {
+        const char* base = uniform_ptr(a.qimg + (size_t)blk * G2_BLK + (size_t)w * 8192);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void*)(base + (uint32_t)(i * 1024 + lane * 16)),
+                                             (lds_void*)(smem + pb * G2_BLK + w * 8192 + i * 1024), 16, 0, 0);
+    };
+    f32x4 acc[2][16];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 16; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto tile_of = [&](int j) { return a.t_first + j * a.t_stride; };
+    // A tile's rows are addressed as (scalar base of the tile's first row) + (32-bit byte offset of the lane's row): fragment
+    // mi = row 32 w + 16 mi + li16 of the tile, at its 32-byte piece lg of a K step; a row past the end of the matrix
+    // re-reads the last row (masked in the epilogue).  A tile spans < 1 MB, so the offset fits 32 bits with room to spare.
+    auto tile_base = [&](int row0) { return uniform_u64((uint64_t)a.E + (uint64_t)row0 * GF_ROWB); };
+    auto row_off = [&](int row0, int mi) -> uint32_t {
+        int64_t r = (int64_t)row0 + 32 * w + 16 * mi + li16;
+        if (r > a.n_rows - 1) r = a.n_rows - 1;
+        return (uint32_t)((r - row0) * GF_ROWB + lg * 32);
+    };
+    int jt = gid;
+    int row0 = a.tile_row[tile_of(jt)], row_end = a.tile_row[tile_of(jt) + 1];
+    int jn = jt + G < a.t_count ? jt + G : jt;
+    int row0n = a.tile_row[tile_of(jn)];
+    uint64_t bp = tile_base(row0), bn = tile_base(row0n);
+    uint32_t vp[2], vn[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) { vp[mi] = row_off(row0, mi); vn[mi] = row_off(row0n, mi); }
+
+    // The row ring is driven by hand (see gemm_stream_kernel): inline-asm loads, explicit s_waitcnt before every use; vmcnt
+    // retires in order.  Issue order per wave: [8 DMAs of the next block] then per step [wait, convert, 4 row loads,
+    // compute].  The rows of step s of a block were loaded during step s of the block BEFORE (ring depth = block length = 4):
+    // younger than them are the loads of three steps (12) and one block's 8 DMAs = 20, whatever s is.  (Epilogue stores and
+    // the inverse-norm DMA only add younger operations: waiting for fewer than are in flight is always safe.)
+    f32x4 ring[G2_NB][2][2];                             // [slot][fragment][16-byte half]
+    auto load_rows = [&](auto slot_c, uint64_t sb, const uint32_t* v, auto off_c) {
+        constexpr int slot = decltype(slot_c)::value, off = decltype(off_c)::value;
+        gload16s<off>(ring[slot][0][0], v[0], sb);
+        gload16s<off + 16>(ring[slot][0][1], v[0], sb);
+        gload16s<off>(ring[slot][1][0], v[1], sb);
+        gload16s<off + 16>(ring[slot][1][1], v[1], sb);
+    };
+    auto pin_rows = [&](auto slot_c) {
+        constexpr int slot = decltype(slot_c)::value;
+        pin4(ring[slot][0][0], ring[slot][0][1], ring[slot][1][0], ring[slot][1][1]);
+    };
+    // ---- prologue: query block 0, rows of steps 0 .. 3 ----
+    stage_b(0, 0);
+#pragma unroll
+    for (int s = 0; s < G2_NB; ++s)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) ring[s][mi][0] = ring[s][mi][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    load_rows(std::integral_constant<int, 0>{}, bp, vp, std::integral_constant<int, 0>{});
+    load_rows(std::integral_constant<int, 1>{}, bp, vp, std::integral_constant<int, 128>{});
+    load_rows(std::integral_constant<int, 2>{}, bp, vp, std::integral_constant<int, 256>{});
+    load_rows(std::integral_constant<int, 3>{}, bp, vp, std::integral_constant<int, 384>{});
+    wait_vm0();
+    pin_rows(std::integral_constant<int, 0>{}); pin_rows(std::integral_constant<int, 1>{});
+    pin_rows(std::integral_constant<int, 2>{}); pin_rows(std::integral_constant<int, 3>{});
+    wg_barrier();
+    int pb = 0;                                          // LDS buffer of the current query block
+
+    const float NEG_INF = -__builtin_inff();
+    // one K step; S4: position in the query block = ring slot (compile time)
+    auto step = [&](auto s4_c, int b6, bool last) {
+        constexpr int s4 = decltype(s4_c)::value;
+        using SL = std::integral_constant<int, s4>;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        pin_rows(SL{});
+        f16x8 af[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) af[mi] = cvt_f16_rtn(ring[s4][mi][0], ring[s4][mi][1]);
+        asm volatile("" :: "v"(af[0]), "v"(af[1]));      // (converted before the slot is reloaded)
+        if (s4 == 1 && last) {                           // this tile's inverse norms (uniform branch), retired by later waits
+            const char* src = uniform_ptr((const char*)(a.inv_pad + (size_t)row0 + w * 32));
+            __builtin_amdgcn_global_load_lds((glb_void*)(src + (uint32_t)(lane * 4)), (lds_void*)inv_lds, 4, 0, 0);
+        }
+        // rows of the same step of the NEXT block: of this tile, or (a tile's last block) of the next tile's first block
+        if (last) load_rows(SL{}, bn, vn, std::integral_constant<int, s4 * 128>{});
+        else load_rows(SL{}, bp + (uint64_t)(b6 + 1) * (G2_NB * 128), vp, std::integral_constant<int, s4 * 128>{});
+        __builtin_amdgcn_sched_barrier(0);
+        const char* bq = smem + pb * G2_BLK + s4 * G2_STEP + foffB;
+#pragma unroll
+        for (int n4 = 0; n4 < 4; ++n4) {
+            f16x8 bh[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bh[i] = *(const f16x8*)(bq + (4 * n4 + i) * 1024);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[mi][4 * n4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bh[i], acc[mi][4 * n4 + i], 0, 0, 0);
+        }
+    };
+    for (int it = 0; it < n_mine; ++it) {
+#pragma unroll 1
+        for (int b6 = 0; b6 < GF_KT / G2_NB; ++b6) {
+            const bool last = b6 == GF_KT / G2_NB - 1;
+            stage_b(last ? 0 : b6 + 1, pb ^ 1);          // the next query block (the image repeats for every tile)
+            step(std::integral_constant<int, 0>{}, b6, last);
+            step(std::integral_constant<int, 1>{}, b6, last);
+            step(std::integral_constant<int, 2>{}, b6, last);
+            step(std::integral_constant<int, 3>{}, b6, last);
+            // end of a query block: the next one has landed once at most the 16 row loads issued behind its DMAs are in
+            // flight; then everyone is done with this one
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            wg_barrier();
+            pb ^= 1;
+        }
+        // (the inverse norms were requested three steps ago and are older than the last 12 row loads; the lanes read what
+        // their own wave's DMA wrote: no barrier)
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        f32x4 inv4[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) inv4[mi] = *(const f32x4*)(inv_lds + mi * 16 + 4 * lg);
+        // ---- epilogue, one block of 16 queries at a time: accumulator (mi, ni)[rr] = row 32 w + mi 16 + 4 lg + rr of the
+        //      tile, query ni 16 + li16 ----
+        const int n_valid = row_end - row0;
+        int col_e = li16;
+        asm volatile("" : "+v"(col_e));
+#pragma unroll
+        for (int ni = 0; ni < 16; ++ni) {
+            f32x4 v[2];
+            float cmax = NEG_INF;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int blk = w * 32 + mi * 16;
+                v[mi] = acc[mi][ni] * inv4[mi];         // cosine = <e, q^> / ||e||
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)          // rows behind the tile: products of the next tile's rows (or of the
+                    if (blk + 4 * lg + rr >= n_valid) v[mi][rr] = NEG_INF;      // clamped last row) -- masked
+                cmax = max2_raw(cmax, max3_raw(max2_raw(v[mi][0], v[mi][1]), v[mi][2], v[mi][3]));
+                acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            if (EMIT) {
+                const float thr = thr_lds[ni * 16 + col_e];
+                if (__ballot(cmax >= thr) != 0) {
+                    const int q = a.q_base + ni * 16 + col_e;
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) {
+                        const int rb = w * 32 + mi * 16 + 4 * lg;
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const float x = v[mi][rr];
+                            const bool hit = x >= thr;
+                            const unsigned long long hm = __ballot(hit);
+                            if (hm != 0) {
+                                const int pos = wave_cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+                                if (hit && pos < a.wv_cap)
+                                    wvbuf[pos] = make_int4(row0 + rb + rr, q, __float_as_int(x), tile_of(jt));
+                                wave_cnt += __popcll(hm);
+                            }
+                        }
+                    }
+                }
+            }
+            float m = cmax;
+            auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+            m = max2_raw(__uint_as_float(s32[0]), __uint_as_float(s32[1]));
+            auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+            m = max2_raw(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
+            if (lg == 0) a.tmax_t[((size_t)jt * 8 + w) * 256 + ni * 16 + col_e] = m;
+        }
+        jt = jn;
+        row0 = row0n;
+        row_end = a.tile_row[tile_of(jt) + 1];
+        jn = jt + G < a.t_count ? jt + G : jt;
+        row0n = a.tile_row[tile_of(jn)];
+        bp = bn; bn = tile_base(row0n);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) { vp[mi] = vn[mi]; vn[mi] = row_off(row0n, mi); }
+    }
+    wait_vm0();                                          // (the prefetched block and rows of a tile that does not exist)
+    if (EMIT && lane == 0) a.wv_count[blockIdx.x * 8 + w] = wave_cnt;
+}
+
+// query image of the 256-query kernel: [kt 24][q 256][physical chunk c' 4] x 16 B, group blockIdx.y = queries 256 g .. + 255
+__global__ __launch_bounds__(256) void build_qimg2_kernel(const float* __restrict__ qn, int nq, f16x8* __restrict__ qimg) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= GF_KT * 256 * 4) return;
+    const int g = blockIdx.y;
+    const int cp = i & 3, ql = (i >> 2) & 255, kt = i >> 10;
+    const int q = 256 * g + ql;
+    const int c = cp ^ (((ql >> 3) & 1) << 1);
+    f16x8 h;
+    if (q < nq) {
+        const float* src = qn + (size_t)q * MSR_DIM + 32 * kt + 8 * c;
+        h = cvt_f16_rtn(*(const f32x4*)src, *(const f32x4*)(src + 4));
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h[j] = (_Float16)0.f;
+    }
+    qimg[(size_t)g * (GF_KT * 256 * 4) + i] = h;
+}
+
 // query image of the streaming kernel: [kt 24][q 128][physical chunk c' 4] x 16 B = f16 of dims 32 kt + 8 c .. + 8 of the
 // normalised query q, c = c' ^ (((q >> 3) & 1) << 1); queries >= nq are zero
 __global__ __launch_bounds__(256) void build_qimg1_kernel(const float* __restrict__ qn, int nq, f16x8* __restrict__ qimg) {
@@ -448,7 +695,20 @@ hipError_t launch_stream_t(const GemmF32Args& a, int grid, hipStream_t stream) {
     gemm_stream_kernel<EMIT><<<grid, GF_THREADS, GS_LDS, stream>>>(a);
     return hipGetLastError();
 }
-hipError_t launch_f32(bool emit, const GemmF32Args& a, int grid, hipStream_t stream) {
+template <bool EMIT>
+hipError_t launch_stream256_t(const GemmF32Args& a, int grid, hipStream_t stream) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t err = hipFuncSetAttribute((const void*)gemm_stream256_kernel<EMIT>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
+        if (err != hipSuccess) return err;
+        attr_done = true;
+    }
+    gemm_stream256_kernel<EMIT><<<grid, G2_THREADS, G2_LDS, stream>>>(a);
+    return hipGetLastError();
+}
+// width: queries per pass (128 or 256; both kernels: 8 waves x 32 rows)
+hipError_t launch_f32(int width, bool emit, const GemmF32Args& a, int grid, hipStream_t stream) {
+    if (width == 256) return emit ? launch_stream256_t<true>(a, grid, stream) : launch_stream256_t<false>(a, grid, stream);
     return emit ? launch_stream_t<true>(a, grid, stream) : launch_stream_t<false>(a, grid, stream);
 }
 
@@ -469,27 +729,32 @@ hipError_t msr_f16_row_error(const float* emb, const float* inv_norm, int64_t n_
     return hipGetLastError();
 }
 
-// Exact f32 top-k of up to 128 x g.max_groups queries, one pass over the f32 rows per group of 128; see the header of this
-// file.  The passes of all groups are queued back to back; everything between and after them (the two selects over tile
-// maxima (gemm_kth_kernel: one launch each), bucketing, candidate lists, rescoring, final sort) runs ONCE for all
-// queries of the call.
+// Exact f32 top-k of up to 128 x g.max_groups queries; see the header of this file.  nq <= 128: one pass of the 128-query
+// kernel; more: groups of 256 queries, one pass of the 256-query kernel each (a last group that is not full is padded with
+// zero queries: the bytes are the same).  The passes of all groups are queued back to back; everything between and after
+// them (the two selects over tile maxima, bucketing, candidate lists, rescoring, final sort) runs ONCE for all queries of
+// the call.
 // qn: [nq][768] normalised queries.  gate[s] != 0 (one word per 64 queries, zero on entry) when a query of slice s overflowed
-// (the caller falls back for that slice).  ev (nullable): events
-// around the sample pass (0, 1) and the emit pass (2, 3) of the first group.
+// (the caller falls back for that slice).  ev (nullable): events around the sample pass (0, 1) and the emit pass (2, 3) of
+// the first group.  *width_out (nullable): queries per pass of the kernel that ran.
 hipError_t msr_gemm_f32_topk(const GemmF32Index& g, const DenseIndex& ix, const float* qn, int nq, int k,
                              int32_t* out_doc, float* out_score, int32_t* out_chunk,
-                             int32_t* out_n, int32_t* gate, hipEvent_t* ev, hipStream_t stream) {
-    const int G = (nq + 127) / 128;
-    if (nq <= 0 || G > g.max_groups || k < 1 || g.n_tiles < 2 * k) return hipErrorInvalidValue;
+                             int32_t* out_n, int32_t* gate, hipEvent_t* ev, int* width_out, hipStream_t stream) {
+    const int W = nq > 128 ? 256 : 128;                 // queries per pass
+    const int waves = 8;                                // waves per workgroup = emission buffers per workgroup (both kernels)
+    const int G = (nq + W - 1) / W;
+    if (nq <= 0 || G * W > 128 * g.max_groups || k < 1 || g.n_tiles < 2 * k) return hipErrorInvalidValue;
+    if (width_out) *width_out = W;
     hipError_t err;
-    build_qimg1_kernel<<<dim3((GF_KT * 128 * 4 + 255) / 256, G), 256, 0, stream>>>(qn, nq, (f16x8*)g.qimg);
+    if (W == 256) build_qimg2_kernel<<<dim3((GF_KT * 256 * 4 + 255) / 256, G), 256, 0, stream>>>(qn, nq, (f16x8*)g.qimg);
+    else build_qimg1_kernel<<<dim3((GF_KT * 128 * 4 + 255) / 256, G), 256, 0, stream>>>(qn, nq, (f16x8*)g.qimg);
     f16_margin_kernel<<<(nq + 3) / 4, 256, 0, stream>>>(qn, nq, g.err_max, g.margin);
     const float* margin = g.margin;
     int ss = g.n_tiles / (3 * k);                       // every ss-th tile bounds the k-th score from below: >= 3 k sampled tiles
     ss = ss < 1 ? 1 : (ss > 64 ? 64 : ss);          // (the weaker the bound, the more entries pass 2 emits: ~150 ss per query)
     const int n_s = (g.n_tiles - ss / 2 + ss - 1) / ss;
     const int grid = g.n_cus;
-    const size_t qimg_bytes = (size_t)GF_KT * GS_STEP;
+    const size_t qimg_bytes = (size_t)GF_KT * W * 64;   // one group's image
     GemmF32Args a{};
     a.dbg = g_f32_dbg;
     a.E = (const char*)ix.emb; a.inv_pad = g.inv_pad; a.tile_row = g.tile_row;
@@ -499,26 +764,26 @@ hipError_t msr_gemm_f32_topk(const GemmF32Index& g, const DenseIndex& ix, const 
     for (int gi = 0; gi < G; ++gi) {
         a.qimg = (const char*)g.qimg + gi * qimg_bytes;
         if (ev && gi == 0 && (err = hipEventRecord(ev[0], stream)) != hipSuccess) return err;
-        if ((err = launch_f32(false, a, grid, stream)) != hipSuccess) return err;
+        if ((err = launch_f32(W, false, a, grid, stream)) != hipSuccess) return err;
         if (ev && gi == 0 && (err = hipEventRecord(ev[1], stream)) != hipSuccess) return err;
-        if ((err = msr_gemm_tmax(g.tmax_t, n_s, 8, 128, g.tmax + (size_t)gi * 128 * g.tmax_stride, g.tmax_stride, stream)) != hipSuccess) return err;
+        if ((err = msr_gemm_tmax(g.tmax_t, n_s, waves, W, g.tmax + (size_t)gi * W * g.tmax_stride, g.tmax_stride, stream)) != hipSuccess) return err;
     }
-    if ((err = msr_gemm_kth(g.tmax, n_s, g.tmax_stride, nq, 128 * G, k, margin, g.thr, g.flag, stream)) != hipSuccess) return err;
+    if ((err = msr_gemm_kth(g.tmax, n_s, g.tmax_stride, nq, W * G, k, margin, g.thr, g.flag, stream)) != hipSuccess) return err;
     // ---- pass 2 of every group: maxima of all tiles + the entries at or above the threshold (one set of wave buffers) ----
     a.t_first = 0; a.t_stride = 1; a.t_count = g.n_tiles;
-    a.wvbuf = (int4*)g.wvbuf; a.wv_cap = g.wv_cap; a.wv_count = g.wv_count;
+    a.wvbuf = (int4*)g.wvbuf; a.wv_cap = g.wv_cap * (8 / waves); a.wv_count = g.wv_count;
     for (int gi = 0; gi < G; ++gi) {
         a.qimg = (const char*)g.qimg + gi * qimg_bytes;
-        a.thr = g.thr + gi * 128; a.q_base = gi * 128; a.append = gi > 0;
+        a.thr = g.thr + gi * W; a.q_base = gi * W; a.append = gi > 0;
         if (ev && gi == 0 && (err = hipEventRecord(ev[2], stream)) != hipSuccess) return err;
-        if ((err = launch_f32(true, a, grid, stream)) != hipSuccess) return err;
+        if ((err = launch_f32(W, true, a, grid, stream)) != hipSuccess) return err;
         if (ev && gi == 0 && (err = hipEventRecord(ev[3], stream)) != hipSuccess) return err;
-        if ((err = msr_gemm_tmax(g.tmax_t, g.n_tiles, 8, 128, g.tmax + (size_t)gi * 128 * g.tmax_stride, g.tmax_stride, stream)) != hipSuccess) return err;
+        if ((err = msr_gemm_tmax(g.tmax_t, g.n_tiles, waves, W, g.tmax + (size_t)gi * W * g.tmax_stride, g.tmax_stride, stream)) != hipSuccess) return err;
     }
-    if ((err = msr_gemm_kth(g.tmax, g.n_tiles, g.tmax_stride, nq, 128 * G, k, margin, g.thr2, nullptr, stream)) != hipSuccess) return err;
-    if ((err = msr_gemm_bucket(g.wvbuf, g.wv_cap, g.wv_count, grid * 8, g.thr2, g.pairs, g.pair_n, stream)) != hipSuccess) return err;
-    gemm_f32_cand_kernel<<<nq, 1024, 0, stream>>>((const int2*)g.pairs, g.pair_n, ix.chunk_doc, ix.n_chunks, g.wv_count, grid * 8,
-                                                  g.wv_cap, g.flag, g.cand_doc, g.cand_n, gate);
+    if ((err = msr_gemm_kth(g.tmax, g.n_tiles, g.tmax_stride, nq, W * G, k, margin, g.thr2, nullptr, stream)) != hipSuccess) return err;
+    if ((err = msr_gemm_bucket(g.wvbuf, a.wv_cap, g.wv_count, grid * waves, g.thr2, g.pairs, g.pair_n, stream)) != hipSuccess) return err;
+    gemm_f32_cand_kernel<<<nq, 1024, 0, stream>>>((const int2*)g.pairs, g.pair_n, ix.chunk_doc, ix.n_chunks, g.wv_count, grid * waves,
+                                                  a.wv_cap, g.flag, g.cand_doc, g.cand_n, gate);
     if ((err = hipGetLastError()) != hipSuccess) return err;
     return msr_batch_rescore(ix, qn, nq, k, 0, g.cand_doc, g.cand_score, g.cand_chunk, g.cand_n, out_doc, out_score, out_chunk,
                              out_n, stream);

@@ -239,8 +239,8 @@ struct GemmF32Index {
     int32_t max_groups;        // groups of 128 queries one call may hold (the per-query arrays below are sized 128 x this)
     const float* inv_pad;      // [n_chunks + 512] inverse row norms, padded with 1
     void* qimg;                // [max_groups] x 24 x 8 KB query images (f16)
-    float* tmax_t;             // [n_tiles][8 waves][128]
-    float* tmax;               // [128][tmax_stride]
+    float* tmax_t;             // [n_tiles][8 waves][128], or [256] when max_groups >= 2 (the 256-query kernel)
+    float* tmax;               // [128 max_groups][tmax_stride]
     int32_t tmax_stride;
     float* thr; float* thr2; int32_t* flag;                 // [128]
     void* wvbuf; int32_t wv_cap; int32_t* wv_count;          // [n_cus * 8][wv_cap] x 16 B / [n_cus * 8]
@@ -256,7 +256,7 @@ hipError_t msr_pad_inv_norm(const float* inv, int64_t n, int64_t n_pad, float* o
 // pass (0, 1) and the emit pass (2, 3).
 hipError_t msr_gemm_f32_topk(const GemmF32Index& g, const DenseIndex& ix, const float* qn, int nq, int k,
                              int32_t* out_doc, float* out_score, int32_t* out_chunk,
-                             int32_t* out_n, int32_t* gate, hipEvent_t* ev, hipStream_t stream);
+                             int32_t* out_n, int32_t* gate, hipEvent_t* ev, int* width_out, hipStream_t stream);
 
 // ---- K5: batched bf16 candidate scan finished exactly in f32 (msr_batch.hip) -----------------------
 // exact f32 rescoring + final sort of candidate lists that are already filled (cand_n zeroed on return)

@@ -153,8 +153,13 @@ class DeviceEngine:
         return bool(self.lib.msr_batch_gemm_ok(self.handle))
 
     def scan_width(self):
-        """Queries served by one sweep of the embedding matrix in dense_topk (64 with the K-split kernel, else 32)."""
+        """Most queries one pass over the embedding matrix serves in dense_topk (256 / 128: streaming pass, 64: K-split sweep,
+        else 32)."""
         return int(self.lib.msr_scan_width(self.handle))
+
+    def dense_path(self):
+        """Queries per pass of the kernel the most recent dense_topk call ran (256 / 128 / 64 / 32; 0 before the first)."""
+        return int(self.lib.msr_dense_path(self.handle))
 
     def pack_queries(self, term_lists):
         """list of term-id lists (repeats allowed, any unknown id < 0) -> device CSR of UNIQUE terms in

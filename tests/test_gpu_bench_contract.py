@@ -29,12 +29,12 @@ def test_default_line_has_the_contract_fields():
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["unit"] == "queries/sec" and d["value"] > 0 and d["ms_per_step"] > 0 and d["data"] == "synthetic"
     assert abs(d["value"] - d["config"]["queries_per_step"] * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
-    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["config"]["queries_per_step"] == 128
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["config"]["queries_per_step"] == 256
     assert "model" not in d["config"] and d["config"]["workload"].startswith("hybrid: 60000 docs")
     assert "f64" in d["dtype"] and d["outputs_sane"] is True and d["bm25_parity_vs_cpu"] is True
     r = d["roofline"]
-    # 128 queries per step: ONE pass of the GEMM scan over the f32 rows (csrc/msr_gemm_f32.hip) per step
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "gemm_stream_kernel<emit>"
+    # 256 queries per step: ONE pass of the 256-query streaming kernel over the f32 rows (csrc/msr_gemm_f32.hip) per step
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "gemm_stream256_kernel<emit>"
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "traffic" in r and r["launches"] == 3   # 1 pass x 3 steps
     assert r["bm25_taat"]["launches"] == 3
     c = d["cpu_baseline"]

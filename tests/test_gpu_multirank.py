@@ -31,6 +31,6 @@ def test_bench_two_ranks_on_one_gpu(nproc, batch):
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == nproc and line["outputs_sane"] and line["sharded_equals_unsharded"] is True
-    # an explicit batch is strong scaling; the default (0) is 128 queries per GPU: weak scaling
+    # an explicit batch is strong scaling; the default (0) is 256 queries per GPU: weak scaling
     assert line["scaling"] == ("strong" if batch else "weak") and line["value"] > 0
-    assert line["config"]["queries_per_step"] == (batch or 128 * nproc)
+    assert line["config"]["queries_per_step"] == (batch or 256 * nproc)

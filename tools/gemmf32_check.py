@@ -28,7 +28,7 @@ ap.add_argument("--dbg", type=int, default=0)
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 ix = synthetic_corpus(a.docs, n_chunks=a.chunks, device=dev, with_postings=False)
-e = DeviceEngine(ix, max_queries=64, max_k=max(a.k, 100), rerank_max_docs=0)
+e = DeviceEngine(ix, max_queries=max(64, a.queries), max_k=max(a.k, 100), rerank_max_docs=0)
 print("scan_width", e.scan_width(), "arith", e.scan_arith(), flush=True)
 g = torch.Generator(device="cpu"); g.manual_seed(5)
 rows = torch.randint(0, a.chunks, (a.queries,), generator=g)
@@ -44,7 +44,8 @@ print(json.dumps({"n_equal": bool(torch.equal(got[3], ref[3])), "max_abs_score_d
                   "chunk_agreement": float(((got[2] == ref[2]) | ~same).float().mean())}), flush=True)
 if a.dbg:
     e._check(e.lib.msr_tune(e.handle, 101, a.dbg))
-for name, fn in (("gemm_128", lambda: e.dense_topk(q, k=a.k)),
+print("dense_path", e.dense_path(), flush=True)
+for name, fn in (("stream_pass", lambda: e.dense_topk(q, k=a.k)),
                  ("sweeps_2x64", lambda: [e.dense_topk(q[s:s + 64], k=a.k) for s in range(0, a.queries, 64)])):
     ts = []
     for it in range(a.iters):
