@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MSR_ABI_VERSION 1
+#define MSR_ABI_VERSION 2
 #define MSR_DIM 768               /* config.py:2 EMBEDDING_DIMENSION */
 #define MSR_MAX_K 1024            /* config.py:13 TOP_K_RETRIEVAL = 1000 */
 #define MSR_MAX_QUERY_TERMS 64
@@ -214,9 +214,10 @@ int msr_merge_topk_payload(msr_engine* e, const int32_t* in_doc, const void* in_
  * its own workspace and synchronises the stream).  Replaces the term counting and table writes of BM25.build_index
  * (indexer/bm25_indexer.py:16-54, 203-250; doc_freq :130-147) given pre-tokenised documents: document i (documents in
  * ascending doc_id order, only those with at least one token) owns tok_ids[tok_off[i] .. tok_off[i+1]), term ids in
- * [0, n_terms).  Writes term_off[n_terms + 1] and, when capacity >= the number of postings, post_doc / post_tf (CSR by term,
- * documents ascending inside a term, tf = occurrences).  *n_postings [host] always receives the number of postings: call
- * once with capacity 0 to size the arrays, then again.  All arrays are device pointers. */
+ * [0, n_terms) -- checked on the device, MSR_ERR_INVALID otherwise.  When capacity >= the number of postings: writes
+ * term_off[n_terms + 1] and post_doc / post_tf (CSR by term, documents ascending inside a term, tf = occurrences).
+ * *n_postings [host] always receives the number of postings: call once with capacity 0 to size the arrays (that call may
+ * return after the counting phase and leave term_off untouched), then again.  All arrays are device pointers. */
 int msr_build_postings(const int64_t* tok_off, const int32_t* tok_ids, int64_t n_docs, int32_t n_terms, int64_t* term_off,
                        int32_t* post_doc, int32_t* post_tf, int64_t capacity, int64_t* n_postings, void* stream);
 

@@ -35,9 +35,11 @@ int msr_enc_layernorm(const float* x, const int32_t* ids, const float* table, co
 /* Self-attention of short sequences.  qkv is [n_tok][3][n_heads][64] (the Wqkv product); sequence b owns tokens
  * [seq_off[b], seq_off[b+1]) (<= 128 each).  Rotary embedding (rotate-half form) with inv_freq[32] applied to q and k,
  * scores q.k / 8, keys farther than `window` positions away masked out (window <= 0: none), softmax, times v.
- * out is [n_tok][n_heads * 64]. */
+ * max_len: an upper bound of the sequence lengths the caller vouches for (<= 128; 0 = no better bound than 128): up to 32
+ * a WAVE serves a (sequence, head) pair instead of a workgroup (a batch of queries: 1536 pairs of 8 tokens); a sequence
+ * longer than the bound gets NaNs.  out is [n_tok][n_heads * 64]. */
 int msr_enc_attention(const float* qkv, const int32_t* seq_off, int32_t n_seq, int32_t n_heads, const float* inv_freq,
-                      int32_t window, float* out, void* stream);
+                      int32_t window, int32_t max_len, float* out, void* stream);
 
 /* y[m][j] = gelu(u[m][j]) * u[m][half + j], j < half (exact erf GELU). */
 int msr_enc_geglu(const float* u, float* y, int64_t n_rows, int32_t half, void* stream);

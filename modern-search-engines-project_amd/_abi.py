@@ -7,7 +7,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libmsretr.so")
 
-MSR_ABI_VERSION = 1
+MSR_ABI_VERSION = 2
 MSR_DIM = 768
 MSR_MAX_K = 1024
 MSR_RERANK_MAX_CHUNKS = 10
@@ -45,7 +45,7 @@ _SIGNATURES = {
     "msr_dense_path": (C.c_int, [_P]),
     # include/msretr_encoder.h
     "msr_enc_layernorm": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
-    "msr_enc_attention": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P]),
+    "msr_enc_attention": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P]),
     "msr_enc_geglu": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
     "msr_enc_linear": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "msr_enc_mean_pool": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),

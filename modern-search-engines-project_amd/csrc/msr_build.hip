@@ -248,6 +248,14 @@ __global__ __launch_bounds__(256) void df_finish_kernel(const int64_t* __restric
     if (t < n_terms && df[t] > 0) df[t] -= first[t];
 }
 
+// *flag |= 1 if any token id lies outside [0, n_terms) (the radix pass count and the doc_freq scatter rely on the range)
+__global__ __launch_bounds__(256) void id_range_kernel(const int32_t* __restrict__ tok, int64_t n, int32_t n_terms, int32_t* __restrict__ flag) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) bad |= (uint32_t)tok[i] >= (uint32_t)n_terms;
+    if (bad) atomicOr(flag, 1);
+}
+
 }  // namespace
 
 extern "C" int msr_build_postings(const int64_t* tok_off, const int32_t* tok_ids, int64_t n_docs, int32_t n_terms,
@@ -257,6 +265,11 @@ extern "C" int msr_build_postings(const int64_t* tok_off, const int32_t* tok_ids
         return msr_fail_global(MSR_ERR_INVALID, "msr_build_postings: bad argument");
     hipStream_t st = (hipStream_t)stream;
     int rc = MSR_OK;
+    {   // handle-less entry point: run on the device that holds the caller's arrays
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, tok_off) == hipSuccess && attr.type == hipMemoryTypeDevice) (void)hipSetDevice(attr.device);
+        else (void)hipGetLastError();
+    }
     std::vector<int64_t> h_off((size_t)n_docs + 1), c_start;
     std::vector<int32_t> c_len, c_doc;
     int64_t *d_cstart = nullptr, *d_cnt = nullptr, *d_coff = nullptr, *d_tmp = nullptr, *d_total = nullptr, *d_hist = nullptr,
@@ -301,11 +314,25 @@ extern "C" int msr_build_postings(const int64_t* tok_off, const int32_t* tok_ids
     BUILD_TRY(hipMemcpyAsync(d_cstart, c_start.data(), n_chunks * 8, hipMemcpyHostToDevice, st));
     BUILD_TRY(hipMemcpyAsync(d_clen, c_len.data(), n_chunks * 4, hipMemcpyHostToDevice, st));
     BUILD_TRY(hipMemcpyAsync(d_cdoc, c_doc.data(), n_chunks * 4, hipMemcpyHostToDevice, st));
+    {   // every token id inside [0, n_terms): checked on the device before anything is indexed with one
+        int32_t h_bad = 0;
+        int32_t* d_bad = (int32_t*)(d_tmp + tmp_words - 1);      // (the last word of the scan scratch: unused by the scans)
+        BUILD_TRY(hipMemsetAsync(d_bad, 0, 4, st));
+        id_range_kernel<<<1024, 256, 0, st>>>(tok_ids, n_tok, n_terms, d_bad);
+        BUILD_TRY(hipGetLastError());
+        BUILD_TRY(hipMemcpyAsync(&h_bad, d_bad, 4, hipMemcpyDeviceToHost, st));
+        BUILD_TRY(hipStreamSynchronize(st));
+        if (h_bad) { rc = msr_fail_global(MSR_ERR_INVALID, "msr_build_postings: token id outside [0, %d)", n_terms); goto done; }
+    }
     unique_kernel<false><<<(unsigned)n_chunks, 256, 0, st>>>(tok_ids, d_cstart, d_clen, d_cdoc, d_cnt, nullptr, nullptr, nullptr, nullptr);
     BUILD_TRY(hipGetLastError());
     BUILD_TRY(exclusive_scan(d_cnt, n_chunks, d_coff, d_tmp, d_total, st));
     BUILD_TRY(hipMemcpyAsync(&P, d_total, 8, hipMemcpyDeviceToHost, st));
     BUILD_TRY(hipStreamSynchronize(st));
+    if (capacity == 0 && !split) {                                 // sizing call: without split documents the count is exact
+        *n_postings = P;
+        goto done;
+    }
     BUILD_TRY(hipMalloc((void**)&a_term, std::max<int64_t>(P, 1) * 4));
     BUILD_TRY(hipMalloc((void**)&a_doc, std::max<int64_t>(P, 1) * 4));
     BUILD_TRY(hipMalloc((void**)&a_tf, std::max<int64_t>(P, 1) * 4));

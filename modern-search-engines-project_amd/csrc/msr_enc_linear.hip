@@ -52,15 +52,26 @@ __global__ __launch_bounds__(256) void enc_linear_kernel(const float* __restrict
 #pragma unroll
         for (int tb = 0; tb < NTB; ++tb) acc[r][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // k-steps of 16; the operands of PF steps are in flight ahead of the MFMAs (a ring of PF register sets, statically
-    // indexed: the loop body is unrolled PF times)
-    const int steps = kslice >> 4;
-    f32x4 a[PF][RB], b[PF][NTB];
+    // k-steps of 32: lane (n, g) loads floats 32 t + 8 g .. + 7 of its rows (two 16-byte loads), so the four lanes g of a row
+    // consume one whole 128-byte line per step and no line is visited twice (with 16-float steps every line was fetched in
+    // two steps, and between them the workgroups of a CU had pushed it out of the 32 KB vector cache: three workgroups per CU
+    // ran 1.4x SLOWER than one).  The operands of PF steps are in flight ahead of the MFMAs (a ring of PF register sets,
+    // statically indexed: the loop body is unrolled PF times).  Which k an MFMA multiplies is only a label: both operands
+    // use the same one.
+    const int steps = kslice >> 5;
+    const int kb2 = wave * kslice + 8 * g - kb;                // (the pointers were set up for 4 g: move them to 8 g)
+    f32x4 a[PF][RB][2], b[PF][NTB][2];
     auto load = [&](int p, int t) {
 #pragma unroll
-        for (int r = 0; r < RB; ++r) a[p][r] = *reinterpret_cast<const f32x4*>(wp[r] + 16 * t);
+        for (int r = 0; r < RB; ++r) {
+            a[p][r][0] = *reinterpret_cast<const f32x4*>(wp[r] + kb2 + 32 * t);
+            a[p][r][1] = *reinterpret_cast<const f32x4*>(wp[r] + kb2 + 32 * t + 4);
+        }
 #pragma unroll
-        for (int tb = 0; tb < NTB; ++tb) b[p][tb] = *reinterpret_cast<const f32x4*>(xp[tb] + 16 * t);
+        for (int tb = 0; tb < NTB; ++tb) {
+            b[p][tb][0] = *reinterpret_cast<const f32x4*>(xp[tb] + kb2 + 32 * t);
+            b[p][tb][1] = *reinterpret_cast<const f32x4*>(xp[tb] + kb2 + 32 * t + 4);
+        }
     };
 #pragma unroll
     for (int p = 0; p < PF; ++p)
@@ -71,12 +82,14 @@ __global__ __launch_bounds__(256) void enc_linear_kernel(const float* __restrict
             const int t = t0 + p;
             if (t < steps) {                                  // (uniform)
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
+                for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-                    for (int r = 0; r < RB; ++r)
+                    for (int c = 0; c < 4; ++c)
 #pragma unroll
-                        for (int tb = 0; tb < NTB; ++tb)
-                            acc[r][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p][r][c], b[p][tb][c], acc[r][tb], 0, 0, 0);
+                        for (int r = 0; r < RB; ++r)
+#pragma unroll
+                            for (int tb = 0; tb < NTB; ++tb)
+                                acc[r][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p][r][hh][c], b[p][tb][hh][c], acc[r][tb], 0, 0, 0);
                 if (t + PF < steps) load(p, t + PF);
             }
         }
@@ -106,11 +119,14 @@ __global__ __launch_bounds__(256) void enc_linear_kernel(const float* __restrict
         }
 }
 
+int g_enc_shape = 0;                                          // (only the diagnostic build can set these two)
+int g_enc_pad_lds = 0;
+
 template <int NTB, int RB, int PF>
 void launch(const float* x, const float* w, const float* resid, float* y, int n_tok, int n_out, int n_in,
-            hipStream_t stream) {
+            hipStream_t stream, int pad_lds = 0) {
     const dim3 grid((unsigned)(n_out / (16 * RB)), (unsigned)((n_tok + 16 * NTB - 1) / (16 * NTB)));
-    enc_linear_kernel<NTB, RB, PF><<<grid, 256, 0, stream>>>(x, w, resid, y, n_tok, n_out, n_in);
+    enc_linear_kernel<NTB, RB, PF><<<grid, 256, pad_lds, stream>>>(x, w, resid, y, n_tok, n_out, n_in);
 }
 
 }  // namespace
@@ -126,12 +142,31 @@ extern "C" int msr_enc_linear(const float* x, const float* w, const float* resid
     if (n_tok == 0) return MSR_OK;
     hipStream_t s = (hipStream_t)stream;
     // token blocks per workgroup: the smallest that covers a single query's tokens (fewer idle MFMAs; the whole K slice
-    // of a wave is in flight at once), 64-token tiles beyond that; batches (> 128 tokens) take 32 weight rows per
-    // workgroup, which halves the L2 traffic of x
-    if (n_tok <= 16) launch<1, 1, 6>(x, w, resid, y, n_tok, n_out, n_in, s);
-    else if (n_tok <= 32) launch<2, 1, 4>(x, w, resid, y, n_tok, n_out, n_in, s);
-    else if (n_tok <= 128) launch<4, 1, 3>(x, w, resid, y, n_tok, n_out, n_in, s);
-    else launch<4, 2, 3>(x, w, resid, y, n_tok, n_out, n_in, s);
+    // of a wave is in flight at once), 64-token tiles beyond that
+    if (n_tok <= 16) launch<1, 1, 3>(x, w, resid, y, n_tok, n_out, n_in, s);
+    else if (n_tok <= 32) launch<2, 1, 2>(x, w, resid, y, n_tok, n_out, n_in, s);
+    else if (n_tok <= 128) launch<4, 1, 2>(x, w, resid, y, n_tok, n_out, n_in, s);
+    else {
+        // Batches (measured at 1024 tokens, profiles/r03_enc_linear_shapes.md): 64 tokens x 48 weight rows per workgroup
+        // (7 operand loads per 48 MFMAs), and ONE workgroup per CU -- each has a wave on every SIMD and the kernel is bound by
+        // the f32 matrix rate, so co-resident workgroups only take turns at the matrix pipes and evict each other's lines:
+        // 2304 x 768 ran 54 us with three (two) workgroups per CU, 43 us with one (the library GEMM: 40 us).  The occupancy
+        // is set with unused dynamic LDS.  Output widths that are not a multiple of 48 take 32 rows per workgroup.
+        const int shape = g_enc_shape ? g_enc_shape : (n_out % 48 == 0 ? 1 : 2);
+        const int pad = g_enc_shape ? g_enc_pad_lds : 40 * 1024;
+        switch (shape) {
+            case 1: launch<4, 3, 2>(x, w, resid, y, n_tok, n_out, n_in, s, pad); break;
+            case 2: launch<4, 2, 2>(x, w, resid, y, n_tok, n_out, n_in, s, pad); break;
+            case 3: launch<2, 3, 2>(x, w, resid, y, n_tok, n_out, n_in, s, pad); break;
+            case 4: launch<2, 2, 2>(x, w, resid, y, n_tok, n_out, n_in, s, pad); break;
+            default: launch<4, 4, 1>(x, w, resid, y, n_tok, n_out, n_in, s, pad); break;
+        }
+    }
     const hipError_t err = hipGetLastError();
     return err == hipSuccess ? MSR_OK : msr_fail_global(MSR_ERR_HIP, "msr_enc_linear: %s", hipGetErrorString(err));
 }
+
+#ifdef MSR_DIAG
+extern "C" void msr_enc_linear_force_shape(int code) { g_enc_shape = code & 15; g_enc_pad_lds = (code >> 4) * 1024; }   // timing experiments:
+// low 4 bits 1 .. 5 = candidate shape (0 = choose), the rest = KB of unused LDS per workgroup
+#endif

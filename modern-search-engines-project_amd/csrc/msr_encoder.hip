@@ -110,6 +110,83 @@ __global__ __launch_bounds__(MAX_SEQ) void enc_attention_kernel(const float* __r
     for (int j = 0; j < HEAD_DIM; ++j) o[j] = acc[j] / den;
 }
 
+// The same for SHORT sequences (at most SMAX tokens each: a batch of queries has 3 .. 20 tokens per sequence): one WAVE per
+// (sequence, head) -- the kernel above gives such a pair a 128-thread workgroup and 64 KB of LDS, of which a query uses 8
+// threads.  Q, K (both rotated) and V of the pair sit in the wave's own slice of LDS (rows padded to 65 floats: a column
+// read hits 64 different banks); lane p computes the scores of (query token, key token) pair p, lane t the softmax of row t,
+// lane j output feature j of every token.  No workgroup barrier: the four waves of a workgroup are independent, a wave's LDS
+// operations execute in program order.
+template <int SMAX>
+__global__ __launch_bounds__(256) void enc_attention_short_kernel(const float* __restrict__ qkv,
+                                                                  const int32_t* __restrict__ seq_off, int n_seq, int n_heads,
+                                                                  const float* __restrict__ inv_freq, int window,
+                                                                  float* __restrict__ out) {
+    constexpr int LD = HEAD_DIM + 1;
+    __shared__ float Qs[4][SMAX][LD], Ks[4][SMAX][LD], Vs[4][SMAX][LD];
+    __shared__ float Ps[4][SMAX][SMAX + 1];                      // exp(score - row max); column SMAX: the row's denominator
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pair = blockIdx.x * 4 + wave;
+    const int b = pair / n_heads, h = pair - b * n_heads;
+    if (b >= n_seq) return;                                      // (wave-uniform)
+    const int t0 = seq_off[b], S = seq_off[b + 1] - t0;
+    if (S <= 0) return;
+    const int stride = 3 * n_heads * HEAD_DIM;
+    float* o = out + (int64_t)t0 * (n_heads * HEAD_DIM) + h * HEAD_DIM + lane;
+    if (S > SMAX) {                                              // the caller's length bound was wrong: fail loudly, touch nothing else
+        for (int t = 0; t < S; ++t) o[(int64_t)t * (n_heads * HEAD_DIM)] = __builtin_nanf("");
+        return;
+    }
+    float (*Q)[LD] = Qs[wave], (*K)[LD] = Ks[wave], (*V)[LD] = Vs[wave];
+    float (*P)[SMAX + 1] = Ps[wave];
+    // rotate-half: x'_j = x_j cos_j - x_{j+32} sin_j (j < 32), x'_j = x_j cos_{j-32} + x_{j-32} sin_{j-32} (j >= 32),
+    // angle_j = position * inv_freq[j]; lane j owns feature j
+    {
+        const float f = inv_freq[lane & 31];
+        const float sgn = lane < 32 ? -1.f : 1.f;
+        for (int t = 0; t < S; ++t) {
+            const float* base = qkv + (int64_t)(t0 + t) * stride + h * HEAD_DIM;
+            const float ang = (float)t * f;
+            const float c = cosf(ang), sn = sinf(ang);
+            const float q1 = base[lane], q2 = base[lane ^ 32];
+            const float k1 = base[n_heads * HEAD_DIM + lane], k2 = base[n_heads * HEAD_DIM + (lane ^ 32)];
+            Q[t][lane] = q1 * c + sgn * (q2 * sn);
+            K[t][lane] = k1 * c + sgn * (k2 * sn);
+            V[t][lane] = base[2 * n_heads * HEAD_DIM + lane];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // scores of the S x S (query token, key token) pairs, 64 pairs at a time
+    for (int p = lane; p < S * S; p += 64) {
+        const int t = p / S, k = p - t * S;
+        const int dist = k > t ? k - t : t - k;
+        float sc = -INFINITY;                                    // outside the local window: weight 0
+        if (!(window > 0 && dist > window)) {
+            float d = 0.f;
+#pragma unroll
+            for (int j = 0; j < HEAD_DIM; ++j) d += Q[t][j] * K[k][j];
+            sc = d * 0.125f;                                     // head_dim ** -0.5
+        }
+        P[t][k] = sc;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < S) {                                              // softmax of row `lane` (its own key is never masked: max is finite)
+        float mx = -INFINITY, den = 0.f;
+        for (int k = 0; k < S; ++k) mx = fmaxf(mx, P[lane][k]);
+        for (int k = 0; k < S; ++k) {
+            const float e = expf(P[lane][k] - mx);
+            P[lane][k] = e;
+            den += e;
+        }
+        P[lane][SMAX] = den;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int t = 0; t < S; ++t) {                                // lane j: feature j of token t
+        float a = 0.f;
+        for (int k = 0; k < S; ++k) a += P[t][k] * V[k][lane];
+        o[(int64_t)t * (n_heads * HEAD_DIM)] = a / P[t][SMAX];
+    }
+}
+
 __global__ __launch_bounds__(256) void enc_geglu_kernel(const float* __restrict__ u, float* __restrict__ y,
                                                         int64_t n_rows, int half) {
     const int64_t n = n_rows * half;
@@ -161,13 +238,21 @@ extern "C" int msr_enc_layernorm(const float* x, const int32_t* ids, const float
 }
 
 extern "C" int msr_enc_attention(const float* qkv, const int32_t* seq_off, int32_t n_seq, int32_t n_heads,
-                                 const float* inv_freq, int32_t window, float* out, void* stream) {
-    if (!qkv || !seq_off || !inv_freq || !out || n_seq < 0 || n_heads < 1 || n_heads > 64)
+                                 const float* inv_freq, int32_t window, int32_t max_len, float* out, void* stream) {
+    if (!qkv || !seq_off || !inv_freq || !out || n_seq < 0 || n_heads < 1 || n_heads > 64 || max_len > MAX_SEQ)
         return msr_fail_global(MSR_ERR_INVALID, "msr_enc_attention: bad argument");
     if (n_seq == 0) return MSR_OK;
-    // (sequence lengths are on the device; the caller guarantees <= 128 tokens per sequence, encoder.py checks it)
-    enc_attention_kernel<<<dim3((unsigned)n_seq, (unsigned)n_heads), MAX_SEQ, 0, (hipStream_t)stream>>>(
-        qkv, seq_off, n_heads, inv_freq, window, out);
+    // (sequence lengths are on the device; the caller guarantees <= max_len (<= 128) tokens per sequence, encoder.py checks it)
+    const unsigned pairs = (unsigned)n_seq * (unsigned)n_heads;
+    hipStream_t st = (hipStream_t)stream;
+    if (max_len >= 1 && max_len <= 8)
+        enc_attention_short_kernel<8><<<(pairs + 3) / 4, 256, 0, st>>>(qkv, seq_off, n_seq, n_heads, inv_freq, window, out);
+    else if (max_len >= 1 && max_len <= 16)
+        enc_attention_short_kernel<16><<<(pairs + 3) / 4, 256, 0, st>>>(qkv, seq_off, n_seq, n_heads, inv_freq, window, out);
+    else if (max_len >= 1 && max_len <= 32)
+        enc_attention_short_kernel<32><<<(pairs + 3) / 4, 256, 0, st>>>(qkv, seq_off, n_seq, n_heads, inv_freq, window, out);
+    else
+        enc_attention_kernel<<<dim3((unsigned)n_seq, (unsigned)n_heads), MAX_SEQ, 0, st>>>(qkv, seq_off, n_heads, inv_freq, window, out);
     const hipError_t err = hipGetLastError();
     return err == hipSuccess ? MSR_OK : msr_fail_global(MSR_ERR_HIP, "msr_enc_attention: %s", hipGetErrorString(err));
 }

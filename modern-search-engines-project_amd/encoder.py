@@ -10,9 +10,9 @@ sentence-transformers `modules.json`), or are random for tests and benchmarks.
 For a query (<= 128 tokens in all) the whole forward pass is hand-written HIP behind the C ABI of
 include/msretr_encoder.h: the matrix products (msr_enc_linear: skinny products on the exact-f32 matrix cores, each weight
 read once) and everything between them -- embedding lookup + LayerNorm, LayerNorm, rotary embedding + attention, GeGLU,
-masked mean pooling; torch owns the buffers and the hipGraph.  Batches of more than 128 tokens keep the library GEMM
-(hipBLASLt through torch.mm / addmm) for the products -- a plain GEMM at that size -- and the same HIP kernels between.  There is no CPU fallback: without the library the class
-raises.  Parity: tests/test_gpu_encoder.py compares the output with transformers' ModernBertModel (the reference's
+masked mean pooling; torch owns the buffers and the hipGraph.  Batches take the same kernels (a tile shape of
+msr_enc_linear for many tokens, the wave-per-(sequence, head) form of the attention for short sequences).  There is no CPU
+fallback: without the library the class raises.  Parity: tests/test_gpu_encoder.py compares the output with transformers' ModernBertModel (the reference's
 dependency) on the same random weights.
 """
 import ctypes as C
@@ -27,7 +27,8 @@ from . import _abi
 HIDDEN, HEADS, LAYERS, INTER, VOCAB = 768, 12, 22, 1152, 50368
 GLOBAL_EVERY, LOCAL_WINDOW, THETA_GLOBAL, THETA_LOCAL, EPS = 3, 128, 160000.0, 10000.0, 1e-5
 MAX_SEQ = 128                                               # msr_enc_attention: tokens per sequence
-LINEAR_HIP_MAX_TOKENS = 128                                 # msr_enc_linear up to here, library GEMM beyond (see _linear)
+LINEAR_HIP_MAX_TOKENS = 1 << 30                             # msr_enc_linear for every batch (tools can lower it to compare
+#                                                             with the library GEMM, see _linear)
 
 
 def _ptr(t):
@@ -135,11 +136,13 @@ class QueryEncoder:
             return out
         ids = torch.tensor([t for s in seqs for t in s], dtype=torch.int32)
         seq_off = torch.from_numpy(off)
+        max_len = max(len(s) for s in seqs)
         if not self.use_graphs:
-            return self._forward(ids.to(self.device), seq_off.to(self.device), len(seqs), n_tok, normalize, out)
+            return self._forward(ids.to(self.device), seq_off.to(self.device), len(seqs), n_tok, normalize, out, max_len)
         # The forward pass is ~200 short launches (launch-bound for a query's few tokens): it is captured once per
         # (token count, sequence count, normalize) into a hipGraph over static buffers and replayed afterwards.
-        key = (n_tok, len(seqs), bool(normalize))
+        max_len = 8 if max_len <= 8 else 16 if max_len <= 16 else 32 if max_len <= 32 else MAX_SEQ   # the attention kernel's classes
+        key = (n_tok, len(seqs), bool(normalize), max_len)
         ent = self._graphs.get(key)
         if ent is None:
             s_ids = torch.zeros(n_tok, dtype=torch.int32, device=self.device)
@@ -149,11 +152,11 @@ class QueryEncoder:
             side = torch.cuda.Stream(self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):                    # warm-up outside the capture (library handles, workspaces)
-                self._forward(s_ids, s_off, len(seqs), n_tok, normalize, s_out)
+                self._forward(s_ids, s_off, len(seqs), n_tok, normalize, s_out, max_len)
             torch.cuda.current_stream(self.device).wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                self._forward(s_ids, s_off, len(seqs), n_tok, normalize, s_out)
+                self._forward(s_ids, s_off, len(seqs), n_tok, normalize, s_out, max_len)
             if len(self._graphs) >= 64:
                 self._graphs.pop(next(iter(self._graphs)))
             ent = self._graphs[key] = (graph, s_ids, s_off, s_out)
@@ -163,10 +166,10 @@ class QueryEncoder:
         return s_out.clone()
 
     def _linear(self, x, weight, y, resid=None):
-        """y = x . weight^T (+ resid).  Up to LINEAR_HIP_MAX_TOKENS tokens -- a query, a handful of queries --
-        msr_enc_linear: the HIP skinny product (weights streamed once, exact-f32 MFMA, K split over the waves).  Larger
-        batches are an ordinary GEMM whose operands want big shared tiles: the library (hipBLASLt through torch) is
-        1.4x faster there (profiles/r02_encoder_bench.json), so it keeps that case."""
+        """y = x . weight^T (+ resid): msr_enc_linear, the HIP product on the exact-f32 matrix cores (K split over the waves of
+        a workgroup; single queries: weights streamed once; batches: 64 x 48 tiles, one workgroup per CU -- on a par with the
+        library GEMM at 1024 tokens, profiles/r03_enc_linear_shapes.md).  The library path (hipBLASLt through torch) only
+        remains as the comparison the tools run (LINEAR_HIP_MAX_TOKENS lowered by tools/encoder_bench.py)."""
         n_out, n_in = weight.shape
         if x.shape[0] > LINEAR_HIP_MAX_TOKENS:
             if resid is None:
@@ -180,7 +183,7 @@ class QueryEncoder:
                                             int(n_in), self._stream()))
         return y
 
-    def _forward(self, ids, seq_off, n_seq, n_tok, normalize, out):
+    def _forward(self, ids, seq_off, n_seq, n_tok, normalize, out, max_len=MAX_SEQ):
         w, st = self.w, self._stream
         h = self._ln(None, w["embeddings.norm.weight"], ids=ids)                      # lookup + LayerNorm
         new = lambda cols: torch.empty((n_tok, cols), dtype=torch.float32, device=self.device)
@@ -191,7 +194,7 @@ class QueryEncoder:
             x = h if l == 0 else self._ln(h, w[p + "attn_norm.weight"])               # layer 0 has no attn_norm
             self._linear(x, w[p + "attn.Wqkv.weight"], qkv)
             self._check(self.lib.msr_enc_attention(_ptr(qkv), _ptr(seq_off), n_seq, HEADS, _ptr(self.inv_freq[glob]),
-                                                   0 if glob else LOCAL_WINDOW // 2, _ptr(att), st()))
+                                                   0 if glob else LOCAL_WINDOW // 2, int(max_len), _ptr(att), st()))
             if l == 0:
                 h = self._linear(att, w[p + "attn.Wo.weight"], new(HIDDEN), resid=h)  # (x is h in layer 0: keep it intact)
             else:

@@ -1092,6 +1092,28 @@ def test_index_build_kernels_on_the_reference_fixture(mods):
         assert set(vocab) == set(case["term_updates"]) and ix.total_docs == len(case["doc_stats"])
 
 
+def test_build_postings_rejects_out_of_range_token_ids(mods):
+    """the C entry point itself (not only its Python wrapper) refuses a token id outside [0, n_terms) -- the radix
+    pass count and the doc_freq scatter index with it."""
+    import ctypes as C
+
+    from msretr import _abi
+    lib = _abi.load()
+    dev = torch.device("cuda", 0)
+    off = torch.tensor([0, 3, 5], dtype=torch.int64, device=dev)
+    term_off = torch.zeros(5, dtype=torch.int64, device=dev)
+    n_post = C.c_int64(-1)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    for bad in ([0, 1, 4, 2, 3], [0, -1, 1, 2, 3]):
+        tok = torch.tensor(bad, dtype=torch.int32, device=dev)
+        rc = lib.msr_build_postings(ptr(off), ptr(tok), 2, 4, ptr(term_off), C.c_void_p(0), C.c_void_p(0), 0, C.byref(n_post), stream)
+        assert rc == -1 and b"token id outside" in lib.msr_last_error(None)
+    tok = torch.tensor([0, 1, 3, 2, 3], dtype=torch.int32, device=dev)
+    rc = lib.msr_build_postings(ptr(off), ptr(tok), 2, 4, ptr(term_off), C.c_void_p(0), C.c_void_p(0), 0, C.byref(n_post), stream)
+    assert rc == 0 and n_post.value == 5
+
+
 def test_index_build_kernels_equal_the_reference_tables(mods):
     """msr_build_postings (per-document sort + run lengths, stable radix sort by term, boundary doc_freq --
     csrc/msr_build.hip) against the oracle's builder (oracle/build_ref.py, pinned to the output of the reference's own

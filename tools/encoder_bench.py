@@ -20,7 +20,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--queries", type=int, default=128)
 ap.add_argument("--tokens", type=int, default=8)
 ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--hip-linear-max", type=int, default=-1,
+                help="tokens up to which the projections run on msr_enc_linear; beyond: the library GEMM, for comparison "
+                     "(default: msr_enc_linear always)")
+ap.add_argument("--no-hf", action="store_true", help="skip the transformers comparison (profiling runs)")
 a = ap.parse_args()
+import msretr.encoder as _enc_mod  # noqa: E402
+if a.hip_linear_max >= 0:
+    _enc_mod.LINEAR_HIP_MAX_TOKENS = a.hip_linear_max
 from transformers import ModernBertConfig, ModernBertModel  # noqa: E402
 torch.manual_seed(0)
 hf = ModernBertModel(ModernBertConfig(reference_compile=False, attn_implementation="eager")).eval().cuda()
@@ -46,7 +53,7 @@ for nq in (1, a.queries):
         finally:
             enc.use_graphs = True
 
-    for name, fn in (("msretr_hipgraph", ours), ("msretr_launches", ours_eager), ("transformers_eager", theirs)):
+    for name, fn in (("msretr_hipgraph", ours), ("msretr_launches", ours_eager)) + (() if a.no_hf else (("transformers_eager", theirs),)):
         for _ in range(3):
             out = fn()
         torch.cuda.synchronize()
@@ -55,5 +62,6 @@ for nq in (1, a.queries):
             out = fn()
         torch.cuda.synchronize()
         res[f"{name}_ms_per_batch_of_{nq}"] = round(1e3 * (time.perf_counter() - t0) / a.iters, 3)
-    res[f"max_abs_diff_batch_of_{nq}"] = float((ours() - theirs()).abs().max())
+    if not a.no_hf:
+        res[f"max_abs_diff_batch_of_{nq}"] = float((ours() - theirs()).abs().max())
 print(json.dumps(res))
