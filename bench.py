@@ -294,6 +294,12 @@ def main():
                     help="OpenMP threads of the CPU baseline (a 1-GPU box is entitled to 16 host cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra timed loop with the bf16 candidate sweep")
+    ap.add_argument("--emulate-ranks", type=int, default=0,
+                    help="ONE GPU does the per-rank GPU work of an N-GPU step (run with 1/N of --docs/--chunks and N times the "
+                         "queries): local stages, the merges of N gathered lists, the rerank gather of the 1/N of the candidates "
+                         "a rank owns, the join of N halves and the fuse of 1/N of the queries; no collective is executed")
+    ap.add_argument("--with-encoder", action="store_true",
+                    help="time the variant that starts from token ids (QueryEncoder -> hybrid step) even with --no-variants")
     ap.add_argument("--latency-queries", type=int, default=20)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--same-device", action="store_true",
@@ -364,6 +370,36 @@ def main():
             m = eng.merge_topk(*[torch.stack([p[j] for p in parts]) for j in range(3)], args.k2)
             d = (m[0], m[1], None, m[2])
         return {"dense": d}
+
+    if args.emulate_ranks > 1:
+        assert world == 1 and args.workload == "hybrid", "--emulate-ranks is a single-process stand-in for the hybrid step"
+        from msretr.distributed import _RerankExchange
+        NE = args.emulate_ranks
+        rx = _RerankExchange(NE, Q, args.k1, args.k2, dev)
+        slot = torch.arange(args.k1, device=dev).unsqueeze(0)
+
+        def step(i, one=None):                          # noqa: F811  (replaces the step above)
+            packed, qv = one if one is not None else batches[i % len(batches)]
+            b = eng.bm25_topk(None, k=args.k1, packed=packed)
+            d = eng.dense_topk(qv, k=args.k2)
+            nq = int(qv.shape[0])
+            # the two merges of NE gathered lists (stand-in operands: NE copies of the local lists)
+            rep = lambda t: t.unsqueeze(0).expand(NE, *t.shape).contiguous()
+            eng.merge_topk(rep(b[0]), rep(b[1]), rep(b[2]), args.k1)
+            eng.merge_topk(rep(d[0]), rep(d[1]), rep(d[3]), args.k2)
+            if nq != Q:                                  # (the single-query latency loop: local stages only)
+                return {"bm25": b, "dense": d}
+            cand = torch.where(slot % NE == 0, b[0], torch.full_like(b[0], -1))   # a rank owns 1 / NE of the merged candidates
+            for o in range(NE):
+                lo, hi = min(Q, o * rx.Qs), min(Q, (o + 1) * rx.Qs)
+                if hi > lo:
+                    cv, mv = rx.send_views(o)
+                    eng.rerank_gather(qv[lo:hi], cand[lo:hi], b[2][lo:hi], out=(cv[:hi - lo], mv[:hi - lo]))
+            rx.a2a_recv.copy_(rx.a2a_send)               # (where the all-to-all would be)
+            cp, mp = rx.recv_parts()
+            cos, meta = eng.rerank_combine(cp, mp, rx.Qs)
+            r = eng.rerank_fuse(b[0][:rx.Qs], b[1][:rx.Qs], b[2][:rx.Qs], cos, meta)
+            return {"bm25": b, "dense": d, "rerank": r}
 
     def fence():
         if world > 1:
@@ -502,6 +538,46 @@ def main():
         except Exception as ex:
             exact = {"error": repr(ex)}
 
+    # The whole query path of search_api.py:69-152 in one number: token ids -> query encoder (ModernBERT-base forward + mean
+    # pooling, reranker_api.py:137-139,355; random weights, 8 tokens per query) -> the hybrid step above with the vectors it
+    # produced.  Reported NEXT TO the headline (the headline's queries arrive as vectors, as BASELINE.json's metric has them).
+    with_enc = None
+    if args.workload == "hybrid" and args.dense_mode == "f32" and (args.with_encoder or not args.no_variants):
+        try:
+            from msretr.encoder import QueryEncoder, random_weights
+            enc = QueryEncoder(random_weights(seed=5), device=local_rank)
+            rng = np.random.default_rng(4242)
+            toks = [[rng.integers(0, 50000, size=8).tolist() for _ in range(Q)] for _ in range(len(batches))]
+
+            def estep(i):
+                qv = enc.encode(toks[i % len(batches)]) * 9.0       # (the served model's vectors are not unit length either)
+                return se.search(None, qv, k1=args.k1, k2=args.k2, packed=batches[i % len(batches)][0])
+            for i in range(2):
+                estep(i)
+            fence()
+            te = time.perf_counter()
+            for i in range(args.steps):
+                eout = estep(args.warmup + i)
+            fence()
+            e_el = time.perf_counter() - te
+            tq = time.perf_counter()
+            for i in range(args.steps):
+                enc.encode(toks[i % len(batches)])
+            torch.cuda.synchronize()
+            enc_ms = 1e3 * (time.perf_counter() - tq) / args.steps
+            if world > 1:
+                t = torch.tensor([e_el], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                e_el = float(t.item())
+            with_enc = {"path": "token ids -> QueryEncoder (ModernBERT-base, 22 layers, random weights, 8 tokens per query, all HIP) -> "
+                                "BM25 top-%d + dense full scan + rerank/fuse" % args.k1,
+                        "value": Q * args.steps / e_el, "unit": "queries/sec", "ms_per_step": 1e3 * e_el / args.steps,
+                        "encoder_ms_per_batch": enc_ms, "queries_per_step": Q,
+                        "outputs_sane": bool((eout["dense"][3] == args.k2).all().item())}
+            del enc
+        except Exception as ex:
+            with_enc = {"error": repr(ex)}
+
     # sanity of the last step's outputs (cheap, outside the timed region)
     ok = True
     if "dense" in out:
@@ -575,10 +651,22 @@ def main():
             tq = batches[0][0][1].long()
             tq = tq[(tq >= 0) & (tq < shard.n_terms)]
             toff = shard.term_off.to(tq.device)
-            bm_bytes = 8 * int((toff[tq + 1] - toff[tq]).sum().item()) + (Q + 3) // 4 * 4 * shard.n_docs   # doc_len: once per 4 queries
+            df_q = (toff[tq + 1] - toff[tq])
+            bm_bytes = 8 * int(df_q.sum().item()) + (Q + 3) // 4 * 4 * shard.n_docs   # doc_len: once per 4 queries
             bm_gbs = bm_bytes / (roof["bm25_taat_ms_per_launch"] * 1e-3) / 1e9 if bm_n else 0.0
+            # what the kernel really moves: the long lists with negative idf are looked up, not streamed (msr_bm25.hip); 12 B per
+            # streamed posting + 8 B per table lookup (one per streamed posting and looked-up term, an upper bound)
+            idf_q = shard.idf.to(tq.device)[tq]
+            pruned = (idf_q < 0) & (df_q >= 2048)
+            streamed = int(df_q[~pruned].sum().item())
             roof["bm25_taat"] = {"achieved": bm_gbs, "unit": "GB/s", "frac": bm_gbs / HBM_PEAK_GBS,
-                                 "algorithmic_bytes_per_launch": bm_bytes, "launches": bm_n}
+                                 "algorithmic_bytes_per_launch": bm_bytes, "launches": bm_n,
+                                 "note": "SURVEY 8d byte model of a term-at-a-time pass over EVERY posting of the query's terms; the kernel "
+                                         "streams only the lists that can raise a score and looks the negative-idf lists up per touched "
+                                         "document, so this is an effective rate, not bytes moved",
+                                 "streamed_postings_per_launch": streamed, "postings_named_per_launch": int(df_q.sum().item()),
+                                 "bytes_moved_per_launch_upper_bound": 32 * streamed,      # posting 12 + lookup 8 + candidate 12
+                                 "moved_GBps": (32 * streamed) / (roof["bm25_taat_ms_per_launch"] * 1e-3) / 1e9 if bm_n else 0.0}
         dense_dt = {"f32": "f32", "f16x2": "f32 (exact f32 cosines of every returned document; candidates filtered by one pass of f16 products with a measured margin; batches <= 64 queries: f16x2-split products, |err| <= 8e-6)",
                     "none": "-"}[eng.scan_arith()]
         names = {"hybrid": "two-stage retrieval top-100 (BM25 top-1000 + dense full scan + rerank/fuse)" +
@@ -600,12 +688,17 @@ def main():
                        "scan_layout": args.scan_layout, "scan_variant": args.scan_variant},
             "p50_latency_ms_single_query": p50_ms, "outputs_sane": ok, "roofline": roof,
         }
+        if args.emulate_ranks > 1:
+            line["emulated_ranks"] = args.emulate_ranks
+            line["metric"] += f" [per-rank GPU work of a {args.emulate_ranks}-GPU step on ONE GPU: no collectives executed]"
         if verified is not None:
             line["sharded_equals_unsharded"] = verified
         if variant is not None:
             line["variant_bf16_candidates"] = variant
         if exact is not None:
             line["roofline_exact_f32"] = exact
+        if with_enc is not None:
+            line["variant_with_encoder"] = with_enc
         if world == 1 and not args.no_cpu_baseline and args.workload == "hybrid":
             try:
                 cb, cres, cdense = cpu_baseline(args, shard, terms, qvec, dev)

@@ -47,6 +47,8 @@ def test_default_line_has_the_contract_fields():
     assert p["queries"] == 2 and p["k"] == 100 and p["within_1e-5"] is True and p["max_abs_score_diff"] <= 1e-5
     assert p["top_k_doc_sets_equal_up_to_boundary_near_ties"] is True and p["same_doc_at_same_rank"] > 0.95
     assert abs(d["vs_cpu_baseline"] - d["value"] / c["value"]) <= 1e-9 * d["vs_cpu_baseline"]
+    e = d["variant_with_encoder"]                             # query path from token ids (search_api.py:69-152 in one number)
+    assert e["value"] > 0 and e["encoder_ms_per_batch"] > 0 and e["outputs_sane"] is True and e["queries_per_step"] == 256
     v = d["variant_bf16_candidates"]
     assert v["value"] > 0 and v["top100_equals_default_path_within_2e-6"] is True
 

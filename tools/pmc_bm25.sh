@@ -11,7 +11,7 @@ for s in "ABC":
     for f in glob.glob("$R/gpurun_out/pmc%s_$TAG/*/*counter_collection.csv" % s):
         agg=collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "bm25_taat" in r["Kernel_Name"] and int(r["Grid_Size_X"]) >= 8192:
+            if "bm25_taat" in r["Kernel_Name"] and int(r["Grid_Size"]) >= 8192 * 64:
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k,v in sorted(agg.items()): print(s, k, "%.4g" % (sum(v)/len(v)), len(v))
 PY
