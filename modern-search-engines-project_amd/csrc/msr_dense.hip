@@ -427,7 +427,7 @@ __global__ __launch_bounds__(64) void best_chunk_kernel(DenseIndex ix, const flo
                                                          const int32_t* __restrict__ out_n,
                                                          int32_t* __restrict__ out_chunk) {
     const int q = blockIdx.y, r = blockIdx.x, lane = threadIdx.x;
-    if (ix.gate && *ix.gate == 0) return;
+    if (ix.gate && ix.gate[ix.gate_per64 ? q >> 6 : 0] == 0) return;
     if (r >= out_n[q]) {
         if (lane == 0) out_chunk[(int64_t)q * k + r] = -1;
         return;

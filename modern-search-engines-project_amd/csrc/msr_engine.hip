@@ -540,7 +540,7 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
         auto alloc = [&](void** p, size_t bytes) { return hipMalloc(p, bytes); };
         if ((herr = alloc((void**)&e->gf_inv_pad, (size_t)(n_chunks + 512) * 4)) != hipSuccess ||
             (herr = alloc(&e->gf_qimg, (size_t)groups * 24 * 8192)) != hipSuccess ||
-            (herr = alloc((void**)&e->gf_qn, QM * MSR_DIM * 4)) != hipSuccess ||
+            (herr = alloc((void**)&e->gf_qn, (QM + 64) * MSR_DIM * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gf_tmax_t, (size_t)n_tiles * 8 * (groups >= 2 ? 256 : 128) * 4)) != hipSuccess ||   // [tile][wave][queries of a pass]
             (herr = alloc((void**)&e->gf_tmax, QM * stride * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gf_thr, QM * 4)) != hipSuccess ||
@@ -719,7 +719,8 @@ extern "C" int msr_dense_topk(msr_engine* e, const float* q, int32_t n_queries, 
         const int left = n_queries - q0;
         if (gemm && left > 64) {
             const int nq = std::min(128 * e->gf.max_groups, left);
-            HIP_TRY(e, msr_prep_queries(q + (int64_t)q0 * MSR_DIM, nq, e->gf_qn, nq, st));
+            // (normalised once for the pass AND for the gated sweeps behind it: zero rows up to the last slice's 64)
+            HIP_TRY(e, msr_prep_queries(q + (int64_t)q0 * MSR_DIM, nq, e->gf_qn, (nq + 63) / 64 * 64, st));
             HIP_TRY(e, hipMemsetAsync(e->gf_gate, 0, 16 * 4, st));
             hipEvent_t ev[4];
             const bool timed = e->timing && e->ev_count[0] < msr_engine::EV_RING && e->ev_count[3] < msr_engine::EV_RING;
@@ -733,10 +734,26 @@ extern "C" int msr_dense_topk(msr_engine* e, const float* q, int32_t n_queries, 
                                          out_n + q0, e->gf_gate, timed ? ev : nullptr, &width, st));
             e->last_dense_width = std::max(e->last_dense_width, width);
             if (timed) { e->ev_count[0]++; e->ev_count[3]++; }
-            // A query whose entries overflowed (huge tie groups) raised the gate: the same batch once more on the sweeps,
-            // which handle any input; when the gate is down (the normal case) these launches return at once.
-            int rc = sweeps(q0, nq, e->gf_gate);
-            if (rc) return rc;
+            // A query whose entries overflowed (huge tie groups, a zero vector) raised the gate word of its 64-query slice: that
+            // slice once more on the sweeps, which handle any input.  One scan per slice, gated on its word, into its own score
+            // rows; then ONE select and ONE best-chunk pass over all rows of the call, in which a query takes part only if its
+            // slice's word is up.  When no gate is up (the normal case) all these launches return at once.
+            {
+                DenseIndex ix = e->dense;
+                for (int s0 = 0; s0 < nq; s0 += 64) {
+                    ix.gate = e->gf_gate + s0 / 64;
+                    HIP_TRY(e, msr_dense_scan(ix, e->gf_qn + (int64_t)s0 * MSR_DIM, std::min(64, nq - s0), 0,
+                                              (float*)e->score_rows + (int64_t)s0 * e->dense.score_stride, st));
+                }
+                SelScratch sel = e->sel;
+                sel.gate = e->gf_gate; sel.gate_per64 = 1;
+                HIP_TRY(e, msr_select_topk(32, e->score_rows, N, e->dense.score_stride, nq, k, sel, out_doc + (int64_t)q0 * k,
+                                           out_score + (int64_t)q0 * k, out_n + q0, st));
+                ix.gate = e->gf_gate; ix.gate_per64 = 1;
+                if (out_chunk)
+                    HIP_TRY(e, msr_best_chunk(ix, e->gf_qn, nq, k, 0, out_doc + (int64_t)q0 * k, out_n + q0,
+                                              out_chunk + (int64_t)q0 * k, st));
+            }
             q0 += nq;
         } else {
             const int nq = std::min(wide ? 64 : 32, left);

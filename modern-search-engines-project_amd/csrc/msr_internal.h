@@ -23,8 +23,10 @@ struct SelScratch {
     uint64_t* cand_hi;   // [nq][MSR_SEL_CAP]
     uint32_t* cand_lo;   // [nq][MSR_SEL_CAP]
     int32_t* cand_n;     // [nq], all zero between calls
-    const int32_t* gate; // optional device word: when non-null and *gate == 0 every kernel of the select returns at once
+    const int32_t* gate; // optional device word(s): when non-null and the word is 0 every kernel of the select returns at once
                          // (fallback launches that are only needed when an earlier kernel raised the flag)
+    int gate_per64;      // 0: gate[0] decides for all queries; 1: gate[q / 64] decides for query q (one select over several
+                         // 64-query slices of which only some need the fallback)
 };
 
 // Select the top-k of scores[q][0..n) (row stride `stride` elements) for q in [0, nq).
@@ -138,6 +140,7 @@ struct DenseIndex {
                                // the row norms and wide_ok allow it; 13 = the same for 17..64 queries only), 7 = wave
                                // streaming with f16-split products, 2 = wave streaming, exact f32 MFMA (default otherwise),
                                // 1 = super-tile kernel of the first profile, others: A/B variants (msr_dense.hip)
+    int32_t gate_per64;        // best-chunk kernel only: 1 = gate[q / 64] decides for query q (0: gate[0] for all)
 };
 // qn: [ceil16(nq)][768] normalised queries (zero rows as padding).
 // docscore[q][ix.score_stride] <- max cosine over the document's chunks (-inf for chunk-less documents).

@@ -144,10 +144,11 @@ template <typename T>
 __global__ __launch_bounds__(SEL_THREADS) void sel_hist_kernel(const T* __restrict__ scores, int64_t n_dense,
                                                                 int64_t stride, RowView view, int digit,
                                                                 const SelState* __restrict__ st,
-                                                                uint32_t* __restrict__ hist, const int32_t* __restrict__ gate) {
+                                                                uint32_t* __restrict__ hist, const int32_t* __restrict__ gate,
+                                                                int gate_per64) {
     constexpr int SB = ScoreTraits<T>::SB;
-    if (gate && *gate == 0) return;                              // a fallback launch that is not needed
     const int q = blockIdx.y;
+    if (gate && gate[gate_per64 ? q >> 6 : 0] == 0) return;      // a fallback launch that is not needed (for this query's slice)
     SelState S;
     S.pref_hi = S.mask_hi = 0; S.pref_lo = S.mask_lo = 0; S.done = 0;
     if (digit > 0) {
@@ -197,8 +198,8 @@ __global__ __launch_bounds__(SEL_THREADS) void sel_hist_kernel(const T* __restri
 template <int SB>
 __global__ __launch_bounds__(SCAN_THREADS) void sel_scan_kernel(SelState* __restrict__ st,
                                                                  uint32_t* __restrict__ hist, int digit, int k,
-                                                                 const int32_t* __restrict__ gate) {
-    if (gate && *gate == 0) return;
+                                                                 const int32_t* __restrict__ gate, int gate_per64) {
+    if (gate && gate[gate_per64 ? (int)blockIdx.x >> 6 : 0] == 0) return;
     __shared__ uint32_t h[MSR_SEL_BINS];
     __shared__ uint32_t suf[SCAN_THREADS + 1];
     __shared__ SelState S_sh;
@@ -236,8 +237,8 @@ __global__ __launch_bounds__(SEL_THREADS) void sel_compact_kernel(const T* __res
                                                                    uint64_t* __restrict__ cand_hi,
                                                                    uint32_t* __restrict__ cand_lo,
                                                                    int32_t* __restrict__ cand_n,
-                                                                   const int32_t* __restrict__ gate) {
-    if (gate && *gate == 0) return;
+                                                                   const int32_t* __restrict__ gate, int gate_per64) {
+    if (gate && gate[gate_per64 ? (int)blockIdx.y >> 6 : 0] == 0) return;
     constexpr int STAGE = 1024;                                  // staged matches per workgroup (12 KB of LDS)
     __shared__ uint64_t s_hi[STAGE];
     __shared__ uint32_t s_lo[STAGE];
@@ -338,9 +339,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void sel_final_kernel(const T* __rest
                                                                   int32_t* __restrict__ out_doc,
                                                                   T* __restrict__ out_score,
                                                                   int32_t* __restrict__ out_n,
-                                                                  const int32_t* __restrict__ gate) {
+                                                                  const int32_t* __restrict__ gate, int gate_per64) {
     constexpr int SB = ScoreTraits<T>::SB;
-    if (gate && *gate == 0) return;
+    if (gate && gate[gate_per64 ? (int)blockIdx.x >> 6 : 0] == 0) return;
     __shared__ uint64_t khi[MSR_SEL_CAP];
     __shared__ uint32_t klo[MSR_SEL_CAP];
     __shared__ uint32_t suf[SCAN_THREADS + 1];
@@ -434,13 +435,13 @@ hipError_t select_impl(const T* scores, int64_t n, int64_t stride, RowView view,
     dim3 grid((unsigned)parts, (unsigned)nq);
     // two streaming histogram passes (24 key bits), one compaction, one exact sort: 6 launches
     for (int d = 0; d < 2; ++d) {
-        sel_hist_kernel<T><<<grid, SEL_THREADS, 0, stream>>>(scores, n, stride, view, d, sc.state, sc.hist, sc.gate);
-        sel_scan_kernel<SB><<<nq, SCAN_THREADS, 0, stream>>>(sc.state, sc.hist, d, k, sc.gate);
+        sel_hist_kernel<T><<<grid, SEL_THREADS, 0, stream>>>(scores, n, stride, view, d, sc.state, sc.hist, sc.gate, sc.gate_per64);
+        sel_scan_kernel<SB><<<nq, SCAN_THREADS, 0, stream>>>(sc.state, sc.hist, d, k, sc.gate, sc.gate_per64);
     }
     sel_compact_kernel<T><<<grid, SEL_THREADS, 0, stream>>>(scores, n, stride, view, sc.state, sc.cand_hi, sc.cand_lo,
-                                                             sc.cand_n, sc.gate);
+                                                             sc.cand_n, sc.gate, sc.gate_per64);
     sel_final_kernel<T><<<nq, SCAN_THREADS, 0, stream>>>(scores, n, stride, view, sc.state, sc.cand_hi, sc.cand_lo,
-                                                          sc.cand_n, k, out_doc, out_score, out_n, sc.gate);
+                                                          sc.cand_n, k, out_doc, out_score, out_n, sc.gate, sc.gate_per64);
     return hipGetLastError();
 }
 
