@@ -673,7 +673,8 @@ hipError_t msr_gemm_candidates(const GemmIndex& g, const DenseIndex& ix, const f
     const int grid = g.n_cus / 8 * 8;
     if (grid < 8 || grid / 8 < nt) return hipErrorInvalidValue;
     hipError_t err;
-    qmat_kernel<<<(nq_pad * (MSR_DIM / 8) + 255) / 256, 256, 0, stream>>>(qn, nq, nq_pad, (bf16x8*)g.qmat);
+    qmat_kernel<<<(nq_pad * (MSR_DIM / 8) + 255) / 256, 256, 0, stream>>>(qn, nq, nq_pad, (bf16x8*)g.qmat);     // (old kernel's operand; the
+    // streaming pass overwrites it with its own image of the same size)
     // ---- pass 1: every ss-th tile, tile maxima only ----
     int ss = g.n_tiles / (8 * k);
     ss = ss < 1 ? 1 : (ss > 16 ? 16 : ss);
@@ -681,23 +682,50 @@ hipError_t msr_gemm_candidates(const GemmIndex& g, const DenseIndex& ix, const f
     if (g_gemm_dbg & 256) ss = 1;                      // timing experiments: the sample pass covers every tile
 #endif
     const int n_s = (g.n_tiles - ss / 2 + ss - 1) / ss;                   // tiles ss/2, ss/2 + ss, ...
-    GemmArgs a{};
-    a.A = (const char*)g.emb_n; a.B = (const char*)g.qmat; a.tile_row = g.tile_row; a.nt = nt;
-    a.tmax_t = g.tmax_t; a.nq_pad = nq_pad;
-    a.t_first = ss / 2; a.t_stride = ss; a.t_count = n_s;
-    if (ev && (err = hipEventRecord(ev[0], stream)) != hipSuccess) return err;
-    if ((err = launch_gemm(false, a, grid, stream)) != hipSuccess) return err;
-    if (ev && (err = hipEventRecord(ev[1], stream)) != hipSuccess) return err;
-    gemm_tmax_kernel<<<dim3((n_s + 31) / 32, nq_pad / 32), 256, 0, stream>>>(g.tmax_t, n_s, 2, nq_pad, (float*)g.tmax, g.tmax_stride);
-    gemm_kth_kernel<<<nq_pad, 1024, 0, stream>>>((const float*)g.tmax, n_s, g.tmax_stride, nq, k, margin, g.thr, g.flag);
-    // ---- pass 2: all tiles; maxima of all tiles + emission against the sample threshold ----
-    a.t_first = 0; a.t_stride = 1; a.t_count = g.n_tiles;
-    a.thr = g.thr; a.wgbuf = (int4*)g.wgbuf; a.wv_cap = g.wv_cap; a.wv_count = g.wv_count;
-    if (ev && (err = hipEventRecord(ev[2], stream)) != hipSuccess) return err;
-    if ((err = launch_gemm(true, a, grid, stream)) != hipSuccess) return err;
-    if (ev && (err = hipEventRecord(ev[3], stream)) != hipSuccess) return err;
-    gemm_tmax_kernel<<<dim3((g.n_tiles + 31) / 32, nq_pad / 32), 256, 0, stream>>>(g.tmax_t, g.n_tiles, 2, nq_pad, (float*)g.tmax, g.tmax_stride);
-    gemm_kth_kernel<<<nq_pad, 1024, 0, stream>>>((const float*)g.tmax, g.n_tiles, g.tmax_stride, nq, k, margin, g.thr2, nullptr);
+#ifdef MSR_DIAG
+    const bool old_gemm = (g_gemm_dbg & 512) != 0;      // timing experiments: the 256 x 256 LDS-tiled kernel of round 2
+#else
+    constexpr bool old_gemm = false;
+#endif
+    if (old_gemm) {
+        GemmArgs a{};
+        a.A = (const char*)g.emb_n; a.B = (const char*)g.qmat; a.tile_row = g.tile_row; a.nt = nt;
+        a.tmax_t = g.tmax_t; a.nq_pad = nq_pad;
+        a.t_first = ss / 2; a.t_stride = ss; a.t_count = n_s;
+        if (ev && (err = hipEventRecord(ev[0], stream)) != hipSuccess) return err;
+        if ((err = launch_gemm(false, a, grid, stream)) != hipSuccess) return err;
+        if (ev && (err = hipEventRecord(ev[1], stream)) != hipSuccess) return err;
+        gemm_tmax_kernel<<<dim3((n_s + 31) / 32, nq_pad / 32), 256, 0, stream>>>(g.tmax_t, n_s, 2, nq_pad, (float*)g.tmax, g.tmax_stride);
+        gemm_kth_kernel<<<nq_pad, 1024, 0, stream>>>((const float*)g.tmax, n_s, g.tmax_stride, nq, k, margin, g.thr, g.flag);
+        a.t_first = 0; a.t_stride = 1; a.t_count = g.n_tiles;
+        a.thr = g.thr; a.wgbuf = (int4*)g.wgbuf; a.wv_cap = g.wv_cap; a.wv_count = g.wv_count;
+        if (ev && (err = hipEventRecord(ev[2], stream)) != hipSuccess) return err;
+        if ((err = launch_gemm(true, a, grid, stream)) != hipSuccess) return err;
+        if (ev && (err = hipEventRecord(ev[3], stream)) != hipSuccess) return err;
+        gemm_tmax_kernel<<<dim3((g.n_tiles + 31) / 32, nq_pad / 32), 256, 0, stream>>>(g.tmax_t, g.n_tiles, 2, nq_pad, (float*)g.tmax, g.tmax_stride);
+        gemm_kth_kernel<<<nq_pad, 1024, 0, stream>>>((const float*)g.tmax, g.n_tiles, g.tmax_stride, nq, k, margin, g.thr2, nullptr);
+    } else {
+        // The pass: the 256-query streaming kernel of msr_gemm_f32.hip over the bf16 unit-row image, nt groups of 256
+        // queries in ONE launch (rows through a register ring -- no LDS, no barrier for them --, the group's query image
+        // through LDS; the nt workgroups that walk the same tiles share an XCD's L2).
+        if ((err = msr_stream256_bf16_qimage(qn, nq, nt, g.qmat, stream)) != hipSuccess) return err;
+        StreamArgs a{};
+        a.E = (const char*)g.emb_n; a.inv_pad = nullptr; a.qimg = (const char*)g.qmat; a.tile_row = g.tile_row;
+        a.n_rows = ix.n_chunks; a.tmax_t = g.tmax_t; a.nt = nt; a.q_base = 0; a.append = 0;
+        a.t_first = ss / 2; a.t_stride = ss; a.t_count = n_s;
+        if (ev && (err = hipEventRecord(ev[0], stream)) != hipSuccess) return err;
+        if ((err = msr_stream256_bf16_launch(false, a, grid, stream)) != hipSuccess) return err;
+        if (ev && (err = hipEventRecord(ev[1], stream)) != hipSuccess) return err;
+        gemm_tmax_kernel<<<dim3((n_s + 31) / 32, nq_pad / 32), 256, 0, stream>>>(g.tmax_t, n_s, 8, nq_pad, (float*)g.tmax, g.tmax_stride);
+        gemm_kth_kernel<<<nq_pad, 1024, 0, stream>>>((const float*)g.tmax, n_s, g.tmax_stride, nq, k, margin, g.thr, g.flag);
+        a.t_first = 0; a.t_stride = 1; a.t_count = g.n_tiles;
+        a.thr = g.thr; a.wvbuf = g.wgbuf; a.wv_cap = g.wv_cap; a.wv_count = g.wv_count;
+        if (ev && (err = hipEventRecord(ev[2], stream)) != hipSuccess) return err;
+        if ((err = msr_stream256_bf16_launch(true, a, grid, stream)) != hipSuccess) return err;
+        if (ev && (err = hipEventRecord(ev[3], stream)) != hipSuccess) return err;
+        gemm_tmax_kernel<<<dim3((g.n_tiles + 31) / 32, nq_pad / 32), 256, 0, stream>>>(g.tmax_t, g.n_tiles, 8, nq_pad, (float*)g.tmax, g.tmax_stride);
+        gemm_kth_kernel<<<nq_pad, 1024, 0, stream>>>((const float*)g.tmax, g.n_tiles, g.tmax_stride, nq, k, margin, g.thr2, nullptr);
+    }
     // ---- finish: bucket, per-document maxima, candidates ----
     gemm_bucket_kernel<<<dim3(2, (unsigned)grid * 8), 256, 0, stream>>>((const int4*)g.wgbuf, g.wv_cap, g.wv_count, g.thr2,
                                                                        (int2*)g.pairs, GM_PAIR_CAP, g.pair_n);

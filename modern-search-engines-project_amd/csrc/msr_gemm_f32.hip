@@ -45,21 +45,7 @@ constexpr int GF_KT = MSR_DIM / 32;             // 24 K steps per tile
 constexpr int GF_ROWB = MSR_DIM * 4;            // bytes per f32 row
 constexpr int GF_PAIR_CAP = 4096;
 
-struct GemmF32Args {
-    const char* E;             // f32 [n_rows][768] (caller's matrix: NOT padded, the last tile clamps its row index)
-    const float* inv_pad;      // [n_rows + 512] inverse norms (engine-owned padded copy)
-    const char* qimg;          // [24 K steps][128 queries][64 B] f16, chunk-swizzled (build_qimg1_kernel)
-    const int32_t* tile_row;   // [n_tiles + 1]
-    int64_t n_rows;
-    int t_first, t_stride, t_count;
-    float* tmax_t;             // [t_count][8 waves][128]
-    const float* thr;          // [128] emit threshold (+inf: never)                                   -- emit pass only
-    int4* wvbuf; int wv_cap; int32_t* wv_count;   // per-wave emission buffers {row, query, score bits, tile}   -- emit pass only
-    int q_base;                // number of the group's first query within the call (the query field of an entry is global)
-    int append;                // emit pass: continue behind the entries earlier groups left in the wave buffers
-    int dbg;                   // -DMSR_DIAG builds only (timing experiments, wrong results): bit 2 no row loads, bit 3 no MFMA,
-                               // bit 4 no query fragment reads, bit 5 no epilogue arithmetic, bit 6 no inverse norms
-};
+typedef StreamArgs GemmF32Args;          // (msr_internal.h: shared with the bf16 candidate pass of msr_gemm.hip)
 
 // a 64-bit value the compiler can prove wave-uniform (scalar registers): lets the DMA use the saddr + 32-bit voffset form
 __device__ __forceinline__ const char* uniform_ptr(const char* p) {
@@ -91,7 +77,7 @@ __global__ __launch_bounds__(GF_THREADS) void gemm_stream_kernel(GemmF32Args a) 
     const int li16 = lane & 15, lg = lane >> 4;
     const int G = (int)gridDim.x, gid = (int)blockIdx.x;
     int wave_cnt = EMIT && a.append ? __builtin_amdgcn_readfirstlane(a.wv_count[blockIdx.x * 8 + w]) : 0;
-    int4* wvbuf = EMIT ? a.wvbuf + ((size_t)blockIdx.x * 8 + w) * a.wv_cap : nullptr;
+    int4* wvbuf = EMIT ? (int4*)a.wvbuf + ((size_t)blockIdx.x * 8 + w) * a.wv_cap : nullptr;
     if (gid >= a.t_count) {                             // workgroup-uniform
         if (EMIT && lane == 0) a.wv_count[blockIdx.x * 8 + w] = wave_cnt;
         return;
@@ -346,27 +332,61 @@ template <int OFF>
 __device__ __forceinline__ void gload16s(f32x4& r, uint32_t voff, uint64_t sbase) {
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(r) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
 }
+// A copy the compiler cannot see through: the fragment of a bf16 row IS the loaded register, and a plain copy would let the
+// register allocator rename the ring slots around the loop with moves of registers whose loads are still in flight (the
+// loads are asynchronous behind its back).  With an opaque copy a slot is dead from here to its reload, like after the f32
+// rows' conversion, and keeps its registers.
+__device__ __forceinline__ f16x8 take16(const f32x4& r) {
+    f32x4 o;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(o[0]) : "v"(r[0]));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(o[1]) : "v"(r[1]));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(o[2]) : "v"(r[2]));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(o[3]) : "v"(r[3]));
+    return __builtin_bit_cast(f16x8, o);
+}
 __device__ __forceinline__ uint64_t uniform_u64(uint64_t u) {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
     return ((uint64_t)hi << 32) | lo;
 }
 
-template <bool EMIT>
+// BF16 = true: the rows are a bf16 image of UNIT rows (1536 B each; msr_gemm.hip's candidate pass for 1024 queries per call):
+// the fragments come out of the row ring as they are (no conversion, no inverse norms), a K step of a row is 64 bytes (one
+// 16-byte load per fragment), and a.nt = 4 query groups of 256 share the rows: the workgroups are dealt so that the nt
+// workgroups with the same tile sequence have the same blockIdx % 8 (one XCD under round-robin dispatch: speed only) -- the
+// rows come from HBM once per call and from that XCD's L2 for the other groups.
+template <bool EMIT, bool BF16>
 __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ROWB = BF16 ? MSR_DIM * 2 : GF_ROWB;             // bytes per row
+    constexpr int RS = BF16 ? 64 : 128;                            // bytes of a row per K step
+    constexpr int NH = BF16 ? 1 : 2;                               // 16-byte loads per fragment and K step
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave w owns rows 32 w .. 32 w + 32 of the tile, ALL 256 queries
     const int li16 = lane & 15, lg = lane >> 4;
-    const int G = (int)gridDim.x, gid = (int)blockIdx.x;
+    // which tiles, which query group: a.nt groups of 256 queries share a tile sequence (nt == 1: every workgroup its own)
+    const int nt = BF16 ? a.nt : 1;                                // (the f32 passes run one group per launch)
+    int G = (int)gridDim.x, gid = (int)blockIdx.x, grp = 0;
+    bool active = true;
+    if (nt > 1) {
+        const int per_x = (int)gridDim.x >> 3, xcd = (int)blockIdx.x & 7, li = (int)blockIdx.x >> 3;
+        const int gpx = per_x / nt, mg = li / nt;
+        grp = li - mg * nt;
+        G = 8 * gpx;
+        gid = xcd * gpx + mg;
+        active = mg < gpx;
+    }
+    const int nq_pad = nt * 256;
     int wave_cnt = EMIT && a.append ? __builtin_amdgcn_readfirstlane(a.wv_count[blockIdx.x * 8 + w]) : 0;
-    int4* wvbuf = EMIT ? a.wvbuf + ((size_t)blockIdx.x * 8 + w) * a.wv_cap : nullptr;
-    if (gid >= a.t_count) {                             // workgroup-uniform
+    int4* wvbuf = EMIT ? (int4*)a.wvbuf + ((size_t)blockIdx.x * 8 + w) * a.wv_cap : nullptr;
+    if (!active || gid >= a.t_count) {                  // workgroup-uniform
         if (EMIT && lane == 0) a.wv_count[blockIdx.x * 8 + w] = wave_cnt;
         return;
     }
     const int n_mine = (a.t_count - gid + G - 1) / G;
+    const char* qimg = a.qimg + (size_t)grp * (GF_KT * G2_STEP);
+    const int q_base = a.q_base + grp * 256;
     float* thr_lds = (float*)(smem + 2 * G2_BLK);
-    if (EMIT && tid < 256) thr_lds[tid] = a.thr[tid];
+    if (EMIT && tid < 256) thr_lds[tid] = a.thr[grp * 256 + tid];
     // the wave's 32 inverse row norms of a tile go through LDS: one DMA in the tile's last block (all 64 lanes take part: 64
     // floats, the upper half belongs to the next wave's rows and is not used; inv_pad is padded by 512 entries)
     float* inv_lds = (float*)(smem + 2 * G2_BLK + 1024) + w * 64;
@@ -374,7 +394,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
     const uint32_t foffB = (uint32_t)(li16 * 64 + ((lg ^ (((li16 >> 3) & 1) << 1)) << 4));
     // one query block: 64 KB, linear; wave w moves 8 KB of it
     auto stage_b = [&](int blk, int pb) {
-        const char* base = uniform_ptr(a.qimg + (size_t)blk * G2_BLK + (size_t)w * 8192);
+        const char* base = uniform_ptr(qimg + (size_t)blk * G2_BLK + (size_t)w * 8192);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             __builtin_amdgcn_global_load_lds((glb_void*)(base + (uint32_t)(i * 1024 + lane * 16)),
@@ -390,11 +410,11 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
     // A tile's rows are addressed as (scalar base of the tile's first row) + (32-bit byte offset of the lane's row): fragment
     // mi = row 32 w + 16 mi + li16 of the tile, at its 32-byte piece lg of a K step; a row past the end of the matrix
     // re-reads the last row (masked in the epilogue).  A tile spans < 1 MB, so the offset fits 32 bits with room to spare.
-    auto tile_base = [&](int row0) { return uniform_u64((uint64_t)a.E + (uint64_t)row0 * GF_ROWB); };
+    auto tile_base = [&](int row0) { return uniform_u64((uint64_t)a.E + (uint64_t)row0 * ROWB); };
     auto row_off = [&](int row0, int mi) -> uint32_t {
         int64_t r = (int64_t)row0 + 32 * w + 16 * mi + li16;
         if (r > a.n_rows - 1) r = a.n_rows - 1;
-        return (uint32_t)((r - row0) * GF_ROWB + lg * 32);
+        return (uint32_t)((r - row0) * ROWB + lg * (RS / 4));
     };
     int jt = gid;
     int row0 = a.tile_row[tile_of(jt)], row_end = a.tile_row[tile_of(jt) + 1];
@@ -408,30 +428,32 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
     // The row ring is driven by hand (see gemm_stream_kernel): inline-asm loads, explicit s_waitcnt before every use; vmcnt
     // retires in order.  Issue order per wave: [8 DMAs of the next block] then per step [wait, convert, 4 row loads,
     // compute].  The rows of step s of a block were loaded during step s of the block BEFORE (ring depth = block length = 4):
-    // younger than them are the loads of three steps (12) and one block's 8 DMAs = 20, whatever s is.  (Epilogue stores and
-    // the inverse-norm DMA only add younger operations: waiting for fewer than are in flight is always safe.)
-    f32x4 ring[G2_NB][2][2];                             // [slot][fragment][16-byte half]
+    // younger than them are the loads of three steps (12; bf16 rows: 6) and one block's 8 DMAs = 20 (14), whatever s is.
+    // (Epilogue stores and the inverse-norm DMA only add younger operations: waiting for fewer than are in flight is always
+    // safe.)
+    f32x4 ring[G2_NB][2][NH];                            // [slot][fragment][16-byte piece]
     auto load_rows = [&](auto slot_c, uint64_t sb, const uint32_t* v, auto off_c) {
         constexpr int slot = decltype(slot_c)::value, off = decltype(off_c)::value;
         gload16s<off>(ring[slot][0][0], v[0], sb);
-        gload16s<off + 16>(ring[slot][0][1], v[0], sb);
+        if (NH == 2) gload16s<off + 16>(ring[slot][0][NH - 1], v[0], sb);
         gload16s<off>(ring[slot][1][0], v[1], sb);
-        gload16s<off + 16>(ring[slot][1][1], v[1], sb);
+        if (NH == 2) gload16s<off + 16>(ring[slot][1][NH - 1], v[1], sb);
     };
     auto pin_rows = [&](auto slot_c) {
         constexpr int slot = decltype(slot_c)::value;
-        pin4(ring[slot][0][0], ring[slot][0][1], ring[slot][1][0], ring[slot][1][1]);
+        if (NH == 2) pin4(ring[slot][0][0], ring[slot][0][NH - 1], ring[slot][1][0], ring[slot][1][NH - 1]);
+        else pin2(ring[slot][0][0], ring[slot][1][0]);
     };
     // ---- prologue: query block 0, rows of steps 0 .. 3 ----
     stage_b(0, 0);
 #pragma unroll
     for (int s = 0; s < G2_NB; ++s)
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) ring[s][mi][0] = ring[s][mi][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int mi = 0; mi < 2; ++mi) ring[s][mi][0] = ring[s][mi][NH - 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     load_rows(std::integral_constant<int, 0>{}, bp, vp, std::integral_constant<int, 0>{});
-    load_rows(std::integral_constant<int, 1>{}, bp, vp, std::integral_constant<int, 128>{});
-    load_rows(std::integral_constant<int, 2>{}, bp, vp, std::integral_constant<int, 256>{});
-    load_rows(std::integral_constant<int, 3>{}, bp, vp, std::integral_constant<int, 384>{});
+    load_rows(std::integral_constant<int, 1>{}, bp, vp, std::integral_constant<int, RS>{});
+    load_rows(std::integral_constant<int, 2>{}, bp, vp, std::integral_constant<int, 2 * RS>{});
+    load_rows(std::integral_constant<int, 3>{}, bp, vp, std::integral_constant<int, 3 * RS>{});
     wait_vm0();
     pin_rows(std::integral_constant<int, 0>{}); pin_rows(std::integral_constant<int, 1>{});
     pin_rows(std::integral_constant<int, 2>{}); pin_rows(std::integral_constant<int, 3>{});
@@ -444,19 +466,21 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
         constexpr int s4 = decltype(s4_c)::value;
         using SL = std::integral_constant<int, s4>;
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        if (BF16) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
         pin_rows(SL{});
-        f16x8 af[2];
+        f16x8 af[2];                                     // (bf16 rows: the same 16 bytes, bf16 x 8)
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) af[mi] = cvt_f16_rtn(ring[s4][mi][0], ring[s4][mi][1]);
-        asm volatile("" :: "v"(af[0]), "v"(af[1]));      // (converted before the slot is reloaded)
-        if (s4 == 1 && last) {                           // this tile's inverse norms (uniform branch), retired by later waits
+        for (int mi = 0; mi < 2; ++mi)
+            af[mi] = BF16 ? take16(ring[s4][mi][0]) : cvt_f16_rtn(ring[s4][mi][0], ring[s4][mi][NH - 1]);
+        asm volatile("" :: "v"(af[0]), "v"(af[1]));      // (taken out of the slot before it is reloaded)
+        if (!BF16 && s4 == 1 && last) {                  // this tile's inverse norms (uniform branch), retired by later waits
             const char* src = uniform_ptr((const char*)(a.inv_pad + (size_t)row0 + w * 32));
             __builtin_amdgcn_global_load_lds((glb_void*)(src + (uint32_t)(lane * 4)), (lds_void*)inv_lds, 4, 0, 0);
         }
         // rows of the same step of the NEXT block: of this tile, or (a tile's last block) of the next tile's first block
-        if (last) load_rows(SL{}, bn, vn, std::integral_constant<int, s4 * 128>{});
-        else load_rows(SL{}, bp + (uint64_t)(b6 + 1) * (G2_NB * 128), vp, std::integral_constant<int, s4 * 128>{});
+        if (last) load_rows(SL{}, bn, vn, std::integral_constant<int, s4 * RS>{});
+        else load_rows(SL{}, bp + (uint64_t)(b6 + 1) * (G2_NB * RS), vp, std::integral_constant<int, s4 * RS>{});
         __builtin_amdgcn_sched_barrier(0);
         const char* bq = smem + pb * G2_BLK + s4 * G2_STEP + foffB;
 #pragma unroll
@@ -467,8 +491,13 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    acc[mi][4 * n4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bh[i], acc[mi][4 * n4 + i], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) {
+                    if (BF16)
+                        acc[mi][4 * n4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, af[mi]), __builtin_bit_cast(bf16x8, bh[i]), acc[mi][4 * n4 + i], 0, 0, 0);
+                    else
+                        acc[mi][4 * n4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bh[i], acc[mi][4 * n4 + i], 0, 0, 0);
+                }
         }
     };
     for (int it = 0; it < n_mine; ++it) {
@@ -480,18 +509,23 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
             step(std::integral_constant<int, 1>{}, b6, last);
             step(std::integral_constant<int, 2>{}, b6, last);
             step(std::integral_constant<int, 3>{}, b6, last);
-            // end of a query block: the next one has landed once at most the 16 row loads issued behind its DMAs are in
+            // end of a query block: the next one has landed once at most the 16 (8) row loads issued behind its DMAs are in
             // flight; then everyone is done with this one
-            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            if (BF16) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             wg_barrier();
             pb ^= 1;
         }
         // (the inverse norms were requested three steps ago and are older than the last 12 row loads; the lanes read what
-        // their own wave's DMA wrote: no barrier)
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        // their own wave's DMA wrote: no barrier.  Unit-row image: nothing to scale with)
         f32x4 inv4[2];
+        if (BF16) {
+            inv4[0] = inv4[1] = (f32x4){1.f, 1.f, 1.f, 1.f};
+        } else {
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) inv4[mi] = *(const f32x4*)(inv_lds + mi * 16 + 4 * lg);
+            for (int mi = 0; mi < 2; ++mi) inv4[mi] = *(const f32x4*)(inv_lds + mi * 16 + 4 * lg);
+        }
         // ---- epilogue, one block of 16 queries at a time: accumulator (mi, ni)[rr] = row 32 w + mi 16 + 4 lg + rr of the
         //      tile, query ni 16 + li16 ----
         const int n_valid = row_end - row0;
@@ -514,7 +548,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
             if (EMIT) {
                 const float thr = thr_lds[ni * 16 + col_e];
                 if (__ballot(cmax >= thr) != 0) {
-                    const int q = a.q_base + ni * 16 + col_e;
+                    const int q = q_base + ni * 16 + col_e;
 #pragma unroll
                     for (int mi = 0; mi < 2; ++mi) {
                         const int rb = w * 32 + mi * 16 + 4 * lg;
@@ -538,7 +572,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
             m = max2_raw(__uint_as_float(s32[0]), __uint_as_float(s32[1]));
             auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
             m = max2_raw(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
-            if (lg == 0) a.tmax_t[((size_t)jt * 8 + w) * 256 + ni * 16 + col_e] = m;
+            if (lg == 0) a.tmax_t[((size_t)jt * 8 + w) * nq_pad + grp * 256 + ni * 16 + col_e] = m;
         }
         jt = jn;
         row0 = row0n;
@@ -554,6 +588,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
 }
 
 // query image of the 256-query kernel: [kt 24][q 256][physical chunk c' 4] x 16 B, group blockIdx.y = queries 256 g .. + 255
+template <bool BF16>
 __global__ __launch_bounds__(256) void build_qimg2_kernel(const float* __restrict__ qn, int nq, f16x8* __restrict__ qimg) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= GF_KT * 256 * 4) return;
@@ -564,10 +599,17 @@ __global__ __launch_bounds__(256) void build_qimg2_kernel(const float* __restric
     f16x8 h;
     if (q < nq) {
         const float* src = qn + (size_t)q * MSR_DIM + 32 * kt + 8 * c;
-        h = cvt_f16_rtn(*(const f32x4*)src, *(const f32x4*)(src + 4));
+        if (BF16) {
+            bf16x8 b;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) b[j] = (__bf16)src[j];
+            h = __builtin_bit_cast(f16x8, b);
+        } else {
+            h = cvt_f16_rtn(*(const f32x4*)src, *(const f32x4*)(src + 4));
+        }
     } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) h[j] = (_Float16)0.f;
+        for (int j = 0; j < 8; ++j) h[j] = (_Float16)0.f;     // (all-zero bits are 0.0 in both formats)
     }
     qimg[(size_t)g * (GF_KT * 256 * 4) + i] = h;
 }
@@ -695,26 +737,35 @@ hipError_t launch_stream_t(const GemmF32Args& a, int grid, hipStream_t stream) {
     gemm_stream_kernel<EMIT><<<grid, GF_THREADS, GS_LDS, stream>>>(a);
     return hipGetLastError();
 }
-template <bool EMIT>
+template <bool EMIT, bool BF16>
 hipError_t launch_stream256_t(const GemmF32Args& a, int grid, hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t err = hipFuncSetAttribute((const void*)gemm_stream256_kernel<EMIT>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
+        hipError_t err = hipFuncSetAttribute((const void*)gemm_stream256_kernel<EMIT, BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
         if (err != hipSuccess) return err;
         attr_done = true;
     }
-    gemm_stream256_kernel<EMIT><<<grid, G2_THREADS, G2_LDS, stream>>>(a);
+    gemm_stream256_kernel<EMIT, BF16><<<grid, G2_THREADS, G2_LDS, stream>>>(a);
     return hipGetLastError();
 }
 // width: queries per pass (128 or 256; both kernels: 8 waves x 32 rows)
 hipError_t launch_f32(int width, bool emit, const GemmF32Args& a, int grid, hipStream_t stream) {
-    if (width == 256) return emit ? launch_stream256_t<true>(a, grid, stream) : launch_stream256_t<false>(a, grid, stream);
+    if (width == 256) return emit ? launch_stream256_t<true, false>(a, grid, stream) : launch_stream256_t<false, false>(a, grid, stream);
     return emit ? launch_stream_t<true>(a, grid, stream) : launch_stream_t<false>(a, grid, stream);
 }
 
 }  // namespace
 
 void msr_gemm_f32_set_dbg(int v) { g_f32_dbg = v; }
+
+hipError_t msr_stream256_bf16_launch(bool emit, const StreamArgs& a, int grid, hipStream_t stream) {
+    if (a.nt < 1 || (grid & 7) || (grid >> 3) < a.nt) return hipErrorInvalidValue;
+    return emit ? launch_stream256_t<true, true>(a, grid, stream) : launch_stream256_t<false, true>(a, grid, stream);
+}
+hipError_t msr_stream256_bf16_qimage(const float* qn, int nq, int n_groups, void* qimg, hipStream_t stream) {
+    build_qimg2_kernel<true><<<dim3((GF_KT * 256 * 4 + 255) / 256, n_groups), 256, 0, stream>>>(qn, nq, (f16x8*)qimg);
+    return hipGetLastError();
+}
 
 hipError_t msr_pad_inv_norm(const float* inv, int64_t n, int64_t n_pad, float* out, hipStream_t stream) {
     if (n_pad <= 0) return hipSuccess;
@@ -746,7 +797,7 @@ hipError_t msr_gemm_f32_topk(const GemmF32Index& g, const DenseIndex& ix, const 
     if (nq <= 0 || G * W > 128 * g.max_groups || k < 1 || g.n_tiles < 2 * k) return hipErrorInvalidValue;
     if (width_out) *width_out = W;
     hipError_t err;
-    if (W == 256) build_qimg2_kernel<<<dim3((GF_KT * 256 * 4 + 255) / 256, G), 256, 0, stream>>>(qn, nq, (f16x8*)g.qimg);
+    if (W == 256) build_qimg2_kernel<false><<<dim3((GF_KT * 256 * 4 + 255) / 256, G), 256, 0, stream>>>(qn, nq, (f16x8*)g.qimg);
     else build_qimg1_kernel<<<dim3((GF_KT * 128 * 4 + 255) / 256, G), 256, 0, stream>>>(qn, nq, (f16x8*)g.qimg);
     f16_margin_kernel<<<(nq + 3) / 4, 256, 0, stream>>>(qn, nq, g.err_max, g.margin);
     const float* margin = g.margin;
@@ -756,7 +807,7 @@ hipError_t msr_gemm_f32_topk(const GemmF32Index& g, const DenseIndex& ix, const 
     const int grid = g.n_cus;
     const size_t qimg_bytes = (size_t)GF_KT * W * 64;   // one group's image
     GemmF32Args a{};
-    a.dbg = g_f32_dbg;
+    a.dbg = g_f32_dbg; a.nt = 1;
     a.E = (const char*)ix.emb; a.inv_pad = g.inv_pad; a.tile_row = g.tile_row;
     a.n_rows = ix.n_chunks; a.tmax_t = g.tmax_t;
     // ---- pass 1 of every group: maxima of every ss-th tile -> emission thresholds ----
@@ -771,7 +822,7 @@ hipError_t msr_gemm_f32_topk(const GemmF32Index& g, const DenseIndex& ix, const 
     if ((err = msr_gemm_kth(g.tmax, n_s, g.tmax_stride, nq, W * G, k, margin, g.thr, g.flag, stream)) != hipSuccess) return err;
     // ---- pass 2 of every group: maxima of all tiles + the entries at or above the threshold (one set of wave buffers) ----
     a.t_first = 0; a.t_stride = 1; a.t_count = g.n_tiles;
-    a.wvbuf = (int4*)g.wvbuf; a.wv_cap = g.wv_cap * (8 / waves); a.wv_count = g.wv_count;
+    a.wvbuf = g.wvbuf; a.wv_cap = g.wv_cap * (8 / waves); a.wv_count = g.wv_count;
     for (int gi = 0; gi < G; ++gi) {
         a.qimg = (const char*)g.qimg + gi * qimg_bytes;
         a.thr = g.thr + gi * W; a.q_base = gi * W; a.append = gi > 0;

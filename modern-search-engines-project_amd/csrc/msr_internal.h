@@ -202,7 +202,7 @@ struct GemmIndex {
     void* qmat;                // bf16 [max_queries][768]
     float* tmax;               // [max_queries][tmax_stride] tile maxima, one row per query (input of the top-k select)
     int32_t tmax_stride;
-    float* tmax_t;             // [n_tiles][2][max_queries] as the GEMM epilogue stores them (see GemmArgs::tmax_t)
+    float* tmax_t;             // [n_tiles][8 waves][max_queries] as the pass' epilogue stores them
     float* thr; float* thr2;   // [max_queries] emission threshold (sample bound) / final threshold (all tiles)
     int32_t* flag;             // [max_queries] 1: the sample could not bound this query (rerun on the exact path)
     void* wgbuf;               // [n_workgroups * 8 waves][wv_cap] x 16 B emitted (row, query, score, tile)
@@ -233,6 +233,29 @@ hipError_t msr_batch_margin(const float* qn, int nq, const uint32_t* err_max, fl
 hipError_t msr_gemm_candidates(const GemmIndex& g, const DenseIndex& ix, const float* qn, int nq, int k, const float* margin,
                                int32_t* cand_doc, int32_t* cand_n, hipEvent_t* ev,
                                hipStream_t stream);
+
+// Arguments of the streaming passes (msr_gemm_f32.hip): one persistent workgroup per CU walks row tiles (<= 256 rows, cut at
+// document boundaries), rows through a register ring, the query image through LDS.
+struct StreamArgs {
+    const char* E;             // rows: f32 [n_rows][768] (caller's matrix: NOT padded, the last tile clamps its row index), or the
+                               // bf16 unit-row image (msr_stream256_bf16_launch)
+    const float* inv_pad;      // [n_rows + 512] inverse norms (engine-owned padded copy; unused for the bf16 image)
+    const char* qimg;          // query image: [group][24 K steps][128 or 256 queries][64 B], chunk-swizzled
+    const int32_t* tile_row;   // [n_tiles + 1]
+    int64_t n_rows;
+    int t_first, t_stride, t_count;
+    float* tmax_t;             // [t_count][8 waves][queries of a pass (x nt)]
+    const float* thr;          // emit thresholds of the pass' queries (+inf: never)                    -- emit pass only
+    void* wvbuf; int wv_cap; int32_t* wv_count;   // per-wave emission buffers {row, query, score bits, tile} (int4)   -- emit pass only
+    int q_base;                // number of the pass' first query within the call (the query field of an entry is global)
+    int append;                // emit pass: continue behind the entries earlier groups left in the wave buffers
+    int nt;                    // 256-query kernel: query groups that share a tile sequence in ONE launch (1: none)
+    int dbg;                   // -DMSR_DIAG builds only (timing experiments, wrong results)
+};
+// the 256-query kernel over the bf16 unit-row image, nt groups of 256 queries per launch (grid: a multiple of 8, >= 8 nt)
+hipError_t msr_stream256_bf16_launch(bool emit, const StreamArgs& a, int grid, hipStream_t stream);
+// its query image: bf16, [n_groups][24][256][64 B]
+hipError_t msr_stream256_bf16_qimage(const float* qn, int nq, int n_groups, void* qimg, hipStream_t stream);
 
 // ---- K2 for 65 .. 128 queries: one streaming pass over the f32 rows, f16 filter + exact f32 finish (msr_gemm_f32.hip) ----
 struct GemmF32Index {
