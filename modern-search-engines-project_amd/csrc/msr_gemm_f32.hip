@@ -344,24 +344,45 @@ __device__ __forceinline__ f16x8 take16(const f32x4& r) {
     asm volatile("v_mov_b32 %0, %1" : "=v"(o[3]) : "v"(r[3]));
     return __builtin_bit_cast(f16x8, o);
 }
+// the lane id, computed where it is needed and opaque to the compiler (not hoisted, not kept in a register)
+__device__ __forceinline__ uint32_t fresh_lane() {
+    uint32_t l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+// a 16-byte LDS read the compiler does not wait for (the caller places s_waitcnt lgkmcnt and re-defines the register)
+typedef __attribute__((address_space(3))) char lds_char;
+template <int OFF>
+__device__ __forceinline__ void lds_read16(f16x8& r, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+}
 __device__ __forceinline__ uint64_t uniform_u64(uint64_t u) {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
     return ((uint64_t)hi << 32) | lo;
 }
 
 // BF16 = true: the rows are a bf16 image of UNIT rows (1536 B each; msr_gemm.hip's candidate pass for 1024 queries per call):
-// the fragments come out of the row ring as they are (no conversion, no inverse norms), a K step of a row is 64 bytes (one
-// 16-byte load per fragment), and a.nt = 4 query groups of 256 share the rows: the workgroups are dealt so that the nt
+// the fragments come out of the row ring as they are (no conversion, no inverse norms), a ring slot (128 bytes of a row) feeds
+// two K steps, and a.nt = 4 query groups of 256 share the rows: the workgroups are dealt so that the nt
 // workgroups with the same tile sequence have the same blockIdx % 8 (one XCD under round-robin dispatch: speed only) -- the
 // rows come from HBM once per call and from that XCD's L2 for the other groups.
 template <bool EMIT, bool BF16>
 __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWB = BF16 ? MSR_DIM * 2 : GF_ROWB;             // bytes per row
-    constexpr int RS = BF16 ? 64 : 128;                            // bytes of a row per K step
-    constexpr int NH = BF16 ? 1 : 2;                               // 16-byte loads per fragment and K step
+    // A ring slot holds 128 bytes of each of the wave's rows = one full cache line per row and load pair (lane (li16, lg)
+    // takes the 32 bytes at lg * 32 with two 16-byte loads): 32 floats = ONE K step of f32 rows, 64 bf16 = TWO K steps of bf16
+    // rows (first the lanes' lower 16 bytes, then the upper: the query image orders K the same way, build_qimg2_kernel).
+    // (bf16 rows loaded 64 bytes per K step -- half a line per row and instruction -- ran the pass at 15.0 ms per 1024
+    // queries x 10 M rows instead of [see DESIGN.md]; with 64 rows x 128 queries per wave, i.e. half the LDS fragment reads
+    // but every row loaded by two waves: 17.9 ms.  The row loads' path through the L1, not LDS, is what the bf16 pass feels.)
+    constexpr int KPS = BF16 ? 2 : 1;                              // K steps per ring slot
+    constexpr int RSLOTS = G2_NB / KPS;                            // ring slots = one query block's worth of rows
+    constexpr int NMI = 2, NNI = 16;                               // the wave's fragments: 32 rows x 256 queries
+    constexpr int WROWS = 16 * NMI, NPARTS = 256 / WROWS;          // rows per wave; row groups per tile (tmax_t's middle index)
     const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave w owns rows 32 w .. 32 w + 32 of the tile, ALL 256 queries
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w, wc = 0;                                      // row group, query half (none)
     const int li16 = lane & 15, lg = lane >> 4;
     // which tiles, which query group: a.nt groups of 256 queries share a tile sequence (nt == 1: every workgroup its own)
     const int nt = BF16 ? a.nt : 1;                                // (the f32 passes run one group per launch)
@@ -371,8 +392,9 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
         const int per_x = (int)gridDim.x >> 3, xcd = (int)blockIdx.x & 7, li = (int)blockIdx.x >> 3;
         const int gpx = per_x / nt, mg = li / nt;
         grp = li - mg * nt;
-        G = 8 * gpx;
-        gid = xcd * gpx + mg;
+        G = __builtin_amdgcn_readfirstlane(8 * gpx);
+        gid = __builtin_amdgcn_readfirstlane(xcd * gpx + mg);
+        grp = __builtin_amdgcn_readfirstlane(grp);
         active = mg < gpx;
     }
     const int nq_pad = nt * 256;
@@ -382,7 +404,9 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
         if (EMIT && lane == 0) a.wv_count[blockIdx.x * 8 + w] = wave_cnt;
         return;
     }
-    const int n_mine = (a.t_count - gid + G - 1) / G;
+    // (the division runs on the vector unit; without the readfirstlane the tile counters and everything derived from them --
+    // tile numbers, the tile table's loads -- stay in vector registers)
+    const int n_mine = __builtin_amdgcn_readfirstlane((a.t_count - gid + G - 1) / G);
     const char* qimg = a.qimg + (size_t)grp * (GF_KT * G2_STEP);
     const int q_base = a.q_base + grp * 256;
     float* thr_lds = (float*)(smem + 2 * G2_BLK);
@@ -391,7 +415,6 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
     // floats, the upper half belongs to the next wave's rows and is not used; inv_pad is padded by 512 entries)
     float* inv_lds = (float*)(smem + 2 * G2_BLK + 1024) + w * 64;
     // query fragments: query 16 ni + li16, logical 16 B chunk lg of its 64 B, stored at physical chunk lg ^ (((q >> 3) & 1) << 1)
-    const uint32_t foffB = (uint32_t)(li16 * 64 + ((lg ^ (((li16 >> 3) & 1) << 1)) << 4));
     // one query block: 64 KB, linear; wave w moves 8 KB of it
     auto stage_b = [&](int blk, int pb) {
         const char* base = uniform_ptr(qimg + (size_t)blk * G2_BLK + (size_t)w * 8192);
@@ -400,117 +423,185 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
             __builtin_amdgcn_global_load_lds((glb_void*)(base + (uint32_t)(i * 1024 + lane * 16)),
                                              (lds_void*)(smem + pb * G2_BLK + w * 8192 + i * 1024), 16, 0, 0);
     };
-    f32x4 acc[2][16];
+    f32x4 acc[NMI][NNI];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < NMI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 16; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int ni = 0; ni < NNI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     auto tile_of = [&](int j) { return a.t_first + j * a.t_stride; };
     // A tile's rows are addressed as (scalar base of the tile's first row) + (32-bit byte offset of the lane's row): fragment
-    // mi = row 32 w + 16 mi + li16 of the tile, at its 32-byte piece lg of a K step; a row past the end of the matrix
+    // mi = row WROWS wr + 16 mi + li16 of the tile, at its 32-byte piece lg of a K step; a row past the end of the matrix
     // re-reads the last row (masked in the epilogue).  A tile spans < 1 MB, so the offset fits 32 bits with room to spare.
     auto tile_base = [&](int row0) { return uniform_u64((uint64_t)a.E + (uint64_t)row0 * ROWB); };
+    // The bf16 image is padded with 512 zero rows (msr_enable_bf16): nothing to clamp, the lane's offset is the same for
+    // every tile and the fragments differ by a constant that goes into the scalar base -- one offset register instead of eight.
+    constexpr int NV = BF16 ? 1 : NMI;
     auto row_off = [&](int row0, int mi) -> uint32_t {
-        int64_t r = (int64_t)row0 + 32 * w + 16 * mi + li16;
+        if (BF16) return (uint32_t)((WROWS * wr + li16) * ROWB + lg * 32);
+        int64_t r = (int64_t)row0 + WROWS * wr + 16 * mi + li16;
         if (r > a.n_rows - 1) r = a.n_rows - 1;
-        return (uint32_t)((r - row0) * ROWB + lg * (RS / 4));
+        return (uint32_t)((r - row0) * ROWB + lg * 32);
     };
     int jt = gid;
     int row0 = a.tile_row[tile_of(jt)], row_end = a.tile_row[tile_of(jt) + 1];
     int jn = jt + G < a.t_count ? jt + G : jt;
     int row0n = a.tile_row[tile_of(jn)];
     uint64_t bp = tile_base(row0), bn = tile_base(row0n);
-    uint32_t vp[2], vn[2];
+    uint32_t vp[NV], vn[NV];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) { vp[mi] = row_off(row0, mi); vn[mi] = row_off(row0n, mi); }
+    for (int mi = 0; mi < NV; ++mi) { vp[mi] = row_off(row0, mi); vn[mi] = row_off(row0n, mi); }
 
     // The row ring is driven by hand (see gemm_stream_kernel): inline-asm loads, explicit s_waitcnt before every use; vmcnt
     // retires in order.  Issue order per wave: [8 DMAs of the next block] then per step [wait, convert, 4 row loads,
-    // compute].  The rows of step s of a block were loaded during step s of the block BEFORE (ring depth = block length = 4):
-    // younger than them are the loads of three steps (12; bf16 rows: 6) and one block's 8 DMAs = 20 (14), whatever s is.
-    // (Epilogue stores and the inverse-norm DMA only add younger operations: waiting for fewer than are in flight is always
-    // safe.)
-    f32x4 ring[G2_NB][2][NH];                            // [slot][fragment][16-byte piece]
+    // compute].  f32 rows: the rows of step s of a block were loaded during step s of the block BEFORE (ring depth = block
+    // length = 4): younger than them are the loads of three steps (12) and one block's 8 DMAs = 20, whatever s is.  bf16
+    // rows: slot p (K steps 2p, 2p + 1) is reloaded in step 2p + 1 and waited for in step 2p of the next block: younger are
+    // the other slot's 4 loads and 8 DMAs = 12.  (Epilogue stores and the inverse-norm DMA only add younger operations:
+    // waiting for fewer than are in flight is always safe.)
+    static_assert(NMI == 2, "the wait counts below assume 4 row loads per ring slot");
+    f32x4 ring[RSLOTS][NMI][2];                          // [slot][fragment][16-byte half]
     auto load_rows = [&](auto slot_c, uint64_t sb, const uint32_t* v, auto off_c) {
         constexpr int slot = decltype(slot_c)::value, off = decltype(off_c)::value;
-        gload16s<off>(ring[slot][0][0], v[0], sb);
-        if (NH == 2) gload16s<off + 16>(ring[slot][0][NH - 1], v[0], sb);
-        gload16s<off>(ring[slot][1][0], v[1], sb);
-        if (NH == 2) gload16s<off + 16>(ring[slot][1][NH - 1], v[1], sb);
+#pragma unroll
+        for (int mi = 0; mi < NMI; ++mi) {
+            const uint64_t b = BF16 ? sb + (uint64_t)(mi * 16 * ROWB) : sb;
+            gload16s<off>(ring[slot][mi][0], v[BF16 ? 0 : mi], b);
+            gload16s<off + 16>(ring[slot][mi][1], v[BF16 ? 0 : mi], b);
+        }
     };
     auto pin_rows = [&](auto slot_c) {
         constexpr int slot = decltype(slot_c)::value;
-        if (NH == 2) pin4(ring[slot][0][0], ring[slot][0][NH - 1], ring[slot][1][0], ring[slot][1][NH - 1]);
-        else pin2(ring[slot][0][0], ring[slot][1][0]);
+        pin4(ring[slot][0][0], ring[slot][0][1], ring[slot][1][0], ring[slot][1][1]);
     };
-    // ---- prologue: query block 0, rows of steps 0 .. 3 ----
+    // (Tried: waves 4 .. 7 half a tile behind waves 0 .. 3 -- K blocks in the order 3 4 5 0 1 2 -- so that a wave's epilogue
+    // runs beside its SIMD partner's MFMAs and loads instead of beside its epilogue: 2 % SLOWER on the f32 rows, 5 % on the
+    // bf16 rows.  The eight waves share every query block and its barrier; a late wave holds the others up either way.)
+    constexpr int NKB = GF_KT / G2_NB;                   // 6 K blocks per tile
+    constexpr int BLKB = RSLOTS * 128;                   // bytes of a row per K block
+    // ---- prologue: query block 0, rows of K block 0 ----
     stage_b(0, 0);
 #pragma unroll
-    for (int s = 0; s < G2_NB; ++s)
+    for (int s = 0; s < RSLOTS; ++s)
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) ring[s][mi][0] = ring[s][mi][NH - 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int mi = 0; mi < NMI; ++mi) ring[s][mi][0] = ring[s][mi][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     load_rows(std::integral_constant<int, 0>{}, bp, vp, std::integral_constant<int, 0>{});
-    load_rows(std::integral_constant<int, 1>{}, bp, vp, std::integral_constant<int, RS>{});
-    load_rows(std::integral_constant<int, 2>{}, bp, vp, std::integral_constant<int, 2 * RS>{});
-    load_rows(std::integral_constant<int, 3>{}, bp, vp, std::integral_constant<int, 3 * RS>{});
+    load_rows(std::integral_constant<int, 1>{}, bp, vp, std::integral_constant<int, 128>{});
+    if (!BF16) {
+        load_rows(std::integral_constant<int, RSLOTS - 2>{}, bp, vp, std::integral_constant<int, 256>{});
+        load_rows(std::integral_constant<int, RSLOTS - 1>{}, bp, vp, std::integral_constant<int, 384>{});
+    }
     wait_vm0();
     pin_rows(std::integral_constant<int, 0>{}); pin_rows(std::integral_constant<int, 1>{});
-    pin_rows(std::integral_constant<int, 2>{}); pin_rows(std::integral_constant<int, 3>{});
+    pin_rows(std::integral_constant<int, RSLOTS - 2>{}); pin_rows(std::integral_constant<int, RSLOTS - 1>{});
     wg_barrier();
     int pb = 0;                                          // LDS buffer of the current query block
 
     const float NEG_INF = -__builtin_inff();
-    // one K step; S4: position in the query block = ring slot (compile time)
-    auto step = [&](auto s4_c, int b6, bool last) {
-        constexpr int s4 = decltype(s4_c)::value;
-        using SL = std::integral_constant<int, s4>;
-        __builtin_amdgcn_sched_barrier(0);
-        if (BF16) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-        pin_rows(SL{});
-        f16x8 af[2];                                     // (bf16 rows: the same 16 bytes, bf16 x 8)
+    f16x8 bh[4];                                         // query fragments in flight (see step)
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-            af[mi] = BF16 ? take16(ring[s4][mi][0]) : cvt_f16_rtn(ring[s4][mi][0], ring[s4][mi][NH - 1]);
-        asm volatile("" :: "v"(af[0]), "v"(af[1]));      // (taken out of the slot before it is reloaded)
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bh[i][j] = (_Float16)0.f;
+    // one K step; S4: position in the query block = ring slot (compile time)
+    auto step = [&](auto s4_c, int kn, bool last) {     // kn: the K block after this one (same tile)
+        constexpr int s4 = decltype(s4_c)::value;
+        constexpr int slot = s4 / KPS, half = s4 % KPS;  // (bf16 rows: K step s4 = half `half` of slot s4 / 2)
+        using SL = std::integral_constant<int, slot>;
+        __builtin_amdgcn_sched_barrier(0);
+        if (half == 0) {
+            if (BF16) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            pin_rows(SL{});
+        }
+        // f32 rows: converted out of the slot.  bf16 rows: the loaded registers ARE the fragments -- taken out with an opaque
+        // copy (take16).  (Reading them in place and reloading the slot behind the step's MFMAs was tried: the register
+        // allocator then spills ring slots.)
+        f16x8 af[NMI];
+#pragma unroll
+        for (int mi = 0; mi < NMI; ++mi)
+            af[mi] = BF16 ? take16(ring[slot][mi][half]) : cvt_f16_rtn(ring[slot][mi][0], ring[slot][mi][1]);
+#pragma unroll
+        for (int mi = 0; mi < NMI; ++mi) asm volatile("" :: "v"(af[mi]));     // (taken out of the slot before it is reloaded)
         if (!BF16 && s4 == 1 && last) {                  // this tile's inverse norms (uniform branch), retired by later waits
             const char* src = uniform_ptr((const char*)(a.inv_pad + (size_t)row0 + w * 32));
-            __builtin_amdgcn_global_load_lds((glb_void*)(src + (uint32_t)(lane * 4)), (lds_void*)inv_lds, 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)(src + (uint32_t)(fresh_lane() * 4)), (lds_void*)inv_lds, 4, 0, 0);
         }
         // rows of the same step of the NEXT block: of this tile, or (a tile's last block) of the next tile's first block
-        if (last) load_rows(SL{}, bn, vn, std::integral_constant<int, s4 * RS>{});
-        else load_rows(SL{}, bp + (uint64_t)(b6 + 1) * (G2_NB * RS), vp, std::integral_constant<int, s4 * RS>{});
-        __builtin_amdgcn_sched_barrier(0);
-        const char* bq = smem + pb * G2_BLK + s4 * G2_STEP + foffB;
-#pragma unroll
-        for (int n4 = 0; n4 < 4; ++n4) {
-            f16x8 bh[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) bh[i] = *(const f16x8*)(bq + (4 * n4 + i) * 1024);
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (BF16)
-                        acc[mi][4 * n4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8, af[mi]), __builtin_bit_cast(bf16x8, bh[i]), acc[mi][4 * n4 + i], 0, 0, 0);
-                    else
-                        acc[mi][4 * n4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bh[i], acc[mi][4 * n4 + i], 0, 0, 0);
-                }
+        if (half == KPS - 1) {                           // (the slot's last K step: everything has been taken out of it)
+            if (last) load_rows(SL{}, bn, vn, std::integral_constant<int, slot * 128>{});
+            else load_rows(SL{}, bp + (uint64_t)(kn * BLKB), vp, std::integral_constant<int, slot * 128>{});
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // (the lane's fragment offset is recomputed from a fresh lane id in every step -- 7 instructions beside 32 MFMAs --
+        // so that it is not one more value held in a register across the whole kernel: the allocator has none to spare, and
+        // what it spills it reloads behind an s_waitcnt vmcnt(0) in the middle of the row pipeline)
+        const uint32_t ln = fresh_lane();
+        const uint32_t fo = (ln & 15) * 64 + (((ln >> 4) ^ (((ln >> 3) & 1) << 1)) << 4);
+        const char* bq = smem + pb * G2_BLK + s4 * G2_STEP + wc * (128 * 64) + fo;
+        // The query fragments roll through four registers sets: fragment f is read into set f % 4 right behind the two
+        // MFMAs of fragment f - 4, i.e. six MFMAs (~100 cycles) before its own -- the LDS latency hides behind this wave's
+        // own MFMAs instead of counting on the SIMD's other wave.  The first four of a step are read by the step before
+        // (same query block); a block's first step reads its own.
+        // (bf16 rows only: the f32 rows' pass waits for HBM, not for LDS, and has no registers for fragments that stay
+        // live across steps)
+        if (!BF16) {
+#pragma unroll
+            for (int n4 = 0; n4 < NNI / 4; ++n4) {
+                f16x8 b4[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) b4[i] = *(const f16x8*)(bq + (4 * n4 + i) * 1024);
+#pragma unroll
+                for (int mi = 0; mi < NMI; ++mi)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[mi][4 * n4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], b4[i], acc[mi][4 * n4 + i], 0, 0, 0);
+            }
+            return;
+        }
+        // The reads are inline asm with hand-placed s_waitcnt lgkmcnt, like the row ring (the compiler, left to itself, waits
+        // for every read right behind it): LDS reads return in order, four are in flight at every wait but the last three of
+        // a block.
+        const uint32_t la = (uint32_t)(uintptr_t)(lds_char*)bq;
+        if (s4 == 0) {
+            lds_read16<0>(bh[0], la); lds_read16<1024>(bh[1], la); lds_read16<2048>(bh[2], la); lds_read16<3072>(bh[3], la);
+        }
+        auto frag = [&](auto f_c) {
+            constexpr int f = decltype(f_c)::value;
+            constexpr int ahead = (s4 + 1 < G2_NB) ? 3 : (NNI - 1 - f < 3 ? NNI - 1 - f : 3);   // reads behind fragment f's
+            if (ahead == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+            else if (ahead == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("" : "+v"(bh[f & 3]));
+#pragma unroll
+            for (int mi = 0; mi < NMI; ++mi)
+                acc[mi][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, af[mi]), __builtin_bit_cast(bf16x8, bh[f & 3]), acc[mi][f], 0, 0, 0);
+            if (f + 4 < NNI) lds_read16<(f + 4) * 1024>(bh[f & 3], la);
+            else if (s4 + 1 < G2_NB) lds_read16<G2_STEP + (f + 4 - NNI) * 1024>(bh[f & 3], la);
+        };
+        frag(std::integral_constant<int, 0>{}); frag(std::integral_constant<int, 1>{});
+        frag(std::integral_constant<int, 2>{}); frag(std::integral_constant<int, 3>{});
+        frag(std::integral_constant<int, 4>{}); frag(std::integral_constant<int, 5>{});
+        frag(std::integral_constant<int, 6>{}); frag(std::integral_constant<int, 7>{});
+        frag(std::integral_constant<int, 8>{}); frag(std::integral_constant<int, 9>{});
+        frag(std::integral_constant<int, 10>{}); frag(std::integral_constant<int, 11>{});
+        frag(std::integral_constant<int, 12>{}); frag(std::integral_constant<int, 13>{});
+        frag(std::integral_constant<int, 14>{}); frag(std::integral_constant<int, 15>{});
     };
     for (int it = 0; it < n_mine; ++it) {
 #pragma unroll 1
-        for (int b6 = 0; b6 < GF_KT / G2_NB; ++b6) {
-            const bool last = b6 == GF_KT / G2_NB - 1;
-            stage_b(last ? 0 : b6 + 1, pb ^ 1);          // the next query block (the image repeats for every tile)
-            step(std::integral_constant<int, 0>{}, b6, last);
-            step(std::integral_constant<int, 1>{}, b6, last);
-            step(std::integral_constant<int, 2>{}, b6, last);
-            step(std::integral_constant<int, 3>{}, b6, last);
-            // end of a query block: the next one has landed once at most the 16 (8) row loads issued behind its DMAs are in
-            // flight; then everyone is done with this one
+        for (int kb = 0; kb < NKB; ++kb) {
+            const bool last = kb == NKB - 1;
+            const int kn = last ? 0 : kb + 1;
+            stage_b(kn, pb ^ 1);                         // the next query block (the image repeats for every tile)
+            step(std::integral_constant<int, 0>{}, kn, last);
+            step(std::integral_constant<int, 1>{}, kn, last);
+            step(std::integral_constant<int, 2>{}, kn, last);
+            step(std::integral_constant<int, 3>{}, kn, last);
+            // end of a query block: the next one has landed once at most the 16 (bf16 rows: 8) row loads issued behind its
+            // DMAs are in flight; then everyone is done with this one
             if (BF16) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             wg_barrier();
@@ -518,30 +609,33 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
         }
         // (the inverse norms were requested three steps ago and are older than the last 12 row loads; the lanes read what
         // their own wave's DMA wrote: no barrier.  Unit-row image: nothing to scale with)
-        f32x4 inv4[2];
-        if (BF16) {
-            inv4[0] = inv4[1] = (f32x4){1.f, 1.f, 1.f, 1.f};
-        } else {
+        // (lane-derived values of the epilogue start from a fresh lane id: derived from the kernel's `lane` they are hoisted
+        // out of the tile loop -- eight row numbers, an address -- and then spilled, to be reloaded one by one behind an
+        // s_waitcnt vmcnt(0) at the start of every tile's epilogue)
+        const int ln_e = (int)fresh_lane();
+        const int lg_e = ln_e >> 4;
+        f32x4 inv4[NMI];
+        if (!BF16) {
             asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) inv4[mi] = *(const f32x4*)(inv_lds + mi * 16 + 4 * lg);
+            for (int mi = 0; mi < NMI; ++mi) inv4[mi] = *(const f32x4*)(inv_lds + mi * 16 + 4 * lg_e);
         }
-        // ---- epilogue, one block of 16 queries at a time: accumulator (mi, ni)[rr] = row 32 w + mi 16 + 4 lg + rr of the
-        //      tile, query ni 16 + li16 ----
+        // ---- epilogue, one block of 16 queries at a time: accumulator (mi, ni)[rr] = row WROWS wr + mi 16 + 4 lg + rr of
+        //      the tile, query 128 wc + ni 16 + li16 of the group ----
         const int n_valid = row_end - row0;
-        int col_e = li16;
-        asm volatile("" : "+v"(col_e));
+        const int col_e = wc * 128 + (ln_e & 15);
 #pragma unroll
-        for (int ni = 0; ni < 16; ++ni) {
-            f32x4 v[2];
+        for (int ni = 0; ni < NNI; ++ni) {
+            f32x4 v[NMI];
             float cmax = NEG_INF;
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                const int blk = w * 32 + mi * 16;
-                v[mi] = acc[mi][ni] * inv4[mi];         // cosine = <e, q^> / ||e||
+            for (int mi = 0; mi < NMI; ++mi) {
+                const int blk = wr * WROWS + mi * 16;
+                if (BF16) v[mi] = acc[mi][ni];          // unit rows: the cosine as it is
+                else v[mi] = acc[mi][ni] * inv4[mi];    // cosine = <e, q^> / ||e||
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr)          // rows behind the tile: products of the next tile's rows (or of the
-                    if (blk + 4 * lg + rr >= n_valid) v[mi][rr] = NEG_INF;      // clamped last row) -- masked
+                    if (blk + 4 * lg_e + rr >= n_valid) v[mi][rr] = NEG_INF;      // clamped last row) -- masked
                 cmax = max2_raw(cmax, max3_raw(max2_raw(v[mi][0], v[mi][1]), v[mi][2], v[mi][3]));
                 acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
@@ -550,8 +644,8 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
                 if (__ballot(cmax >= thr) != 0) {
                     const int q = q_base + ni * 16 + col_e;
 #pragma unroll
-                    for (int mi = 0; mi < 2; ++mi) {
-                        const int rb = w * 32 + mi * 16 + 4 * lg;
+                    for (int mi = 0; mi < NMI; ++mi) {
+                        const int rb = wr * WROWS + mi * 16 + 4 * lg_e;
 #pragma unroll
                         for (int rr = 0; rr < 4; ++rr) {
                             const float x = v[mi][rr];
@@ -572,7 +666,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
             m = max2_raw(__uint_as_float(s32[0]), __uint_as_float(s32[1]));
             auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
             m = max2_raw(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
-            if (lg == 0) a.tmax_t[((size_t)jt * 8 + w) * nq_pad + grp * 256 + ni * 16 + col_e] = m;
+            if (lg_e == 0) a.tmax_t[((size_t)jt * NPARTS + wr) * nq_pad + grp * 256 + ni * 16 + col_e] = m;
         }
         jt = jn;
         row0 = row0n;
@@ -581,7 +675,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
         row0n = a.tile_row[tile_of(jn)];
         bp = bn; bn = tile_base(row0n);
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) { vp[mi] = vn[mi]; vn[mi] = row_off(row0n, mi); }
+        for (int mi = 0; mi < NV; ++mi) { vp[mi] = vn[mi]; vn[mi] = row_off(row0n, mi); }
     }
     wait_vm0();                                          // (the prefetched block and rows of a tile that does not exist)
     if (EMIT && lane == 0) a.wv_count[blockIdx.x * 8 + w] = wave_cnt;
@@ -598,7 +692,9 @@ __global__ __launch_bounds__(256) void build_qimg2_kernel(const float* __restric
     const int c = cp ^ (((ql >> 3) & 1) << 1);
     f16x8 h;
     if (q < nq) {
-        const float* src = qn + (size_t)q * MSR_DIM + 32 * kt + 8 * c;
+        // f16 image: chunk c of K step kt = K elements 32 kt + 8 c ..; bf16 image: the kernel takes K steps 2 p and 2 p + 1
+        // from the lower / upper 16 bytes of the 32 bytes a lane loads at lg * 32 of a row's 128-byte line
+        const float* src = qn + (size_t)q * MSR_DIM + (BF16 ? 64 * (kt >> 1) + 16 * c + 8 * (kt & 1) : 32 * kt + 8 * c);
         if (BF16) {
             bf16x8 b;
 #pragma unroll
