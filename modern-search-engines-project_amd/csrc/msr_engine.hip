@@ -537,11 +537,12 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
         // emitted entries per wave and call: ~600 per 128 queries at 5 M rows (150 x sample stride per query over 2048 waves)
         const int GF_WV_CAP = 4096 * std::max(1, groups / 2);
         const size_t QM = (size_t)groups * 128;
+        const int max_nt = std::max(1, std::min(4, groups / 2));      // 256-query groups that share the rows of one launch
         auto alloc = [&](void** p, size_t bytes) { return hipMalloc(p, bytes); };
         if ((herr = alloc((void**)&e->gf_inv_pad, (size_t)(n_chunks + 512) * 4)) != hipSuccess ||
             (herr = alloc(&e->gf_qimg, (size_t)groups * 24 * 8192)) != hipSuccess ||
             (herr = alloc((void**)&e->gf_qn, (QM + 64) * MSR_DIM * 4)) != hipSuccess ||
-            (herr = alloc((void**)&e->gf_tmax_t, (size_t)n_tiles * 8 * (groups >= 2 ? 256 : 128) * 4)) != hipSuccess ||   // [tile][wave][queries of a pass]
+            (herr = alloc((void**)&e->gf_tmax_t, (size_t)n_tiles * 8 * (groups >= 2 ? 256 * max_nt : 128) * 4)) != hipSuccess ||   // [tile][wave][queries of a launch]
             (herr = alloc((void**)&e->gf_tmax, QM * stride * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gf_thr, QM * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gf_thr2, QM * 4)) != hipSuccess ||
@@ -566,7 +567,7 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
         e->gf = GemmF32Index{e->tile_row, n_tiles, e->n_cus, groups, e->gf_inv_pad, e->gf_qimg, e->gf_tmax_t, e->gf_tmax, stride,
                              e->gf_thr, e->gf_thr2, e->gf_flag, e->gf_wvbuf,
                              GF_WV_CAP, e->gf_wv_count, e->gf_pairs, e->gf_pair_n, e->gf_err, e->gf_margin, e->gf_cand_doc,
-                             e->gf_cand_score, e->gf_cand_chunk, e->gf_cand_n};
+                             e->gf_cand_score, e->gf_cand_chunk, e->gf_cand_n, max_nt};
         e->gf_ok = true;
     }
     e->have_chunks = true;

@@ -385,7 +385,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
     const int wr = w, wc = 0;                                      // row group, query half (none)
     const int li16 = lane & 15, lg = lane >> 4;
     // which tiles, which query group: a.nt groups of 256 queries share a tile sequence (nt == 1: every workgroup its own)
-    const int nt = BF16 ? a.nt : 1;                                // (the f32 passes run one group per launch)
+    const int nt = a.nt;
     int G = (int)gridDim.x, gid = (int)blockIdx.x, grp = 0;
     bool active = true;
     if (nt > 1) {
@@ -902,30 +902,40 @@ hipError_t msr_gemm_f32_topk(const GemmF32Index& g, const DenseIndex& ix, const 
     const int n_s = (g.n_tiles - ss / 2 + ss - 1) / ss;
     const int grid = g.n_cus;
     const size_t qimg_bytes = (size_t)GF_KT * W * 64;   // one group's image
+    // 256-query kernel: up to 4 groups per launch walk the same tile sequence on CUs of one XCD -- the rows come from HBM
+    // once per launch and from that XCD's L2 for the other groups (the bytes per query are what the pass costs)
+    int NT = 1;
+    if (W == 256 && (grid & 7) == 0) NT = std::min(std::min(G, g.max_nt), grid >> 3);
+#ifdef MSR_DIAG
+    if (g_f32_dbg & 2048) NT = 1;                       // timing experiments: one group per launch
+    if (g_f32_dbg & 4096) NT = std::min(NT, 2);
+#endif
     GemmF32Args a{};
     a.dbg = g_f32_dbg; a.nt = 1;
     a.E = (const char*)ix.emb; a.inv_pad = g.inv_pad; a.tile_row = g.tile_row;
     a.n_rows = ix.n_chunks; a.tmax_t = g.tmax_t;
     // ---- pass 1 of every group: maxima of every ss-th tile -> emission thresholds ----
     a.t_first = ss / 2; a.t_stride = ss; a.t_count = n_s;
-    for (int gi = 0; gi < G; ++gi) {
+    for (int gi = 0; gi < G; gi += NT) {
+        a.nt = std::min(NT, G - gi);
         a.qimg = (const char*)g.qimg + gi * qimg_bytes;
         if (ev && gi == 0 && (err = hipEventRecord(ev[0], stream)) != hipSuccess) return err;
         if ((err = launch_f32(W, false, a, grid, stream)) != hipSuccess) return err;
         if (ev && gi == 0 && (err = hipEventRecord(ev[1], stream)) != hipSuccess) return err;
-        if ((err = msr_gemm_tmax(g.tmax_t, n_s, waves, W, g.tmax + (size_t)gi * W * g.tmax_stride, g.tmax_stride, stream)) != hipSuccess) return err;
+        if ((err = msr_gemm_tmax(g.tmax_t, n_s, waves, W * a.nt, g.tmax + (size_t)gi * W * g.tmax_stride, g.tmax_stride, stream)) != hipSuccess) return err;
     }
     if ((err = msr_gemm_kth(g.tmax, n_s, g.tmax_stride, nq, W * G, k, margin, g.thr, g.flag, stream)) != hipSuccess) return err;
     // ---- pass 2 of every group: maxima of all tiles + the entries at or above the threshold (one set of wave buffers) ----
     a.t_first = 0; a.t_stride = 1; a.t_count = g.n_tiles;
     a.wvbuf = g.wvbuf; a.wv_cap = g.wv_cap * (8 / waves); a.wv_count = g.wv_count;
-    for (int gi = 0; gi < G; ++gi) {
+    for (int gi = 0; gi < G; gi += NT) {
+        a.nt = std::min(NT, G - gi);
         a.qimg = (const char*)g.qimg + gi * qimg_bytes;
         a.thr = g.thr + gi * W; a.q_base = gi * W; a.append = gi > 0;
         if (ev && gi == 0 && (err = hipEventRecord(ev[2], stream)) != hipSuccess) return err;
         if ((err = launch_f32(W, true, a, grid, stream)) != hipSuccess) return err;
         if (ev && gi == 0 && (err = hipEventRecord(ev[3], stream)) != hipSuccess) return err;
-        if ((err = msr_gemm_tmax(g.tmax_t, g.n_tiles, waves, W, g.tmax + (size_t)gi * W * g.tmax_stride, g.tmax_stride, stream)) != hipSuccess) return err;
+        if ((err = msr_gemm_tmax(g.tmax_t, g.n_tiles, waves, W * a.nt, g.tmax + (size_t)gi * W * g.tmax_stride, g.tmax_stride, stream)) != hipSuccess) return err;
     }
     if ((err = msr_gemm_kth(g.tmax, g.n_tiles, g.tmax_stride, nq, W * G, k, margin, g.thr2, nullptr, stream)) != hipSuccess) return err;
     if ((err = msr_gemm_bucket(g.wvbuf, a.wv_cap, g.wv_count, grid * waves, g.thr2, g.pairs, g.pair_n, stream)) != hipSuccess) return err;

@@ -265,7 +265,7 @@ struct GemmF32Index {
     int32_t max_groups;        // groups of 128 queries one call may hold (the per-query arrays below are sized 128 x this)
     const float* inv_pad;      // [n_chunks + 512] inverse row norms, padded with 1
     void* qimg;                // [max_groups] x 24 x 8 KB query images (f16)
-    float* tmax_t;             // [n_tiles][8 waves][128], or [256] when max_groups >= 2 (the 256-query kernel)
+    float* tmax_t;             // [n_tiles][8 waves][128], or [256 max_nt] when max_groups >= 2 (the 256-query kernel)
     float* tmax;               // [128 max_groups][tmax_stride]
     int32_t tmax_stride;
     float* thr; float* thr2; int32_t* flag;                 // [128]
@@ -273,6 +273,7 @@ struct GemmF32Index {
     void* pairs; int32_t* pair_n;                            // [128][4096] x 8 B / [128], zero between calls
     uint32_t* err_max; float* margin;                        // measured f16 rounding error of the rows (1 word) / margin [128]
     int32_t* cand_doc; float* cand_score; int32_t* cand_chunk; int32_t* cand_n;   // [128][MSR_SEL_CAP] x 3 / [128] (zero between calls)
+    int32_t max_nt;            // groups of 256 queries one launch of the 256-query kernel may serve (tmax_t holds 256 x this per row)
 };
 hipError_t msr_f16_row_error(const float* emb, const float* inv_norm, int64_t n_rows, uint32_t* err_max, hipStream_t stream);
 void msr_gemm_f32_set_dbg(int v);   // honoured by -DMSR_DIAG builds only
