@@ -612,6 +612,11 @@ def main():
             # queries served by one pass over the matrix: of the kernel the timed calls actually ran (msr_dense_path)
             width = eng.batch_width() if bf else (dense_width or eng.scan_width())
             q_launch = min(Q, width)
+            if not bf and width == 256:
+                # the 256-query kernel serves up to 4 groups of 256 queries per launch (they share the rows: HBM once, the
+                # XCD's L2 for the other groups; msr_gemm_f32_topk) -- mirrors the engine's choice for this batch size
+                groups128 = min(8, max(Q, 128) // 128)
+                q_launch = 256 * max(1, min((min(Q, 128 * groups128) + 255) // 256, min(4, groups128 // 2)))
             alg_bytes = n_ch * 768 * (2 if bf else 4) + (shard.n_docs + 1) * 4 + q_launch * 768 * 4
             wide_kernel = q_launch > 32                         # 33..64 queries per sweep run on the K-split kernel
             k_ms, k_n = scan_ms, scan_n
@@ -619,13 +624,15 @@ def main():
             if not bf and q_launch > 64:                        # more than 64 queries: one streaming pass over the f32 rows
                 kname = "gemm_stream256_kernel<emit>" if width == 256 else "gemm_stream_kernel<emit>"
             if gemm:
-                kname = "gemm_kernel<emit>"
+                kname = "gemm_stream256_kernel<bf16, emit>"
                 alg_bytes = n_ch * 768 * 2 + min(Q, 1024) * 768 * 2     # E (bf16) once per 1024-query pass + the queries
         per_launch_ms = k_ms / max(1, k_n)
         achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, world, kname),
                 "algorithmic_bytes_per_launch": alg_bytes, "launches": k_n, "ms_per_launch": per_launch_ms}
+        if args.workload != "bm25" and not gemm:
+            roof["queries_per_launch"] = q_launch
         if args.workload != "bm25" and args.dense_mode == "f32" and eng.scan_arith() == "f32" and q_launch > 32:
             # exact-f32 products at 64 queries per sweep: v_mfma_f32_16x16x4_f32 runs at the f32 vector rate
             # (157.3 TFLOP/s, MI355X_MICROARCH.md), which binds before HBM does (2 * 768 flop per row and query)

@@ -24,54 +24,79 @@ constexpr int RR_MAXC = 10;           // scratch slots per candidate (MSR_RERANK
 constexpr int RR_THREADS = 1024;
 constexpr int RR_MAXM = 1024;
 
+// One workgroup (4 waves) per query and block of 64 candidate slots: wave 0 sorts the slots into "mine" (the document lies in
+// this shard) and "not mine" (zeros: the owner's words arrive through the join of the shards' halves), then the waves share the
+// slots that are mine, one candidate at a time per wave.  (One wave per slot, as before, launches N times the waves a rank of an
+// N-way sharded run has work for: 2 M waves per 2048-query step at N = 8, most of which only wrote zeros.)
+constexpr int RC_SLOTS = 64;
 template <bool TILED>
-__global__ __launch_bounds__(64) void rerank_cos_kernel(DenseIndex ix, const int32_t* __restrict__ url_group,
-                                                         const float* __restrict__ qn,
-                                                         const int32_t* __restrict__ cand_doc,
-                                                         const int32_t* __restrict__ cand_n, int max_cand,
-                                                         int doc_base, int row_base, int max_chunks,
-                                                         float* __restrict__ cos_out, int32_t* __restrict__ meta) {
+__global__ __launch_bounds__(256) void rerank_cos_kernel(DenseIndex ix, const int32_t* __restrict__ url_group,
+                                                          const float* __restrict__ qn,
+                                                          const int32_t* __restrict__ cand_doc,
+                                                          const int32_t* __restrict__ cand_n, int max_cand,
+                                                          int doc_base, int row_base, int max_chunks,
+                                                          float* __restrict__ cos_out, int32_t* __restrict__ meta) {
     // cand_doc holds GLOBAL document indices; this shard owns [doc_base, doc_base + n_docs).
-    const int q = blockIdx.y, m = blockIdx.x, lane = threadIdx.x;
-    float* out = cos_out + ((int64_t)q * max_cand + m) * RR_MAXC;
-    int32_t* mt = meta + ((int64_t)q * max_cand + m) * 3;
-    const int d = m < cand_n[q] ? cand_doc[(int64_t)q * max_cand + m] - doc_base : -1;
-    if (d < 0 || d >= ix.n_docs) {                       // not a candidate, or owned by another shard
-        if (lane < RR_MAXC) out[lane] = 0.f;
-        if (lane < 3) mt[lane] = 0;
-        return;
+    __shared__ int32_t s_doc[RC_SLOTS], s_slot[RC_SLOTS];
+    __shared__ int s_n;
+    const int q = blockIdx.y, m0 = blockIdx.x * RC_SLOTS, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (w == 0) {
+        const int m = m0 + lane;
+        int d = -1;
+        if (m < max_cand && m < cand_n[q]) d = cand_doc[(int64_t)q * max_cand + m] - doc_base;
+        const bool own = d >= 0 && d < ix.n_docs;
+        const unsigned long long mask = __ballot(own);
+        if (own) {
+            const int pos = __popcll(mask & ((1ull << lane) - 1ull));
+            s_doc[pos] = d; s_slot[pos] = m;
+        } else if (m < max_cand) {                       // not a candidate, or owned by another shard
+            float* out = cos_out + ((int64_t)q * max_cand + m) * RR_MAXC;
+            int32_t* mt = meta + ((int64_t)q * max_cand + m) * 3;
+#pragma unroll
+            for (int i = 0; i < RR_MAXC; ++i) out[i] = 0.f;
+            mt[0] = 0; mt[1] = 0; mt[2] = 0;
+        }
+        if (lane == 0) s_n = __popcll(mask);
     }
-    const int64_t ds = ix.doc_off[d];
-    int64_t de = ix.doc_off[d + 1];
-    if (ds + max_chunks < de) de = ds + max_chunks;
-    if (lane == 0) {
-        mt[0] = (int32_t)(de - ds);                      // chunk rows that take part (<= max_chunks)
-        // URL group + 2, so that after the cross-shard sum 0 = nobody owns it, 1 = owned, not in urlsDB
-        mt[1] = (url_group ? url_group[d] : d + doc_base) + 2;
-        mt[2] = (int32_t)ds + row_base;                  // global row of the document's first chunk
-    }
-    if (lane >= (int)(de - ds) && lane < RR_MAXC) out[lane] = 0.f;
+    __syncthreads();
+    const int n_own = s_n;
+    if (w >= n_own) return;
     const f32x4* q4 = (const f32x4*)(qn + (size_t)q * MSR_DIM);
     const f32x4 qa = q4[lane], qb = q4[lane + 64], qc = q4[lane + 128];
-    for (int64_t c = ds; c < de; ++c) {
-        f32x4 a, b, e;
-        if (TILED) {
-            const f32x4* base = (const f32x4*)(ix.emb + (size_t)(c >> 4) * (16 * MSR_DIM));
-            const int i = (int)(c & 15);
-            // float4 number v of the row (dims 4v..4v+3) lives at block t = v >> 2, lane 16 (v & 3) + i
-            const int v0 = lane, v1 = lane + 64, v2 = lane + 128;
-            a = base[(v0 >> 2) * 64 + (v0 & 3) * 16 + i];
-            b = base[(v1 >> 2) * 64 + (v1 & 3) * 16 + i];
-            e = base[(v2 >> 2) * 64 + (v2 & 3) * 16 + i];
-        } else {
-            const f32x4* p = (const f32x4*)(ix.emb + (size_t)c * MSR_DIM);
-            a = p[lane]; b = p[lane + 64]; e = p[lane + 128];
+    for (int it = w; it < n_own; it += 4) {
+        const int d = s_doc[it], m = s_slot[it];
+        float* out = cos_out + ((int64_t)q * max_cand + m) * RR_MAXC;
+        int32_t* mt = meta + ((int64_t)q * max_cand + m) * 3;
+        const int64_t ds = ix.doc_off[d];
+        int64_t de = ix.doc_off[d + 1];
+        if (ds + max_chunks < de) de = ds + max_chunks;
+        if (lane == 0) {
+            mt[0] = (int32_t)(de - ds);                      // chunk rows that take part (<= max_chunks)
+            // URL group + 2, so that after the join of the shards' halves 0 = nobody owns it, 1 = owned, not in urlsDB
+            mt[1] = (url_group ? url_group[d] : d + doc_base) + 2;
+            mt[2] = (int32_t)ds + row_base;                  // global row of the document's first chunk
         }
-        float s = a.x * qa.x + a.y * qa.y + a.z * qa.z + a.w * qa.w;
-        s += b.x * qb.x + b.y * qb.y + b.z * qb.z + b.w * qb.w;
-        s += e.x * qc.x + e.y * qc.y + e.z * qc.z + e.w * qc.w;
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) out[c - ds] = s * ix.inv_norm[c];
+        if (lane >= (int)(de - ds) && lane < RR_MAXC) out[lane] = 0.f;
+        for (int64_t c = ds; c < de; ++c) {
+            f32x4 a, b, e;
+            if (TILED) {
+                const f32x4* base = (const f32x4*)(ix.emb + (size_t)(c >> 4) * (16 * MSR_DIM));
+                const int i = (int)(c & 15);
+                // float4 number v of the row (dims 4v..4v+3) lives at block t = v >> 2, lane 16 (v & 3) + i
+                const int v0 = lane, v1 = lane + 64, v2 = lane + 128;
+                a = base[(v0 >> 2) * 64 + (v0 & 3) * 16 + i];
+                b = base[(v1 >> 2) * 64 + (v1 & 3) * 16 + i];
+                e = base[(v2 >> 2) * 64 + (v2 & 3) * 16 + i];
+            } else {
+                const f32x4* p = (const f32x4*)(ix.emb + (size_t)c * MSR_DIM);
+                a = p[lane]; b = p[lane + 64]; e = p[lane + 128];
+            }
+            float s = a.x * qa.x + a.y * qa.y + a.z * qa.z + a.w * qa.w;
+            s += b.x * qb.x + b.y * qb.y + b.z * qb.z + b.w * qb.w;
+            s += e.x * qc.x + e.y * qc.y + e.z * qc.z + e.w * qc.w;
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (lane == 0) out[c - ds] = s * ix.inv_norm[c];
+        }
     }
 }
 
@@ -243,12 +268,12 @@ hipError_t msr_rerank_gather(const DenseIndex& ix, const int32_t* url_group, con
                              int row_base, int max_chunks, float* cos_out, int32_t* meta, hipStream_t stream) {
     if (nq <= 0) return hipSuccess;
     if (max_cand <= 0 || max_cand > RR_MAXM || max_chunks <= 0 || max_chunks > RR_MAXC) return hipErrorInvalidValue;
-    dim3 grid((unsigned)max_cand, (unsigned)nq);
+    dim3 grid((unsigned)((max_cand + RC_SLOTS - 1) / RC_SLOTS), (unsigned)nq);
     if (ix.layout == 1)
-        rerank_cos_kernel<true><<<grid, 64, 0, stream>>>(ix, url_group, qn, cand_doc, cand_n, max_cand, doc_base,
+        rerank_cos_kernel<true><<<grid, 256, 0, stream>>>(ix, url_group, qn, cand_doc, cand_n, max_cand, doc_base,
                                                          row_base, max_chunks, cos_out, meta);
     else
-        rerank_cos_kernel<false><<<grid, 64, 0, stream>>>(ix, url_group, qn, cand_doc, cand_n, max_cand, doc_base,
+        rerank_cos_kernel<false><<<grid, 256, 0, stream>>>(ix, url_group, qn, cand_doc, cand_n, max_cand, doc_base,
                                                           row_base, max_chunks, cos_out, meta);
     return hipGetLastError();
 }

@@ -467,6 +467,12 @@ __device__ void bitonic_desc_pay(uint64_t* khi, uint32_t* klo, int32_t* pay, int
     }
 }
 
+// Merge of n_parts lists of <= k records, EACH SORTED by (score descending, index ascending) -- what every *_topk entry
+// point returns -- into the k best.  One workgroup per query.  The lists sit side by side in LDS (Pk = k rounded up to a power
+// of two entries each, missing lists and tails filled with the smallest key) and are reduced pairwise: the element-wise
+// maximum of list A and the REVERSED list B is a bitonic sequence that holds the Pk best of both, log2 Pk compare-exchange
+// stages put it in order again.  log2(parts) rounds on half as many lists each: 33 stages over 5 k + 2.5 k + 1.3 k entries
+// for 8 x 1000 records instead of the 91 stages over 8192 entries of a full sort.
 template <typename T>
 __global__ __launch_bounds__(SCAN_THREADS) void merge_kernel(const int32_t* __restrict__ in_doc,
                                                               const T* __restrict__ in_score,
@@ -478,9 +484,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void merge_kernel(const int32_t* __re
                                                               int32_t* __restrict__ out_pay) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int q = blockIdx.x;
-    const int total = n_parts * k;
-    int P = 64;
-    while (P < total) P <<= 1;
+    int lg = 6;
+    while ((1 << lg) < k) ++lg;
+    const int Pk = 1 << lg;                                       // entries per list
+    int NP = 1;
+    while (NP < n_parts) NP <<= 1;                                // lists, phantom ones included
+    const int P = NP * Pk;
     uint64_t* khi = (uint64_t*)smem;
     uint32_t* klo = (uint32_t*)(smem + (size_t)P * 8);
     int32_t* pay = (int32_t*)(smem + (size_t)P * 12);            // (only touched when in_pay is given)
@@ -500,8 +509,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void merge_kernel(const int32_t* __re
     }
     for (int i = threadIdx.x; i < P; i += SCAN_THREADS) {
         uint64_t h = 0; uint32_t l = 0; int32_t v = -1;
-        if (i < total) {
-            const int p = i / k, r = i % k;
+        const int p = i >> lg, r = i & (Pk - 1);
+        if (p < n_parts && r < k) {
             int c = part(in_n, p, nq)[q];
             if (r < c) {
                 const int64_t off = (int64_t)q * k + r;
@@ -517,8 +526,31 @@ __global__ __launch_bounds__(SCAN_THREADS) void merge_kernel(const int32_t* __re
         if (in_pay) pay[i] = v;
     }
     __syncthreads();
-    if (in_pay) bitonic_desc_pay<SCAN_THREADS>(khi, klo, pay, P);
-    else bitonic_desc<SCAN_THREADS>(khi, klo, P);
+    auto less = [&](int x, int y) { return khi[x] < khi[y] || (khi[x] == khi[y] && klo[x] < klo[y]); };
+    for (int step = 1; step < NP; step <<= 1) {                   // lists a = 2 m step and b = a + step -> a
+        const int n_pairs = NP / (2 * step);
+        for (int idx = threadIdx.x; idx < (n_pairs << lg); idx += SCAN_THREADS) {
+            const int m = idx >> lg, i = idx & (Pk - 1);
+            const int ai = ((2 * m * step) << lg) + i, bi = ((2 * m * step + step) << lg) + (Pk - 1 - i);
+            if (less(ai, bi)) {
+                khi[ai] = khi[bi]; klo[ai] = klo[bi];
+                if (in_pay) pay[ai] = pay[bi];
+            }
+        }
+        __syncthreads();
+        for (int j = Pk >> 1; j > 0; j >>= 1) {
+            for (int idx = threadIdx.x; idx < (n_pairs << (lg - 1)); idx += SCAN_THREADS) {
+                const int m = idx >> (lg - 1), t = idx & ((Pk >> 1) - 1);
+                const int a0 = ((2 * m * step) << lg) + (((t & ~(j - 1)) << 1) | (t & (j - 1))), b0 = a0 + j;
+                if (less(a0, b0)) {
+                    const uint64_t h = khi[a0]; khi[a0] = khi[b0]; khi[b0] = h;
+                    const uint32_t l = klo[a0]; klo[a0] = klo[b0]; klo[b0] = l;
+                    if (in_pay) { const int32_t v = pay[a0]; pay[a0] = pay[b0]; pay[b0] = v; }
+                }
+            }
+            __syncthreads();
+        }
+    }
     const int n_sel = n_valid < k ? n_valid : k;
     for (int i = threadIdx.x; i < k; i += SCAN_THREADS) {
         const bool ok = i < n_sel && !(khi[i] == 0 && klo[i] == 0);
@@ -551,10 +583,11 @@ hipError_t msr_select_topk_list(const double* scores, const int32_t* idx, const 
 hipError_t msr_merge_lists(int score_bits, const int32_t* in_doc, const void* in_score, const int32_t* in_n,
                            const int32_t* in_pay, int n_parts, int64_t part_stride_bytes, int nq, int k, int32_t* out_doc,
                            void* out_score, int32_t* out_n, int32_t* out_pay, hipStream_t stream) {
-    const int total = n_parts * k;
-    int P = 64;
-    while (P < total) P <<= 1;
-    const size_t lds = (size_t)P * (in_pay ? 16 : 12);
+    if (n_parts < 1 || k < 1) return hipErrorInvalidValue;
+    int Pk = 64, NP = 1;                                // the kernel's layout: NP lists of Pk entries
+    while (Pk < k) Pk <<= 1;
+    while (NP < n_parts) NP <<= 1;
+    const size_t lds = (size_t)NP * Pk * (in_pay ? 16 : 12);
     if (lds > 150 * 1024) return hipErrorInvalidValue;
     if (score_bits == 32) {
         if (lds > 48 * 1024)
