@@ -24,47 +24,44 @@ constexpr int RR_MAXC = 10;           // scratch slots per candidate (MSR_RERANK
 constexpr int RR_THREADS = 1024;
 constexpr int RR_MAXM = 1024;
 
-// One workgroup (4 waves) per query and block of 64 candidate slots: wave 0 sorts the slots into "mine" (the document lies in
-// this shard) and "not mine" (zeros: the owner's words arrive through the join of the shards' halves), then the waves share the
-// slots that are mine, one candidate at a time per wave.  (One wave per slot, as before, launches N times the waves a rank of an
-// N-way sharded run has work for: 2 M waves per 2048-query step at N = 8, most of which only wrote zeros.)
-constexpr int RC_SLOTS = 64;
+// One wave per query and block of 8 candidate slots: lanes 0 .. 7 sort the slots into "mine" (the document lies in this
+// shard) and "not mine" (zeros: the owner's words arrive through the join of the shards' halves), then the wave takes the
+// slots that are mine one after the other.  (One wave per slot, as before, launches N times the waves a rank of an N-way
+// sharded run has work for -- 2 M waves per 2048-query step at N = 8, most of which only wrote zeros: 2.2 ms instead of 0.7;
+// workgroups of several waves sharing a block lose 12 % on the unsharded corpus, where every slot is work: a workgroup
+// keeps its place on the CU until its slowest wave is done.)
+constexpr int RC_SLOTS = 8;
 template <bool TILED>
-__global__ __launch_bounds__(256) void rerank_cos_kernel(DenseIndex ix, const int32_t* __restrict__ url_group,
-                                                          const float* __restrict__ qn,
-                                                          const int32_t* __restrict__ cand_doc,
-                                                          const int32_t* __restrict__ cand_n, int max_cand,
-                                                          int doc_base, int row_base, int max_chunks,
-                                                          float* __restrict__ cos_out, int32_t* __restrict__ meta) {
+__global__ __launch_bounds__(64) void rerank_cos_kernel(DenseIndex ix, const int32_t* __restrict__ url_group,
+                                                         const float* __restrict__ qn,
+                                                         const int32_t* __restrict__ cand_doc,
+                                                         const int32_t* __restrict__ cand_n, int max_cand,
+                                                         int doc_base, int row_base, int max_chunks,
+                                                         float* __restrict__ cos_out, int32_t* __restrict__ meta) {
     // cand_doc holds GLOBAL document indices; this shard owns [doc_base, doc_base + n_docs).
-    __shared__ int32_t s_doc[RC_SLOTS], s_slot[RC_SLOTS];
-    __shared__ int s_n;
-    const int q = blockIdx.y, m0 = blockIdx.x * RC_SLOTS, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (w == 0) {
+    const int q = blockIdx.y, m0 = blockIdx.x * RC_SLOTS, lane = threadIdx.x;
+    int d_mine = -1;
+    {
         const int m = m0 + lane;
-        int d = -1;
-        if (m < max_cand && m < cand_n[q]) d = cand_doc[(int64_t)q * max_cand + m] - doc_base;
-        const bool own = d >= 0 && d < ix.n_docs;
-        const unsigned long long mask = __ballot(own);
-        if (own) {
-            const int pos = __popcll(mask & ((1ull << lane) - 1ull));
-            s_doc[pos] = d; s_slot[pos] = m;
-        } else if (m < max_cand) {                       // not a candidate, or owned by another shard
+        const bool slot = lane < RC_SLOTS && m < max_cand;
+        if (slot && m < cand_n[q]) d_mine = cand_doc[(int64_t)q * max_cand + m] - doc_base;
+        const bool own = d_mine >= 0 && d_mine < ix.n_docs;
+        if (!own) d_mine = -1;
+        if (slot && !own) {                              // not a candidate, or owned by another shard
             float* out = cos_out + ((int64_t)q * max_cand + m) * RR_MAXC;
             int32_t* mt = meta + ((int64_t)q * max_cand + m) * 3;
 #pragma unroll
             for (int i = 0; i < RR_MAXC; ++i) out[i] = 0.f;
             mt[0] = 0; mt[1] = 0; mt[2] = 0;
         }
-        if (lane == 0) s_n = __popcll(mask);
     }
-    __syncthreads();
-    const int n_own = s_n;
-    if (w >= n_own) return;
+    unsigned long long todo = __ballot(d_mine >= 0);
+    if (todo == 0) return;
     const f32x4* q4 = (const f32x4*)(qn + (size_t)q * MSR_DIM);
     const f32x4 qa = q4[lane], qb = q4[lane + 64], qc = q4[lane + 128];
-    for (int it = w; it < n_own; it += 4) {
-        const int d = s_doc[it], m = s_slot[it];
+    for (; todo != 0; todo &= todo - 1) {
+        const int sl = __builtin_ctzll(todo);            // (wave-uniform)
+        const int d = __builtin_amdgcn_readlane(d_mine, sl), m = m0 + sl;
         float* out = cos_out + ((int64_t)q * max_cand + m) * RR_MAXC;
         int32_t* mt = meta + ((int64_t)q * max_cand + m) * 3;
         const int64_t ds = ix.doc_off[d];
@@ -270,10 +267,10 @@ hipError_t msr_rerank_gather(const DenseIndex& ix, const int32_t* url_group, con
     if (max_cand <= 0 || max_cand > RR_MAXM || max_chunks <= 0 || max_chunks > RR_MAXC) return hipErrorInvalidValue;
     dim3 grid((unsigned)((max_cand + RC_SLOTS - 1) / RC_SLOTS), (unsigned)nq);
     if (ix.layout == 1)
-        rerank_cos_kernel<true><<<grid, 256, 0, stream>>>(ix, url_group, qn, cand_doc, cand_n, max_cand, doc_base,
+        rerank_cos_kernel<true><<<grid, 64, 0, stream>>>(ix, url_group, qn, cand_doc, cand_n, max_cand, doc_base,
                                                          row_base, max_chunks, cos_out, meta);
     else
-        rerank_cos_kernel<false><<<grid, 256, 0, stream>>>(ix, url_group, qn, cand_doc, cand_n, max_cand, doc_base,
+        rerank_cos_kernel<false><<<grid, 64, 0, stream>>>(ix, url_group, qn, cand_doc, cand_n, max_cand, doc_base,
                                                           row_base, max_chunks, cos_out, meta);
     return hipGetLastError();
 }
