@@ -630,6 +630,8 @@ def main():
         achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, world, kname),
+                "traffic_source": "profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on an "
+                                  "earlier run (not measured by this process); null: no such measurement for this kernel and workload",
                 "algorithmic_bytes_per_launch": alg_bytes, "launches": k_n, "ms_per_launch": per_launch_ms}
         if args.workload != "bm25" and not gemm:
             roof["queries_per_launch"] = q_launch

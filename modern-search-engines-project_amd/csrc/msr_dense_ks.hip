@@ -59,6 +59,8 @@ template <int QB, int MODE, int NBUF, int PIPE, int RING_DOCS, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void dense_ksplit_kernel(DenseIndex ix, const void* __restrict__ emb,
                                                            const f32x4* __restrict__ qimg, int nq,
                                                            float* __restrict__ docscore, int dbg) {
+    // blockIdx.y = slice of 16 QB queries of the call (one slice in every launch but the gated fallback of the streaming
+    // pass, msr_dense_scan_slices: there a slice runs only if its gate word is up)
     using L = KsCfg<QB, MODE, RING_DOCS, NWAVES>;
     constexpr int KT = L::KT, NLU = L::NLU, PIECES = L::PIECES, NQ = L::NQ, RING = L::RING, PER = L::PER;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -75,7 +77,11 @@ __global__ __launch_bounds__(NWAVES * 64) void dense_ksplit_kernel(DenseIndex ix
     const bool pw = red && (PIPE == 1 || (PIPE == 2 && w >= 4));
     const int s = blockIdx.x;
     if (s >= ix.n_spans) return;                                 // workgroup-uniform
-    if (ix.gate && *ix.gate == 0) return;                        // a fallback launch that is not needed (msr_engine.hip)
+    const int sl = blockIdx.y;
+    if (ix.gate && ix.gate[sl] == 0) return;                     // a fallback slice that is not needed (msr_engine.hip)
+    qimg += (size_t)sl * (QB * L::KS * PIECES * 64);
+    docscore += (int64_t)sl * NQ * ix.score_stride;
+    nq = nq - sl * NQ < NQ ? nq - sl * NQ : NQ;
     const int64_t C = ix.n_chunks;
     const float NEG_INF = -__builtin_inff();
     const int d0 = ix.span_doc[s], d1 = ix.span_doc[s + 1];
@@ -340,16 +346,18 @@ int ks_pipe_knob(int dflt) {
 
 template <int QB, int MODE, int NBUF, int PIPE = 1, int RING_DOCS = MSR_WIDE_RING, int NWAVES = 8>
 hipError_t launch_ksplit(const DenseIndex& ix, const void* emb, const float* qn, int nq, float* docscore,
-                         hipStream_t stream) {
+                         hipStream_t stream, int n_slices = 1, void* qimg_slices = nullptr) {
     using L = KsCfg<QB, MODE, RING_DOCS, NWAVES>;
     static_assert(L::total <= 160 * 1024, "LDS budget");
     hipError_t err = hipFuncSetAttribute((const void*)dense_ksplit_kernel<QB, MODE, NBUF, PIPE, RING_DOCS, NWAVES>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::total);
     if (err != hipSuccess) return err;
-    err = msr_build_qimage(MODE == MODE_PRE ? MODE_F16X2 : MODE, qn, QB, ix.qimg, stream);
+    void* qimg = qimg_slices ? qimg_slices : ix.qimg;           // (ix.qimg holds ONE slice's image)
+    err = msr_build_qimage(MODE == MODE_PRE ? MODE_F16X2 : MODE, qn, QB * n_slices, qimg, stream);
     if (err != hipSuccess) return err;
-    dense_ksplit_kernel<QB, MODE, NBUF, PIPE, RING_DOCS, NWAVES><<<ix.n_spans, L::THREADS, L::total, stream>>>(
-        ix, emb, (const f32x4*)ix.qimg, nq, docscore, scan_debug_flags());
+    dense_ksplit_kernel<QB, MODE, NBUF, PIPE, RING_DOCS, NWAVES><<<dim3((unsigned)ix.n_spans, (unsigned)n_slices), L::THREADS,
+                                                                 L::total, stream>>>(
+        ix, emb, (const f32x4*)qimg, nq, docscore, scan_debug_flags());
     return hipGetLastError();
 }
 
@@ -387,6 +395,17 @@ hipError_t msr_dense_scan_wide(const DenseIndex& ix, const float* qn, int nq, fl
 #endif
     (void)pipe;
     return launch_ksplit<4, MODE_F16X2, 2, 0, MSR_WIDE_RING, 12>(ix, ix.emb, qn, nq, docscore, stream);
+}
+
+// The gated fallback behind the streaming pass: ceil(nq / 64) slices of 64 queries in ONE launch (grid.y = slice), slice s
+// gated on ix.gate[s]; qn holds the normalised queries padded with zero rows to a multiple of 64, qimg_slices room for
+// msr_ksplit_slice_image_bytes() per slice, docscore 64 rows per slice.  f16-split products (the 64-query instance).
+size_t msr_ksplit_slice_image_bytes() { return (size_t)4 * KsCfg<4, MODE_F16X2, MSR_WIDE_RING, 12>::KS * 2 * 64 * 16; }
+hipError_t msr_dense_scan_slices(const DenseIndex& ix, const float* qn, int nq, float* docscore, void* qimg_slices,
+                                 hipStream_t stream) {
+    if (nq <= 0 || ix.n_docs <= 0) return hipSuccess;
+    if (ix.layout != 0 || !ix.wide_ok || !ix.row_meta || !ix.gate || !qimg_slices || ix.variant != 14) return hipErrorInvalidValue;
+    return launch_ksplit<4, MODE_F16X2, 2, 0, MSR_WIDE_RING, 12>(ix, ix.emb, qn, nq, docscore, stream, (nq + 63) / 64, qimg_slices);
 }
 
 // f32 rows, exact f32 products (v_mfma_f32_16x16x4_f32), up to 64 queries per sweep: matrix-core bound above 32 queries.

@@ -61,7 +61,7 @@ struct msr_engine {
     float* gf_thr = nullptr; float* gf_thr2 = nullptr; int32_t* gf_flag = nullptr; void* gf_wvbuf = nullptr;
     int32_t* gf_wv_count = nullptr; void* gf_pairs = nullptr; int32_t* gf_pair_n = nullptr; int32_t* gf_gate = nullptr;
     uint32_t* gf_err = nullptr; float* gf_margin = nullptr; int32_t* gf_cand_doc = nullptr; float* gf_cand_score = nullptr;
-    int32_t* gf_cand_chunk = nullptr; int32_t* gf_cand_n = nullptr; float* gf_qn = nullptr;
+    int32_t* gf_cand_chunk = nullptr; int32_t* gf_cand_n = nullptr; float* gf_qn = nullptr; void* gf_fb_qimg = nullptr;
     // batched path as a tiled GEMM (msr_gemm.hip): unit-row bf16 image + tile table + scratch for GM_SLICE queries per pass
     GemmIndex gemm{};
     bool gemm_ok = false;
@@ -124,6 +124,7 @@ static void free_gf(msr_engine* e) {
     free_dev(e->gf_flag); free_dev(e->gf_wvbuf); free_dev(e->gf_wv_count); free_dev(e->gf_pairs); free_dev(e->gf_pair_n);
     free_dev(e->gf_gate); free_dev(e->gf_err); free_dev(e->gf_margin); free_dev(e->gf_cand_doc); free_dev(e->gf_cand_score);
     free_dev(e->gf_cand_chunk); free_dev(e->gf_cand_n); free_dev(e->gf_qn); e->gf_qn = nullptr;
+    free_dev(e->gf_fb_qimg); e->gf_fb_qimg = nullptr;
     e->gf_err = nullptr; e->gf_margin = nullptr; e->gf_cand_doc = nullptr; e->gf_cand_score = nullptr; e->gf_cand_chunk = nullptr;
     e->gf_cand_n = nullptr;
     e->tile_row = nullptr; e->gf_inv_pad = nullptr; e->gf_qimg = nullptr; e->gf_tmax_t = nullptr; e->gf_tmax = nullptr;
@@ -542,6 +543,7 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
         if ((herr = alloc((void**)&e->gf_inv_pad, (size_t)(n_chunks + 512) * 4)) != hipSuccess ||
             (herr = alloc(&e->gf_qimg, (size_t)groups * 24 * 8192)) != hipSuccess ||
             (herr = alloc((void**)&e->gf_qn, (QM + 64) * MSR_DIM * 4)) != hipSuccess ||
+            (herr = alloc(&e->gf_fb_qimg, (QM + 63) / 64 * msr_ksplit_slice_image_bytes())) != hipSuccess ||
             (herr = alloc((void**)&e->gf_tmax_t, (size_t)n_tiles * 8 * (groups >= 2 ? 256 * max_nt : 128) * 4)) != hipSuccess ||   // [tile][wave][queries of a launch]
             (herr = alloc((void**)&e->gf_tmax, QM * stride * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gf_thr, QM * 4)) != hipSuccess ||
@@ -741,11 +743,8 @@ extern "C" int msr_dense_topk(msr_engine* e, const float* q, int32_t n_queries, 
             // slice's word is up.  When no gate is up (the normal case) all these launches return at once.
             {
                 DenseIndex ix = e->dense;
-                for (int s0 = 0; s0 < nq; s0 += 64) {
-                    ix.gate = e->gf_gate + s0 / 64;
-                    HIP_TRY(e, msr_dense_scan(ix, e->gf_qn + (int64_t)s0 * MSR_DIM, std::min(64, nq - s0), 0,
-                                              (float*)e->score_rows + (int64_t)s0 * e->dense.score_stride, st));
-                }
+                ix.gate = e->gf_gate;
+                HIP_TRY(e, msr_dense_scan_slices(ix, e->gf_qn, nq, (float*)e->score_rows, e->gf_fb_qimg, st));
                 SelScratch sel = e->sel;
                 sel.gate = e->gf_gate; sel.gate_per64 = 1;
                 HIP_TRY(e, msr_select_topk(32, e->score_rows, N, e->dense.score_stride, nq, k, sel, out_doc + (int64_t)q0 * k,
@@ -827,7 +826,7 @@ extern "C" int msr_enable_bf16(msr_engine* e, void* stream) {
         if ((herr = alloc(&e->gm_qmat, (size_t)GM_SLICE * MSR_DIM * 2)) != hipSuccess ||
             (herr = alloc((void**)&e->gm_qn, (size_t)GM_SLICE * MSR_DIM * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gm_tmax, (size_t)GM_SLICE * stride * 4)) != hipSuccess ||
-            (herr = alloc((void**)&e->gm_tmax_t, (size_t)n_tiles * 8 * GM_SLICE * 4)) != hipSuccess ||     // [tile][wave][query]
+            (herr = alloc((void**)&e->gm_tmax_t, (size_t)n_tiles * GM_SLICE * 4)) != hipSuccess ||     // [tile][query]
             (herr = alloc((void**)&e->gm_thr, (size_t)GM_SLICE * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gm_thr2, (size_t)GM_SLICE * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gm_flag, (size_t)GM_SLICE * 4)) != hipSuccess ||

@@ -716,14 +716,14 @@ hipError_t msr_gemm_candidates(const GemmIndex& g, const DenseIndex& ix, const f
         if (ev && (err = hipEventRecord(ev[0], stream)) != hipSuccess) return err;
         if ((err = msr_stream256_bf16_launch(false, a, grid, stream)) != hipSuccess) return err;
         if (ev && (err = hipEventRecord(ev[1], stream)) != hipSuccess) return err;
-        gemm_tmax_kernel<<<dim3((n_s + 31) / 32, nq_pad / 32), 256, 0, stream>>>(g.tmax_t, n_s, 8, nq_pad, (float*)g.tmax, g.tmax_stride);
+        gemm_tmax_kernel<<<dim3((n_s + 31) / 32, nq_pad / 32), 256, 0, stream>>>(g.tmax_t, n_s, 1, nq_pad, (float*)g.tmax, g.tmax_stride);
         gemm_kth_kernel<<<nq_pad, 1024, 0, stream>>>((const float*)g.tmax, n_s, g.tmax_stride, nq, k, margin, g.thr, g.flag);
         a.t_first = 0; a.t_stride = 1; a.t_count = g.n_tiles;
         a.thr = g.thr; a.wvbuf = g.wgbuf; a.wv_cap = g.wv_cap; a.wv_count = g.wv_count;
         if (ev && (err = hipEventRecord(ev[2], stream)) != hipSuccess) return err;
         if ((err = msr_stream256_bf16_launch(true, a, grid, stream)) != hipSuccess) return err;
         if (ev && (err = hipEventRecord(ev[3], stream)) != hipSuccess) return err;
-        gemm_tmax_kernel<<<dim3((g.n_tiles + 31) / 32, nq_pad / 32), 256, 0, stream>>>(g.tmax_t, g.n_tiles, 8, nq_pad, (float*)g.tmax, g.tmax_stride);
+        gemm_tmax_kernel<<<dim3((g.n_tiles + 31) / 32, nq_pad / 32), 256, 0, stream>>>(g.tmax_t, g.n_tiles, 1, nq_pad, (float*)g.tmax, g.tmax_stride);
         gemm_kth_kernel<<<nq_pad, 1024, 0, stream>>>((const float*)g.tmax, g.n_tiles, g.tmax_stride, nq, k, margin, g.thr2, nullptr);
     }
     // ---- finish: bucket, per-document maxima, candidates ----

@@ -325,7 +325,14 @@ constexpr int G2_THREADS = 512;
 constexpr int G2_NB = 4;                        // K steps per query block (= the depth of the row ring)
 constexpr int G2_STEP = 16384;                  // bytes of one K step of the image: 256 queries x 64 B
 constexpr int G2_BLK = G2_NB * G2_STEP;         // 64 KB
-constexpr int G2_LDS = 2 * G2_BLK + 1024 + 8 * 256;   // + the 256 emission thresholds + 64 inverse row norms per wave
+constexpr int G2_TMX = 2 * G2_BLK + 1024 + 8 * 256;   // offset of the tile maxima (below)
+constexpr int G2_LDS = G2_TMX + 2 * 1024;             // + the 256 emission thresholds + 64 inverse row norms per wave + 2 x 256 tile maxima
+// tile maxima are joined across the workgroup's waves in LDS as unsigned keys that order like the floats (atomic max on words)
+__device__ __forceinline__ uint32_t ord_key(float x) {
+    const uint32_t b = __float_as_uint(x);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ord_val(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
 
 // a 16-byte global load in the scalar-base + 32-bit lane-offset form: one register per row pointer instead of two
 template <int OFF>
@@ -379,7 +386,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
     constexpr int KPS = BF16 ? 2 : 1;                              // K steps per ring slot
     constexpr int RSLOTS = G2_NB / KPS;                            // ring slots = one query block's worth of rows
     constexpr int NMI = 2, NNI = 16;                               // the wave's fragments: 32 rows x 256 queries
-    constexpr int WROWS = 16 * NMI, NPARTS = 256 / WROWS;          // rows per wave; row groups per tile (tmax_t's middle index)
+    constexpr int WROWS = 16 * NMI;                                // rows per wave
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = w, wc = 0;                                      // row group, query half (none)
@@ -411,6 +418,22 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
     const int q_base = a.q_base + grp * 256;
     float* thr_lds = (float*)(smem + 2 * G2_BLK);
     if (EMIT && tid < 256) thr_lds[tid] = a.thr[grp * 256 + tid];
+    // Tile maxima, bf16 rows (1024 queries per pass: eight rows of maxima per tile would be 640 MB of writes per pass): the
+    // eight waves' maxima of a (tile, query) are joined in LDS (atomic max on order-preserving keys; two sets, by tile
+    // parity) and written as ONE row of 256 per tile -- after the first barrier of the NEXT tile, which every wave passes
+    // only with its epilogue behind it.  f32 rows (160 MB per 256-query pass, 1 % of its traffic): every wave stores its own
+    // row as before -- the join costs the pass 1.3 % and saves the transposing kernel the same.
+    constexpr bool JOIN = BF16;
+    uint32_t* tmx = (uint32_t*)(smem + G2_TMX);
+    if (JOIN) tmx[tid] = 0u;                            // (512 threads, 2 x 256 keys; 0 orders below every float)
+    auto flush_tmax = [&](int tile_j, int par) {        // wave w: queries 32 w .. + 31 of the tile whose maxima sit in set par
+        const int ln = (int)fresh_lane();               // (not the kernel's `lane`: nothing here is worth a register held across the kernel)
+        if (ln < 32) {
+            uint32_t* slot = tmx + par * 256 + w * 32 + ln;
+            a.tmax_t[(size_t)tile_j * nq_pad + grp * 256 + w * 32 + ln] = ord_val(*slot);
+            *slot = 0u;
+        }
+    };
     // the wave's 32 inverse row norms of a tile go through LDS: one DMA in the tile's last block (all 64 lanes take part: 64
     // floats, the upper half belongs to the next wave's rows and is not used; inv_pad is padded by 512 entries)
     float* inv_lds = (float*)(smem + 2 * G2_BLK + 1024) + w * 64;
@@ -590,6 +613,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
         frag(std::integral_constant<int, 12>{}); frag(std::integral_constant<int, 13>{});
         frag(std::integral_constant<int, 14>{}); frag(std::integral_constant<int, 15>{});
     };
+    int jt_prev = jt;
     for (int it = 0; it < n_mine; ++it) {
 #pragma unroll 1
         for (int kb = 0; kb < NKB; ++kb) {
@@ -606,6 +630,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
             else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             wg_barrier();
             pb ^= 1;
+            if (JOIN && kb == 0 && it > 0) flush_tmax(jt_prev, (it - 1) & 1);
         }
         // (the inverse norms were requested three steps ago and are older than the last 12 row loads; the lanes read what
         // their own wave's DMA wrote: no barrier.  Unit-row image: nothing to scale with)
@@ -666,8 +691,13 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
             m = max2_raw(__uint_as_float(s32[0]), __uint_as_float(s32[1]));
             auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
             m = max2_raw(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
-            if (lg_e == 0) a.tmax_t[((size_t)jt * NPARTS + wr) * nq_pad + grp * 256 + ni * 16 + col_e] = m;
+            if (JOIN) {
+                if (lg_e == 0) atomicMax(tmx + (it & 1) * 256 + ni * 16 + col_e, ord_key(m));
+            } else {
+                if (lg_e == 0) a.tmax_t[((size_t)jt * 8 + w) * nq_pad + grp * 256 + ni * 16 + col_e] = m;
+            }
         }
+        jt_prev = jt;
         jt = jn;
         row0 = row0n;
         row_end = a.tile_row[tile_of(jt) + 1];
@@ -678,6 +708,10 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
         for (int mi = 0; mi < NV; ++mi) { vp[mi] = vn[mi]; vn[mi] = row_off(row0n, mi); }
     }
     wait_vm0();                                          // (the prefetched block and rows of a tile that does not exist)
+    if (JOIN) {
+        wg_barrier();                                    // (every wave's last epilogue is behind it)
+        flush_tmax(jt_prev, (n_mine - 1) & 1);
+    }
     if (EMIT && lane == 0) a.wv_count[blockIdx.x * 8 + w] = wave_cnt;
 }
 

@@ -153,6 +153,10 @@ hipError_t msr_dense_scan_bf16(const DenseIndex& ix, const float* qn, int nq, in
 // or <= 128 with ix.wide_ok64.
 // Both need ix.wide_ok and have no per-document row limit (max_chunks = 0).
 hipError_t msr_dense_scan_wide(const DenseIndex& ix, const float* qn, int nq, float* docscore, hipStream_t stream);
+// gated fallback of the streaming pass: all 64-query slices of a call in one launch (msr_dense_ks.hip)
+size_t msr_ksplit_slice_image_bytes();
+hipError_t msr_dense_scan_slices(const DenseIndex& ix, const float* qn, int nq, float* docscore, void* qimg_slices,
+                                 hipStream_t stream);
 hipError_t msr_dense_scan_wide_exact(const DenseIndex& ix, const float* qn, int nq, float* docscore, hipStream_t stream);
 hipError_t msr_dense_scan_bf16_wide(const DenseIndex& ix, const float* qn, int nq, float* docscore,
                                     hipStream_t stream);
@@ -202,7 +206,7 @@ struct GemmIndex {
     void* qmat;                // bf16 [max_queries][768]
     float* tmax;               // [max_queries][tmax_stride] tile maxima, one row per query (input of the top-k select)
     int32_t tmax_stride;
-    float* tmax_t;             // [n_tiles][8 waves][max_queries] as the pass' epilogue stores them
+    float* tmax_t;             // [n_tiles][max_queries] as the pass stores them (one row of maxima per tile)
     float* thr; float* thr2;   // [max_queries] emission threshold (sample bound) / final threshold (all tiles)
     int32_t* flag;             // [max_queries] 1: the sample could not bound this query (rerun on the exact path)
     void* wgbuf;               // [n_workgroups * 8 waves][wv_cap] x 16 B emitted (row, query, score, tile)
@@ -244,7 +248,7 @@ struct StreamArgs {
     const int32_t* tile_row;   // [n_tiles + 1]
     int64_t n_rows;
     int t_first, t_stride, t_count;
-    float* tmax_t;             // [t_count][8 waves][queries of a pass (x nt)]
+    float* tmax_t;             // f32 rows: [t_count][8 waves][queries of a launch]; bf16 rows: [t_count][256 nt] (joined in LDS)
     const float* thr;          // emit thresholds of the pass' queries (+inf: never)                    -- emit pass only
     void* wvbuf; int wv_cap; int32_t* wv_count;   // per-wave emission buffers {row, query, score bits, tile} (int4)   -- emit pass only
     int q_base;                // number of the pass' first query within the call (the query field of an entry is global)

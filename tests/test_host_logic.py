@@ -419,3 +419,16 @@ def test_duckdb_loader_is_columnar_at_ten_million_postings(tmp_path):
     back = CorpusIndex.load_dir(snap)
     assert np.array_equal(back.post_doc, ix.post_doc) and np.array_equal(np.asarray(back.emb), emb)
     assert back.url_group().tolist() == ix.url_group().tolist()
+
+
+def test_streaming_kernels_keep_their_row_rings_in_place():
+    """The streaming passes drive their row rings by hand (inline-asm loads + counted s_waitcnt).  The compiler must not spill
+    inside that pipeline nor rename ring slots with moves of registers whose loads are in flight: tools/ring_check.py compiles
+    msr_gemm_f32.hip to gfx950 assembly (no GPU needed) and checks spills, vmcnt(0) inside the pipeline and the load
+    destinations of every streaming kernel."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ring_check.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("ok  ") == 6, r.stdout
