@@ -196,7 +196,9 @@ int msr_rerank_combine(msr_engine* e, const float* cos_parts, const int32_t* met
 
 /* Merge n_parts per-shard top-k lists (the payload of the RCCL all-gather) into the global top-k.
  * in_doc [n_parts][n_queries][k] i32 GLOBAL doc indices, in_score same shape (score_bits = 32: f32,
- * 64: f64), in_n [n_parts][n_queries].  Order: score desc, doc index asc -- identical on every rank. */
+ * 64: f64), in_n [n_parts][n_queries].  Order: score desc, doc index asc -- identical on every rank.
+ * Every part must be in that order already (what msr_bm25_topk / msr_dense_topk return, with doc indices made global by
+ * adding the shard's base): the kernel merges sorted lists, it does not sort. */
 int msr_merge_topk(msr_engine* e, const int32_t* in_doc, const void* in_score, const int32_t* in_n,
                    int32_t n_parts, int32_t n_queries, int32_t k, int32_t score_bits, int32_t* out_doc,
                    void* out_score, int32_t* out_n, void* stream);
