@@ -826,7 +826,7 @@ extern "C" int msr_enable_bf16(msr_engine* e, void* stream) {
         if ((herr = alloc(&e->gm_qmat, (size_t)GM_SLICE * MSR_DIM * 2)) != hipSuccess ||
             (herr = alloc((void**)&e->gm_qn, (size_t)GM_SLICE * MSR_DIM * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gm_tmax, (size_t)GM_SLICE * stride * 4)) != hipSuccess ||
-            (herr = alloc((void**)&e->gm_tmax_t, (size_t)n_tiles * GM_SLICE * 4)) != hipSuccess ||     // [tile][query]
+            (herr = alloc((void**)&e->gm_tmax_t, (size_t)n_tiles * 2 * GM_SLICE * 4)) != hipSuccess ||     // [tile][query] (x 2: the diagnostic build's round-2 kernel stores two rows per tile)
             (herr = alloc((void**)&e->gm_thr, (size_t)GM_SLICE * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gm_thr2, (size_t)GM_SLICE * 4)) != hipSuccess ||
             (herr = alloc((void**)&e->gm_flag, (size_t)GM_SLICE * 4)) != hipSuccess ||

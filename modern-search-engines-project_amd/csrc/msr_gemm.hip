@@ -1,4 +1,4 @@
-// K5 -- batched candidate generation as a tiled bf16 GEMM on the matrix cores (gfx950).
+// K5 -- batched candidate generation as a bf16 GEMM on the matrix cores (gfx950): the scheme around the pass.
 //
 // BASELINE configs[4]: S = E (C x 768, bf16) . Q^T (768 x nq, bf16), f32 accumulate, for batches of hundreds to
 // thousands of queries.  Same mathematics as the cosine of the reference (reranker/reranker_api.py:285) and its
@@ -12,8 +12,8 @@
 //                    tighter bound t' afterwards), (b) every (query, row, score) with score >= t_s - margin is
 //                    appended to a buffer private to the WAVE (scalar counter + lane prefix count, plain 16 B stores:
 //                    no atomic of any kind, nothing that would drain the load pipeline).
-//   finish           msr_gemm_finish: entries >= t' - margin are bucketed per query, reduced to per-document maxima,
-//                    and the survivors are re-scored exactly in f32 by the kernels of msr_batch.hip.
+//   finish           entries >= t' - margin are bucketed per query, reduced to per-document maxima, and the survivors
+//                    are re-scored exactly in f32 by the kernels of msr_batch.hip.
 //
 // Both operands are bf16 images of UNIT vectors (rows are normalised when the image is built).  The margin is MEASURED,
 // not a worst case: unit_bf16_rows_kernel records dE = the largest rounding-error norm |e - bf16(e)| over all rows,
@@ -21,18 +21,13 @@
 // eps_q = dE (1 + dq) + dq; margin_q = 2 eps_q + 1e-4 makes the survivor set a superset of the exact top-k
 // (derivation: DESIGN.md section 3, K5).  Typical: margin 0.0046 instead of the worst-case 2^-6.
 //
-// Kernel shape (one persistent workgroup per CU, 8 waves, 256 x 256 output tile, K step 64; details at the K loop):
-//   * LDS, all 160 KB: 3 buffers x {A rows 0-127, A rows 128-255} + 2 buffers x {B queries 0-127, B queries 128-255},
-//     16 KB each, filled by global_load_lds_dwordx4 (no VGPR staging); image rows are 128 B with the 16 B chunk index
-//     XORed by (row >> 1) & 7 -- applied to the per-lane SOURCE address, the LDS side of the DMA stays linear -- which
-//     makes every ds_read_b128 of an MFMA fragment conflict-free (SQ_LDS_BANK_CONFLICT = 0 measured).
-//   * wave (wr, wc) owns rows {wr 64 .. +64} of both A halves and queries {wc 32 .. +32} of both B halves: a 128 x 64
-//     piece, 64 v_mfma_f32_16x16x32_bf16 per K step, 128 accumulator registers.
-//   * per K step: issue the queries of step + 1 and the rows of step + 2, then 4 x (fragment reads, 16 MFMAs),
-//     s_waitcnt vmcnt(4), ONE barrier.
-//   * the NT = nq / 256 workgroups that share a row tile sit on the same XCD (blockIdx % 8) and walk the same tile
-//     sequence, so E comes from HBM once per batch and from the XCD's L2 for the others (measured: 8.9 GB of HBM reads
-//     per 1024 queries for 7.68 GB of rows).
+// The passes themselves run on the streaming kernel of msr_gemm_f32.hip (gemm_stream256_kernel<., BF16 = true>: rows from
+// HBM / L2 straight into the register ring of the one wave that uses them, only the query image through LDS, up to four
+// groups of 256 queries per launch co-scheduled per XCD).  This file holds what surrounds them: the image builders and
+// margins, the tile-maximum transposition and k-th maximum, the bucket / candidate kernels.
+//
+// -DMSR_DIAG builds only: the round-2 kernel (256 x 256 output tiles, rows AND queries through 160 KB of LDS by LDS-DMA,
+// one barrier per K step; 0.44-0.46 of the bf16 peak) stays as the A/B partner of the streaming pass (msr_tune(100, 512)).
 #include <type_traits>
 
 #include "msr_common.h"
@@ -42,6 +37,7 @@
 
 namespace {
 
+#ifdef MSR_DIAG
 constexpr int GM_THREADS = 512;
 constexpr int GM_KT = MSR_DIM / 64;            // K steps per output tile
 constexpr int GM_HALF = 16384;                 // bytes of one half-tile image: 128 rows x 128 B
@@ -332,6 +328,8 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
     if (EMIT && lane == 0) a.wv_count[blockIdx.x * 8 + w] = wave_cnt;
 }
 
+#endif  // MSR_DIAG (the round-2 kernel)
+
 // ---- image builders -----------------------------------------------------------------------------------------------
 // dst[r] = bf16(src[r] * inv_norm[r]) for r < n_rows, zero rows up to n_pad (the GEMM reads 256 rows from a tile start).
 // One wave per row at a time.  err_max (device word, bits of a non-negative float, atomicMax on the bits) receives
@@ -587,6 +585,7 @@ __global__ __launch_bounds__(1024) void gemm_cand_kernel(const int2* __restrict_
     if (t == 0) { cand_n[q] = s_keep; pair_n[q] = 0; }
 }
 
+#ifdef MSR_DIAG
 // qmat[q] = bf16(qn[q]) for q < nq, zero rows up to nq_pad
 __global__ __launch_bounds__(256) void qmat_kernel(const float* __restrict__ qn, int nq, int nq_pad, bf16x8* __restrict__ dst) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -604,8 +603,10 @@ __global__ __launch_bounds__(256) void qmat_kernel(const float* __restrict__ qn,
     dst[i] = v;
 }
 
+#endif
 int g_gemm_dbg = 0;
 
+#ifdef MSR_DIAG
 template <bool EMIT>
 hipError_t launch_gemm_t(const GemmArgs& a, int grid, hipStream_t stream) {
     static bool attr_done = false;
@@ -624,6 +625,8 @@ hipError_t launch_gemm_t(const GemmArgs& a, int grid, hipStream_t stream) {
 hipError_t launch_gemm(bool emit, const GemmArgs& a, int grid, hipStream_t stream) {
     return emit ? launch_gemm_t<true>(a, grid, stream) : launch_gemm_t<false>(a, grid, stream);
 }
+
+#endif
 
 }  // namespace
 
@@ -673,8 +676,6 @@ hipError_t msr_gemm_candidates(const GemmIndex& g, const DenseIndex& ix, const f
     const int grid = g.n_cus / 8 * 8;
     if (grid < 8 || grid / 8 < nt) return hipErrorInvalidValue;
     hipError_t err;
-    qmat_kernel<<<(nq_pad * (MSR_DIM / 8) + 255) / 256, 256, 0, stream>>>(qn, nq, nq_pad, (bf16x8*)g.qmat);     // (old kernel's operand; the
-    // streaming pass overwrites it with its own image of the same size)
     // ---- pass 1: every ss-th tile, tile maxima only ----
     int ss = g.n_tiles / (8 * k);
     ss = ss < 1 ? 1 : (ss > 16 ? 16 : ss);
@@ -683,11 +684,8 @@ hipError_t msr_gemm_candidates(const GemmIndex& g, const DenseIndex& ix, const f
 #endif
     const int n_s = (g.n_tiles - ss / 2 + ss - 1) / ss;                   // tiles ss/2, ss/2 + ss, ...
 #ifdef MSR_DIAG
-    const bool old_gemm = (g_gemm_dbg & 512) != 0;      // timing experiments: the 256 x 256 LDS-tiled kernel of round 2
-#else
-    constexpr bool old_gemm = false;
-#endif
-    if (old_gemm) {
+    if (g_gemm_dbg & 512) {                             // timing experiments: the 256 x 256 LDS-tiled kernel of round 2
+        qmat_kernel<<<(nq_pad * (MSR_DIM / 8) + 255) / 256, 256, 0, stream>>>(qn, nq, nq_pad, (bf16x8*)g.qmat);
         GemmArgs a{};
         a.A = (const char*)g.emb_n; a.B = (const char*)g.qmat; a.tile_row = g.tile_row; a.nt = nt;
         a.tmax_t = g.tmax_t; a.nq_pad = nq_pad;
@@ -704,7 +702,9 @@ hipError_t msr_gemm_candidates(const GemmIndex& g, const DenseIndex& ix, const f
         if (ev && (err = hipEventRecord(ev[3], stream)) != hipSuccess) return err;
         gemm_tmax_kernel<<<dim3((g.n_tiles + 31) / 32, nq_pad / 32), 256, 0, stream>>>(g.tmax_t, g.n_tiles, 2, nq_pad, (float*)g.tmax, g.tmax_stride);
         gemm_kth_kernel<<<nq_pad, 1024, 0, stream>>>((const float*)g.tmax, g.n_tiles, g.tmax_stride, nq, k, margin, g.thr2, nullptr);
-    } else {
+    } else
+#endif
+    {
         // The pass: the 256-query streaming kernel of msr_gemm_f32.hip over the bf16 unit-row image, nt groups of 256
         // queries in ONE launch (rows through a register ring -- no LDS, no barrier for them --, the group's query image
         // through LDS; the nt workgroups that walk the same tiles share an XCD's L2).
