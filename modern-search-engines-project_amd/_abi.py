@@ -83,6 +83,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise MsrError(-100, f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
                              f"g.build()'` (the product path has no CPU fallback)")
+    # One HIP runtime per process: torch ships its own libamdhip64 and owns device memory and streams here, so it must be
+    # the one our library's HIP symbols resolve to.  Loaded the other way round (libmsretr.so first pulls in the system
+    # runtime, torch then brings its own) the second runtime finds no device: msr_create fails with "no HIP device".
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if a symbol from msretr.h is not exported

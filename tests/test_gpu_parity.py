@@ -528,6 +528,16 @@ def test_streaming_pass_vs_oracle_and_query_groups(mods):
         assert all(np.array_equal(a_[r:r + 128], b_[r:r + 128]) for a_, b_ in zip(one, many)), r
     assert np.array_equal(one[3], many[3]) and np.abs(one[1] - many[1]).max() <= 1e-6
     eng4.close()
+    # room for 1024 queries per call: the 700 queries are THREE groups of 256 that share the rows of one launch (an odd number
+    # of groups per XCD: some workgroups of the launch stay idle)
+    eng8 = mods["DeviceEngine"](ix, max_queries=1024, max_k=100, rerank_max_docs=0)
+    assert eng8.scan_width() == 256
+    many = [x.cpu().numpy() for x in eng8.dense_topk(q, k=100)]
+    assert eng8.dense_path() == 256
+    for r in range(0, 640, 128):
+        assert all(np.array_equal(a_[r:r + 128], b_[r:r + 128]) for a_, b_ in zip(one, many)), r
+    assert np.array_equal(one[3], many[3]) and np.abs(one[1] - many[1]).max() <= 1e-6
+    eng8.close()
     # (c) the zero query
     qz = q[:100].copy(); qz[1] = 0.0
     got = eng.dense_topk(qz, k=100)
