@@ -696,7 +696,8 @@ def test_merge_topk(mods, bits):
                              post_tf=np.ones(1, np.int32), idf=np.ones(1, np.float32), avgdl=1.0, total_docs=4)
     eng = mods["DeviceEngine"](ix, max_queries=2, max_k=16)
     dt = np.float32 if bits == 32 else np.float64
-    for G_, Q, k in ((2, 3, 10), (8, 5, 100), (8, 2, 1000), (1, 1, 1)):
+    for G_, Q, k in ((2, 3, 10), (8, 5, 100), (8, 2, 1000), (1, 1, 1), (3, 4, 100), (5, 2, 37), (6, 3, 1000)):   # (the kernel is a
+        # merge tree over power-of-two list counts and lengths: odd part counts and ks exercise its phantom lists and tails)
         docs = np.full((G_, Q, k), -1, np.int32); sc = np.full((G_, Q, k), -np.inf, dt); ns = np.zeros((G_, Q), np.int32)
         for g in range(G_):
             for qi in range(Q):
