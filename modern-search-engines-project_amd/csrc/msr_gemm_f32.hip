@@ -569,11 +569,21 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
         // (bf16 rows only: the f32 rows' pass waits for HBM, not for LDS, and has no registers for fragments that stay
         // live across steps)
         if (!BF16) {
+#ifdef MSR_DIAG
+            if (a.dbg & 8) return;                       // timing experiments (wrong results): rows and query blocks move, nothing is multiplied
+#endif
 #pragma unroll
             for (int n4 = 0; n4 < NNI / 4; ++n4) {
                 f16x8 b4[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) b4[i] = *(const f16x8*)(bq + (4 * n4 + i) * 1024);
+#ifdef MSR_DIAG
+                if (a.dbg & 16) {                        // timing experiments: fragment reads, no MFMA
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(b4[i]));
+                    continue;
+                }
+#endif
 #pragma unroll
                 for (int mi = 0; mi < NMI; ++mi)
 #pragma unroll
