@@ -62,6 +62,7 @@ struct msr_engine {
     int32_t* gf_wv_count = nullptr; void* gf_pairs = nullptr; int32_t* gf_pair_n = nullptr; int32_t* gf_gate = nullptr;
     uint32_t* gf_err = nullptr; float* gf_margin = nullptr; int32_t* gf_cand_doc = nullptr; float* gf_cand_score = nullptr;
     int32_t* gf_cand_chunk = nullptr; int32_t* gf_cand_n = nullptr; float* gf_qn = nullptr; void* gf_fb_qimg = nullptr;
+    void* gf_emb_tiled = nullptr; int32_t* gf_tile_trow = nullptr;
     // batched path as a tiled GEMM (msr_gemm.hip): unit-row bf16 image + tile table + scratch for GM_SLICE queries per pass
     GemmIndex gemm{};
     bool gemm_ok = false;
@@ -125,6 +126,7 @@ static void free_gf(msr_engine* e) {
     free_dev(e->gf_gate); free_dev(e->gf_err); free_dev(e->gf_margin); free_dev(e->gf_cand_doc); free_dev(e->gf_cand_score);
     free_dev(e->gf_cand_chunk); free_dev(e->gf_cand_n); free_dev(e->gf_qn); e->gf_qn = nullptr;
     free_dev(e->gf_fb_qimg); e->gf_fb_qimg = nullptr;
+    free_dev(e->gf_emb_tiled); e->gf_emb_tiled = nullptr; free_dev(e->gf_tile_trow); e->gf_tile_trow = nullptr;
     e->gf_err = nullptr; e->gf_margin = nullptr; e->gf_cand_doc = nullptr; e->gf_cand_score = nullptr; e->gf_cand_chunk = nullptr;
     e->gf_cand_n = nullptr;
     e->tile_row = nullptr; e->gf_inv_pad = nullptr; e->gf_qimg = nullptr; e->gf_tmax_t = nullptr; e->gf_tmax = nullptr;
@@ -509,6 +511,8 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
     free_gemm(e);
     free_gf(e);
     // ---- row tiles for the GEMM paths: <= 256 rows, cut at document boundaries (a longer document: no GEMM paths) ----
+    std::vector<int32_t> h_trow;                          // first row of each tile in the fragment-order copy (below)
+    int64_t n_trows = 0;
     {
         std::vector<int32_t> tiles;
         bool ok = true;
@@ -527,6 +531,11 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
             HIP_TRY(e, hipStreamSynchronize(st));
             e->n_tiles = (int)tiles.size() - 1;
             e->tiles_ok = true;
+            h_trow.resize(e->n_tiles);
+            for (int t = 0; t < e->n_tiles; ++t) {
+                h_trow[t] = (int32_t)n_trows;
+                n_trows += (tiles[t + 1] - tiles[t] + 15) / 16 * 16;
+            }
         }
     }
     // batches of 65..128 queries take ONE streaming pass over the f32 rows (f16 filter + exact f32 finish, msr_gemm_f32.hip)
@@ -566,10 +575,23 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
         HIP_TRY(e, hipMemsetAsync(e->gf_gate, 0, 16 * 4, st));
         HIP_TRY(e, hipMemsetAsync(e->gf_cand_n, 0, QM * 4, st));
         HIP_TRY(e, msr_f16_row_error(emb, inv_norm, n_chunks, e->gf_err, st));   // measured once: the margin of the f16 filter
+        // The 256-query kernel streams a copy of the rows in fragment order (whole cache lines per load instruction; +3 % rows
+        // of padding: every tile starts at a multiple of 16 rows; 256 rows of slack behind the last tile, which loads 256 rows
+        // like every other).  The row-major matrix stays what every other kernel reads.
+        if (groups >= 2 && n_trows + 256 < ((int64_t)1 << 31)) {
+            if ((herr = alloc((void**)&e->gf_tile_trow, (size_t)n_tiles * 4)) != hipSuccess ||
+                (herr = alloc(&e->gf_emb_tiled, (size_t)(n_trows + 256) * MSR_DIM * 4)) != hipSuccess)
+                return fail(e, MSR_ERR_NOMEM, "fragment-order copy of the rows (%zu bytes): %s", (size_t)(n_trows + 256) * MSR_DIM * 4,
+                            hipGetErrorString(herr));
+            HIP_TRY(e, hipMemcpyAsync(e->gf_tile_trow, h_trow.data(), (size_t)n_tiles * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(e, hipMemsetAsync((char*)e->gf_emb_tiled + (size_t)n_trows * MSR_DIM * 4, 0, (size_t)256 * MSR_DIM * 4, st));
+            HIP_TRY(e, msr_tile_rows(emb, e->tile_row, e->gf_tile_trow, n_tiles, e->gf_emb_tiled, st));
+            HIP_TRY(e, hipStreamSynchronize(st));        // (h_trow leaves scope)
+        }
         e->gf = GemmF32Index{e->tile_row, n_tiles, e->n_cus, groups, e->gf_inv_pad, e->gf_qimg, e->gf_tmax_t, e->gf_tmax, stride,
                              e->gf_thr, e->gf_thr2, e->gf_flag, e->gf_wvbuf,
                              GF_WV_CAP, e->gf_wv_count, e->gf_pairs, e->gf_pair_n, e->gf_err, e->gf_margin, e->gf_cand_doc,
-                             e->gf_cand_score, e->gf_cand_chunk, e->gf_cand_n, max_nt};
+                             e->gf_cand_score, e->gf_cand_chunk, e->gf_cand_n, max_nt, e->gf_emb_tiled, e->gf_tile_trow};
         e->gf_ok = true;
     }
     e->have_chunks = true;

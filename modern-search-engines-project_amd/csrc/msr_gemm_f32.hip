@@ -373,8 +373,16 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t u) {
 // two K steps, and a.nt = 4 query groups of 256 share the rows: the workgroups are dealt so that the nt
 // workgroups with the same tile sequence have the same blockIdx % 8 (one XCD under round-robin dispatch: speed only) -- the
 // rows come from HBM once per call and from that XCD's L2 for the other groups.
-template <bool EMIT, bool BF16>
+//
+// TILED = true (f32 rows): the rows come from a copy of the matrix in FRAGMENT ORDER (tile_rows_kernel below): for every
+// group of 16 rows and K step, the 2 KB the wave's two loads of that fragment and step take -- piece (lane, half) at
+// half * 1024 + lane * 16 -- are contiguous, and every tile starts at a multiple of 16 rows of the copy.  A load instruction
+// then reads 1 KB = 8 whole cache lines of its own; on the row-major matrix it reads 64 of the 128 bytes of 16 lines, the
+// other halves follow in the next instruction and find their lines pending in the L1 (TCP_READ_TAGCONFLICT_STALL_CYCLES:
+// 23 % of the L1's cycles).
+template <bool EMIT, bool BF16, bool TILED = false>
 __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args a) {
+    static_assert(!(BF16 && TILED), "the fragment-order copy exists for the f32 rows");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWB = BF16 ? MSR_DIM * 2 : GF_ROWB;             // bytes per row
     // A ring slot holds 128 bytes of each of the wave's rows = one full cache line per row and load pair (lane (li16, lg)
@@ -456,11 +464,14 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
     // A tile's rows are addressed as (scalar base of the tile's first row) + (32-bit byte offset of the lane's row): fragment
     // mi = row WROWS wr + 16 mi + li16 of the tile, at its 32-byte piece lg of a K step; a row past the end of the matrix
     // re-reads the last row (masked in the epilogue).  A tile spans < 1 MB, so the offset fits 32 bits with room to spare.
+    // (TILED: row0 here is the tile's first row IN THE COPY, a multiple of 16: 16-row group g of the copy starts at g * 24 * 2 KB
+    // = 16 g rows * 3072 B, the same product)
     auto tile_base = [&](int row0) { return uniform_u64((uint64_t)a.E + (uint64_t)row0 * ROWB); };
     // The bf16 image is padded with 512 zero rows (msr_enable_bf16): nothing to clamp, the lane's offset is the same for
     // every tile and the fragments differ by a constant that goes into the scalar base -- one offset register instead of eight.
-    constexpr int NV = BF16 ? 1 : NMI;
+    constexpr int NV = (BF16 || TILED) ? 1 : NMI;
     auto row_off = [&](int row0, int mi) -> uint32_t {
+        if (TILED) return (uint32_t)(lane * 16);
         if (BF16) return (uint32_t)((WROWS * wr + li16) * ROWB + lg * 32);
         int64_t r = (int64_t)row0 + WROWS * wr + 16 * mi + li16;
         if (r > a.n_rows - 1) r = a.n_rows - 1;
@@ -470,7 +481,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
     int row0 = a.tile_row[tile_of(jt)], row_end = a.tile_row[tile_of(jt) + 1];
     int jn = jt + G < a.t_count ? jt + G : jt;
     int row0n = a.tile_row[tile_of(jn)];
-    uint64_t bp = tile_base(row0), bn = tile_base(row0n);
+    uint64_t bp = tile_base(TILED ? a.tile_trow[tile_of(jt)] : row0), bn = tile_base(TILED ? a.tile_trow[tile_of(jn)] : row0n);
     uint32_t vp[NV], vn[NV];
 #pragma unroll
     for (int mi = 0; mi < NV; ++mi) { vp[mi] = row_off(row0, mi); vn[mi] = row_off(row0n, mi); }
@@ -488,9 +499,15 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
         constexpr int slot = decltype(slot_c)::value, off = decltype(off_c)::value;
 #pragma unroll
         for (int mi = 0; mi < NMI; ++mi) {
-            const uint64_t b = BF16 ? sb + (uint64_t)(mi * 16 * ROWB) : sb;
-            gload16s<off>(ring[slot][mi][0], v[BF16 ? 0 : mi], b);
-            gload16s<off + 16>(ring[slot][mi][1], v[BF16 ? 0 : mi], b);
+            if (TILED) {                                 // group 2 wr + mi of the tile, K step `slot` of the block at sb
+                const uint64_t b = sb + (uint64_t)((2 * wr + mi) * (GF_KT * 2048) + slot * 2048);
+                gload16s<0>(ring[slot][mi][0], v[0], b);
+                gload16s<1024>(ring[slot][mi][1], v[0], b);
+            } else {
+                const uint64_t b = BF16 ? sb + (uint64_t)(mi * 16 * ROWB) : sb;
+                gload16s<off>(ring[slot][mi][0], v[BF16 ? 0 : mi], b);
+                gload16s<off + 16>(ring[slot][mi][1], v[BF16 ? 0 : mi], b);
+            }
         }
     };
     auto pin_rows = [&](auto slot_c) {
@@ -501,7 +518,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
     // runs beside its SIMD partner's MFMAs and loads instead of beside its epilogue: 2 % SLOWER on the f32 rows, 5 % on the
     // bf16 rows.  The eight waves share every query block and its barrier; a late wave holds the others up either way.)
     constexpr int NKB = GF_KT / G2_NB;                   // 6 K blocks per tile
-    constexpr int BLKB = RSLOTS * 128;                   // bytes of a row per K block
+    constexpr int BLKB = TILED ? G2_NB * 2048 : RSLOTS * 128;     // address step of a K block (row-major: bytes of a row)
     // ---- prologue: query block 0, rows of K block 0 ----
     stage_b(0, 0);
 #pragma unroll
@@ -713,7 +730,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
         row_end = a.tile_row[tile_of(jt) + 1];
         jn = jt + G < a.t_count ? jt + G : jt;
         row0n = a.tile_row[tile_of(jn)];
-        bp = bn; bn = tile_base(row0n);
+        bp = bn; bn = tile_base(TILED ? a.tile_trow[tile_of(jn)] : row0n);
 #pragma unroll
         for (int mi = 0; mi < NV; ++mi) { vp[mi] = vn[mi]; vn[mi] = row_off(row0n, mi); }
     }
@@ -877,19 +894,40 @@ hipError_t launch_stream_t(const GemmF32Args& a, int grid, hipStream_t stream) {
     gemm_stream_kernel<EMIT><<<grid, GF_THREADS, GS_LDS, stream>>>(a);
     return hipGetLastError();
 }
-template <bool EMIT, bool BF16>
+template <bool EMIT, bool BF16, bool TILED = false>
 hipError_t launch_stream256_t(const GemmF32Args& a, int grid, hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t err = hipFuncSetAttribute((const void*)gemm_stream256_kernel<EMIT, BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
+        hipError_t err = hipFuncSetAttribute((const void*)gemm_stream256_kernel<EMIT, BF16, TILED>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
         if (err != hipSuccess) return err;
         attr_done = true;
     }
-    gemm_stream256_kernel<EMIT, BF16><<<grid, G2_THREADS, G2_LDS, stream>>>(a);
+    gemm_stream256_kernel<EMIT, BF16, TILED><<<grid, G2_THREADS, G2_LDS, stream>>>(a);
     return hipGetLastError();
 }
+
+// The fragment-order copy of the f32 rows (see gemm_stream256_kernel, TILED): one workgroup per tile; piece (lane, half) of
+// (16-row group g, K step t) of the copy = floats 32 t + 8 (lane >> 4) + 4 half .. + 3 of row 16 g + (lane & 15) of the tile.
+// Rows of a tile's last group behind the tile's end are zero.
+__global__ __launch_bounds__(256) void tile_rows_kernel(const float* __restrict__ E, const int32_t* __restrict__ tile_row,
+                                                         const int32_t* __restrict__ tile_trow, f32x4* __restrict__ Et) {
+    const int t_ = blockIdx.x;
+    const int row0 = tile_row[t_], n = tile_row[t_ + 1] - row0;
+    const int groups = (n + 15) >> 4;
+    f32x4* dst = Et + (size_t)tile_trow[t_] * (MSR_DIM / 4);
+    const int pieces = groups * GF_KT * 128;             // 16-byte pieces of the tile's copy
+    for (int i = threadIdx.x; i < pieces; i += 256) {
+        const int lane = i & 63, half = (i >> 6) & 1, kt = (i >> 7) % GF_KT, g = i / (128 * GF_KT);
+        const int lr = 16 * g + (lane & 15);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (lr < n) v = *(const f32x4*)(E + (size_t)(row0 + lr) * MSR_DIM + 32 * kt + 8 * (lane >> 4) + 4 * half);
+        dst[i] = v;
+    }
+}
 // width: queries per pass (128 or 256; both kernels: 8 waves x 32 rows)
-hipError_t launch_f32(int width, bool emit, const GemmF32Args& a, int grid, hipStream_t stream) {
+hipError_t launch_f32(int width, bool emit, const GemmF32Args& a, int grid, hipStream_t stream, bool tiled = false) {
+    if (width == 256 && tiled)
+        return emit ? launch_stream256_t<true, false, true>(a, grid, stream) : launch_stream256_t<false, false, true>(a, grid, stream);
     if (width == 256) return emit ? launch_stream256_t<true, false>(a, grid, stream) : launch_stream256_t<false, false>(a, grid, stream);
     return emit ? launch_stream_t<true>(a, grid, stream) : launch_stream_t<false>(a, grid, stream);
 }
@@ -904,6 +942,13 @@ hipError_t msr_stream256_bf16_launch(bool emit, const StreamArgs& a, int grid, h
 }
 hipError_t msr_stream256_bf16_qimage(const float* qn, int nq, int n_groups, void* qimg, hipStream_t stream) {
     build_qimg2_kernel<true><<<dim3((GF_KT * 256 * 4 + 255) / 256, n_groups), 256, 0, stream>>>(qn, nq, (f16x8*)qimg);
+    return hipGetLastError();
+}
+
+hipError_t msr_tile_rows(const float* emb, const int32_t* tile_row, const int32_t* tile_trow, int n_tiles, void* emb_tiled,
+                         hipStream_t stream) {
+    if (n_tiles <= 0) return hipSuccess;
+    tile_rows_kernel<<<n_tiles, 256, 0, stream>>>(emb, tile_row, tile_trow, (f32x4*)emb_tiled);
     return hipGetLastError();
 }
 
@@ -957,6 +1002,11 @@ hipError_t msr_gemm_f32_topk(const GemmF32Index& g, const DenseIndex& ix, const 
     GemmF32Args a{};
     a.dbg = g_f32_dbg; a.nt = 1;
     a.E = (const char*)ix.emb; a.inv_pad = g.inv_pad; a.tile_row = g.tile_row;
+    bool tiled = W == 256 && g.emb_tiled != nullptr;
+#ifdef MSR_DIAG
+    if (g_f32_dbg & 8192) tiled = false;               // timing experiments: the row-major matrix
+#endif
+    if (tiled) { a.E = (const char*)g.emb_tiled; a.tile_trow = g.tile_trow; }
     a.n_rows = ix.n_chunks; a.tmax_t = g.tmax_t;
     // ---- pass 1 of every group: maxima of every ss-th tile -> emission thresholds ----
     a.t_first = ss / 2; a.t_stride = ss; a.t_count = n_s;
@@ -964,7 +1014,7 @@ hipError_t msr_gemm_f32_topk(const GemmF32Index& g, const DenseIndex& ix, const 
         a.nt = std::min(NT, G - gi);
         a.qimg = (const char*)g.qimg + gi * qimg_bytes;
         if (ev && gi == 0 && (err = hipEventRecord(ev[0], stream)) != hipSuccess) return err;
-        if ((err = launch_f32(W, false, a, grid, stream)) != hipSuccess) return err;
+        if ((err = launch_f32(W, false, a, grid, stream, tiled)) != hipSuccess) return err;
         if (ev && gi == 0 && (err = hipEventRecord(ev[1], stream)) != hipSuccess) return err;
         if ((err = msr_gemm_tmax(g.tmax_t, n_s, waves, W * a.nt, g.tmax + (size_t)gi * W * g.tmax_stride, g.tmax_stride, stream)) != hipSuccess) return err;
     }
@@ -977,7 +1027,7 @@ hipError_t msr_gemm_f32_topk(const GemmF32Index& g, const DenseIndex& ix, const 
         a.qimg = (const char*)g.qimg + gi * qimg_bytes;
         a.thr = g.thr + gi * W; a.q_base = gi * W; a.append = gi > 0;
         if (ev && gi == 0 && (err = hipEventRecord(ev[2], stream)) != hipSuccess) return err;
-        if ((err = launch_f32(W, true, a, grid, stream)) != hipSuccess) return err;
+        if ((err = launch_f32(W, true, a, grid, stream, tiled)) != hipSuccess) return err;
         if (ev && gi == 0 && (err = hipEventRecord(ev[3], stream)) != hipSuccess) return err;
         if ((err = msr_gemm_tmax(g.tmax_t, g.n_tiles, waves, W * a.nt, g.tmax + (size_t)gi * W * g.tmax_stride, g.tmax_stride, stream)) != hipSuccess) return err;
     }

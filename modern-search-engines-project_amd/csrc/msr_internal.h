@@ -246,6 +246,7 @@ struct StreamArgs {
     const float* inv_pad;      // [n_rows + 512] inverse norms (engine-owned padded copy; unused for the bf16 image)
     const char* qimg;          // query image: [group][24 K steps][128 or 256 queries][64 B], chunk-swizzled
     const int32_t* tile_row;   // [n_tiles + 1]
+    const int32_t* tile_trow;  // [n_tiles] first row of each tile in the fragment-order copy (a multiple of 16; TILED kernels only)
     int64_t n_rows;
     int t_first, t_stride, t_count;
     float* tmax_t;             // f32 rows: [t_count][8 waves][queries of a launch]; bf16 rows: [t_count][256 nt] (joined in LDS)
@@ -278,7 +279,12 @@ struct GemmF32Index {
     uint32_t* err_max; float* margin;                        // measured f16 rounding error of the rows (1 word) / margin [128]
     int32_t* cand_doc; float* cand_score; int32_t* cand_chunk; int32_t* cand_n;   // [128][MSR_SEL_CAP] x 3 / [128] (zero between calls)
     int32_t max_nt;            // groups of 256 queries one launch of the 256-query kernel may serve (tmax_t holds 256 x this per row)
+    const void* emb_tiled;     // fragment-order copy of the f32 rows for the 256-query kernel (nullptr: none), see msr_tile_rows
+    const int32_t* tile_trow;  // [n_tiles] first row of each tile in that copy
 };
+// emb_tiled <- fragment-order copy of emb: tile t's rows at tile_trow[t] (multiples of 16), 16-row groups x 24 K steps x 2 KB
+hipError_t msr_tile_rows(const float* emb, const int32_t* tile_row, const int32_t* tile_trow, int n_tiles, void* emb_tiled,
+                         hipStream_t stream);
 hipError_t msr_f16_row_error(const float* emb, const float* inv_norm, int64_t n_rows, uint32_t* err_max, hipStream_t stream);
 void msr_gemm_f32_set_dbg(int v);   // honoured by -DMSR_DIAG builds only
 hipError_t msr_pad_inv_norm(const float* inv, int64_t n, int64_t n_pad, float* out, hipStream_t stream);
