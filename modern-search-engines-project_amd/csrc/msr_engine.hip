@@ -62,7 +62,10 @@ struct msr_engine {
     int32_t* gf_wv_count = nullptr; void* gf_pairs = nullptr; int32_t* gf_pair_n = nullptr; int32_t* gf_gate = nullptr;
     uint32_t* gf_err = nullptr; float* gf_margin = nullptr; int32_t* gf_cand_doc = nullptr; float* gf_cand_score = nullptr;
     int32_t* gf_cand_chunk = nullptr; int32_t* gf_cand_n = nullptr; float* gf_qn = nullptr; void* gf_fb_qimg = nullptr;
-    void* gf_emb_tiled = nullptr; int32_t* gf_tile_trow = nullptr;
+    void* gf_emb_tiled = nullptr;     // fragment-order copy of the f32 rows (256-query streaming pass)
+    void* gm_emb_tiled = nullptr;     // ... of the bf16 unit-row image (batched candidate pass)
+    int32_t* tile_trow = nullptr;     // [n_tiles] first row of each tile in those copies
+    int64_t n_trows = 0;
     // batched path as a tiled GEMM (msr_gemm.hip): unit-row bf16 image + tile table + scratch for GM_SLICE queries per pass
     GemmIndex gemm{};
     bool gemm_ok = false;
@@ -108,6 +111,7 @@ static void free_dev(void* p) {
 
 static void free_gemm(msr_engine* e) {
     free_dev(e->gm_emb_n); free_dev(e->gm_qmat); free_dev(e->gm_tmax); free_dev(e->gm_tmax_t);
+    free_dev(e->gm_emb_tiled); e->gm_emb_tiled = nullptr;
     free_dev(e->gm_thr); free_dev(e->gm_thr2); free_dev(e->gm_flag);
     free_dev(e->gm_wgbuf); free_dev(e->gm_wv_count); free_dev(e->gm_pairs); free_dev(e->gm_pair_n); free_dev(e->gm_qn);
     free_dev(e->bf_ones); free_dev(e->bf_row_meta); free_dev(e->bf_err); free_dev(e->bf_margin);
@@ -120,13 +124,13 @@ static void free_gemm(msr_engine* e) {
 }
 
 static void free_gf(msr_engine* e) {
-    free_dev(e->tile_row); free_dev(e->gf_inv_pad); free_dev(e->gf_qimg); free_dev(e->gf_tmax_t); free_dev(e->gf_tmax);
+    free_dev(e->tile_row); free_dev(e->tile_trow); e->tile_trow = nullptr; e->n_trows = 0; free_dev(e->gf_inv_pad); free_dev(e->gf_qimg); free_dev(e->gf_tmax_t); free_dev(e->gf_tmax);
     free_dev(e->gf_thr); free_dev(e->gf_thr2);
     free_dev(e->gf_flag); free_dev(e->gf_wvbuf); free_dev(e->gf_wv_count); free_dev(e->gf_pairs); free_dev(e->gf_pair_n);
     free_dev(e->gf_gate); free_dev(e->gf_err); free_dev(e->gf_margin); free_dev(e->gf_cand_doc); free_dev(e->gf_cand_score);
     free_dev(e->gf_cand_chunk); free_dev(e->gf_cand_n); free_dev(e->gf_qn); e->gf_qn = nullptr;
     free_dev(e->gf_fb_qimg); e->gf_fb_qimg = nullptr;
-    free_dev(e->gf_emb_tiled); e->gf_emb_tiled = nullptr; free_dev(e->gf_tile_trow); e->gf_tile_trow = nullptr;
+    free_dev(e->gf_emb_tiled); e->gf_emb_tiled = nullptr;
     e->gf_err = nullptr; e->gf_margin = nullptr; e->gf_cand_doc = nullptr; e->gf_cand_score = nullptr; e->gf_cand_chunk = nullptr;
     e->gf_cand_n = nullptr;
     e->tile_row = nullptr; e->gf_inv_pad = nullptr; e->gf_qimg = nullptr; e->gf_tmax_t = nullptr; e->gf_tmax = nullptr;
@@ -511,8 +515,8 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
     free_gemm(e);
     free_gf(e);
     // ---- row tiles for the GEMM paths: <= 256 rows, cut at document boundaries (a longer document: no GEMM paths) ----
-    std::vector<int32_t> h_trow;                          // first row of each tile in the fragment-order copy (below)
-    int64_t n_trows = 0;
+    std::vector<int32_t> h_trow;                          // first row of each tile in the fragment-order copies (below, and
+    int64_t n_trows = 0;                                  // msr_enable_bf16): every tile starts at a multiple of 16 rows
     {
         std::vector<int32_t> tiles;
         bool ok = true;
@@ -535,6 +539,13 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
             for (int t = 0; t < e->n_tiles; ++t) {
                 h_trow[t] = (int32_t)n_trows;
                 n_trows += (tiles[t + 1] - tiles[t] + 15) / 16 * 16;
+            }
+            if (n_trows + 256 < ((int64_t)1 << 31)) {
+                if ((herr = hipMalloc((void**)&e->tile_trow, (size_t)e->n_tiles * 4)) != hipSuccess)
+                    return fail(e, MSR_ERR_NOMEM, "tile table: %s", hipGetErrorString(herr));
+                HIP_TRY(e, hipMemcpyAsync(e->tile_trow, h_trow.data(), (size_t)e->n_tiles * 4, hipMemcpyHostToDevice, st));
+                HIP_TRY(e, hipStreamSynchronize(st));
+                e->n_trows = n_trows;
             }
         }
     }
@@ -578,20 +589,17 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
         // The 256-query kernel streams a copy of the rows in fragment order (whole cache lines per load instruction; +3 % rows
         // of padding: every tile starts at a multiple of 16 rows; 256 rows of slack behind the last tile, which loads 256 rows
         // like every other).  The row-major matrix stays what every other kernel reads.
-        if (groups >= 2 && n_trows + 256 < ((int64_t)1 << 31)) {
-            if ((herr = alloc((void**)&e->gf_tile_trow, (size_t)n_tiles * 4)) != hipSuccess ||
-                (herr = alloc(&e->gf_emb_tiled, (size_t)(n_trows + 256) * MSR_DIM * 4)) != hipSuccess)
+        if (groups >= 2 && e->tile_trow) {
+            if ((herr = alloc(&e->gf_emb_tiled, (size_t)(n_trows + 256) * MSR_DIM * 4)) != hipSuccess)
                 return fail(e, MSR_ERR_NOMEM, "fragment-order copy of the rows (%zu bytes): %s", (size_t)(n_trows + 256) * MSR_DIM * 4,
                             hipGetErrorString(herr));
-            HIP_TRY(e, hipMemcpyAsync(e->gf_tile_trow, h_trow.data(), (size_t)n_tiles * 4, hipMemcpyHostToDevice, st));
             HIP_TRY(e, hipMemsetAsync((char*)e->gf_emb_tiled + (size_t)n_trows * MSR_DIM * 4, 0, (size_t)256 * MSR_DIM * 4, st));
-            HIP_TRY(e, msr_tile_rows(emb, e->tile_row, e->gf_tile_trow, n_tiles, e->gf_emb_tiled, st));
-            HIP_TRY(e, hipStreamSynchronize(st));        // (h_trow leaves scope)
+            HIP_TRY(e, msr_tile_rows(emb, e->tile_row, e->tile_trow, n_tiles, e->gf_emb_tiled, st));
         }
         e->gf = GemmF32Index{e->tile_row, n_tiles, e->n_cus, groups, e->gf_inv_pad, e->gf_qimg, e->gf_tmax_t, e->gf_tmax, stride,
                              e->gf_thr, e->gf_thr2, e->gf_flag, e->gf_wvbuf,
                              GF_WV_CAP, e->gf_wv_count, e->gf_pairs, e->gf_pair_n, e->gf_err, e->gf_margin, e->gf_cand_doc,
-                             e->gf_cand_score, e->gf_cand_chunk, e->gf_cand_n, max_nt, e->gf_emb_tiled, e->gf_tile_trow};
+                             e->gf_cand_score, e->gf_cand_chunk, e->gf_cand_n, max_nt, e->gf_emb_tiled, e->gf_emb_tiled ? e->tile_trow : nullptr};
         e->gf_ok = true;
     }
     e->have_chunks = true;
@@ -858,7 +866,15 @@ extern "C" int msr_enable_bf16(msr_engine* e, void* stream) {
             (herr = alloc((void**)&e->gm_pair_n, (size_t)GM_SLICE * 4)) != hipSuccess)
             return fail(e, MSR_ERR_NOMEM, "GEMM path scratch: %s", hipGetErrorString(herr));
         HIP_TRY(e, hipMemsetAsync(e->gm_pair_n, 0, (size_t)GM_SLICE * 4, st));
-        e->gemm = GemmIndex{e->emb_bf16, e->tile_row, n_tiles, e->n_cus, GM_SLICE, e->gm_qmat, e->gm_tmax, stride,
+        // the streaming pass reads a fragment-order copy of the image (whole cache lines per load instruction, as on the f32 rows)
+        if (e->tile_trow) {
+            if ((herr = alloc(&e->gm_emb_tiled, (size_t)(e->n_trows + 256) * MSR_DIM * 2)) != hipSuccess)
+                return fail(e, MSR_ERR_NOMEM, "fragment-order copy of the bf16 image: %s", hipGetErrorString(herr));
+            HIP_TRY(e, hipMemsetAsync((char*)e->gm_emb_tiled + (size_t)e->n_trows * MSR_DIM * 2, 0, (size_t)256 * MSR_DIM * 2, st));
+            HIP_TRY(e, msr_tile_rows_bf16(e->emb_bf16, e->tile_row, e->tile_trow, n_tiles, e->gm_emb_tiled, st));
+        }
+        e->gemm = GemmIndex{e->emb_bf16, e->tile_row, n_tiles, e->n_cus, GM_SLICE, e->gm_emb_tiled,
+                            e->gm_emb_tiled ? e->tile_trow : nullptr, e->gm_qmat, e->gm_tmax, stride,
                             e->gm_tmax_t, e->gm_thr, e->gm_thr2, e->gm_flag, e->gm_wgbuf,
                             GM_WV_CAP, e->gm_wv_count, e->gm_pairs, e->gm_pair_n};
         e->gemm_ok = true;

@@ -374,15 +374,15 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t u) {
 // workgroups with the same tile sequence have the same blockIdx % 8 (one XCD under round-robin dispatch: speed only) -- the
 // rows come from HBM once per call and from that XCD's L2 for the other groups.
 //
-// TILED = true (f32 rows): the rows come from a copy of the matrix in FRAGMENT ORDER (tile_rows_kernel below): for every
-// group of 16 rows and K step, the 2 KB the wave's two loads of that fragment and step take -- piece (lane, half) at
+// TILED = true: the rows come from a copy of the matrix (or of the bf16 image) in FRAGMENT ORDER (tile_rows_kernel below): for
+// every group of 16 rows and ring slot (f32: one K step; bf16: two), the 2 KB the wave's two loads of that fragment take --
+// piece (lane, half) at
 // half * 1024 + lane * 16 -- are contiguous, and every tile starts at a multiple of 16 rows of the copy.  A load instruction
 // then reads 1 KB = 8 whole cache lines of its own; on the row-major matrix it reads 64 of the 128 bytes of 16 lines, the
 // other halves follow in the next instruction and find their lines pending in the L1 (TCP_READ_TAGCONFLICT_STALL_CYCLES:
 // 23 % of the L1's cycles).
 template <bool EMIT, bool BF16, bool TILED = false>
 __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args a) {
-    static_assert(!(BF16 && TILED), "the fragment-order copy exists for the f32 rows");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWB = BF16 ? MSR_DIM * 2 : GF_ROWB;             // bytes per row
     // A ring slot holds 128 bytes of each of the wave's rows = one full cache line per row and load pair (lane (li16, lg)
@@ -499,8 +499,8 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
         constexpr int slot = decltype(slot_c)::value, off = decltype(off_c)::value;
 #pragma unroll
         for (int mi = 0; mi < NMI; ++mi) {
-            if (TILED) {                                 // group 2 wr + mi of the tile, K step `slot` of the block at sb
-                const uint64_t b = sb + (uint64_t)((2 * wr + mi) * (GF_KT * 2048) + slot * 2048);
+            if (TILED) {                                 // group 2 wr + mi of the tile, ring slot `slot` of the block at sb
+                const uint64_t b = sb + (uint64_t)((2 * wr + mi) * ((GF_KT / KPS) * 2048) + slot * 2048);
                 gload16s<0>(ring[slot][mi][0], v[0], b);
                 gload16s<1024>(ring[slot][mi][1], v[0], b);
             } else {
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
     // runs beside its SIMD partner's MFMAs and loads instead of beside its epilogue: 2 % SLOWER on the f32 rows, 5 % on the
     // bf16 rows.  The eight waves share every query block and its barrier; a late wave holds the others up either way.)
     constexpr int NKB = GF_KT / G2_NB;                   // 6 K blocks per tile
-    constexpr int BLKB = TILED ? G2_NB * 2048 : RSLOTS * 128;     // address step of a K block (row-major: bytes of a row)
+    constexpr int BLKB = TILED ? RSLOTS * 2048 : RSLOTS * 128;    // address step of a K block (row-major: bytes of a row)
     // ---- prologue: query block 0, rows of K block 0 ----
     stage_b(0, 0);
 #pragma unroll
@@ -909,18 +909,21 @@ hipError_t launch_stream256_t(const GemmF32Args& a, int grid, hipStream_t stream
 // The fragment-order copy of the f32 rows (see gemm_stream256_kernel, TILED): one workgroup per tile; piece (lane, half) of
 // (16-row group g, K step t) of the copy = floats 32 t + 8 (lane >> 4) + 4 half .. + 3 of row 16 g + (lane & 15) of the tile.
 // Rows of a tile's last group behind the tile's end are zero.
-__global__ __launch_bounds__(256) void tile_rows_kernel(const float* __restrict__ E, const int32_t* __restrict__ tile_row,
+// ROWB: bytes of a row (3072: f32 rows; 1536: the bf16 image); a row has ROWB / 128 slots of 128 bytes.
+template <int ROWB>
+__global__ __launch_bounds__(256) void tile_rows_kernel(const char* __restrict__ E, const int32_t* __restrict__ tile_row,
                                                          const int32_t* __restrict__ tile_trow, f32x4* __restrict__ Et) {
+    constexpr int SLOTS = ROWB / 128;
     const int t_ = blockIdx.x;
     const int row0 = tile_row[t_], n = tile_row[t_ + 1] - row0;
     const int groups = (n + 15) >> 4;
-    f32x4* dst = Et + (size_t)tile_trow[t_] * (MSR_DIM / 4);
-    const int pieces = groups * GF_KT * 128;             // 16-byte pieces of the tile's copy
+    f32x4* dst = Et + (size_t)tile_trow[t_] * (ROWB / 16);
+    const int pieces = groups * SLOTS * 128;             // 16-byte pieces of the tile's copy
     for (int i = threadIdx.x; i < pieces; i += 256) {
-        const int lane = i & 63, half = (i >> 6) & 1, kt = (i >> 7) % GF_KT, g = i / (128 * GF_KT);
+        const int lane = i & 63, half = (i >> 6) & 1, sl = (i >> 7) % SLOTS, g = i / (128 * SLOTS);
         const int lr = 16 * g + (lane & 15);
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (lr < n) v = *(const f32x4*)(E + (size_t)(row0 + lr) * MSR_DIM + 32 * kt + 8 * (lane >> 4) + 4 * half);
+        if (lr < n) v = *(const f32x4*)(E + (size_t)(row0 + lr) * ROWB + 128 * sl + 32 * (lane >> 4) + 16 * half);
         dst[i] = v;
     }
 }
@@ -938,6 +941,8 @@ void msr_gemm_f32_set_dbg(int v) { g_f32_dbg = v; }
 
 hipError_t msr_stream256_bf16_launch(bool emit, const StreamArgs& a, int grid, hipStream_t stream) {
     if (a.nt < 1 || (grid & 7) || (grid >> 3) < a.nt) return hipErrorInvalidValue;
+    if (a.tile_trow)                                    // a.E is the fragment-order copy of the image
+        return emit ? launch_stream256_t<true, true, true>(a, grid, stream) : launch_stream256_t<false, true, true>(a, grid, stream);
     return emit ? launch_stream256_t<true, true>(a, grid, stream) : launch_stream256_t<false, true>(a, grid, stream);
 }
 hipError_t msr_stream256_bf16_qimage(const float* qn, int nq, int n_groups, void* qimg, hipStream_t stream) {
@@ -948,7 +953,13 @@ hipError_t msr_stream256_bf16_qimage(const float* qn, int nq, int n_groups, void
 hipError_t msr_tile_rows(const float* emb, const int32_t* tile_row, const int32_t* tile_trow, int n_tiles, void* emb_tiled,
                          hipStream_t stream) {
     if (n_tiles <= 0) return hipSuccess;
-    tile_rows_kernel<<<n_tiles, 256, 0, stream>>>(emb, tile_row, tile_trow, (f32x4*)emb_tiled);
+    tile_rows_kernel<MSR_DIM * 4><<<n_tiles, 256, 0, stream>>>((const char*)emb, tile_row, tile_trow, (f32x4*)emb_tiled);
+    return hipGetLastError();
+}
+hipError_t msr_tile_rows_bf16(const void* emb_bf16, const int32_t* tile_row, const int32_t* tile_trow, int n_tiles, void* out,
+                              hipStream_t stream) {
+    if (n_tiles <= 0) return hipSuccess;
+    tile_rows_kernel<MSR_DIM * 2><<<n_tiles, 256, 0, stream>>>((const char*)emb_bf16, tile_row, tile_trow, (f32x4*)out);
     return hipGetLastError();
 }
 

@@ -8,9 +8,11 @@ i=0
 for C in "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum GRBM_GUI_ACTIVE" \
          "TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_TAG_STALL_sum" \
          "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum TCP_UTCL1_STALL_MULTI_MISS_sum" \
-         "TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_TA_BUSY_sum TCP_TCR_TCP_STALL_CYCLES_sum"; do
+         "TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_LFIFO_STALL_CYCLES_sum TCP_RFIFO_STALL_CYCLES_sum TCP_GATE_EN1_sum"; do
+  # (a pass with TA_ADDR_STALLED_BY_TC_CYCLES / TA_DATA_STALLED_BY_TC_CYCLES / TA_TA_BUSY aborted rocprofv3 on this pool: left out)
   i=$((i+1))
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/${T}_m$i -- python3 $R/bench.py $B "$@" > /dev/null 2> $O/${T}_m$i.err
+  echo "pass $i: $C"
+  timeout -k 10 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/${T}_m$i -- python3 $R/bench.py $B "$@" > /dev/null 2> $O/${T}_m$i.err
 done
 python3 - <<PY
 import csv,glob,collections,json
