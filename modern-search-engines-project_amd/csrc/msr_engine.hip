@@ -63,7 +63,6 @@ struct msr_engine {
     uint32_t* gf_err = nullptr; float* gf_margin = nullptr; int32_t* gf_cand_doc = nullptr; float* gf_cand_score = nullptr;
     int32_t* gf_cand_chunk = nullptr; int32_t* gf_cand_n = nullptr; float* gf_qn = nullptr; void* gf_fb_qimg = nullptr;
     void* gf_emb_tiled = nullptr;     // fragment-order copy of the f32 rows (256-query streaming pass)
-    void* gm_emb_tiled = nullptr;     // ... of the bf16 unit-row image (batched candidate pass)
     int32_t* tile_trow = nullptr;     // [n_tiles] first row of each tile in those copies
     int64_t n_trows = 0;
     // batched path as a tiled GEMM (msr_gemm.hip): unit-row bf16 image + tile table + scratch for GM_SLICE queries per pass
@@ -111,7 +110,6 @@ static void free_dev(void* p) {
 
 static void free_gemm(msr_engine* e) {
     free_dev(e->gm_emb_n); free_dev(e->gm_qmat); free_dev(e->gm_tmax); free_dev(e->gm_tmax_t);
-    free_dev(e->gm_emb_tiled); e->gm_emb_tiled = nullptr;
     free_dev(e->gm_thr); free_dev(e->gm_thr2); free_dev(e->gm_flag);
     free_dev(e->gm_wgbuf); free_dev(e->gm_wv_count); free_dev(e->gm_pairs); free_dev(e->gm_pair_n); free_dev(e->gm_qn);
     free_dev(e->bf_ones); free_dev(e->bf_row_meta); free_dev(e->bf_err); free_dev(e->bf_margin);
@@ -515,8 +513,8 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
     free_gemm(e);
     free_gf(e);
     // ---- row tiles for the GEMM paths: <= 256 rows, cut at document boundaries (a longer document: no GEMM paths) ----
-    std::vector<int32_t> h_trow;                          // first row of each tile in the fragment-order copies (below, and
-    int64_t n_trows = 0;                                  // msr_enable_bf16): every tile starts at a multiple of 16 rows
+    std::vector<int32_t> h_trow;                          // first row of each tile in the fragment-order copy (below): every
+    int64_t n_trows = 0;                                  // tile starts at a multiple of 16 rows
     {
         std::vector<int32_t> tiles;
         bool ok = true;
@@ -866,15 +864,7 @@ extern "C" int msr_enable_bf16(msr_engine* e, void* stream) {
             (herr = alloc((void**)&e->gm_pair_n, (size_t)GM_SLICE * 4)) != hipSuccess)
             return fail(e, MSR_ERR_NOMEM, "GEMM path scratch: %s", hipGetErrorString(herr));
         HIP_TRY(e, hipMemsetAsync(e->gm_pair_n, 0, (size_t)GM_SLICE * 4, st));
-        // the streaming pass reads a fragment-order copy of the image (whole cache lines per load instruction, as on the f32 rows)
-        if (e->tile_trow) {
-            if ((herr = alloc(&e->gm_emb_tiled, (size_t)(e->n_trows + 256) * MSR_DIM * 2)) != hipSuccess)
-                return fail(e, MSR_ERR_NOMEM, "fragment-order copy of the bf16 image: %s", hipGetErrorString(herr));
-            HIP_TRY(e, hipMemsetAsync((char*)e->gm_emb_tiled + (size_t)e->n_trows * MSR_DIM * 2, 0, (size_t)256 * MSR_DIM * 2, st));
-            HIP_TRY(e, msr_tile_rows_bf16(e->emb_bf16, e->tile_row, e->tile_trow, n_tiles, e->gm_emb_tiled, st));
-        }
-        e->gemm = GemmIndex{e->emb_bf16, e->tile_row, n_tiles, e->n_cus, GM_SLICE, e->gm_emb_tiled,
-                            e->gm_emb_tiled ? e->tile_trow : nullptr, e->gm_qmat, e->gm_tmax, stride,
+        e->gemm = GemmIndex{e->emb_bf16, e->tile_row, n_tiles, e->n_cus, GM_SLICE, e->gm_qmat, e->gm_tmax, stride,
                             e->gm_tmax_t, e->gm_thr, e->gm_thr2, e->gm_flag, e->gm_wgbuf,
                             GM_WV_CAP, e->gm_wv_count, e->gm_pairs, e->gm_pair_n};
         e->gemm_ok = true;

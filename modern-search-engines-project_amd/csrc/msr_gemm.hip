@@ -710,11 +710,7 @@ hipError_t msr_gemm_candidates(const GemmIndex& g, const DenseIndex& ix, const f
         // through LDS; the nt workgroups that walk the same tiles share an XCD's L2).
         if ((err = msr_stream256_bf16_qimage(qn, nq, nt, g.qmat, stream)) != hipSuccess) return err;
         StreamArgs a{};
-        a.E = (const char*)(g.emb_tiled ? g.emb_tiled : g.emb_n); a.tile_trow = g.emb_tiled ? g.tile_trow : nullptr;
-#ifdef MSR_DIAG
-        if (g_gemm_dbg & 1024) { a.E = (const char*)g.emb_n; a.tile_trow = nullptr; }      // timing experiments: the row-major image
-#endif
-        a.inv_pad = nullptr; a.qimg = (const char*)g.qmat; a.tile_row = g.tile_row;
+        a.E = (const char*)g.emb_n; a.inv_pad = nullptr; a.qimg = (const char*)g.qmat; a.tile_row = g.tile_row;
         a.n_rows = ix.n_chunks; a.tmax_t = g.tmax_t; a.nt = nt; a.q_base = 0; a.append = 0;
         a.t_first = ss / 2; a.t_stride = ss; a.t_count = n_s;
         if (ev && (err = hipEventRecord(ev[0], stream)) != hipSuccess) return err;

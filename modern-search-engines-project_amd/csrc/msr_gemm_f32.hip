@@ -374,15 +374,17 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t u) {
 // workgroups with the same tile sequence have the same blockIdx % 8 (one XCD under round-robin dispatch: speed only) -- the
 // rows come from HBM once per call and from that XCD's L2 for the other groups.
 //
-// TILED = true: the rows come from a copy of the matrix (or of the bf16 image) in FRAGMENT ORDER (tile_rows_kernel below): for
-// every group of 16 rows and ring slot (f32: one K step; bf16: two), the 2 KB the wave's two loads of that fragment take --
-// piece (lane, half) at
+// TILED = true (f32 rows): the rows come from a copy of the matrix in FRAGMENT ORDER (tile_rows_kernel below): for every
+// group of 16 rows and K step, the 2 KB the wave's two loads of that fragment and step take -- piece (lane, half) at
 // half * 1024 + lane * 16 -- are contiguous, and every tile starts at a multiple of 16 rows of the copy.  A load instruction
 // then reads 1 KB = 8 whole cache lines of its own; on the row-major matrix it reads 64 of the 128 bytes of 16 lines, the
 // other halves follow in the next instruction and find their lines pending in the L1 (TCP_READ_TAGCONFLICT_STALL_CYCLES:
 // 23 % of the L1's cycles).
 template <bool EMIT, bool BF16, bool TILED = false>
 __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args a) {
+    // (A fragment-order copy of the bf16 image was measured too: 13.71 vs 13.97 ms per 1024 queries x 10 M rows, but 1.33 x
+    // instead of 1.21 x the rows in HBM reads at 5 M rows and 7.9 GB more memory: not kept.  The addressing below stays general.)
+    static_assert(!(BF16 && TILED), "the fragment-order copy exists for the f32 rows only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWB = BF16 ? MSR_DIM * 2 : GF_ROWB;             // bytes per row
     // A ring slot holds 128 bytes of each of the wave's rows = one full cache line per row and load pair (lane (li16, lg)
@@ -941,8 +943,6 @@ void msr_gemm_f32_set_dbg(int v) { g_f32_dbg = v; }
 
 hipError_t msr_stream256_bf16_launch(bool emit, const StreamArgs& a, int grid, hipStream_t stream) {
     if (a.nt < 1 || (grid & 7) || (grid >> 3) < a.nt) return hipErrorInvalidValue;
-    if (a.tile_trow)                                    // a.E is the fragment-order copy of the image
-        return emit ? launch_stream256_t<true, true, true>(a, grid, stream) : launch_stream256_t<false, true, true>(a, grid, stream);
     return emit ? launch_stream256_t<true, true>(a, grid, stream) : launch_stream256_t<false, true>(a, grid, stream);
 }
 hipError_t msr_stream256_bf16_qimage(const float* qn, int nq, int n_groups, void* qimg, hipStream_t stream) {
@@ -956,12 +956,7 @@ hipError_t msr_tile_rows(const float* emb, const int32_t* tile_row, const int32_
     tile_rows_kernel<MSR_DIM * 4><<<n_tiles, 256, 0, stream>>>((const char*)emb, tile_row, tile_trow, (f32x4*)emb_tiled);
     return hipGetLastError();
 }
-hipError_t msr_tile_rows_bf16(const void* emb_bf16, const int32_t* tile_row, const int32_t* tile_trow, int n_tiles, void* out,
-                              hipStream_t stream) {
-    if (n_tiles <= 0) return hipSuccess;
-    tile_rows_kernel<MSR_DIM * 2><<<n_tiles, 256, 0, stream>>>((const char*)emb_bf16, tile_row, tile_trow, (f32x4*)out);
-    return hipGetLastError();
-}
+
 
 hipError_t msr_pad_inv_norm(const float* inv, int64_t n, int64_t n_pad, float* out, hipStream_t stream) {
     if (n_pad <= 0) return hipSuccess;

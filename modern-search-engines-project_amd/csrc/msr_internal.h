@@ -203,8 +203,6 @@ struct GemmIndex {
     int32_t n_tiles;
     int32_t n_cus;
     int32_t max_queries;       // queries per call the scratch below is sized for (multiple of 256)
-    const void* emb_tiled;     // fragment-order copy of the image for the streaming pass (nullptr: none) and
-    const int32_t* tile_trow;  // [n_tiles] the first row of each tile in it (multiples of 16)
     void* qmat;                // bf16 [max_queries][768]
     float* tmax;               // [max_queries][tmax_stride] tile maxima, one row per query (input of the top-k select)
     int32_t tmax_stride;
@@ -287,9 +285,6 @@ struct GemmF32Index {
 // emb_tiled <- fragment-order copy of emb: tile t's rows at tile_trow[t] (multiples of 16), 16-row groups x 24 K steps x 2 KB
 hipError_t msr_tile_rows(const float* emb, const int32_t* tile_row, const int32_t* tile_trow, int n_tiles, void* emb_tiled,
                          hipStream_t stream);
-// the same for the bf16 unit-row image (1536-byte rows)
-hipError_t msr_tile_rows_bf16(const void* emb_bf16, const int32_t* tile_row, const int32_t* tile_trow, int n_tiles, void* out,
-                              hipStream_t stream);
 hipError_t msr_f16_row_error(const float* emb, const float* inv_norm, int64_t n_rows, uint32_t* err_max, hipStream_t stream);
 void msr_gemm_f32_set_dbg(int v);   // honoured by -DMSR_DIAG builds only
 hipError_t msr_pad_inv_norm(const float* inv, int64_t n, int64_t n_pad, float* out, hipStream_t stream);

@@ -431,4 +431,4 @@ def test_streaming_kernels_keep_their_row_rings_in_place():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "ring_check.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("ok  ") == 10, r.stdout
+    assert r.stdout.count("ok  ") == 8, r.stdout
