@@ -635,6 +635,9 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes, "launches": k_n, "ms_per_launch": per_launch_ms}
         if args.workload != "bm25" and not gemm:
             roof["queries_per_launch"] = q_launch
+            if kname.startswith("gemm_stream256"):
+                roof["rows_read_from"] = ("the engine's fragment-order copy of the f32 matrix (the same values, laid out so that a load "
+                                          "instruction reads whole cache lines; + 3 % padding rows)")
         if args.workload != "bm25" and args.dense_mode == "f32" and eng.scan_arith() == "f32" and q_launch > 32:
             # exact-f32 products at 64 queries per sweep: v_mfma_f32_16x16x4_f32 runs at the f32 vector rate
             # (157.3 TFLOP/s, MI355X_MICROARCH.md), which binds before HBM does (2 * 768 flop per row and query)
