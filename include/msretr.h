@@ -92,7 +92,11 @@ int msr_bind_postings(msr_engine* e, const int64_t* term_off, int64_t n_terms, c
 /* Stage-2 index: chunk embeddings sorted by (doc index, chunk_id); doc d owns rows
  * [doc_off[d], doc_off[d+1]).  emb is f32 [n_chunks][768] row-major (scan_layout 0) or the interleaved
  * image produced by msr_interleave_rows (scan_layout 1).  inv_norm[n_chunks] f32 = 1/||row|| (0-norm -> 1),
- * or NULL to have the engine compute it.       indexer/embedder.py:31-52, indexer/indexer.py:165 */
+ * or NULL to have the engine compute it.       indexer/embedder.py:31-52, indexer/indexer.py:165
+ * Engine-owned memory this call allocates besides small tables: when cfg.max_queries >= 256 (and the corpus qualifies for
+ * the streaming pass: row-major, documents of <= 256 chunks, >= 64 row tiles) a copy of the matrix in the order the
+ * 256-query pass loads it, 1.03 x n_chunks x 3072 bytes; the caller's matrix stays bound and is what
+ * every other kernel reads, so it must stay alive. */
 int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks, const int32_t* doc_off,
                     int64_t n_docs, const float* inv_norm, void* stream);
 
