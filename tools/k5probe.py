@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Batched candidate path (msr_dense_topk_bf16, > 128 queries) against 64-query calls of the exact scan on a small corpus, with
+planted near-duplicate queries -- the quick correctness probe used while the streaming kernel was brought up on bf16 rows.
+    [MSR_DIAG_LIB=1] python tools/k5probe.py <queries> <docs> <chunks> [dbg]      (dbg: msr_tune(100, dbg), diagnostic build only)"""
 import sys, torch, numpy as np
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from msretr import _abi
