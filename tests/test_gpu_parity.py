@@ -487,6 +487,18 @@ def test_streaming_pass_last_tile_with_a_partly_filled_fragment(mods):
         sw = [np.concatenate(p) for p in zip(*[[x.cpu().numpy() for x in eng.dense_topk(q[s:s + 50], k=100)] for s in (0, 50)])]
         assert np.array_equal(g[3], sw[3]) and np.abs(g[1] - sw[1]).max() <= 1e-5 and (g[0] == sw[0]).mean() > 0.99
         eng.close()
+        # the same on the 256-query kernel, which streams the fragment-order copy of the rows: there the rows behind a tile are
+        # the copy's zero padding (every tile starts at a multiple of 16 rows) or the next tile's -- masked all the same
+        eng = mods["DeviceEngine"](ix, max_queries=256, max_k=100, rerank_max_docs=0)
+        assert eng.scan_width() == 256
+        q2 = np.concatenate([q, rng.standard_normal((100, 768)).astype(np.float32)])
+        got = eng.dense_topk(q2, k=100)
+        assert eng.dense_path() == 256
+        _check_dense(mods, eng, doc_off, emb, q2[[3, 5, 70, 99, 150]], 100, 0, [x[[3, 5, 70, 99, 150]] for x in got])
+        g2 = [x.cpu().numpy() for x in got]
+        assert g2[0][3, 0] == n_docs - 1 and g2[2][3, 0] == C - 1 and abs(g2[1][3, 0] - 1.0) <= 1e-5
+        assert all(np.array_equal(a_[:100], b_) for a_, b_ in zip(g2, g))          # (exact f32 rescoring: the kernels agree bit for bit)
+        eng.close()
 
 
 def test_streaming_pass_vs_oracle_and_query_groups(mods):
