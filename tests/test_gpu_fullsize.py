@@ -161,6 +161,60 @@ def test_stream_pass_fullsize_vs_torch_f32(world):
     eng.close()
 
 
+def test_stream256_pass_fullsize_vs_torch_f32(world):
+    """The kernel behind bench.py's `value` since round 3 -- gemm_stream256_kernel on the fragment-order copy of the rows, 256
+    queries per workgroup pass -- against the plain torch f32 reference at the full size: an exact hit, a near-duplicate,
+    random and planted queries, the last row of the matrix; then 1024 queries in ONE call (four groups of 256 sharing the
+    rows of a launch): the first group bit for bit what the 256-query call returned, queries of the other groups against
+    torch, a NaN query that returns nothing and leaves every other 64-query slice of the call bit for bit alone."""
+    from msretr.synthetic import synthetic_queries
+    ix, dev = world["ix"], world["dev"]
+    eng = world["DeviceEngine"](ix, max_queries=1024, max_k=100, rerank_max_docs=0)
+    assert eng.scan_width() == 256
+    _, qvec = synthetic_queries(ix, 1024, seed=321)
+    q = qvec.clone()
+    g = torch.Generator(device="cpu"); g.manual_seed(6)
+    noise = torch.nn.functional.normalize(torch.randn(768, generator=g), dim=0).to(dev)
+    q[0] = ix.emb[3_210_987] * 2.5                                                 # exact hit: cosine 1
+    q[1] = (ix.emb[91] + 0.05 * noise) * 0.4                                       # near-duplicate of a row in the first tile
+    q[2] = torch.randn(768, generator=g).to(dev) * 9.0                             # random direction
+    q[255] = (ix.emb[N_CHUNKS - 1] + 0.2 * noise) * 6.0                            # near the LAST row of the matrix
+    q[700] = ix.emb[1_234_567] * 0.7                                               # an exact hit in the third group
+    q[1023] = (ix.emb[N_CHUNKS - 2] + 0.1 * noise) * 2.0                           # the last tile again, last query of the call
+
+    def check(i, doc, score, chunk, k):
+        best, ti, tv = _dense_torch(ix, q[i], k)
+        assert float((score - best[doc.long()]).abs().max()) <= 1e-5              # every reported score is right
+        assert float((score - tv).abs().max()) <= 1e-5                            # and the list is the top-k
+        missing = set(ti.tolist()) ^ set(doc.tolist())
+        assert all(abs(float(best[d]) - float(tv[-1])) <= 2e-5 for d in missing)   # only boundary near-ties may swap
+        lo = ix.doc_off[doc.long()].long(); hi = ix.doc_off[doc.long() + 1].long()
+        assert bool(((chunk >= lo) & (chunk < hi)).all())
+
+    for k in (100, 10):
+        doc, score, chunk, n = eng.dense_topk(q[:256], k=k)
+        assert eng.dense_path() == 256 and bool((n == k).all())
+        for i in (0, 1, 2, 130, 255):
+            check(i, doc[i], score[i], chunk[i], k)
+        assert abs(float(score[0, 0]) - 1.0) <= 1e-5 and int(chunk[0, 0]) == 3_210_987
+        assert int(chunk[255, 0]) == N_CHUNKS - 1
+    one = eng.dense_topk(q[:256], k=100)
+    four = eng.dense_topk(q, k=100)
+    assert eng.dense_path() == 256 and bool((four[3] == 100).all())
+    for a, b in zip(four, one):
+        assert torch.equal(a[:256], b)                                             # exact f32 finish: the same bits
+    for i in (300, 511, 700, 1023):
+        check(i, four[0][i], four[1][i], four[2][i], 100)
+    assert abs(float(four[1][700, 0]) - 1.0) <= 1e-5 and int(four[2][700, 0]) == 1_234_567
+    qn = q.clone(); qn[600, 9] = float("nan")
+    got = eng.dense_topk(qn, k=100)
+    keep = torch.ones(1024, dtype=torch.bool, device=dev); keep[576:640] = False    # the NaN query's 64-query slice
+    assert int(got[3][600]) == 0 and bool((got[3][torch.arange(1024, device=dev) != 600] == 100).all())
+    for a, b in zip(got, four):
+        assert torch.equal(a[keep], b[keep])
+    eng.close()
+
+
 def test_dense_fullsize_f16split_vs_exact(world):
     """The default (f16-split) scan against the exact f32 MFMA scan on the full corpus: same top-100 up to
     near-ties, scores within the proven bound."""
