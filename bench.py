@@ -138,7 +138,7 @@ def cpu_baseline(args, shard, terms, qvec, dev):
       literal     the reference's own shape: pure-Python dict / loop BM25 on a 100 k-document corpus and the pandas
                   iterrows / groupby rerank chain on 1000 candidates x <= 10 chunks, 1 thread
     >= 20 timed queries per leg after 3 warm-ups, p50 per query.  Returns (cpu_baseline object, port BM25 results, port
-    dense results): the results of the timed queries, against which the GPU path's parity is reported."""
+    dense results, port rerank results): the results of the timed queries, against which the GPU path's parity is reported."""
     from oracle import bm25_ref, c_oracle, dense_ref, rerank_ref
     from msretr.synthetic import synthetic_corpus, synthetic_queries
     threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
@@ -155,7 +155,7 @@ def cpu_baseline(args, shard, terms, qvec, dev):
     log(f"[cpu baseline] host copy of {int(ix['post_doc'].size)} postings + {shard.n_chunks} chunk rows: {time.time() - t0:.1f}s")
     q_host = qvec[:nq + warm].cpu().numpy()
     chunk_doc = np.repeat(np.arange(shard.n_docs, dtype=np.int64), np.diff(doc_off.astype(np.int64)))
-    tb, td, tr, results, dense_results = [], [], [], [], []
+    tb, td, tr, results, dense_results, rerank_results = [], [], [], [], [], []
     for i in range(nq + warm):                              # ---- port
         ut, qtf = bm25_ref.prepare_query(terms[i], ix["term_off"])
         t1 = time.perf_counter()
@@ -164,25 +164,20 @@ def cpu_baseline(args, shard, terms, qvec, dev):
         dres = c_oracle.dense_topk(emb, doc_off, q_host[i], args.k2)
         t3 = time.perf_counter()
         # rerank / fuse of the stage-1 candidates: first <= 10 chunks each, cosine, min-max, blend, positional, arg-max, sort
-        rows = [(int(d), int(c), None) for d in r[0] for c in range(doc_off[d], min(doc_off[d + 1], doc_off[d] + 10))]
-        if rows:
-            ridx = np.fromiter((c for _, c, _ in rows), np.int64, len(rows))
+        # (oracle/rerank_ref.py: the restatement pinned to the reference's per-stage outputs, tests/golden/rerank_chain.json)
+        cd_ = [(int(d), float(b), int(doc_off[d]), min(int(doc_off[d + 1] - doc_off[d]), 10)) for d, b in zip(r[0], r[1])]
+        cd_ = [c for c in cd_ if c[3] > 0]
+        best = []
+        if cd_:
+            ridx = np.concatenate([np.arange(lo, lo + n, dtype=np.int64) for _, _, lo, n in cd_])
             cos = rerank_ref.cosine_f32(q_host[i], emb[ridx])
-            new = rerank_ref.normalise([float(x) for x in cos])
-            bm = dict(zip(r[0].tolist(), r[1].tolist()))
-            old = rerank_ref.normalise([bm[d] for d, _, _ in rows])
-            new = [a * 0.85 + b * 0.15 for a, b in zip(new, old)]
-            best, p = [], 0
-            for d in r[0].tolist():
-                n = min(int(doc_off[d + 1] - doc_off[d]), 10)
-                if n:
-                    adj = rerank_ref.positional_adjust(new[p:p + n], n)
-                    best.append((max(adj), d))
-                    p += n
-            best.sort(key=lambda x: (-x[0], x[1]))
+            pooled, _ = rerank_ref.chain_from_cosines([c[0] for c in cd_], [c[3] for c in cd_], [c[1] for c in cd_], cos)
+            lo_of = {c[0]: c[2] for c in cd_}
+            best = sorted(((d, s_, o_, lo_of[d] + b_) for d, s_, o_, b_ in pooled), key=lambda x: (-x[1], x[0]))
         t4 = time.perf_counter()
         if i >= warm:
             tb.append(t2 - t1); td.append(t3 - t2); tr.append(t4 - t3); results.append(r); dense_results.append(dres)
+            rerank_results.append(best)
     port = {"queries": nq, "cores": threads, "p50_ms": _p50([a + b + c for a, b, c in zip(tb, td, tr)]),
             "bm25_p50_ms": _p50(tb), "dense_p50_ms": _p50(td), "rerank_p50_ms": _p50(tr),
             "what": f"C + OpenMP ({threads} threads): BM25 top-{args.k1} over all {int(ix['post_doc'].size)} postings, cosine / per-document "
@@ -240,7 +235,7 @@ def cpu_baseline(args, shard, terms, qvec, dev):
            "sample": f"{nq} queries (after {warm} warm-ups) of the benchmark's own query pool, whole corpus, per-query p50; see "
                      "port / vectorised / literal",
            "port": port, "vectorised": vec, "literal": lit}
-    return obj, results, dense_results
+    return obj, results, dense_results, rerank_results
 
 
 def dense_parity(gpu, cpu, k):
@@ -271,6 +266,43 @@ def dense_parity(gpu, cpu, k):
             "top_k_doc_sets_equal_up_to_boundary_near_ties": bool(sets_ok),
             "same_doc_at_same_rank": same_rank / max(1, total),
             "kernel": "the batch of the timed steps in one msr_dense_topk call (streaming pass + exact f32 rescoring), rows of the CPU sample"}
+
+
+def rerank_parity(gpu, cpu, tol=5e-6):
+    """The fused lists of the GPU step (msr_rerank_gather + msr_rerank_fuse on the GPU's own stage-1 candidates) against the
+    CPU restatement of reranker_api.py:357-372 on ITS stage-1 candidates (bit-equal lists: bm25_parity_vs_cpu), query by query:
+    same documents, new_similarity within `tol` rank by rank (the f64 chain sees f32 cosines that differ in the last bit
+    between sklearn's and the kernel's summation order, amplified by the min-max division), normalised BM25 of the winning row
+    within 1e-12, and the same document at the same rank except where neighbouring scores are within 2 tol.
+    gpu: (doc, score, orig, chunk, n, rows) numpy arrays; cpu: per query the list of (doc, score, orig, row) in rank order."""
+    gd, gs, go, gc, gn, _ = gpu
+    worst, worst_o, same_rank, total, sets_ok, order_ok, chunk_same = 0.0, 0.0, 0, 0, True, True, 0
+    for i, exp in enumerate(cpu):
+        n = int(gn[i])
+        sets_ok = sets_ok and n == len(exp) and sorted(gd[i, :n].tolist()) == sorted(e[0] for e in exp)
+        m = min(n, len(exp))
+        if m == 0:
+            continue
+        es = np.array([e[1] for e in exp[:m]])
+        worst = max(worst, float(np.abs(gs[i, :m] - es).max()))
+        emap = {e[0]: e for e in exp}
+        for j in range(m):
+            d = int(gd[i, j])
+            e = emap.get(d)
+            if e is None:
+                continue
+            worst_o = max(worst_o, abs(float(go[i, j]) - e[2]))
+            chunk_same += int(int(gc[i, j]) == e[3])
+            if d == exp[j][0]:
+                same_rank += 1
+            elif abs(exp[j][1] - e[1]) > 2 * tol:
+                order_ok = False
+        total += m
+    return {"queries": len(cpu), "entries": total, "max_abs_new_similarity_diff": worst, "within_tol": worst <= tol, "tol": tol,
+            "max_abs_original_similarity_diff": worst_o, "doc_sets_equal": bool(sets_ok),
+            "order_equal_up_to_near_ties": bool(order_ok), "same_doc_at_same_rank": same_rank / max(1, total),
+            "same_winning_chunk": chunk_same / max(1, total),
+            "reference": "reranker_api.py:285,357-372 restated in oracle/rerank_ref.py (sklearn-form f32 cosine, Python-float chain)"}
 
 
 def main():
@@ -713,7 +745,7 @@ def main():
             line["variant_with_encoder"] = with_enc
         if world == 1 and not args.no_cpu_baseline and args.workload == "hybrid":
             try:
-                cb, cres, cdense = cpu_baseline(args, shard, terms, qvec, dev)
+                cb, cres, cdense, crerank = cpu_baseline(args, shard, terms, qvec, dev)
                 line["cpu_baseline"] = cb
                 # BASELINE.md publishes no number for this metric (vs_baseline stays null); the ratio to the CPU port timed in
                 # this very run, on this box's host cores, is reported under its own name
@@ -729,6 +761,11 @@ def main():
                 dd, ds, _, dn = [x.cpu().numpy() for x in eng.dense_topk(qvec[:max(Q, 3 + len(cdense))].contiguous(), k=args.k2)]
                 sl = slice(3, 3 + len(cdense))
                 line["dense_parity_vs_cpu"] = dense_parity((dd[sl], ds[sl], dn[sl]), cdense, args.k2)
+                # rerank / fuse parity: the step's own call shape (batch 0 of the timed steps), rows of the CPU sample
+                rr = se.search(None, batches[0][1], k1=args.k1, k2=args.k2, packed=batches[0][0])["rerank"] if Q >= 3 + len(crerank) \
+                    else se.search([shard.term_ids(t) for t in terms[:3 + len(crerank)]], qvec[:3 + len(crerank)].contiguous(),
+                                   k1=args.k1, k2=args.k2)["rerank"]
+                line["rerank_parity_vs_cpu"] = rerank_parity([x[sl].cpu().numpy() for x in rr], crerank)
             except Exception as ex:  # the baseline must never take the GPU numbers down with it
                 line["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(line), flush=True)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MSR_ABI_VERSION 2
+#define MSR_ABI_VERSION 3
 #define MSR_DIM 768               /* config.py:2 EMBEDDING_DIMENSION */
 #define MSR_MAX_K 1024            /* config.py:13 TOP_K_RETRIEVAL = 1000 */
 #define MSR_MAX_QUERY_TERMS 64
@@ -62,7 +62,13 @@ typedef struct msr_config {
                                  2 = always the exact-f32 MFMA kernel; 7 = f16-split on the 32-query kernel; 14 = the K-split kernel
                                  (what 0 resolves to on unit-norm rows); 15 = the K-split kernel over a pre-split f16 hi/lo copy of
                                  the rows (+4 bytes per value of HBM, ~4 % faster).  Any other value: msr_create fails */
+    int32_t flags;            /* MSR_CFG_* bits; unknown bits: msr_create fails (ABI 3) */
 } msr_config;
+
+/* msr_config.flags */
+#define MSR_CFG_NO_ROW_COPY 1 /* do not build the fragment-order copy of the embedding matrix (msr_bind_chunks): the 256-query
+                                 pass then reads the caller's row-major matrix (same results bit for bit, ~13 % slower pass,
+                                 half the embedding footprint) */
 
 /* BM25 parameters travel with the postings (bm25_indexer.py:57 k1=1.2, b=0.75). */
 typedef struct msr_rerank_params {
@@ -96,9 +102,17 @@ int msr_bind_postings(msr_engine* e, const int64_t* term_off, int64_t n_terms, c
  * Engine-owned memory this call allocates besides small tables: when cfg.max_queries >= 256 (and the corpus qualifies for
  * the streaming pass: row-major, documents of <= 256 chunks, >= 64 row tiles) a copy of the matrix in the order the
  * 256-query pass loads it, 1.03 x n_chunks x 3072 bytes; the caller's matrix stays bound and is what
- * every other kernel reads, so it must stay alive. */
+ * every other kernel reads, so it must stay alive.  SURVEY 8b's "the handle owns only small scratch" is deliberately not
+ * kept here: the copy is a trade of HBM for bandwidth, with a switch (MSR_CFG_NO_ROW_COPY) and a fallback (msr_row_copy_state). */
 int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks, const int32_t* doc_off,
                     int64_t n_docs, const float* inv_norm, void* stream);
+/* What became of that copy: 0 = not applicable (max_queries < 256 or the corpus does not qualify), 1 = built and used,
+ * 2 = declined by MSR_CFG_NO_ROW_COPY, 3 = its allocation failed and the engine fell back to the row-major matrix (the bind
+ * still succeeds).  -1: null handle. */
+int msr_row_copy_state(const msr_engine* e);
+/* Device memory the handle owns right now, in bytes (scratch, tables built at bind, the copies above); the caller's bound
+ * arrays are not included. */
+int64_t msr_owned_bytes(const msr_engine* e);
 
 /* Per-document metadata the rerank stage needs: url_group[n_docs] i32 = id of the document's URL with
  * the query string removed, or -1 when the document is not in urlsDB.   reranker_api.py:38-47 */

@@ -7,7 +7,8 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libmsretr.so")
 
-MSR_ABI_VERSION = 2
+MSR_ABI_VERSION = 3
+MSR_CFG_NO_ROW_COPY = 1
 MSR_DIM = 768
 MSR_MAX_K = 1024
 MSR_RERANK_MAX_CHUNKS = 10
@@ -22,7 +23,7 @@ class MsrError(RuntimeError):
 class MsrConfig(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("dim", C.c_int32),
                 ("max_queries", C.c_int32), ("max_k", C.c_int32), ("rerank_max_docs", C.c_int32),
-                ("scan_layout", C.c_int32), ("scan_variant", C.c_int32)]
+                ("scan_layout", C.c_int32), ("scan_variant", C.c_int32), ("flags", C.c_int32)]
 
 
 class MsrRerankParams(C.Structure):
@@ -43,6 +44,8 @@ _SIGNATURES = {
     "msr_scan_arith": (C.c_int, [_P]),
     "msr_scan_width": (C.c_int, [_P]),
     "msr_dense_path": (C.c_int, [_P]),
+    "msr_row_copy_state": (C.c_int, [_P]),
+    "msr_owned_bytes": (C.c_int64, [_P]),
     # include/msretr_encoder.h
     "msr_enc_layernorm": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
     "msr_enc_attention": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P]),

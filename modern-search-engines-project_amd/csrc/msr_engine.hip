@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <new>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/msretr.h"
@@ -77,6 +78,9 @@ struct msr_engine {
     void* bf_row_meta = nullptr;       // {document, 1.0f} per row for the K-split bf16 sweeps
     DenseIndex dense_bf16{};           // `dense` with the unit-row image, its inverse norms and row meta
     int n_cus = 256;
+    std::unordered_map<void*, size_t> owned;   // engine-owned device allocations (msr_owned_bytes)
+    int row_copy_state = 0;            // fragment-order copy of the rows: 0 not wanted / not applicable, 1 built, 2 declined by
+                                       // msr_config.flags, 3 allocation failed (the row-major instantiation of the kernel runs)
     int last_dense_width = 0;          // queries per pass over the matrix of the most recent msr_dense_topk call (msr_dense_path)
     // timing
     bool timing = false;
@@ -104,15 +108,23 @@ static int fail(msr_engine* e, int code, const char* fmt, ...) {
         if (_err != hipSuccess) return fail(e, MSR_ERR_HIP, "%s: %s", #call, hipGetErrorString(_err)); \
     } while (0)
 
-static void free_dev(void* p) {
-    if (p) (void)hipFree(p);
+// Every device allocation of an engine goes through these two: msr_owned_bytes() reports what the handle holds.
+static hipError_t eng_malloc(msr_engine* e, void** p, size_t bytes) {
+    hipError_t err = hipMalloc(p, bytes);
+    if (err == hipSuccess && *p) e->owned[*p] = bytes;
+    return err;
+}
+static void free_dev(msr_engine* e, void* p) {
+    if (!p) return;
+    e->owned.erase(p);
+    (void)hipFree(p);
 }
 
 static void free_gemm(msr_engine* e) {
-    free_dev(e->gm_emb_n); free_dev(e->gm_qmat); free_dev(e->gm_tmax); free_dev(e->gm_tmax_t);
-    free_dev(e->gm_thr); free_dev(e->gm_thr2); free_dev(e->gm_flag);
-    free_dev(e->gm_wgbuf); free_dev(e->gm_wv_count); free_dev(e->gm_pairs); free_dev(e->gm_pair_n); free_dev(e->gm_qn);
-    free_dev(e->bf_ones); free_dev(e->bf_row_meta); free_dev(e->bf_err); free_dev(e->bf_margin);
+    free_dev(e, e->gm_emb_n); free_dev(e, e->gm_qmat); free_dev(e, e->gm_tmax); free_dev(e, e->gm_tmax_t);
+    free_dev(e, e->gm_thr); free_dev(e, e->gm_thr2); free_dev(e, e->gm_flag);
+    free_dev(e, e->gm_wgbuf); free_dev(e, e->gm_wv_count); free_dev(e, e->gm_pairs); free_dev(e, e->gm_pair_n); free_dev(e, e->gm_qn);
+    free_dev(e, e->bf_ones); free_dev(e, e->bf_row_meta); free_dev(e, e->bf_err); free_dev(e, e->bf_margin);
     e->bf_err = nullptr; e->bf_margin = nullptr;
     e->gm_emb_n = nullptr; e->gm_qmat = nullptr; e->gm_tmax = nullptr; e->gm_tmax_t = nullptr;
     e->gm_thr = e->gm_thr2 = nullptr; e->gm_flag = nullptr;
@@ -122,13 +134,13 @@ static void free_gemm(msr_engine* e) {
 }
 
 static void free_gf(msr_engine* e) {
-    free_dev(e->tile_row); free_dev(e->tile_trow); e->tile_trow = nullptr; e->n_trows = 0; free_dev(e->gf_inv_pad); free_dev(e->gf_qimg); free_dev(e->gf_tmax_t); free_dev(e->gf_tmax);
-    free_dev(e->gf_thr); free_dev(e->gf_thr2);
-    free_dev(e->gf_flag); free_dev(e->gf_wvbuf); free_dev(e->gf_wv_count); free_dev(e->gf_pairs); free_dev(e->gf_pair_n);
-    free_dev(e->gf_gate); free_dev(e->gf_err); free_dev(e->gf_margin); free_dev(e->gf_cand_doc); free_dev(e->gf_cand_score);
-    free_dev(e->gf_cand_chunk); free_dev(e->gf_cand_n); free_dev(e->gf_qn); e->gf_qn = nullptr;
-    free_dev(e->gf_fb_qimg); e->gf_fb_qimg = nullptr;
-    free_dev(e->gf_emb_tiled); e->gf_emb_tiled = nullptr;
+    free_dev(e, e->tile_row); free_dev(e, e->tile_trow); e->tile_trow = nullptr; e->n_trows = 0; free_dev(e, e->gf_inv_pad); free_dev(e, e->gf_qimg); free_dev(e, e->gf_tmax_t); free_dev(e, e->gf_tmax);
+    free_dev(e, e->gf_thr); free_dev(e, e->gf_thr2);
+    free_dev(e, e->gf_flag); free_dev(e, e->gf_wvbuf); free_dev(e, e->gf_wv_count); free_dev(e, e->gf_pairs); free_dev(e, e->gf_pair_n);
+    free_dev(e, e->gf_gate); free_dev(e, e->gf_err); free_dev(e, e->gf_margin); free_dev(e, e->gf_cand_doc); free_dev(e, e->gf_cand_score);
+    free_dev(e, e->gf_cand_chunk); free_dev(e, e->gf_cand_n); free_dev(e, e->gf_qn); e->gf_qn = nullptr;
+    free_dev(e, e->gf_fb_qimg); e->gf_fb_qimg = nullptr;
+    free_dev(e, e->gf_emb_tiled); e->gf_emb_tiled = nullptr;
     e->gf_err = nullptr; e->gf_margin = nullptr; e->gf_cand_doc = nullptr; e->gf_cand_score = nullptr; e->gf_cand_chunk = nullptr;
     e->gf_cand_n = nullptr;
     e->tile_row = nullptr; e->gf_inv_pad = nullptr; e->gf_qimg = nullptr; e->gf_tmax_t = nullptr; e->gf_tmax = nullptr;
@@ -168,6 +180,8 @@ extern "C" int msr_create(const msr_config* cfg, msr_engine** out) {
     if (cfg->scan_variant != 0 && cfg->scan_variant != 2 && cfg->scan_variant != 7 && cfg->scan_variant != 14 &&
         cfg->scan_variant != 15)
         return fail(nullptr, MSR_ERR_INVALID, "msr_create: scan_variant must be 0, 2, 7, 14 or 15");
+    if (cfg->flags & ~(int32_t)MSR_CFG_NO_ROW_COPY)
+        return fail(nullptr, MSR_ERR_INVALID, "msr_create: unknown flag bits 0x%x", cfg->flags);
     int ndev = 0;
     hipError_t herr = hipGetDeviceCount(&ndev);
     if (herr != hipSuccess || ndev <= 0)
@@ -192,19 +206,19 @@ extern "C" int msr_create(const msr_config* cfg, msr_engine** out) {
     e->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     // select scratch and query buffers cover the widest sweep (128 queries) whatever max_queries says
     const size_t nq = (size_t)std::max(cfg->max_queries, 128);
-    if ((herr = hipMalloc((void**)&e->qn, 128 * MSR_DIM * sizeof(float))) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc qn", herr);
-    if ((herr = hipMalloc(&e->qimg, 256 * 1024)) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc qimg", herr);
-    if ((herr = hipMalloc((void**)&e->sel.hist, nq * MSR_SEL_BINS * sizeof(uint32_t))) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc hist", herr);
-    if ((herr = hipMalloc((void**)&e->sel.state, nq * sizeof(SelState))) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc state", herr);
-    if ((herr = hipMalloc((void**)&e->sel.cand_hi, nq * MSR_SEL_CAP * sizeof(uint64_t))) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc cand_hi", herr);
-    if ((herr = hipMalloc((void**)&e->sel.cand_lo, nq * MSR_SEL_CAP * sizeof(uint32_t))) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc cand_lo", herr);
-    if ((herr = hipMalloc((void**)&e->sel.cand_n, nq * sizeof(int32_t))) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc cand_n", herr);
+    if ((herr = eng_malloc(e, (void**)&e->qn, 128 * MSR_DIM * sizeof(float))) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc qn", herr);
+    if ((herr = eng_malloc(e, &e->qimg, 256 * 1024)) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc qimg", herr);
+    if ((herr = eng_malloc(e, (void**)&e->sel.hist, nq * MSR_SEL_BINS * sizeof(uint32_t))) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc hist", herr);
+    if ((herr = eng_malloc(e, (void**)&e->sel.state, nq * sizeof(SelState))) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc state", herr);
+    if ((herr = eng_malloc(e, (void**)&e->sel.cand_hi, nq * MSR_SEL_CAP * sizeof(uint64_t))) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc cand_hi", herr);
+    if ((herr = eng_malloc(e, (void**)&e->sel.cand_lo, nq * MSR_SEL_CAP * sizeof(uint32_t))) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc cand_lo", herr);
+    if ((herr = eng_malloc(e, (void**)&e->sel.cand_n, nq * sizeof(int32_t))) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc cand_n", herr);
     if ((herr = hipMemset(e->sel.hist, 0, nq * MSR_SEL_BINS * sizeof(uint32_t))) != hipSuccess) return bail(MSR_ERR_HIP, "hipMemset hist", herr);
     if ((herr = hipMemset(e->sel.cand_n, 0, nq * sizeof(int32_t))) != hipSuccess) return bail(MSR_ERR_HIP, "hipMemset cand_n", herr);
     if (cfg->rerank_max_docs > 0) {
         const size_t bytes = nq * (size_t)cfg->rerank_max_docs * MSR_RERANK_MAX_CHUNKS * sizeof(float);
-        if ((herr = hipMalloc((void**)&e->rerank_cos, bytes)) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc rerank_cos", herr);
-        if ((herr = hipMalloc((void**)&e->rerank_meta, nq * (size_t)cfg->rerank_max_docs * 3 * sizeof(int32_t))) != hipSuccess)
+        if ((herr = eng_malloc(e, (void**)&e->rerank_cos, bytes)) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc rerank_cos", herr);
+        if ((herr = eng_malloc(e, (void**)&e->rerank_meta, nq * (size_t)cfg->rerank_max_docs * 3 * sizeof(int32_t))) != hipSuccess)
             return bail(MSR_ERR_NOMEM, "hipMalloc rerank_meta", herr);
     }
     for (int w = 0; w < msr_engine::EV_KINDS; ++w)
@@ -218,11 +232,11 @@ extern "C" int msr_create(const msr_config* cfg, msr_engine** out) {
 
 extern "C" int msr_destroy(msr_engine* e) {
     if (!e) return MSR_OK;
-    free_dev(e->chunk_doc); free_dev(e->emb_presplit); free_dev(e->row_meta); free_dev(e->inv_norm_own); free_dev(e->span_doc); free_dev(e->wspan_doc); free_dev(e->wspan12_doc); free_dev(e->qn); free_dev(e->qimg); free_dev(e->emb_bf16);
-    free_dev(e->score_rows); free_dev(e->bm_heavy_id); free_dev(e->bm_post); free_dev(e->bm_dense_id); free_dev(e->bm_dense); free_dev(e->bm_tile_off); free_dev(e->bm_cand_doc); free_dev(e->bm_cand_n); free_dev(e->sel.hist); free_dev(e->sel.state); free_dev(e->sel.cand_hi);
-    free_dev(e->sel.cand_lo); free_dev(e->sel.cand_n); free_dev(e->rerank_cos); free_dev(e->rerank_meta);
-    free_dev(e->bt_top_doc); free_dev(e->bt_top_score); free_dev(e->bt_top_n); free_dev(e->bt_cand_doc);
-    free_dev(e->bt_cand_score); free_dev(e->bt_cand_chunk); free_dev(e->bt_cand_n);
+    free_dev(e, e->chunk_doc); free_dev(e, e->emb_presplit); free_dev(e, e->row_meta); free_dev(e, e->inv_norm_own); free_dev(e, e->span_doc); free_dev(e, e->wspan_doc); free_dev(e, e->wspan12_doc); free_dev(e, e->qn); free_dev(e, e->qimg); free_dev(e, e->emb_bf16);
+    free_dev(e, e->score_rows); free_dev(e, e->bm_heavy_id); free_dev(e, e->bm_post); free_dev(e, e->bm_dense_id); free_dev(e, e->bm_dense); free_dev(e, e->bm_tile_off); free_dev(e, e->bm_cand_doc); free_dev(e, e->bm_cand_n); free_dev(e, e->sel.hist); free_dev(e, e->sel.state); free_dev(e, e->sel.cand_hi);
+    free_dev(e, e->sel.cand_lo); free_dev(e, e->sel.cand_n); free_dev(e, e->rerank_cos); free_dev(e, e->rerank_meta);
+    free_dev(e, e->bt_top_doc); free_dev(e, e->bt_top_score); free_dev(e, e->bt_top_n); free_dev(e, e->bt_cand_doc);
+    free_dev(e, e->bt_cand_score); free_dev(e, e->bt_cand_chunk); free_dev(e, e->bt_cand_n);
     free_gemm(e);
     free_gf(e);
     for (int w = 0; w < msr_engine::EV_KINDS; ++w)
@@ -240,10 +254,10 @@ static int ensure_score_rows(msr_engine* e, int64_t n_docs) {
     const size_t pad = (size_t)(n_docs + 31) / 32 * 32;
     const size_t need = std::max((size_t)e->cfg.max_queries * pad * sizeof(double), (size_t)128 * pad * sizeof(float));
     if (need <= e->score_rows_bytes) return MSR_OK;
-    free_dev(e->score_rows);
+    free_dev(e, e->score_rows);
     e->score_rows = nullptr;
     e->score_rows_bytes = 0;
-    hipError_t herr = hipMalloc(&e->score_rows, need);
+    hipError_t herr = eng_malloc(e, &e->score_rows, need);
     if (herr != hipSuccess) return fail(e, MSR_ERR_NOMEM, "score rows (%zu bytes): %s", need, hipGetErrorString(herr));
     e->score_rows_bytes = need;
     return MSR_OK;
@@ -260,19 +274,22 @@ extern "C" int msr_bind_postings(msr_engine* e, const int64_t* term_off, int64_t
         return fail(e, MSR_ERR_INVALID, "msr_bind_postings: n_docs %lld differs from bound chunks (%lld)",
                     (long long)n_docs, (long long)e->dense.n_docs);
     HIP_TRY(e, hipSetDevice(e->cfg.device));
+    // from here on the previous binding's tables are being replaced: the engine counts as unbound until this call succeeds
+    // (a failed re-bind must not leave msr_bm25_topk reading freed tables)
+    e->have_postings = false;
     int rc = ensure_score_rows(e, n_docs);
     if (rc) return rc;
     {   // candidate lists of the BM25 stage: worst case every document of every query
         const size_t need = (size_t)e->cfg.max_queries * (size_t)n_docs * sizeof(int32_t);
         hipError_t herr;
         if (need > e->bm_cand_bytes) {
-            free_dev(e->bm_cand_doc); e->bm_cand_doc = nullptr; e->bm_cand_bytes = 0;
-            if ((herr = hipMalloc((void**)&e->bm_cand_doc, need)) != hipSuccess)
+            free_dev(e, e->bm_cand_doc); e->bm_cand_doc = nullptr; e->bm_cand_bytes = 0;
+            if ((herr = eng_malloc(e, (void**)&e->bm_cand_doc, need)) != hipSuccess)
                 return fail(e, MSR_ERR_NOMEM, "BM25 candidate lists (%zu bytes): %s", need, hipGetErrorString(herr));
             e->bm_cand_bytes = need;
         }
-        free_dev(e->bm_cand_n); e->bm_cand_n = nullptr;
-        if ((herr = hipMalloc((void**)&e->bm_cand_n, (size_t)e->cfg.max_queries * msr_bm25_max_segments(n_docs) * sizeof(int32_t))) != hipSuccess)
+        free_dev(e, e->bm_cand_n); e->bm_cand_n = nullptr;
+        if ((herr = eng_malloc(e, (void**)&e->bm_cand_n, (size_t)e->cfg.max_queries * msr_bm25_max_segments(n_docs) * sizeof(int32_t))) != hipSuccess)
             return fail(e, MSR_ERR_NOMEM, "BM25 candidate counts: %s", hipGetErrorString(herr));
 
     }
@@ -295,10 +312,10 @@ extern "C" int msr_bind_postings(msr_engine* e, const int64_t* term_off, int64_t
     if (!(avgdl > 0.0f) || !(k1 >= 0.0) || !(b >= 0.0 && b <= 1.0))
         return fail(e, MSR_ERR_INVALID, "msr_bind_postings: avgdl must be > 0, k1 >= 0, 0 <= b <= 1");
     // skip table for the long posting lists (one-time; the offsets come to the host once for this)
-    free_dev(e->bm_heavy_id); e->bm_heavy_id = nullptr;
-    free_dev(e->bm_tile_off); e->bm_tile_off = nullptr;
-    free_dev(e->bm_dense_id); e->bm_dense_id = nullptr;
-    free_dev(e->bm_dense); e->bm_dense = nullptr;
+    free_dev(e, e->bm_heavy_id); e->bm_heavy_id = nullptr;
+    free_dev(e, e->bm_tile_off); e->bm_tile_off = nullptr;
+    free_dev(e, e->bm_dense_id); e->bm_dense_id = nullptr;
+    free_dev(e, e->bm_dense); e->bm_dense = nullptr;
     std::vector<int32_t> dense_terms;                         // long lists with negative idf, longest first (tables below)
     if (n_terms > 0) {
         std::vector<int64_t> h_toff((size_t)n_terms + 1);
@@ -317,17 +334,19 @@ extern "C" int msr_bind_postings(msr_engine* e, const int64_t* term_off, int64_t
             hipError_t herr;
             int32_t* d_terms = nullptr;
             const size_t rows = heavy_terms.size() * (size_t)(cand.n_tiles + 1);
-            if ((herr = hipMalloc((void**)&e->bm_heavy_id, heavy_id.size() * sizeof(int32_t))) != hipSuccess ||
-                (herr = hipMalloc((void**)&e->bm_tile_off, rows * sizeof(uint32_t))) != hipSuccess ||
-                (herr = hipMalloc((void**)&d_terms, heavy_terms.size() * sizeof(int32_t))) != hipSuccess) {
-                free_dev(d_terms);
+            if ((herr = eng_malloc(e, (void**)&e->bm_heavy_id, heavy_id.size() * sizeof(int32_t))) != hipSuccess ||
+                (herr = eng_malloc(e, (void**)&e->bm_tile_off, rows * sizeof(uint32_t))) != hipSuccess ||
+                (herr = eng_malloc(e, (void**)&d_terms, heavy_terms.size() * sizeof(int32_t))) != hipSuccess) {
+                free_dev(e, d_terms);
                 return fail(e, MSR_ERR_NOMEM, "BM25 skip table: %s", hipGetErrorString(herr));
             }
-            HIP_TRY(e, hipMemcpyAsync(e->bm_heavy_id, heavy_id.data(), heavy_id.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-            HIP_TRY(e, hipMemcpyAsync(d_terms, heavy_terms.data(), heavy_terms.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-            HIP_TRY(e, msr_bm25_build_skip(cand, d_terms, (int)heavy_terms.size(), e->bm_tile_off, st));
-            HIP_TRY(e, hipStreamSynchronize(st));
-            free_dev(d_terms);
+            hipError_t h1 = hipMemcpyAsync(e->bm_heavy_id, heavy_id.data(), heavy_id.size() * sizeof(int32_t), hipMemcpyHostToDevice, st);
+            if (h1 == hipSuccess) h1 = hipMemcpyAsync(d_terms, heavy_terms.data(), heavy_terms.size() * sizeof(int32_t), hipMemcpyHostToDevice, st);
+            if (h1 == hipSuccess) h1 = msr_bm25_build_skip(cand, d_terms, (int)heavy_terms.size(), e->bm_tile_off, st);
+            const hipError_t h2 = hipStreamSynchronize(st);
+            free_dev(e, d_terms);                             // (on every path)
+            if (h1 != hipSuccess || h2 != hipSuccess)
+                return fail(e, MSR_ERR_HIP, "BM25 skip table: %s", hipGetErrorString(h1 != hipSuccess ? h1 : h2));
             cand.heavy_id = e->bm_heavy_id;
             cand.tile_off = e->bm_tile_off;
         }
@@ -341,20 +360,22 @@ extern "C" int msr_bind_postings(msr_engine* e, const int64_t* term_off, int64_t
     }
     // the copy the scoring kernel streams (after the validation above: the copy is of a well-formed index): every posting with
     // its tf_component, from the per-document length norms k1 (1 - b + b dl / avgdl)
-    free_dev(e->bm_post); e->bm_post = nullptr;
+    free_dev(e, e->bm_post); e->bm_post = nullptr;
     {
         const int64_t n_pad = (int64_t)cand.n_tiles * MSR_BM25_TILE;
         double* dnorm = nullptr;
         const size_t bytes = (size_t)(n_postings + 1) * sizeof(Bm25Post);      // + the sentinel posting
-        hipError_t herr = hipMalloc(&e->bm_post, bytes);
+        hipError_t herr = eng_malloc(e, &e->bm_post, bytes);
         if (herr != hipSuccess)
             return fail(e, MSR_ERR_NOMEM, "postings with tf components (%zu bytes): %s", bytes, hipGetErrorString(herr));
-        if ((herr = hipMalloc((void**)&dnorm, (size_t)n_pad * sizeof(double))) != hipSuccess)
+        if ((herr = eng_malloc(e, (void**)&dnorm, (size_t)n_pad * sizeof(double))) != hipSuccess) {
+            free_dev(e, e->bm_post); e->bm_post = nullptr;
             return fail(e, MSR_ERR_NOMEM, "length norms: %s", hipGetErrorString(herr));
+        }
         hipError_t h1 = msr_bm25_dnorm(doc_len, n_docs, n_pad, k1, b, (double)avgdl, dnorm, st);
         hipError_t h2 = h1 == hipSuccess ? msr_bm25_post_comp(post_doc, post_tf, dnorm, k1, n_postings, (Bm25Post*)e->bm_post, st) : h1;
         hipError_t h3 = hipStreamSynchronize(st);
-        free_dev(dnorm);
+        free_dev(e, dnorm);
         if (h2 != hipSuccess || h3 != hipSuccess)
             return fail(e, MSR_ERR_HIP, "tf components: %s", hipGetErrorString(h2 != hipSuccess ? h2 : h3));
     }
@@ -365,18 +386,20 @@ extern "C" int msr_bind_postings(msr_engine* e, const int64_t* term_off, int64_t
         for (size_t h = 0; h < dense_terms.size(); ++h) dense_id[dense_terms[h]] = (int32_t)h;
         hipError_t herr;
         int32_t* d_terms = nullptr;
-        if ((herr = hipMalloc((void**)&e->bm_dense_id, dense_id.size() * sizeof(int32_t))) != hipSuccess ||
-            (herr = hipMalloc((void**)&e->bm_dense, dense_terms.size() * (size_t)stride * sizeof(double))) != hipSuccess ||
-            (herr = hipMalloc((void**)&d_terms, dense_terms.size() * sizeof(int32_t))) != hipSuccess) {
-            free_dev(d_terms);
+        if ((herr = eng_malloc(e, (void**)&e->bm_dense_id, dense_id.size() * sizeof(int32_t))) != hipSuccess ||
+            (herr = eng_malloc(e, (void**)&e->bm_dense, dense_terms.size() * (size_t)stride * sizeof(double))) != hipSuccess ||
+            (herr = eng_malloc(e, (void**)&d_terms, dense_terms.size() * sizeof(int32_t))) != hipSuccess) {
+            free_dev(e, d_terms);
             return fail(e, MSR_ERR_NOMEM, "BM25 dense tables: %s", hipGetErrorString(herr));
         }
-        HIP_TRY(e, hipMemcpyAsync(e->bm_dense_id, dense_id.data(), dense_id.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-        HIP_TRY(e, hipMemcpyAsync(d_terms, dense_terms.data(), dense_terms.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-        HIP_TRY(e, hipMemsetAsync(e->bm_dense, 0, dense_terms.size() * (size_t)stride * sizeof(double), st));
-        HIP_TRY(e, msr_bm25_build_dense(cand, d_terms, (int)dense_terms.size(), e->bm_dense, stride, st));
-        HIP_TRY(e, hipStreamSynchronize(st));
-        free_dev(d_terms);
+        hipError_t h1 = hipMemcpyAsync(e->bm_dense_id, dense_id.data(), dense_id.size() * sizeof(int32_t), hipMemcpyHostToDevice, st);
+        if (h1 == hipSuccess) h1 = hipMemcpyAsync(d_terms, dense_terms.data(), dense_terms.size() * sizeof(int32_t), hipMemcpyHostToDevice, st);
+        if (h1 == hipSuccess) h1 = hipMemsetAsync(e->bm_dense, 0, dense_terms.size() * (size_t)stride * sizeof(double), st);
+        if (h1 == hipSuccess) h1 = msr_bm25_build_dense(cand, d_terms, (int)dense_terms.size(), e->bm_dense, stride, st);
+        const hipError_t h2 = hipStreamSynchronize(st);
+        free_dev(e, d_terms);                                 // (on every path)
+        if (h1 != hipSuccess || h2 != hipSuccess)
+            return fail(e, MSR_ERR_HIP, "BM25 dense tables: %s", hipGetErrorString(h1 != hipSuccess ? h1 : h2));
         cand.dense_id = e->bm_dense_id;
         cand.dense_comp = e->bm_dense;
         cand.dense_stride = stride;
@@ -449,34 +472,34 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
     const int n_wspans = (int)wspans.size() - 1;
     const int n_wspans12 = (int)wspans12.size() - 1;
 
-    free_dev(e->chunk_doc); e->chunk_doc = nullptr;
-    free_dev(e->row_meta); e->row_meta = nullptr;
-    free_dev(e->emb_presplit); e->emb_presplit = nullptr;
-    free_dev(e->inv_norm_own); e->inv_norm_own = nullptr;
-    free_dev(e->span_doc); e->span_doc = nullptr;
-    free_dev(e->wspan_doc); e->wspan_doc = nullptr;
-    free_dev(e->wspan12_doc); e->wspan12_doc = nullptr;
+    free_dev(e, e->chunk_doc); e->chunk_doc = nullptr;
+    free_dev(e, e->row_meta); e->row_meta = nullptr;
+    free_dev(e, e->emb_presplit); e->emb_presplit = nullptr;
+    free_dev(e, e->inv_norm_own); e->inv_norm_own = nullptr;
+    free_dev(e, e->span_doc); e->span_doc = nullptr;
+    free_dev(e, e->wspan_doc); e->wspan_doc = nullptr;
+    free_dev(e, e->wspan12_doc); e->wspan12_doc = nullptr;
     hipError_t herr;
-    if ((herr = hipMalloc((void**)&e->chunk_doc, (size_t)n_chunks * sizeof(int32_t))) != hipSuccess)
+    if ((herr = eng_malloc(e, (void**)&e->chunk_doc, (size_t)n_chunks * sizeof(int32_t))) != hipSuccess)
         return fail(e, MSR_ERR_NOMEM, "chunk_doc: %s", hipGetErrorString(herr));
-    if ((herr = hipMalloc((void**)&e->span_doc, spans.size() * sizeof(int32_t))) != hipSuccess)
+    if ((herr = eng_malloc(e, (void**)&e->span_doc, spans.size() * sizeof(int32_t))) != hipSuccess)
         return fail(e, MSR_ERR_NOMEM, "span_doc: %s", hipGetErrorString(herr));
-    if ((herr = hipMalloc((void**)&e->wspan_doc, wspans.size() * sizeof(int32_t))) != hipSuccess)
+    if ((herr = eng_malloc(e, (void**)&e->wspan_doc, wspans.size() * sizeof(int32_t))) != hipSuccess)
         return fail(e, MSR_ERR_NOMEM, "wspan_doc: %s", hipGetErrorString(herr));
     HIP_TRY(e, hipMemcpyAsync(e->span_doc, spans.data(), spans.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     HIP_TRY(e, hipMemcpyAsync(e->wspan_doc, wspans.data(), wspans.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    if ((herr = hipMalloc((void**)&e->wspan12_doc, wspans12.size() * sizeof(int32_t))) != hipSuccess)
+    if ((herr = eng_malloc(e, (void**)&e->wspan12_doc, wspans12.size() * sizeof(int32_t))) != hipSuccess)
         return fail(e, MSR_ERR_NOMEM, "wspan12_doc: %s", hipGetErrorString(herr));
     HIP_TRY(e, hipMemcpyAsync(e->wspan12_doc, wspans12.data(), wspans12.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     HIP_TRY(e, msr_fill_chunk_doc(doc_off, n_docs, e->chunk_doc, st));
     if (!inv_norm) {
-        if ((herr = hipMalloc((void**)&e->inv_norm_own, (size_t)n_chunks * sizeof(float))) != hipSuccess)
+        if ((herr = eng_malloc(e, (void**)&e->inv_norm_own, (size_t)n_chunks * sizeof(float))) != hipSuccess)
             return fail(e, MSR_ERR_NOMEM, "inv_norm: %s", hipGetErrorString(herr));
         HIP_TRY(e, msr_row_inv_norm(emb, n_chunks, e->inv_norm_own, st));
         inv_norm = e->inv_norm_own;
     }
     if (wide_ok) {
-        if ((herr = hipMalloc(&e->row_meta, (size_t)(n_chunks + 16) * 8)) != hipSuccess)
+        if ((herr = eng_malloc(e, &e->row_meta, (size_t)(n_chunks + 16) * 8)) != hipSuccess)
             return fail(e, MSR_ERR_NOMEM, "row_meta: %s", hipGetErrorString(herr));
         HIP_TRY(e, msr_pack_row_meta(e->chunk_doc, inv_norm, n_chunks, e->row_meta, st));
     }
@@ -498,7 +521,7 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
         if (e->cfg.scan_layout != 0 || !wide_ok) {
             variant = 7;                                  // preconditions of the K-split kernel not met
         } else {
-            if ((herr = hipMalloc(&e->emb_presplit, (size_t)n_chunks * MSR_DIM * sizeof(float))) != hipSuccess)
+            if ((herr = eng_malloc(e, &e->emb_presplit, (size_t)n_chunks * MSR_DIM * sizeof(float))) != hipSuccess)
                 return fail(e, MSR_ERR_NOMEM, "pre-split rows (%zu bytes): %s", (size_t)n_chunks * MSR_DIM * sizeof(float),
                             hipGetErrorString(herr));
             HIP_TRY(e, msr_presplit_rows(emb, n_chunks, e->emb_presplit, st));
@@ -508,7 +531,7 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
     e->dense = DenseIndex{emb, doc_off, e->chunk_doc, inv_norm, e->span_doc, n_chunks, n_docs, (n_docs + 31) / 32 * 32, n_spans,
                           e->cfg.scan_layout, e->wspan_doc, n_wspans, e->wspan12_doc, n_wspans12, e->qimg, nullptr,
                           e->emb_presplit, e->row_meta, wide_ok, wide_ok && wide_ok64, nullptr, variant};
-    free_dev(e->emb_bf16);                                // a new binding invalidates the bf16 copy
+    free_dev(e, e->emb_bf16);                                // a new binding invalidates the bf16 copy
     e->emb_bf16 = nullptr;
     free_gemm(e);
     free_gf(e);
@@ -527,7 +550,7 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
         }
         if (tiles.back() != (int32_t)n_chunks) tiles.push_back((int32_t)n_chunks);
         if (ok) {
-            if ((herr = hipMalloc((void**)&e->tile_row, tiles.size() * 4)) != hipSuccess)
+            if ((herr = eng_malloc(e, (void**)&e->tile_row, tiles.size() * 4)) != hipSuccess)
                 return fail(e, MSR_ERR_NOMEM, "tile table: %s", hipGetErrorString(herr));
             HIP_TRY(e, hipMemcpyAsync(e->tile_row, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, st));
             HIP_TRY(e, hipStreamSynchronize(st));
@@ -538,8 +561,8 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
                 h_trow[t] = (int32_t)n_trows;
                 n_trows += (tiles[t + 1] - tiles[t] + 15) / 16 * 16;
             }
-            if (n_trows + 256 < ((int64_t)1 << 31)) {
-                if ((herr = hipMalloc((void**)&e->tile_trow, (size_t)e->n_tiles * 4)) != hipSuccess)
+            if (n_trows + MSR_STREAM256_TILE_ROWS < ((int64_t)1 << 31)) {
+                if ((herr = eng_malloc(e, (void**)&e->tile_trow, (size_t)e->n_tiles * 4)) != hipSuccess)
                     return fail(e, MSR_ERR_NOMEM, "tile table: %s", hipGetErrorString(herr));
                 HIP_TRY(e, hipMemcpyAsync(e->tile_trow, h_trow.data(), (size_t)e->n_tiles * 4, hipMemcpyHostToDevice, st));
                 HIP_TRY(e, hipStreamSynchronize(st));
@@ -557,7 +580,7 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
         const int GF_WV_CAP = 4096 * std::max(1, groups / 2);
         const size_t QM = (size_t)groups * 128;
         const int max_nt = std::max(1, std::min(4, groups / 2));      // 256-query groups that share the rows of one launch
-        auto alloc = [&](void** p, size_t bytes) { return hipMalloc(p, bytes); };
+        auto alloc = [&](void** p, size_t bytes) { return eng_malloc(e, p, bytes); };
         if ((herr = alloc((void**)&e->gf_inv_pad, (size_t)(n_chunks + 512) * 4)) != hipSuccess ||
             (herr = alloc(&e->gf_qimg, (size_t)groups * 24 * 8192)) != hipSuccess ||
             (herr = alloc((void**)&e->gf_qn, (QM + 64) * MSR_DIM * 4)) != hipSuccess ||
@@ -585,14 +608,32 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
         HIP_TRY(e, hipMemsetAsync(e->gf_cand_n, 0, QM * 4, st));
         HIP_TRY(e, msr_f16_row_error(emb, inv_norm, n_chunks, e->gf_err, st));   // measured once: the margin of the f16 filter
         // The 256-query kernel streams a copy of the rows in fragment order (whole cache lines per load instruction; +3 % rows
-        // of padding: every tile starts at a multiple of 16 rows; 256 rows of slack behind the last tile, which loads 256 rows
-        // like every other).  The row-major matrix stays what every other kernel reads.
+        // of padding: every tile starts at a multiple of 16 rows).  Size of the copy: a workgroup's tile visit ALWAYS loads
+        // MSR_STREAM256_TILE_ROWS = 8 waves x 32 rows from the tile's first row on, whatever the tile's own length (rows behind
+        // the tile are masked in the epilogue); all K blocks of a visit, and the prefetch of the next visit's first block,
+        // address rows of [first row of a tile, first row + MSR_STREAM256_TILE_ROWS) -- the "next" tile of a workgroup's last
+        // visit is that same tile again (jn == jt).  So the highest row the kernel touches is max_t tile_trow[t] +
+        // MSR_STREAM256_TILE_ROWS - 1 < n_trows + MSR_STREAM256_TILE_ROWS: that many rows of zero padding behind the last
+        // tile are exactly enough, for every prefetch depth (checked against the tile table here, not assumed).
+        // The row-major matrix stays what every other kernel reads.  Declined by MSR_CFG_NO_ROW_COPY, or when the allocation
+        // fails (the copy doubles the matrix): the TILED = false instantiation of the same kernel reads the caller's matrix.
+        e->row_copy_state = 0;
         if (groups >= 2 && e->tile_trow) {
-            if ((herr = alloc(&e->gf_emb_tiled, (size_t)(n_trows + 256) * MSR_DIM * 4)) != hipSuccess)
-                return fail(e, MSR_ERR_NOMEM, "fragment-order copy of the rows (%zu bytes): %s", (size_t)(n_trows + 256) * MSR_DIM * 4,
-                            hipGetErrorString(herr));
-            HIP_TRY(e, hipMemsetAsync((char*)e->gf_emb_tiled + (size_t)n_trows * MSR_DIM * 4, 0, (size_t)256 * MSR_DIM * 4, st));
-            HIP_TRY(e, msr_tile_rows(emb, e->tile_row, e->tile_trow, n_tiles, e->gf_emb_tiled, st));
+            const size_t copy_rows = (size_t)n_trows + MSR_STREAM256_TILE_ROWS;
+            if ((int64_t)h_trow.back() + MSR_STREAM256_TILE_ROWS > (int64_t)copy_rows)
+                return fail(e, MSR_ERR_INVALID, "msr_bind_chunks: internal: tile table exceeds the fragment-order copy");
+            if (e->cfg.flags & MSR_CFG_NO_ROW_COPY) {
+                e->row_copy_state = 2;
+            } else if ((herr = alloc(&e->gf_emb_tiled, copy_rows * MSR_DIM * 4)) != hipSuccess) {
+                (void)hipGetLastError();                      // clear the sticky error: the engine works without the copy
+                e->gf_emb_tiled = nullptr;
+                e->row_copy_state = 3;
+            } else {
+                HIP_TRY(e, hipMemsetAsync((char*)e->gf_emb_tiled + (size_t)n_trows * MSR_DIM * 4, 0,
+                                          (size_t)MSR_STREAM256_TILE_ROWS * MSR_DIM * 4, st));
+                HIP_TRY(e, msr_tile_rows(emb, e->tile_row, e->tile_trow, n_tiles, e->gf_emb_tiled, st));
+                e->row_copy_state = 1;
+            }
         }
         e->gf = GemmF32Index{e->tile_row, n_tiles, e->n_cus, groups, e->gf_inv_pad, e->gf_qimg, e->gf_tmax_t, e->gf_tmax, stride,
                              e->gf_thr, e->gf_thr2, e->gf_flag, e->gf_wvbuf,
@@ -639,6 +680,15 @@ extern "C" int msr_scan_width(const msr_engine* e) {
 }
 
 extern "C" int msr_dense_path(const msr_engine* e) { return e ? e->last_dense_width : -1; }
+
+extern "C" int64_t msr_owned_bytes(const msr_engine* e) {
+    if (!e) return -1;
+    int64_t total = 0;
+    for (const auto& kv : e->owned) total += (int64_t)kv.second;
+    return total;
+}
+
+extern "C" int msr_row_copy_state(const msr_engine* e) { return e ? e->row_copy_state : -1; }
 
 extern "C" int msr_batch_width(const msr_engine* e) {
     if (!e || !e->have_chunks || !e->emb_bf16) return -1;
@@ -749,7 +799,9 @@ extern "C" int msr_dense_topk(msr_engine* e, const float* q, int32_t n_queries, 
     while (q0 < n_queries) {
         const int left = n_queries - q0;
         if (gemm && left > 64) {
-            const int nq = std::min(128 * e->gf.max_groups, left);
+            // more than 128 queries run in groups of 256: with an odd number of 128-query groups only the even part is usable
+            const int cap = e->gf.max_groups >= 2 ? (e->gf.max_groups & ~1) * 128 : 128;
+            const int nq = std::min(cap, left);
             // (normalised once for the pass AND for the gated sweeps behind it: zero rows up to the last slice's 64)
             HIP_TRY(e, msr_prep_queries(q + (int64_t)q0 * MSR_DIM, nq, e->gf_qn, (nq + 63) / 64 * 64, st));
             HIP_TRY(e, hipMemsetAsync(e->gf_gate, 0, 16 * 4, st));
@@ -818,9 +870,9 @@ extern "C" int msr_enable_bf16(msr_engine* e, void* stream) {
     // The image holds the rows NORMALISED and then rounded to bf16 (so a score needs no per-row scale and the error bound
     // of msr_batch.hip is about unit vectors), padded with 512 zero rows: the GEMM reads 256 rows from any tile start.
     const int64_t n_pad = C + 512;
-    if ((herr = hipMalloc(&e->emb_bf16, (size_t)n_pad * MSR_DIM * 2)) != hipSuccess)
+    if ((herr = eng_malloc(e, &e->emb_bf16, (size_t)n_pad * MSR_DIM * 2)) != hipSuccess)
         return fail(e, MSR_ERR_NOMEM, "bf16 embeddings (%zu bytes): %s", (size_t)n_pad * MSR_DIM * 2, hipGetErrorString(herr));
-    auto alloc = [&](void** p, size_t bytes) { return *p ? hipSuccess : hipMalloc(p, bytes); };
+    auto alloc = [&](void** p, size_t bytes) { return *p ? hipSuccess : eng_malloc(e, p, bytes); };
     const size_t QS = GM_SLICE;                             // the candidate scratch serves both the sweeps and the GEMM path
     if ((herr = alloc((void**)&e->bt_top_doc, (size_t)BT_SLICE * MSR_MAX_K * 4)) != hipSuccess ||
         (herr = alloc((void**)&e->bt_top_score, (size_t)BT_SLICE * MSR_MAX_K * 4)) != hipSuccess ||

@@ -397,6 +397,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
     constexpr int RSLOTS = G2_NB / KPS;                            // ring slots = one query block's worth of rows
     constexpr int NMI = 2, NNI = 16;                               // the wave's fragments: 32 rows x 256 queries
     constexpr int WROWS = 16 * NMI;                                // rows per wave
+    static_assert((G2_THREADS / 64) * WROWS == MSR_STREAM256_TILE_ROWS, "the fragment-order copy is padded for this many rows per tile visit");
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = w, wc = 0;                                      // row group, query half (none)

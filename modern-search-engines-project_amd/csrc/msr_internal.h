@@ -238,6 +238,10 @@ hipError_t msr_gemm_candidates(const GemmIndex& g, const DenseIndex& ix, const f
                                int32_t* cand_doc, int32_t* cand_n, hipEvent_t* ev,
                                hipStream_t stream);
 
+// Rows a workgroup of the 256-query streaming kernel loads per tile visit, from the tile's first row on and whatever the
+// tile's own length: 8 waves x 32 rows.  Sizes the zero padding behind the last tile of the fragment-order copy (msr_engine.hip).
+constexpr int MSR_STREAM256_TILE_ROWS = 256;
+
 // Arguments of the streaming passes (msr_gemm_f32.hip): one persistent workgroup per CU walks row tiles (<= 256 rows, cut at
 // document boundaries), rows through a register ring, the query image through LDS.
 struct StreamArgs {

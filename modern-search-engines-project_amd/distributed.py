@@ -161,6 +161,14 @@ class ShardedEngine:
         return res
 
     @staticmethod
+    def _truncate(fused, keep):
+        """rerank_keep: the first `keep` columns of the fused lists, with the COUNT clamped to match (a caller iterating
+        range(n[q]) stays inside the truncated rows); `rows` (chunk rows that took part, RerankResponse.total_documents) is
+        a property of the request, not of the list, and stays."""
+        doc, score, orig, chunk, n, rows = fused
+        return (doc[:, :keep], score[:, :keep], orig[:, :keep], chunk[:, :keep], torch.clamp(n, max=keep), rows)
+
+    @staticmethod
     def _globalise(idx, base):
         return idx if base == 0 else torch.where(idx >= 0, idx + base, idx)
 
@@ -209,7 +217,7 @@ class ShardedEngine:
         if self.world == 1:
             cos, meta = e.rerank_gather(qvec, b_doc, b_n, doc_base=self.doc_base, row_base=self.row_base, max_chunks=max_chunks)
             r = e.rerank_fuse(b_doc, b_score, b_n, cos, meta, **rerank_params)
-            out["rerank"] = r if keep == k1 else tuple(x[:, :keep] if x.dim() == 2 else x for x in r)
+            out["rerank"] = r if keep == k1 else self._truncate(r, keep)
             return out
         rx = ex.rerank.get((k1, keep))
         if rx is None:
@@ -231,8 +239,10 @@ class ShardedEngine:
             cp, mp = rx.recv_parts()
             cos, meta = e.rerank_combine(cp, mp, hi - lo)
             fused = e.rerank_fuse(b_doc[lo:hi], b_score[lo:hi], b_n[lo:hi], cos, meta, **rerank_params)
+            if keep < k1:
+                fused = self._truncate(fused, keep)
             for (name, _, per_k), x in zip(_FUSED, fused):
-                rx.out_view(name)[:hi - lo].copy_(x[:, :keep] if per_k else x)
+                rx.out_view(name)[:hi - lo].copy_(x)
         # d. the fused lists of all queries to every rank
         dist.all_gather_into_tensor(rx.out_recv, rx.out_send, group=self.group)
         out["rerank"] = tuple(rx.gathered(name)[:Q] for name, _, _ in _FUSED)

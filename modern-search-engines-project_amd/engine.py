@@ -56,7 +56,9 @@ def stream_to_device(arr, device, block_bytes=128 << 20):
 
 class DeviceEngine:
     def __init__(self, index: CorpusIndex, device=0, max_queries=32, max_k=1000, rerank_max_docs=1000,
-                 scan_layout=0, scan_variant=0):
+                 scan_layout=0, scan_variant=0, row_copy=True):
+        """row_copy=False: MSR_CFG_NO_ROW_COPY -- the 256-query pass reads the row-major matrix instead of an engine-owned
+        fragment-order copy of it (half the embedding footprint, a slower pass, the same results)."""
         if not torch.cuda.is_available():
             raise _abi.MsrError(-102, "no GPU visible: the retrieval path runs on MI355X only (no CPU fallback)")
         self.lib = _abi.load()
@@ -66,7 +68,8 @@ class DeviceEngine:
         self.scan_layout = int(scan_layout)
         self.rerank_max_docs = int(rerank_max_docs)
         cfg = _abi.MsrConfig(C.sizeof(_abi.MsrConfig), self.device.index or 0, DIM, int(max_queries), int(max_k),
-                             int(rerank_max_docs), int(scan_layout), int(scan_variant))
+                             int(rerank_max_docs), int(scan_layout), int(scan_variant),
+                             0 if row_copy else _abi.MSR_CFG_NO_ROW_COPY)
         self.handle = C.c_void_p()
         rc = self.lib.msr_create(C.byref(cfg), C.byref(self.handle))
         if rc != 0:
@@ -156,6 +159,14 @@ class DeviceEngine:
         """Most queries one pass over the embedding matrix serves in dense_topk (256 / 128: streaming pass, 64: K-split sweep,
         else 32)."""
         return int(self.lib.msr_scan_width(self.handle))
+
+    def row_copy_state(self):
+        """'none' (not applicable), 'built', 'declined' (row_copy=False) or 'alloc_failed' (fell back to the row-major matrix)."""
+        return {0: "none", 1: "built", 2: "declined", 3: "alloc_failed"}.get(self.lib.msr_row_copy_state(self.handle), "?")
+
+    def owned_bytes(self):
+        """Device bytes the handle owns (scratch, tables and copies built at bind); the bound index tensors are not included."""
+        return int(self.lib.msr_owned_bytes(self.handle))
 
     def dense_path(self):
         """Queries per pass of the kernel the most recent dense_topk call ran (256 / 128 / 64 / 32; 0 before the first)."""

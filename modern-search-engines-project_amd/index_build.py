@@ -10,6 +10,8 @@ The result is a CorpusIndex in the engine's layout (CSR by term, documents ascen
 """
 from collections import Counter
 
+import math
+
 import numpy as np
 
 from .index import CorpusIndex
@@ -28,7 +30,13 @@ def idf_real(total_docs, doc_freq):
     float64, stored REAL (float32); N itself round-trips through a REAL column (:361-364, :133).  doc_freq: integer array."""
     n_real = float(np.float32(total_docs))
     df = np.asarray(doc_freq, np.float64)
-    return np.log10((n_real - df + 0.5) / (df + 0.5)).astype(np.float32)
+    ratio = (n_real - df + 0.5) / (df + 0.5)
+    # the logarithm goes through libm's log10 (what DuckDB's LOG and the reference-executed fixture resolve to): numpy's
+    # vectorised log10 differs from it in the last float64 ulp on ~1.6 % of inputs, which could flip a float32 rounding.
+    # Evaluated once per DISTINCT document frequency (a Zipfian vocabulary has few of them).
+    uniq, inv = np.unique(ratio, return_inverse=True)
+    logs = np.fromiter((math.log10(x) for x in uniq.tolist()), np.float64, len(uniq))
+    return logs[inv].reshape(ratio.shape).astype(np.float32)
 
 
 def bm25_index_from_tokens(doc_ids, token_lists, k1=1.2, b=0.75):

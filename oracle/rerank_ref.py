@@ -114,6 +114,28 @@ def positional_adjust(new, n):
     return new
 
 
+def chain_from_cosines(docs, n_rows, bm25, cos, smoothing=0.15):
+    """reranker_api.py:360-372 on the cosines of the candidates' chunk rows: min-max of the cosines and of the BM25 scores
+    (repeated per chunk row) over ALL rows, blend, positional weighting per document, per-document first maximum.
+    docs: the kept documents in the order of their rows; n_rows[i] chunk rows of docs[i] (>= 1), bm25[i] its stage-1 score;
+    cos: one float per chunk row, documents in that order, chunks in chunk_id order.
+    -> ([(doc, new_similarity, old_similarity, index of the winning chunk within the document)] in `docs` order, stages)."""
+    new = normalise([float(x) for x in cos])
+    old = normalise([float(b) for b, n in zip(bm25, n_rows) for _ in range(n)])
+    st = {"cos_norm": list(new), "bm25_norm": list(old)}
+    new = [a * (1 - smoothing) + o * smoothing for a, o in zip(new, old)]
+    st["blend"] = list(new)
+    out, pos, p = [], [], 0
+    for d, n in zip(docs, n_rows):
+        adj = positional_adjust(new[p:p + n], n)
+        pos += adj
+        best = max(range(n), key=lambda i: (adj[i], -i))
+        out.append((d, adj[best], old[p + best], best))
+        p += n
+    st["positional"] = pos
+    return out, st
+
+
 def rerank(urls, chunk_id, chunk_doc, emb, qvec, doc_ids, similarities, smoothing=0.15, top_k=100,
            diversification=True, return_stages=False):
     """Restatement of the /rerank endpoint body (reranker_api.py:337-412).  Returns the response as a
@@ -127,23 +149,11 @@ def rerank(urls, chunk_id, chunk_doc, emb, qvec, doc_ids, similarities, smoothin
     kept = [d for d in kept if d in old_of]
     flat = [(d, r) for d in kept for r in rows[d]]
     cos = cosine_f32(qvec, emb[[r for _, r in flat]])
-    stages = {"cos": [float(x) for x in cos]}
-    new = normalise([float(x) for x in cos])
-    old = normalise([old_of[d] for d, _ in flat])
-    stages["cos_norm"], stages["bm25_norm"] = list(new), list(old)
-    new = [n * (1 - smoothing) + o * smoothing for n, o in zip(new, old)]
-    stages["blend"] = list(new)
-    out, pos, p = [], [], 0
-    for d in kept:
-        n = len(rows[d])
-        adj = positional_adjust(new[p:p + n], n)
-        pos += adj
-        best = max(range(n), key=lambda i: (adj[i], -i))
-        out.append({"doc_id": str(d), "title": urls[d][1], "url": urls[d][0],
-                    "similarity_score": adj[best], "original_similarity": old[p + best],
-                    "window_index": int(chunk_id[rows[d][best]]), "window_score": adj[best]})
-        p += n
-    stages["positional"] = pos
+    pooled, st = chain_from_cosines(kept, [len(rows[d]) for d in kept], [old_of[d] for d in kept], cos, smoothing)
+    stages = {"cos": [float(x) for x in cos], "cos_norm": st["cos_norm"], "bm25_norm": st["bm25_norm"], "blend": st["blend"],
+              "positional": st["positional"]}
+    out = [{"doc_id": str(d), "title": urls[d][1], "url": urls[d][0], "similarity_score": s_, "original_similarity": o_,
+            "window_index": int(chunk_id[rows[d][b_]]), "window_score": s_} for d, s_, o_, b_ in pooled]
     stages["rows"] = [(d, int(chunk_id[r])) for d, r in flat]
     out.sort(key=lambda x: (-x["similarity_score"], int(x["doc_id"])))
     stages["pooled"] = [(int(x["doc_id"]), x["window_index"], x["similarity_score"], x["original_similarity"]) for x in out]

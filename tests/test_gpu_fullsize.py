@@ -310,7 +310,20 @@ def test_fullsize_gemm_1024_queries_equals_exact(world):
     rows = torch.randint(0, N_CHUNKS, (1024,), generator=g)
     noise = torch.nn.functional.normalize(torch.randn((1024, 768), generator=g), dim=1).to(dev)
     q = (ix.emb[rows.to(dev)] + 0.5 * noise) * 9.0
+    q[0] = ix.emb[2_468_013] * 4.0                                                 # exact hit, first query group
+    q[600] = torch.randn(768, generator=g).to(dev) * 3.0                           # random direction: a flat score landscape
+    q[1023] = (ix.emb[N_CHUNKS - 1] + 0.1 * noise[0]) * 0.6                        # the last row of the last tile, last group
     got = eng.dense_topk_batched(q, k=100)
+    # the comparator above 128 queries is NOT another HIP path: plain torch f32 (reranker_api.py:285 arithmetic, per-document
+    # max :370) for queries of the first / a middle / the last group of 256 -- an exact hit, a flat landscape, the last tile
+    for i in (0, 1, 255, 256, 600, 777, 1022, 1023):
+        best, ti, tv = _dense_torch(ix, q[i], 100)
+        assert float((got[1][i] - best[got[0][i].long()]).abs().max()) <= 1e-5    # every reported score is right
+        assert float((got[1][i] - tv).abs().max()) <= 1e-5                        # and the list is the top-k
+        missing = set(ti.tolist()) ^ set(got[0][i].tolist())
+        assert all(abs(float(best[d]) - float(tv[-1])) <= 2e-5 for d in missing)   # only boundary near-ties may swap
+    assert abs(float(got[1][0, 0]) - 1.0) <= 1e-5 and int(got[2][0, 0]) == 2_468_013
+    assert int(got[2][1023, 0]) == N_CHUNKS - 1
     assert bool((got[3] == 100).all())
     assert bool((torch.diff(got[1], dim=1) <= 0).all())                            # sorted
     eq = torch.diff(got[1], dim=1) == 0
@@ -326,3 +339,104 @@ def test_fullsize_gemm_1024_queries_equals_exact(world):
     again = eng.dense_topk_batched(q, k=100)                                       # idempotent, bit for bit
     for x, y in zip(got, again):
         assert torch.equal(x, y)
+
+
+def _rerank_expected(ix, q, cand_doc, cand_bm25, n):
+    """The /rerank arithmetic (reranker_api.py:27-63 fetch of <= 10 chunks per candidate, :285 f32 cosine as sklearn computes it,
+    :360-372 chain) for ONE query at the full size: rows gathered and multiplied by plain torch f32 on the GPU, the float64
+    chain by the oracle's Python-float restatement (oracle.rerank_ref.chain_from_cosines, pinned to rerank_chain.json).
+    The synthetic corpus has no urlsDB strings: every document is its own URL group and none is missing."""
+    from oracle import rerank_ref
+    docs = cand_doc[:n].long()
+    order = torch.argsort(docs)                                        # the reference's rows come out in doc_id order
+    docs, bm = docs[order], cand_bm25[:n][order]
+    lo = ix.doc_off[docs].long(); cnt = torch.clamp(ix.doc_off[docs + 1].long() - lo, max=10)
+    keep = cnt > 0
+    docs, bm, lo, cnt = docs[keep], bm[keep], lo[keep], cnt[keep]
+    rows = torch.cat([torch.arange(int(a), int(a) + int(c), device=q.device) for a, c in zip(lo.tolist(), cnt.tolist())])
+    e = ix.emb[rows]
+    en = torch.linalg.vector_norm(e, dim=1); en[en == 0] = 1.0
+    qn = torch.linalg.vector_norm(q); qn = qn if float(qn) != 0.0 else torch.ones_like(qn)
+    cos = ((e / en[:, None]) @ (q / qn)).float().cpu().numpy()
+    pooled, _ = rerank_ref.chain_from_cosines(docs.tolist(), cnt.tolist(), bm.tolist(), cos)
+    first = dict(zip(docs.tolist(), lo.tolist()))
+    pooled = sorted(pooled, key=lambda x: (-x[1], x[0]))
+    return [(d, s, o, first[d] + b) for d, s, o, b in pooled], int(cnt.sum())
+
+
+def _check_rerank(ix, q, b, r, i, tol=5e-6):
+    """row i of a rerank result r = (doc, score, orig, chunk, n, rows) against _rerank_expected."""
+    exp, n_rows = _rerank_expected(ix, q, b[0][i], b[1][i], int(b[2][i]))
+    n = int(r[4][i])
+    assert n == len(exp) and int(r[5][i]) == n_rows
+    gd, gs, go, gc = r[0][i, :n].tolist(), r[1][i, :n].tolist(), r[2][i, :n].tolist(), r[3][i, :n].tolist()
+    assert float(np.abs(np.array(gs) - np.array([e[1] for e in exp])).max()) <= tol
+    assert sorted(gd) == sorted(e[0] for e in exp)
+    emap = {e[0]: e for e in exp}
+    swaps = 0
+    for j, d in enumerate(gd):
+        e = emap[d]
+        assert abs(gs[j] - e[1]) <= tol and abs(go[j] - e[2]) <= 1e-12
+        if gc[j] != e[3]:                                             # arg-max chunk: may differ only on a near-tie inside the doc
+            swaps += 1
+        if d != exp[j][0]:                                            # rank swap: only between scores within rounding
+            assert abs(exp[j][1] - e[1]) <= 2 * tol
+    assert swaps <= max(1, n // 100)
+    assert all(gs[j] >= gs[j + 1] for j in range(n - 1))
+
+
+def test_fullsize_single_query(world):
+    """BASELINE configs[2] as worded -- ONE query on 1 M docs / 5 M chunks: the Q = 1 instantiation of the K-split sweep (the
+    kernel behind p50_latency_ms_single_query) and the whole hybrid step with one query, against torch f64 (BM25, bitwise),
+    torch f32 (dense, 1e-5) and the oracle's chain (rerank, 5e-6)."""
+    from msretr.distributed import ShardedEngine
+    ix, eng, dev = world["ix"], world["eng"], world["dev"]
+    g = torch.Generator(device="cpu"); g.manual_seed(77)
+    noise = torch.nn.functional.normalize(torch.randn(768, generator=g), dim=0).to(dev)
+    singles = [world["qvec"][3], ix.emb[1_357_911] * 2.0, (ix.emb[N_CHUNKS - 1] + 0.1 * noise) * 5.0,
+               torch.randn(768, generator=g).to(dev) * 7.0]
+    for j, q1 in enumerate(singles):
+        doc, score, chunk, n = eng.dense_topk(q1.reshape(1, 768), k=100)
+        assert int(n[0]) == 100
+        best, ti, tv = _dense_torch(ix, q1, 100)
+        assert float((score[0] - best[doc[0].long()]).abs().max()) <= 1e-5
+        assert float((score[0] - tv).abs().max()) <= 1e-5
+        missing = set(ti.tolist()) ^ set(doc[0].tolist())
+        assert all(abs(float(best[d]) - float(tv[-1])) <= 2e-5 for d in missing)
+        if j == 1:
+            assert abs(float(score[0, 0]) - 1.0) <= 1e-5 and int(chunk[0, 0]) == 1_357_911
+        if j == 2:
+            assert int(chunk[0, 0]) == N_CHUNKS - 1
+    se = ShardedEngine(eng, 0, 0)
+    for i in (0, 5, 11):
+        tl = [ix.term_ids(world["terms"][i])]
+        q1 = world["qvec"][i:i + 1].contiguous()
+        out = se.search(tl, q1, k1=1000, k2=100)
+        ri, rs = _bm25_torch(ix, tl[0], 1000, 0.0)
+        b = out["bm25"]
+        assert int(b[2][0]) == len(ri) and torch.equal(b[0][0, :len(ri)].long(), ri) and torch.equal(b[1][0, :len(ri)], rs)
+        best, ti, tv = _dense_torch(ix, q1[0], 100)
+        d = out["dense"]
+        assert float((d[1][0] - tv).abs().max()) <= 1e-5 and float((d[1][0] - best[d[0][0].long()]).abs().max()) <= 1e-5
+        _check_rerank(ix, q1[0], b, out["rerank"], 0)
+
+
+def test_fullsize_rerank_vs_oracle_chain(world):
+    """Rerank / fuse at the benchmark's size and batch shape (256 queries per step on the headline path): rows of the step's
+    rerank output against the reference's arithmetic (reranker_api.py:285, 357-372) restated by torch f32 + the oracle."""
+    from msretr.distributed import ShardedEngine
+    from msretr.synthetic import synthetic_queries
+    ix = world["ix"]
+    eng = world["DeviceEngine"](ix, max_queries=256, max_k=1000, rerank_max_docs=1000)
+    terms, qvec = synthetic_queries(ix, 256, seed=4242)
+    se = ShardedEngine(eng, 0, 0)
+    tl = [ix.term_ids(t) for t in terms]
+    out = se.search(tl, qvec, k1=1000, k2=100)
+    assert eng.dense_path() == 256
+    for i in (0, 63, 128, 200, 255):
+        _check_rerank(ix, qvec[i], out["bm25"], out["rerank"], i)
+    # rerank_keep truncates the lists AND the counts (ADVICE r3)
+    cut = se.search(tl, qvec, k1=1000, k2=100, rerank_keep=100)["rerank"]
+    assert tuple(cut[0].shape) == (256, 100) and int(cut[4].max()) <= 100
+    assert torch.equal(cut[0], out["rerank"][0][:, :100]) and torch.equal(cut[1], out["rerank"][1][:, :100])
+    eng.close()

@@ -622,6 +622,16 @@ def test_batched_gemm_path_equals_exact_scan(mods):
             # where the documents agree the arg-max chunk agrees too, unless two chunks of the document tie within rounding
             agree = (got[2] == exact[2]) | ~same
             assert agree.mean() > 0.999
+            # ... and against the CPU oracle (oracle/dense_ref.py: sklearn's f32 cosine, per-document max, stable order), not
+            # only against the engine's own exact path: queries of every 256-group the call holds
+            for i in sorted({0, 2, 39, 128, Q - 1, Q // 2, min(Q - 1, 256), min(Q - 1, 511), min(Q - 1, 600)}):
+                if i == 1:
+                    continue
+                oi, os_, oa = mods["dense_ref"].quick_search(emb, doc_off, q[i], k)
+                assert got[3][i] == len(oi)
+                np.testing.assert_allclose(got[1][i], os_, rtol=0, atol=1e-5)
+                ok = (got[0][i] == oi) | (np.abs(np.r_[np.diff(os_), 1.0]) <= 4e-6) | (np.abs(np.r_[1.0, np.diff(os_)]) <= 4e-6)
+                assert ok.all()
     assert eng.lib.msr_tune(eng.handle, 1, 3) < 0           # the product library has no tuning keys
     # msr_dense_topk with room for several groups of 128 queries per call (max_queries = 512: the passes of up to 4 groups
     # are queued back to back and finished together, 700 queries = 512 + 188) returns what one group per call returns
@@ -630,6 +640,15 @@ def test_batched_gemm_path_equals_exact_scan(mods):
     many = [x.cpu().numpy() for x in eng4.dense_topk(q, k=100)]
     assert all(np.array_equal(a_, b_) for a_, b_ in zip(one, many))
     eng4.close()
+    # an engine whose max_queries / 128 is odd (a chunk of 300 .. 384 queries rounded up to 512 > 384 and was
+    # refused): the call is cut into whole 256-query groups that fit (256 + the rest)
+    eng3 = mods["DeviceEngine"](ix, max_queries=384, max_k=100, rerank_max_docs=0)
+    for Q in (300, 384, 700):
+        odd = [x.cpu().numpy() for x in eng3.dense_topk(q[:Q], k=100)]
+        assert all(np.array_equal(a_[:256], b_[:256]) for a_, b_ in zip(one, odd))      # exact f32 finish on both: same bits
+        assert np.array_equal(one[3][:Q], odd[3]) and np.abs(one[1][:Q] - odd[1]).max() <= 1e-5
+        assert np.all((one[0][:Q] == odd[0]) | (np.abs(one[1][:Q] - odd[1]) <= 1e-5)) and (one[0][:Q] == odd[0]).mean() > 0.99
+    eng3.close()
     # zero query: every cosine is exactly 0 -> the k lowest-indexed documents that have chunks, in order
     z = [x.cpu().numpy() for x in eng.dense_topk_batched(q[:200], k=100)]
     has = np.nonzero(n > 0)[0][:100]

@@ -54,7 +54,7 @@ def test_diversify_matches_reference_outputs():
 def test_library_exports_every_declared_symbol():
     from msretr import _abi
     hdr = "".join(open(os.path.join(ROOT, "include", h), encoding="utf-8").read() for h in ("msretr.h", "msretr_encoder.h"))
-    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(msr_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|int64_t|const char\*)\s+(msr_\w+)\s*\(", hdr, flags=re.M))
     assert declared, "no prototypes found in msretr.h"
     lib = _abi.load()
     for name in declared:
@@ -72,6 +72,9 @@ def test_create_rejects_bad_config_and_reports_why():
     assert b"dim" in lib.msr_last_error(None)
     cfg = _abi.MsrConfig(4, 0, 768, 8, 100, 100, 0, 0)                               # wrong struct size
     assert lib.msr_create(C.byref(cfg), C.byref(h)) == -1
+    cfg = _abi.MsrConfig(C.sizeof(_abi.MsrConfig), 0, 768, 8, 100, 100, 0, 0, 0x40)  # a flag bit this ABI does not know
+    assert lib.msr_create(C.byref(cfg), C.byref(h)) == -1 and b"flag" in lib.msr_last_error(None)
+    assert lib.msr_owned_bytes(None) == -1 and lib.msr_row_copy_state(None) == -1
     assert lib.msr_destroy(None) == 0
 
 

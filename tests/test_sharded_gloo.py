@@ -43,7 +43,10 @@ def _run(rank, world, port, ret, snap_dir=None):
         se = ShardedEngine(OracleEngine(sh), sh.doc_base, sh.row_base)
         assert se.world == world and se.rank == rank
         out = se.search([sh.term_ids(t) for t in terms], qvec, k1=200, k2=50)
-        ret[rank] = {k: [x.numpy() for x in v] for k, v in out.items()}
+        res = {k: [x.numpy() for x in v] for k, v in out.items()}
+        cut = se.search([sh.term_ids(t) for t in terms], qvec, k1=200, k2=50, rerank_keep=20)
+        res["rerank_cut"] = [x.numpy() for x in cut["rerank"]]
+        ret[rank] = res
     finally:
         dist.destroy_process_group()
 
@@ -70,6 +73,12 @@ def test_two_rank_sharded_equals_unsharded(via_snapshot, tmp_path):
         for key in ("bm25", "dense", "rerank"):
             for a, b in zip(got[key], ref[key]):
                 assert a.shape == b.shape and np.array_equal(a, b), (r, key)
+        # rerank_keep < k1: lists AND counts are cut (a caller iterating range(n[q]) stays inside the rows it was given)
+        cut = got["rerank_cut"]
+        assert cut[0].shape == (len(terms), 20) and int(cut[4].max()) <= 20
+        assert np.array_equal(cut[4], np.minimum(ref["rerank"][4], 20)) and np.array_equal(cut[5], ref["rerank"][5])
+        for j in range(4):
+            assert np.array_equal(cut[j], ref["rerank"][j][:, :20])
     # both ranks hold identical results
     for key in ("bm25", "dense", "rerank"):
         for a, b in zip(ret[0][key], ret[1][key]):
