@@ -268,6 +268,117 @@ def dense_parity(gpu, cpu, k):
             "kernel": "the batch of the timed steps in one msr_dense_topk call (streaming pass + exact f32 rescoring), rows of the CPU sample"}
 
 
+def _term_name(t):
+    """an alphabetic name for synthetic term id t (so that the facade's default tokeniser -- lower-cased alphabetic tokens,
+    the stand-in for the reference's spaCy lemmatiser -- reads it back): 'q' + base-26 digits."""
+    s = ""
+    t = int(t)
+    while True:
+        s = chr(97 + t % 26) + s
+        t //= 26
+        if t == 0:
+            return "q" + s
+
+
+def facade_bench(args, shard, eng, terms, qvec, n_queries=1024, single=20):
+    """The drop-in API a maintainer of the reference calls, timed end to end on the HOST clock: `Retriever.batch_search_to_file`
+    (search_api.py:331-367: queries.txt -> preprocess_query -> tokenise -> BM25 top-1000 -> rerank -> diversification ->
+    `qnum<TAB>rank<TAB>url<TAB>score` lines in a file) for n_queries queries.txt-shaped queries, and `Retriever.search` (the
+    /api/search path, one query, UI dicts) for the p50.  The synthetic corpus gets URL / title / text strings (5003 domains)
+    for this; query strings are the benchmark's term lists spelled as words (the city term is appended by preprocess_query,
+    as in the reference); query vectors are given (the headline's queries arrive as vectors too)."""
+    import tempfile
+    from msretr.retriever import Retriever
+    from msretr.text import CITY
+    t0 = time.time()
+    N = shard.n_docs
+    ids = shard.doc_ids.cpu().numpy() if hasattr(shard.doc_ids, "cpu") else np.asarray(shard.doc_ids)
+    pool = ["Synthetic page text. " * (2 + j % 17) for j in range(64)]
+    shard.urls = [f"https://site{int(d) % 5003}.example/page/{int(d)}" for d in ids]
+    shard.titles = [f"Title {int(d)}" for d in ids]
+    shard.texts = [pool[i & 63] for i in range(N)]
+    shard._url_group = None
+    used = sorted({int(t) for tl in terms[:n_queries] for t in tl})
+    shard.vocab = {_term_name(t): t for t in used if t != 0}
+    shard.vocab[CITY] = 0
+    rt = Retriever(indexer=eng)
+    # (the engine was bound before the URL strings existed: every document is its own URL group, which is what these URLs
+    # say too -- one page per document)
+    texts = [" ".join(_term_name(t) for t in tl if t != 0) for tl in terms[:n_queries]]
+    embs = qvec[:n_queries].cpu().numpy()
+    tmp = tempfile.mkdtemp(prefix="msr_facade_")
+    qf, of = os.path.join(tmp, "queries.txt"), os.path.join(tmp, "batch_search_results.txt")
+    with open(qf, "w", encoding="utf-8") as f:
+        for i, t in enumerate(texts):
+            f.write(f"{i + 1}\t{t}\n")
+    setup_s = time.time() - t0
+    from msretr.text import read_queries_file
+    nq = read_queries_file(qf)
+    rt.batch_search(nq[:64], query_embeddings=embs[:64]).text()          # warm-up (binds the domain table, builds the URL blob)
+    torch.cuda.synchronize()
+    times = []
+    for rep in range(3):
+        t1 = time.perf_counter()
+        n_lines = rt.batch_search_to_file(qf, of, query_embeddings=embs)
+        times.append(time.perf_counter() - t1)
+    total = min(times)
+    # where the time goes (one more pass, stage by stage)
+    t1 = time.perf_counter()
+    idl, qv = rt._prepare([q for _, q in nq], embs, None)
+    t2 = time.perf_counter()
+    doc, score, _, n = rt.final_lists(idl, qv)
+    t3 = time.perf_counter()
+    from msretr.retriever import BatchLines
+    BatchLines([a for a, _ in nq], doc, score, n, rt.index.urls, rt._formatter).write(of)
+    t4 = time.perf_counter()
+    # the engine's share alone: the same calls with the inputs packed and resident, device time only
+    packed = [eng.pack_queries(idl[a:a + 256]) for a in range(0, n_queries, 256)]
+    qd = qvec[:n_queries].contiguous()
+
+    def engine_only():
+        for j, a in enumerate(range(0, n_queries, 256)):
+            b = eng.bm25_topk(None, k=1000, packed=packed[j])
+            cos, meta = eng.rerank_gather(qd[a:a + 256], b[0], b[2])
+            eng.diversify(eng.rerank_fuse(b[0], b[1], b[2], cos, meta))
+    engine_only(); torch.cuda.synchronize()
+    t5 = time.perf_counter()
+    for _ in range(3):
+        engine_only()
+    torch.cuda.synchronize()
+    eng_ms = 1e3 * (time.perf_counter() - t5) / 3
+    # the list-of-dicts form of the same results (search_api.py:276-292 builds it per result in Python): materialised on demand
+    t6 = time.perf_counter()
+    as_list = list(rt.batch_search(nq, query_embeddings=embs))
+    t7 = time.perf_counter()
+    lat = []
+    for rep in range(2):
+        for i in range(single):
+            torch.cuda.synchronize()
+            t8 = time.perf_counter()
+            docs = rt.search(texts[i], query_embedding=embs[i])
+            if rep:
+                lat.append(time.perf_counter() - t8)
+    with open(of, "rb") as f:
+        head = f.readline().decode().rstrip("\n")
+    ok = n_lines == int(n.sum()) and len(as_list) == n_lines and as_list[0]["formatted_line"] == head and len(docs) > 0
+    return {"api": "Retriever.batch_search_to_file (search_api.py:331-367 /api/batch_search_file): queries.txt -> preprocess_query -> "
+                   "tokenise -> BM25 top-1000 -> rerank/fuse -> diversification -> top-100 lines written to a file; host clock, "
+                   "everything included",
+            "queries": n_queries, "value": n_queries / total, "unit": "queries/sec", "ms_per_batch": 1e3 * total,
+            "lines_written": int(n_lines), "results_per_query": float(n.mean()),
+            "breakdown_ms": {"read + preprocess + tokenise + term ids + vectors": 1e3 * (t2 - t1),
+                             "device path incl. packing, H2D, D2H of the final rows": 1e3 * (t3 - t2),
+                             "native line formatting + file write": 1e3 * (t4 - t3)},
+            "engine_ms_same_batch": eng_ms, "ratio_to_engine": 1e3 * total / eng_ms,
+            "engine_calls": "msr_bm25_topk + msr_rerank_gather + msr_rerank_fuse + msr_diversify, 256 queries per call, inputs resident",
+            "as_list_of_dicts_ms": 1e3 * (t7 - t6),
+            "p50_latency_ms_single_query": 1e3 * float(np.median(lat)),
+            "single_query_api": "Retriever.search (search_api.py:69-152 /api/search without the LLM call): UI dicts of the top 100",
+            "outputs_sane": bool(ok), "setup_s": setup_s,
+            "note": "the reference's live path has no dense full scan (BM25 -> rerank of the 1000 candidates); the headline step adds "
+                    "one, so its engine time is not this path's"}
+
+
 def rerank_parity(gpu, cpu, tol=5e-6):
     """The fused lists of the GPU step (msr_rerank_gather + msr_rerank_fuse on the GPU's own stage-1 candidates) against the
     CPU restatement of reranker_api.py:357-372 on ITS stage-1 candidates (bit-equal lists: bm25_parity_vs_cpu), query by query:
@@ -332,6 +443,8 @@ def main():
                          "a rank owns, the join of N halves and the fuse of 1/N of the queries; no collective is executed")
     ap.add_argument("--with-encoder", action="store_true",
                     help="time the variant that starts from token ids (QueryEncoder -> hybrid step) even with --no-variants")
+    ap.add_argument("--facade", action="store_true",
+                    help="time the drop-in API (Retriever.batch_search_to_file / Retriever.search) even with --no-variants")
     ap.add_argument("--latency-queries", type=int, default=20)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--same-device", action="store_true",
@@ -743,6 +856,11 @@ def main():
             line["roofline_exact_f32"] = exact
         if with_enc is not None:
             line["variant_with_encoder"] = with_enc
+        if world == 1 and args.workload == "hybrid" and (args.facade or not args.no_variants):
+            try:
+                line["facade"] = facade_bench(args, shard, eng, terms, qvec, n_queries=min(1024, n_pool))
+            except Exception as ex:
+                line["facade"] = {"error": repr(ex)}
         if world == 1 and not args.no_cpu_baseline and args.workload == "hybrid":
             try:
                 cb, cres, cdense, crerank = cpu_baseline(args, shard, terms, qvec, dev)

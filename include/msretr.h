@@ -185,6 +185,34 @@ int msr_rerank(msr_engine* e, const float* q, int32_t n_queries, const int32_t* 
                const msr_rerank_params* params, int32_t* out_doc, double* out_score, double* out_orig,
                int32_t* out_chunk, int32_t* out_n, int32_t* out_rows, void* stream);
 
+/* Domain diversification of fused lists on the device (reranker_api.py:170-236 hybrid_diversification; :376-397 the response
+ * models rejecting NULL title / url / text), so that a batch brings back top_k rows per query instead of max_cand.
+ *   msr_bind_doc_domains: domain[d] i32 for every document index the fused lists may hold (GLOBAL indices): the id of
+ *     urlparse(url).netloc.lower() (any numbering; equal ids = same domain), or -1 for a document that never appears in a
+ *     response.  Borrowed like the other bound arrays; NULL unbinds (every document accepted, each its own domain).
+ *   msr_diversify: fused_* [n_queries][max_cand] / fused_n [n_queries] as msr_rerank / msr_rerank_fuse return them (ordered by
+ *     (new_similarity desc, doc asc)).  diversify != 0: one result per domain among the domains whose best entry scores
+ *     >= relevance_threshold (0.8), then one per remaining domain up to top_k, then -- if still short of top_k -- the dropped
+ *     entries with their scores shifted below the last kept one (delta = first_dropped - last_kept + 1e-4, clamped at 0),
+ *     float64, the reference's operations in the reference's order.  diversify == 0: the first top_k accepted entries.
+ *     out_* [n_queries][max_cand] (like the reference, the list may exceed top_k when more than top_k domains are "high");
+ *     rows past out_n[q] are -1 / -inf. */
+int msr_bind_doc_domains(msr_engine* e, const int32_t* domain, int64_t n_docs, void* stream);
+int msr_diversify(msr_engine* e, int32_t n_queries, const int32_t* fused_doc, const double* fused_score,
+                  const double* fused_orig, const int32_t* fused_chunk, const int32_t* fused_n, int32_t max_cand,
+                  int32_t top_k, double relevance_threshold, int32_t diversify, int32_t* out_doc, double* out_score,
+                  double* out_orig, int32_t* out_chunk, int32_t* out_n, void* stream);
+
+/* HOST function (every pointer is host memory; no device is touched): the batch result lines of search_api.py:290,
+ * "{query_num}\t{rank}\t{url}\t{score:.3f}\n", for n_queries final lists in one call.  Query q's number is the bytes
+ * qnum_blob[qnum_off[q] .. qnum_off[q+1]); its list is doc / score [q * stride .. + n[q]) (rank = position + 1); the URL of
+ * document d is url_blob[url_off[d] .. url_off[d+1]) (UTF-8; d outside [0, n_docs): empty).  The score is printed exactly as
+ * Python's format(score, ".3f").  Returns the bytes written; if `capacity` is below the function's upper bound of them nothing
+ * is written and the result is -(that bound) (call with capacity 0 to size the buffer); INT64_MIN for a bad argument. */
+int64_t msr_format_lines(const char* qnum_blob, const int64_t* qnum_off, int32_t n_queries, const int32_t* doc,
+                         const double* score, const int32_t* n, int32_t stride, const char* url_blob, const int64_t* url_off,
+                         int64_t n_docs, char* out, int64_t capacity);
+
 /* The two halves of msr_rerank, for a doc-sharded index (the reference-exact hybrid needs a
  * second exchange).  cand_doc holds GLOBAL document indices and is identical on every rank.
  *   msr_rerank_gather: for the candidates this shard owns (doc_base <= doc < doc_base + n_docs) writes the

@@ -29,6 +29,7 @@ UNITS = {
     "msr_gemm_f32.hip": [],
     "msr_build.hip": [],
     "msr_encoder.hip": ["-ffp-contract=off"],
+    "msr_format.cpp": [],             # host-only C++ (result-line formatter)
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
@@ -57,10 +58,11 @@ def build_library(force=False, verbose=False, save_temps=False, diag=False):
     objs, jobs = [], []
     for src, extra in UNITS.items():
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", suffix))
+        o = os.path.join(CSRC, os.path.splitext(src)[0] + suffix)
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            cmd = [hipcc] + COMMON + extra + (["-DMSR_DIAG"] if diag else []) + ["-c", s, "-o", o]
+            common = COMMON if src.endswith(".hip") else [f for f in COMMON if not f.startswith("--offload-arch")]
+            cmd = [hipcc] + common + extra + (["-DMSR_DIAG"] if diag else []) + ["-c", s, "-o", o]
             if save_temps:
                 cmd.insert(1, "-save-temps=obj")
             jobs.append(cmd)

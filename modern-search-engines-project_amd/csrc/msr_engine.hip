@@ -23,6 +23,8 @@ struct msr_engine {
     bool have_chunks = false;
     const int32_t* url_group = nullptr;
     int64_t url_group_n = 0;
+    const int32_t* doc_domain = nullptr;   // msr_bind_doc_domains (borrowed): domain id per document, -1 = rejected from responses
+    int64_t doc_domain_n = 0;
     // engine-owned device memory
     int32_t* chunk_doc = nullptr;
     void* emb_presplit = nullptr;     // scan_variant 15: f16 hi/lo image of the rows
@@ -652,6 +654,33 @@ extern "C" int msr_bind_doc_meta(msr_engine* e, const int32_t* url_group, int64_
         return fail(e, MSR_ERR_INVALID, "msr_bind_doc_meta: n_docs mismatch");
     e->url_group = url_group;
     e->url_group_n = n_docs;
+    return MSR_OK;
+}
+
+extern "C" int msr_bind_doc_domains(msr_engine* e, const int32_t* domain, int64_t n_docs, void* stream) {
+    (void)stream;
+    if (!e) return MSR_ERR_INVALID;
+    if (n_docs < 0 || (domain && n_docs == 0)) return fail(e, MSR_ERR_INVALID, "msr_bind_doc_domains: bad argument");
+    e->doc_domain = domain;
+    e->doc_domain_n = domain ? n_docs : 0;
+    return MSR_OK;
+}
+
+extern "C" int msr_diversify(msr_engine* e, int32_t n_queries, const int32_t* fused_doc, const double* fused_score,
+                             const double* fused_orig, const int32_t* fused_chunk, const int32_t* fused_n, int32_t max_cand,
+                             int32_t top_k, double relevance_threshold, int32_t diversify, int32_t* out_doc, double* out_score,
+                             double* out_orig, int32_t* out_chunk, int32_t* out_n, void* stream) {
+    if (!e) return MSR_ERR_INVALID;
+    if (!fused_doc || !fused_score || !fused_orig || !fused_chunk || !fused_n || !out_doc || !out_score || !out_orig || !out_chunk ||
+        !out_n)
+        return fail(e, MSR_ERR_INVALID, "msr_diversify: null argument");
+    if (n_queries < 0 || max_cand < 1 || max_cand > 1024 || top_k < 1)
+        return fail(e, MSR_ERR_INVALID, "msr_diversify: bad argument (max_cand=%d, top_k=%d)", max_cand, top_k);
+    if (n_queries == 0) return MSR_OK;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, msr_diversify_run(n_queries, fused_doc, fused_score, fused_orig, fused_chunk, fused_n, max_cand, e->doc_domain,
+                                 e->doc_domain_n, top_k, relevance_threshold, diversify, out_doc, out_score, out_orig, out_chunk,
+                                 out_n, (hipStream_t)stream));
     return MSR_OK;
 }
 

@@ -193,6 +193,13 @@ hipError_t msr_rerank_fuse_run(int nq, const int32_t* cand_doc, const double* ca
                                int32_t* out_doc, double* out_score, double* out_orig, int32_t* out_chunk,
                                int32_t* out_n, int32_t* out_rows, hipStream_t stream);
 
+// domain diversification of fused lists (reranker_api.py:178-236): f_* as msr_rerank_fuse_run leaves them; doc_domain[d] =
+// domain id of document d, -1 = rejected from responses (nullptr: every document accepted, its own domain)
+hipError_t msr_diversify_run(int nq, const int32_t* f_doc, const double* f_score, const double* f_orig, const int32_t* f_chunk,
+                             const int32_t* f_n, int max_cand, const int32_t* doc_domain, int64_t n_domain_docs, int top_k,
+                             double threshold, int diversify, int32_t* out_doc, double* out_score, double* out_orig,
+                             int32_t* out_chunk, int32_t* out_n, hipStream_t stream);
+
 // out[0 .. n_words) = OR over the n_parts arrays in + p * part_stride_bytes (32-bit words)
 hipError_t msr_or_parts(const void* in, int n_parts, int64_t part_stride_bytes, int64_t n_words, void* out, hipStream_t stream);
 

@@ -258,7 +258,144 @@ __global__ __launch_bounds__(RR_THREADS) void rerank_fuse_kernel(
     if (tid == 0) { out_n[q] = n_keep; out_rows[q] = cnt[0]; }
 }
 
+
+// ---- domain diversification of the fused lists (reranker_api.py:178-236), one workgroup per query ----------------------
+// Input: the fused list of a query as rerank_fuse_kernel leaves it -- (new_similarity desc, document asc) -- and one word
+// per document: its DOMAIN id (urlparse(url).netloc.lower(), :170-176, numbered by the host at bind) or -1 for a document
+// the reference's response models reject (NULL title / url / text, :376-397; dropped BEFORE the diversification).
+// hybrid_diversification on a list in that order reduces to (derivation in DESIGN.md section 3, K6b):
+//   * a domain is "high" iff its FIRST entry scores >= threshold (the list is sorted, the first entry is the domain's best);
+//     every entry of a domain is in the same tier, so apply_domain_cap(.., 1) on either tier keeps exactly the first entry
+//     of each domain: kept-high entries (score >= threshold) precede kept-medium ones in list order;
+//   * final = kept-high + kept-medium[: top_k - #kept-high]   (Python slice semantics, a NEGATIVE bound included);
+//   * if that is short of top_k: the dropped entries, stably sorted by score with the high tier's drops first on ties, fill
+//     it up with their scores shifted by delta = first_dropped - last_kept + 1e-4, clamped at 0 -- all float64, the
+//     reference's operations in the reference's order (the file is compiled with -ffp-contract=off);
+//   * the closing sorted() is then the identity (kept scores descend, shifted scores descend from last_kept - 1e-4).
+// diversify == 0 (config.yaml similarity.diversification false): the first top_k accepted entries.
+constexpr int DV_THREADS = 1024;
+
+__device__ __forceinline__ int dv_excl_scan(bool flag, int* wsum, int* total) {
+    // exclusive prefix count of `flag` over the workgroup (thread order); *total = the count.  Two barriers.
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(flag);
+    const int within = __popcll(m & ((1ull << lane) - 1ull));
+    __syncthreads();                                     // (wsum may still be read from an earlier scan)
+    if (lane == 0) wsum[wv] = __popcll(m);
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int i = 0; i < DV_THREADS / 64; ++i) {
+        const int c = wsum[i];
+        if (i < wv) base += c;
+        tot += c;
+    }
+    *total = tot;
+    return base + within;
+}
+
+__global__ __launch_bounds__(DV_THREADS) void diversify_kernel(
+    const int32_t* __restrict__ f_doc, const double* __restrict__ f_score, const double* __restrict__ f_orig,
+    const int32_t* __restrict__ f_chunk, const int32_t* __restrict__ f_n, int max_cand,
+    const int32_t* __restrict__ doc_domain, int64_t n_domain_docs, int top_k, double threshold, int diversify,
+    int32_t* __restrict__ out_doc, double* __restrict__ out_score, double* __restrict__ out_orig,
+    int32_t* __restrict__ out_chunk, int32_t* __restrict__ out_n) {
+    __shared__ int32_t Ldom[RR_MAXM];
+    __shared__ double Ls[RR_MAXM];
+    __shared__ int16_t Lsrc[RR_MAXM];
+    __shared__ uint8_t Lhi[RR_MAXM], Ldrop[RR_MAXM];
+    __shared__ int wsum[DV_THREADS / 64];
+    __shared__ double s_last, s_a0;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    int n = f_n[q];
+    n = n < 0 ? 0 : (n > max_cand ? max_cand : n);
+    n = n > RR_MAXM ? RR_MAXM : n;
+    const int64_t row = (int64_t)q * max_cand;
+    // 1. accepted entries, in list order
+    int dm = -1;
+    double sc = 0.0;
+    if (tid < n) {
+        const int d = f_doc[row + tid];
+        sc = f_score[row + tid];
+        if (d >= 0) dm = doc_domain ? ((int64_t)d < n_domain_docs ? doc_domain[d] : -1) : d;     // (no table: every document its own domain)
+    }
+    int nv = 0;
+    const int v = dv_excl_scan(dm >= 0, wsum, &nv);
+    if (dm >= 0) { Ldom[v] = dm; Ls[v] = sc; Lsrc[v] = (int16_t)tid; }
+    __syncthreads();
+    auto emit = [&](int pos, int src, double score) {
+        out_doc[row + pos] = f_doc[row + src]; out_score[row + pos] = score;
+        out_orig[row + pos] = f_orig[row + src]; out_chunk[row + pos] = f_chunk[row + src];
+    };
+    int n_out = 0;
+    if (!diversify) {
+        n_out = nv < top_k ? nv : top_k;
+        if (tid < n_out) emit(tid, Lsrc[tid], Ls[tid]);
+    } else {
+        // 2. first entry of each domain; tier of the domain
+        bool kept = false, hi = false;
+        if (tid < nv) {
+            const int mine = Ldom[tid];
+            int f = 0;
+            while (Ldom[f] != mine) ++f;                 // (terminates at f == tid at the latest)
+            kept = f == tid;
+            hi = Ls[f] >= threshold;
+            Lhi[tid] = hi ? 1 : 0; Ldrop[tid] = kept ? 0 : 1;
+        }
+        int n_kept = 0, n_hi = 0;
+        const int kr = dv_excl_scan(kept, wsum, &n_kept);
+        (void)dv_excl_scan(kept && hi, wsum, &n_hi);
+        const int n_med = n_kept - n_hi, remaining = top_k - n_hi;
+        const int take_med = remaining >= 0 ? (n_med < remaining ? n_med : remaining) : (n_med + remaining > 0 ? n_med + remaining : 0);
+        const int n_final = n_hi + take_med;
+        const bool in_final = kept && kr < n_final;       // (kept-high entries have kr < n_hi, kept-medium ones kr - n_hi < take_med)
+        if (in_final) {
+            emit(kr, Lsrc[tid], Ls[tid]);
+            if (kr == n_final - 1) s_last = Ls[tid];
+        }
+        n_out = n_final;
+        const int need = top_k - n_final, n_drop = nv - n_kept;
+        if (need > 0 && n_drop > 0) {                     // (workgroup-uniform)
+            // 3. the dropped entries in the order of sorted(dropped_high + dropped_medium, key=score, reverse=True)
+            int rr = 0;
+            const bool dropped = tid < nv && !kept;
+            if (dropped) {
+                const double ms = Ls[tid];
+                for (int j = 0; j < nv; ++j) {
+                    if (!Ldrop[j] || j == tid) continue;
+                    const double js = Ls[j];
+                    const bool before = js > ms || (js == ms && (Lhi[j] > (uint8_t)hi || (Lhi[j] == (uint8_t)hi && j < tid)));
+                    rr += before ? 1 : 0;
+                }
+                if (rr == 0) s_a0 = Ls[tid];
+            }
+            __syncthreads();
+            const int n_add = need < n_drop ? need : n_drop;
+            if (dropped && rr < n_add) {
+                const double delta = (s_a0 - s_last) + 1e-4;
+                const double x = Ls[tid] - delta;
+                emit(n_final + rr, Lsrc[tid], x > 0.0 ? x : 0.0);
+            }
+            n_out = n_final + n_add;
+        }
+    }
+    for (int i = n_out + tid; i < max_cand; i += DV_THREADS) {
+        out_doc[row + i] = -1; out_score[row + i] = -__builtin_inf(); out_orig[row + i] = 0.0; out_chunk[row + i] = -1;
+    }
+    if (tid == 0) out_n[q] = n_out;
+}
+
 }  // namespace
+
+hipError_t msr_diversify_run(int nq, const int32_t* f_doc, const double* f_score, const double* f_orig, const int32_t* f_chunk,
+                             const int32_t* f_n, int max_cand, const int32_t* doc_domain, int64_t n_domain_docs, int top_k,
+                             double threshold, int diversify, int32_t* out_doc, double* out_score, double* out_orig,
+                             int32_t* out_chunk, int32_t* out_n, hipStream_t stream) {
+    if (nq <= 0) return hipSuccess;
+    if (max_cand <= 0 || max_cand > RR_MAXM || top_k < 1) return hipErrorInvalidValue;
+    diversify_kernel<<<nq, DV_THREADS, 0, stream>>>(f_doc, f_score, f_orig, f_chunk, f_n, max_cand, doc_domain, n_domain_docs,
+                                                    top_k, threshold, diversify, out_doc, out_score, out_orig, out_chunk, out_n);
+    return hipGetLastError();
+}
 
 hipError_t msr_rerank_gather(const DenseIndex& ix, const int32_t* url_group, const float* qn, int nq,
                              const int32_t* cand_doc, const int32_t* cand_n, int max_cand, int doc_base,

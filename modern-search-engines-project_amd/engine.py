@@ -308,6 +308,28 @@ class DeviceEngine:
                                              self._stream()))
         return out_doc, out_score, out_orig, out_chunk, out_n, out_rows
 
+    # ------------------------------------------------------------------ response assembly on the device
+    def bind_doc_domains(self, domain):
+        """domain int32 [N_global]: domain id of every document (equal ids = same urlparse(url).netloc.lower()), -1 = a
+        document the response models reject (NULL title / url / text, reranker_api.py:376-397).  None unbinds."""
+        t = None if domain is None else self._dev(domain, torch.int32)
+        self._t["doc_domain"] = t
+        self._check(self.lib.msr_bind_doc_domains(self.handle, _ptr(t), 0 if t is None else int(t.numel()), self._stream()))
+
+    def diversify(self, fused, top_k=100, relevance_threshold=0.8, diversification=True):
+        """fused = (doc, score, orig, chunk, n, ...) of rerank / rerank_fuse -> (doc, score f64, orig f64, chunk, n): the final
+        list of every query after reranker_api.py:178-236 (or, diversification=False, its first top_k accepted entries)."""
+        doc, score, orig, chunk, n = fused[:5]
+        Q, M = int(doc.shape[0]), int(doc.shape[1])
+        mk = lambda dt: torch.empty((Q, M), dtype=dt, device=self.device)
+        o_doc, o_score, o_orig, o_chunk = mk(torch.int32), mk(torch.float64), mk(torch.float64), mk(torch.int32)
+        o_n = torch.empty((Q,), dtype=torch.int32, device=self.device)
+        self._check(self.lib.msr_diversify(self.handle, Q, _ptr(doc.contiguous()), _ptr(score.contiguous()), _ptr(orig.contiguous()),
+                                           _ptr(chunk.contiguous()), _ptr(n.contiguous()), M, int(top_k),
+                                           C.c_double(relevance_threshold), 1 if diversification else 0, _ptr(o_doc),
+                                           _ptr(o_score), _ptr(o_orig), _ptr(o_chunk), _ptr(o_n), self._stream()))
+        return o_doc, o_score, o_orig, o_chunk, o_n
+
     # ------------------------------------------------------------------ shard merge
     def merge_topk(self, docs, scores, ns, k):
         """docs int32 [G, Q, k] GLOBAL indices, scores f32/f64 [G, Q, k], ns int32 [G, Q] -> merged top-k."""

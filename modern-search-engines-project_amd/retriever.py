@@ -12,11 +12,13 @@ import numpy as np
 from .bm25 import BM25
 from .engine import DeviceEngine
 from .index import CorpusIndex
-from .reranker import Reranker, RerankNotFound
-from .text import extract_domain_topic, format_result_line, preprocess_query, read_queries_file
+from .reranker import Reranker
+from .text import (LineFormatter, extract_domain, extract_domain_topic, format_result_line, preprocess_query,
+                   read_queries_file)
 
 TOP_K_RETRIEVAL = 1000     # config.py:13
 TOP_K_RERANKING = 100      # config.py:14
+RERANK_MAX_CHUNKS = 10     # reranker_api.py:58
 
 
 class Retriever:
@@ -32,6 +34,8 @@ class Retriever:
         self.reranker = Reranker(self.engine, encoder=embedder) if self.index.doc_off is not None else None
         ids = self.index.doc_ids
         self._ids = ids.cpu().numpy() if hasattr(ids, "cpu") else np.asarray(ids)
+        self._domains_bound = False
+        self._formatter = None
 
     def _embed(self, query, query_embedding=None):
         if query_embedding is not None:
@@ -103,45 +107,89 @@ class Retriever:
                                        None if query_embedding is None else [query_embedding], max_chunks_per_doc)[0]
 
     # ------------------------------------------------------------------ live two-stage path
-    def search_batch(self, queries, top_k=TOP_K_RETRIEVAL, query_embeddings=None, term_lists=None, query_ids=None):
-        """-> per query the list of UI documents (search_api.py:110-130); [] when stage 1 finds nothing."""
+    # search_api.py:88-130 (single query) and :243-304 (batch): preprocess_query -> bm_25.search(top 1000) -> POST /rerank ->
+    # formatted rows.  In the reference every arrow is a Python list of dicts (1000 per query, each with a 200-character
+    # snippet or the full document text) and an HTTP/JSON hop.  Here stage 1 -> stage 2 -> diversification stay on the
+    # device: msr_bm25_topk -> msr_rerank_gather -> msr_rerank_fuse -> msr_diversify, and only the FINAL <= ~100 rows per
+    # query come back to the host, as arrays; URLs / titles / snippets are looked up for those rows only.
+    def _doc_domains(self):
+        """int32 [N]: domain id (extract_domain(url), reranker_api.py:170-176) of every document, -1 for documents that never
+        appear in a response: no urlsDB row, or a NULL title / url / text (the reference's pydantic models reject them,
+        :376-397).  Without URL metadata every url is "" -- ONE domain, as the facade's Reranker has it."""
+        ix = self.index
+        N = ix.n_docs
+        if ix.urls is None:
+            return np.zeros(N, np.int32)
+        ids, out = {}, np.empty(N, np.int32)
+        titles, texts = ix.titles, ix.texts
+        for i, u in enumerate(ix.urls):
+            if u is None or (titles is not None and titles[i] is None) or (texts is not None and texts[i] is None):
+                out[i] = -1
+            else:
+                out[i] = ids.setdefault(extract_domain(u), len(ids))
+        return out
+
+    def _ensure_response_tables(self):
+        if not self._domains_bound:
+            self.engine.bind_doc_domains(self._doc_domains())
+            self._domains_bound = True
+
+    def final_lists(self, term_id_lists, query_vectors, top_k=TOP_K_RETRIEVAL, chunk=None):
+        """The whole live path for a batch, on the device: -> host arrays (doc index int32 [Q, S], new_similarity float64 [Q, S],
+        winning chunk row int32 [Q, S], n int32 [Q]); row q holds n[q] entries in final rank order (S = max n, normally the
+        reranker's top_k = 100).  term_id_lists: per query its term ids (repeats allowed, unknown < 0); query_vectors [Q, 768]."""
+        import torch
+        eng, cfg = self.engine, self.reranker.cfg
+        if top_k > eng.rerank_max_docs or top_k > eng.max_k:
+            raise ValueError(f"top_k {top_k} exceeds the engine's max_k / rerank_max_docs ({eng.max_k} / {eng.rerank_max_docs})")
+        self._ensure_response_tables()
+        Q = len(term_id_lists)
+        qv = eng._dev(np.asarray(query_vectors, np.float32) if not torch.is_tensor(query_vectors) else query_vectors, torch.float32).reshape(-1, 768)
+        step = int(chunk or max(256, eng.max_queries))
+        parts = []
+        for a in range(0, Q, step):                          # every call below only ENQUEUES: the host packs the next chunk's
+            b = eng.bm25_topk(term_id_lists[a:a + step], k=top_k)                     # terms while the GPU works on this one
+            cos, meta = eng.rerank_gather(qv[a:a + step], b[0], b[2], max_chunks=RERANK_MAX_CHUNKS)
+            fused = eng.rerank_fuse(b[0], b[1], b[2], cos, meta, smoothing=cfg["smoothing"], max_chunks=RERANK_MAX_CHUNKS)
+            parts.append(eng.diversify(fused, top_k=int(cfg["top_k"]), diversification=bool(cfg.get("diversification", False))))
+        if not parts:
+            z = np.zeros((0, 0), np.int32)
+            return z, np.zeros((0, 0), np.float64), z, np.zeros(0, np.int32)
+        n = torch.cat([p[4] for p in parts]).cpu().numpy()   # (the one synchronisation of the batch)
+        S = int(n.max()) if len(n) else 0
+        doc = torch.cat([p[0][:, :S] for p in parts]).cpu().numpy()
+        score = torch.cat([p[1][:, :S] for p in parts]).cpu().numpy()
+        chunk_row = torch.cat([p[3][:, :S] for p in parts]).cpu().numpy()
+        return doc, score, chunk_row, n
+
+    def _prepare(self, queries, query_embeddings, term_lists):
         processed = [preprocess_query(q) for q in queries]
         if term_lists is None:
             term_lists = [self.bm25._tokenize(q) for q in processed]
-        stage1 = [self.bm25._finish(r) for r in self.bm25.search_terms_batch(term_lists, top_k)]
-        reqs, slot = [], []
-        for i, res in enumerate(stage1):
-            if res:
-                reqs.append(dict(doc_ids=[str(r["doc_id"]) for r in res], similarities=[r["score"] for r in res],
-                                 query=processed[i],
-                                 query_embedding=None if query_embeddings is None else query_embeddings[i]))
-                slot.append(i)
-        out = [[] for _ in queries]
-        if reqs:
-            M = self.engine.rerank_max_docs
-            for a in range(0, len(reqs), 32):
-                chunk = reqs[a:a + 32]
-                try:
-                    resp = self.reranker.rerank_batch(chunk)
-                except RerankNotFound:
-                    resp = []
-                    for rq in chunk:                       # isolate the query that has no chunk rows
-                        try:
-                            resp.append(self.reranker.rerank_batch([rq])[0])
-                        except RerankNotFound:
-                            resp.append(None)
-                for i, rp in zip(slot[a:a + 32], resp):
-                    if rp is None:
-                        continue
-                    docs = []
-                    for rank, (d, w) in enumerate(zip(rp["document_scores"], rp["top_windows"]), start=1):
-                        text = w.get("text", "")
-                        docs.append({"query_id": None if query_ids is None else query_ids[i], "rank": rank,
-                                     "url": d["url"], "score": d["similarity_score"],
-                                     "title": d["title"] or "No Title",
-                                     "snippet": (text[:200] + "..." if len(text) > 200 else text) or "No content available",
-                                     "domain": extract_domain_topic(d["url"]), "doc_id": d["doc_id"]})
-                    out[i] = docs
+        ids = [self.index.term_ids(t) for t in term_lists]
+        qv = np.stack([self._embed(processed[i], None if query_embeddings is None else query_embeddings[i])
+                       for i in range(len(queries))]) if len(queries) else np.zeros((0, 768), np.float32)
+        return ids, qv
+
+    def search_batch(self, queries, top_k=TOP_K_RETRIEVAL, query_embeddings=None, term_lists=None, query_ids=None):
+        """-> per query the list of UI documents (search_api.py:110-130); [] when stage 1 finds nothing."""
+        ids, qv = self._prepare(queries, query_embeddings, term_lists)
+        doc, score, _, n = self.final_lists(ids, qv, top_k)
+        ix = self.index
+        out = []
+        for q in range(len(queries)):
+            rows = []
+            qid = None if query_ids is None else query_ids[q]
+            for r in range(int(n[q])):
+                i = int(doc[q, r])
+                url = ix.urls[i] if ix.urls is not None else ""
+                title = ix.titles[i] if ix.titles is not None else ""
+                text = ix.texts[i] if ix.texts is not None else ""
+                rows.append({"query_id": qid, "rank": r + 1, "url": url, "score": float(score[q, r]),
+                             "title": title or "No Title",
+                             "snippet": (text[:200] + "..." if len(text) > 200 else text) or "No content available",
+                             "domain": extract_domain_topic(url), "doc_id": str(int(self._ids[i]))})
+            out.append(rows)
         return out
 
     def search(self, query, top_k=TOP_K_RETRIEVAL, query_embedding=None, terms=None, query_id=None):
@@ -149,18 +197,64 @@ class Retriever:
                                  None if terms is None else [terms], None if query_id is None else [query_id])[0]
 
     def batch_search(self, numbered_queries, query_embeddings=None, term_lists=None):
-        """numbered_queries: [(query_num, text)] -> result entries with 'formatted_line' (search_api.py:276-292)."""
-        docs = self.search_batch([q for _, q in numbered_queries], TOP_K_RETRIEVAL, query_embeddings, term_lists)
-        out = []
-        for (qn, _), ds in zip(numbered_queries, docs):
-            for d in ds:
-                out.append({"query_num": qn, "rank": d["rank"], "url": d["url"], "score": f"{d['score']:.3f}",
-                            "formatted_line": format_result_line(qn, d["rank"], d["url"], d["score"])})
-        return out
+        """numbered_queries: [(query_num, text)] -> the result entries of search_api.py:276-292 ({query_num, rank, url, score,
+        formatted_line}) as a BatchLines sequence: len / indexing / iteration give the reference's dicts, built on access;
+        .text() / .write() produce all formatted lines natively (msr_format_lines) without building any."""
+        ids, qv = self._prepare([q for _, q in numbered_queries], query_embeddings, term_lists)
+        doc, score, _, n = self.final_lists(ids, qv, TOP_K_RETRIEVAL)
+        if self._formatter is None:
+            self._formatter = LineFormatter(self.index.urls, self.index.n_docs)
+        return BatchLines([qn for qn, _ in numbered_queries], doc, score, n, self.index.urls, self._formatter)
 
     def batch_search_to_file(self, queries_path, out_path, query_embeddings=None, term_lists=None):
         res = self.batch_search(read_queries_file(queries_path), query_embeddings, term_lists)
-        with open(out_path, "w", encoding="utf-8") as f:
-            for r in res:
-                f.write(r["formatted_line"] + "\n")
+        res.write(out_path)
         return len(res)
+
+
+class BatchLines:
+    """The `results` list of /api/batch_search (search_api.py:276-292, 312-320) over the arrays the device returned: behaves
+    like the reference's list of dicts (len, indexing, iteration, equality with a list), but an entry is built when it is
+    asked for; the text of all lines comes from the native formatter in one call."""
+
+    def __init__(self, query_nums, doc, score, n, urls, formatter):
+        self.query_nums, self.doc, self.score, self.n, self.urls, self._fmt = query_nums, doc, score, n, urls, formatter
+        self._start = np.zeros(len(n) + 1, np.int64)
+        np.cumsum(n, out=self._start[1:])
+
+    def __len__(self):
+        return int(self._start[-1])
+
+    def _entry(self, q, r):
+        i = int(self.doc[q, r])
+        url = (self.urls[i] if self.urls is not None else "") or ""
+        sc = float(self.score[q, r])
+        qn = self.query_nums[q]
+        return {"query_num": qn, "rank": r + 1, "url": url, "score": f"{sc:.3f}",
+                "formatted_line": format_result_line(qn, r + 1, url, sc)}
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return [self[j] for j in range(*k.indices(len(self)))]
+        if k < 0:
+            k += len(self)
+        if not 0 <= k < len(self):
+            raise IndexError(k)
+        q = int(np.searchsorted(self._start, k, side="right") - 1)
+        return self._entry(q, int(k - self._start[q]))
+
+    def __iter__(self):
+        for q in range(len(self.n)):
+            for r in range(int(self.n[q])):
+                yield self._entry(q, r)
+
+    def __eq__(self, other):
+        return list(self) == list(other)
+
+    def text(self) -> bytes:
+        """All formatted lines, each ending in a newline (UTF-8)."""
+        return self._fmt.format(self.query_nums, self.doc, self.score, self.n)
+
+    def write(self, path):
+        with open(path, "wb") as f:
+            f.write(self.text())

@@ -82,7 +82,7 @@ def create_app(retriever, llm=None, queries_file="queries.txt", results_file="ba
             if not queries:
                 return 400, {"error": "No valid queries found in queries.txt"}
             results = retriever.batch_search(queries)
-            return 200, {"total_queries": len(queries), "total_results": len(results), "results": results,
+            return 200, {"total_queries": len(queries), "total_results": len(results), "results": list(results), "_lines": results,
                          "queries_processed": [{"query_num": n, "query_text": t} for n, t in queries]}
         except Exception as e:
             return 500, {"error": f"Internal server error: {e}"}
@@ -90,6 +90,7 @@ def create_app(retriever, llm=None, queries_file="queries.txt", results_file="ba
     @app.post("/api/batch_search")
     def batch_search():
         status, body = _batch()
+        body.pop("_lines", None)
         return body if status == 200 else JSONResponse(status_code=status, content=body)
 
     @app.post("/api/batch_search_file")
@@ -100,9 +101,13 @@ def create_app(retriever, llm=None, queries_file="queries.txt", results_file="ba
             status, body = _batch()
             if status != 200:
                 return JSONResponse(status_code=status, content=body)
-            with open(results_file, "w", encoding="utf-8") as f:
-                for r in body["results"]:
-                    f.write(r["formatted_line"] + "\n")
+            lines = body.get("_lines")
+            if hasattr(lines, "write"):                       # Retriever.batch_search: all lines formatted natively in one call
+                lines.write(results_file)
+            else:
+                with open(results_file, "w", encoding="utf-8") as f:
+                    for r in body["results"]:
+                        f.write(r["formatted_line"] + "\n")
             return {"message": f"Results saved to {results_file}", "total_queries": body["total_queries"],
                     "total_results": body["total_results"], "output_file": str(results_file),
                     "format": "query_num<tab>rank<tab>url<tab>score per line"}

@@ -80,3 +80,47 @@ def read_queries_file(path):
             if len(parts) >= 2:
                 out.append((parts[0].strip(), parts[1].strip()))
     return out
+
+
+class LineFormatter:
+    """The batch lines of search_api.py:290 for whole batches: the URLs as one UTF-8 blob + offsets (built once), the
+    formatting in native code (msr_format_lines, include/msretr.h: a HOST function, no GPU involved).  Byte for byte what
+    "\n".join(format_result_line(...)) + "\n" gives."""
+
+    def __init__(self, urls, n_docs=None):
+        import numpy as np
+        from . import _abi
+        self._lib = _abi.load()
+        n = len(urls) if urls is not None else int(n_docs or 0)
+        enc = [u.encode("utf-8") if u else b"" for u in urls] if urls is not None else []
+        self.blob = b"".join(enc)
+        self.off = np.zeros(n + 1, np.int64)
+        if enc:
+            np.cumsum(np.fromiter((len(b) for b in enc), np.int64, n), out=self.off[1:])
+        self.n_docs = n
+
+    def format(self, query_nums, doc, score, n):
+        """query_nums: list of str; doc int32 [Q, S], score float64 [Q, S], n int32 [Q] (host arrays) -> bytes."""
+        import ctypes as C
+
+        import numpy as np
+        doc = np.ascontiguousarray(doc, np.int32); score = np.ascontiguousarray(score, np.float64)
+        n = np.ascontiguousarray(n, np.int32)
+        Q = len(query_nums)
+        assert doc.shape == score.shape and doc.ndim == 2 and doc.shape[0] == Q and n.shape == (Q,)
+        qb = [str(x).encode("utf-8") for x in query_nums]
+        qblob = b"".join(qb)
+        qoff = np.zeros(Q + 1, np.int64)
+        if Q:
+            np.cumsum(np.fromiter((len(b) for b in qb), np.int64, Q), out=qoff[1:])
+        ptr = lambda a: C.c_void_p(a.ctypes.data)
+        args = (C.c_char_p(qblob), ptr(qoff), Q, ptr(doc), ptr(score), ptr(n), int(doc.shape[1]), C.c_char_p(self.blob),
+                ptr(self.off), self.n_docs)
+        need = -int(self._lib.msr_format_lines(*args, None, 0))
+        if need <= 0:
+            return b""
+        buf = C.create_string_buffer(need)
+        got = int(self._lib.msr_format_lines(*args, buf, need))
+        if got < 0:
+            raise RuntimeError(f"msr_format_lines failed ({got})")
+        return buf.raw[:got]

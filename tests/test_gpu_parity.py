@@ -1206,3 +1206,77 @@ def test_index_build_kernels_equal_the_reference_tables(mods):
         oi, os_ = mods["bm25_ref"].topk(z, t, 50)
         assert doc[i, :cnt[i]].tolist() == oi.tolist() and score[i, :cnt[i]].tolist() == os_.tolist()
     eng.close()
+
+
+def test_diversify_kernel_matches_reference(mods):
+    """msr_diversify against the reference's hybrid_diversification: the executed fixture (tests/golden/diversification.json)
+    and random lists -- many score ties, more "high" domains than top_k, lists shorter than top_k, rejected documents,
+    diversification off -- against oracle.rerank_ref.hybrid_diversification (pinned to the same fixture).  Scores must be
+    EQUAL as float64: the kernel performs the reference's operations (delta = first_dropped - last_kept + 1e-4, max(0, s - delta))."""
+    import json
+    from urllib.parse import urlparse
+    rr = mods["rerank_ref"]
+    ix = mods["CorpusIndex"](doc_ids=np.arange(5000, dtype=np.int64), doc_off=np.arange(5001, dtype=np.int32),
+                             chunk_ids=np.arange(5000, dtype=np.int64),
+                             emb=np.eye(768, dtype=np.float32)[np.arange(5000) % 768], total_docs=5000)
+    eng = mods["DeviceEngine"](ix, max_queries=8, max_k=100, rerank_max_docs=1000)
+    dev = eng.device
+
+    def run(cases, top_k, diversification=True):
+        """cases: list of lists of (doc, domain id or -1, score), each sorted by (score desc, doc asc)."""
+        M = 1000
+        Q = len(cases)
+        doc = torch.full((Q, M), -1, dtype=torch.int32); score = torch.full((Q, M), -float("inf"), dtype=torch.float64)
+        n = torch.zeros(Q, dtype=torch.int32)
+        dom = np.full(5000, -1, np.int32)
+        for q, c in enumerate(cases):
+            n[q] = len(c)
+            for j, (d, g, s_) in enumerate(c):
+                doc[q, j] = d; score[q, j] = s_
+                assert dom[d] in (-1, g) or g == -1
+                dom[d] = g
+        eng.bind_doc_domains(dom)
+        orig = score.clone() * 0.5
+        chunk = doc.clone()
+        out = eng.diversify((doc.to(dev), score.to(dev), orig.to(dev), chunk.to(dev), n.to(dev)), top_k=top_k,
+                            diversification=diversification)
+        od, os_, oo, oc, on = [x.cpu().numpy() for x in out]
+        res = []
+        for q in range(Q):
+            k = int(on[q])
+            assert np.all(od[q, k:] == -1) and np.all(oc[q, :k] == od[q, :k])
+            res.append([(int(od[q, j]), float(os_[q, j])) for j in range(k)])
+        return res
+
+    # (1) the reference-executed fixture
+    with open(os.path.join(G, "diversification.json")) as f:
+        fx = json.load(f)["cases"]
+    for c in fx:
+        doms = {}
+        case = [(int(i), doms.setdefault(urlparse(u).netloc.lower(), len(doms)), float(s_)) for i, u, s_ in c["input"]]
+        got = run([case], c["top_k"])[0]
+        assert [[d, s_] for d, s_ in got] == c["expected"], (got, c["expected"])
+    # (2) random lists against the oracle's restatement
+    rng = np.random.default_rng(5)
+    for trial in range(12):
+        n_items = int(rng.choice([1, 7, 60, 99, 100, 101, 400, 1000]))
+        n_dom = int(rng.choice([1, 3, 40, 150, 900]))
+        top_k = int(rng.choice([5, 100]))
+        hi_frac = float(rng.choice([0.0, 0.02, 0.3, 0.9]))
+        docs = np.sort(rng.choice(5000, n_items, replace=False))
+        sc = np.where(rng.random(n_items) < hi_frac, 0.8 + 0.2 * rng.random(n_items), 0.8 * rng.random(n_items))
+        if trial % 2:
+            sc = np.round(sc, 2)                                   # many exact ties, also across the two tiers' drops
+        if trial == 3:
+            sc[:] = 0.0                                            # last_kept = 0: the shifted tail clamps at 0
+        order = np.lexsort((docs, -sc))
+        docs, sc = docs[order], sc[order]
+        dom = rng.integers(0, n_dom, n_items)
+        rejected = rng.random(n_items) < (0.1 if trial % 3 == 0 else 0.0)
+        case = [(int(d), -1 if r else int(g), float(s_)) for d, g, s_, r in zip(docs, dom, sc, rejected)]
+        for div in (True, False):
+            got = run([case], top_k, div)[0]
+            items = [{"doc_id": d, "url": f"https://h{g}.de/x", "similarity_score": s_} for d, g, s_ in case if g >= 0]
+            exp = rr.hybrid_diversification(items, top_k=top_k) if div else items[:top_k]
+            assert got == [(e["doc_id"], e["similarity_score"]) for e in exp], (trial, div)
+    eng.close()

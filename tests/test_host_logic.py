@@ -435,3 +435,30 @@ def test_streaming_kernels_keep_their_row_rings_in_place():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "ring_check.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok  ") == 8, r.stdout
+
+
+def test_native_line_formatter_equals_python_format():
+    """msr_format_lines (host function of libmsretr: no GPU) writes byte for byte what the reference's f-string does
+    (search_api.py:290 `f"{query_num}\\t{rank}\\t{url}\\t{score:.3f}"`), including the half-to-even rounding of the EXACT
+    binary value at the third decimal, negative zero, documents without a URL and non-ASCII URLs."""
+    import random
+    from msretr.text import LineFormatter, format_result_line
+    urls = [f"https://ex{i}.de/p?x={i}" if i % 7 else None for i in range(50)]
+    urls[3] = "https://tübingen.de/ü"
+    lf = LineFormatter(urls)
+    rng = random.Random(1)
+    vals = [0.0, -0.0, 0.0005, 0.0015, 0.0025, 0.5, 0.9995, 0.99949999999999994, 1.0, 0.1235, 0.1245, 2.675, 1e-9, 123456.7895,
+            -0.0004, -1.2345, 0.3335, float(np.nextafter(0.0005, 1)), float(np.nextafter(0.0005, 0)), 5e-324, 1e11 + 0.0005,
+            1e13, float("inf"), float("nan")]
+    vals += [rng.random() for _ in range(20000)] + [round(rng.random(), 3) + 0.0005 for _ in range(20000)]
+    Q = len(vals) // 100
+    doc = np.array([rng.randrange(-1, 52) for _ in range(Q * 100)], np.int32).reshape(Q, 100)
+    score = np.array(vals[:Q * 100]).reshape(Q, 100)
+    n = np.array([rng.randrange(0, 101) for _ in range(Q)], np.int32)
+    n[0] = 100
+    qn = [str(i * 3) for i in range(Q)]
+    got = lf.format(qn, doc, score, n)
+    exp = "".join(format_result_line(qn[q], r + 1, (urls[doc[q, r]] or "") if 0 <= doc[q, r] < 50 else "", score[q, r]) + "\n"
+                  for q in range(Q) for r in range(n[q])).encode()
+    assert got == exp
+    assert lf.format([], np.zeros((0, 0), np.int32), np.zeros((0, 0)), np.zeros(0, np.int32)) == b""
