@@ -535,11 +535,7 @@ def main():
             if nq != Q:                                  # (the single-query latency loop: local stages only)
                 return {"bm25": b, "dense": d}
             cand = torch.where(slot % NE == 0, b[0], torch.full_like(b[0], -1))   # a rank owns 1 / NE of the merged candidates
-            for o in range(NE):
-                lo, hi = min(Q, o * rx.Qs), min(Q, (o + 1) * rx.Qs)
-                if hi > lo:
-                    cv, mv = rx.send_views(o)
-                    eng.rerank_gather(qv[lo:hi], cand[lo:hi], b[2][lo:hi], out=(cv[:hi - lo], mv[:hi - lo]))
+            eng.rerank_gather_blocks(qv, cand, b[2], rx.a2a_send.view(NE, rx.block), rx.Qs)      # one launch, all destination blocks
             rx.a2a_recv.copy_(rx.a2a_send)               # (where the all-to-all would be)
             cp, mp = rx.recv_parts()
             cos, meta = eng.rerank_combine(cp, mp, rx.Qs)

@@ -225,6 +225,16 @@ int64_t msr_format_lines(const char* qnum_blob, const int64_t* qnum_off, int32_t
 int msr_rerank_gather(msr_engine* e, const float* q, int32_t n_queries, const int32_t* cand_doc,
                       const int32_t* cand_n, int32_t max_cand, int32_t doc_base, int32_t row_base,
                       int32_t max_chunks, float* out_cos, int32_t* out_meta, void* stream);
+/* msr_rerank_gather writing straight into the send buffer of the all-to-all that carries every query's halves to the rank
+ * that fuses it (msretr/distributed.py): out_blocks is [n_blocks][block_words] int32; block b belongs to the rank that owns
+ * queries [b * queries_per_block, (b + 1) * queries_per_block) and holds their cos rows ([queries_per_block][max_cand][10],
+ * float bits) followed by their meta rows ([queries_per_block][max_cand][3]); block_words >= queries_per_block * max_cand * 13
+ * (any padding is left untouched).  One launch for all queries of the call (cfg.max_queries of them at a time; for larger
+ * calls max_queries must be a multiple of queries_per_block). */
+int msr_rerank_gather_blocks(msr_engine* e, const float* q, int32_t n_queries, const int32_t* cand_doc,
+                             const int32_t* cand_n, int32_t max_cand, int32_t doc_base, int32_t row_base,
+                             int32_t max_chunks, int32_t* out_blocks, int32_t queries_per_block, int64_t block_words,
+                             void* stream);
 int msr_rerank_fuse(msr_engine* e, int32_t n_queries, const int32_t* cand_doc, const double* cand_bm25,
                     const int32_t* cand_n, int32_t max_cand, const float* cos, const int32_t* meta,
                     const msr_rerank_params* params, int32_t* out_doc, double* out_score, double* out_orig,

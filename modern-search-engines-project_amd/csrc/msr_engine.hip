@@ -34,6 +34,7 @@ struct msr_engine {
     int32_t* wspan_doc = nullptr;
     int32_t* wspan12_doc = nullptr;
     float* qn = nullptr;              // [128][768] normalised queries of the current slice
+    float* rr_qn = nullptr;           // [max(max_queries, 128)][768] normalised queries of a rerank gather (one launch per call)
     void* qimg = nullptr;             // query image in fragment order (<= 256 KB)
     void* emb_bf16 = nullptr;         // bf16 copy of the embeddings (msr_enable_bf16)
     void* score_rows = nullptr;       // max_queries rows of n_docs float64 (reused as float32 rows)
@@ -210,6 +211,8 @@ extern "C" int msr_create(const msr_config* cfg, msr_engine** out) {
     const size_t nq = (size_t)std::max(cfg->max_queries, 128);
     if ((herr = eng_malloc(e, (void**)&e->qn, 128 * MSR_DIM * sizeof(float))) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc qn", herr);
     if ((herr = eng_malloc(e, &e->qimg, 256 * 1024)) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc qimg", herr);
+    if (cfg->rerank_max_docs > 0 && (herr = eng_malloc(e, (void**)&e->rr_qn, nq * MSR_DIM * sizeof(float))) != hipSuccess)
+        return bail(MSR_ERR_NOMEM, "hipMalloc rr_qn", herr);
     if ((herr = eng_malloc(e, (void**)&e->sel.hist, nq * MSR_SEL_BINS * sizeof(uint32_t))) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc hist", herr);
     if ((herr = eng_malloc(e, (void**)&e->sel.state, nq * sizeof(SelState))) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc state", herr);
     if ((herr = eng_malloc(e, (void**)&e->sel.cand_hi, nq * MSR_SEL_CAP * sizeof(uint64_t))) != hipSuccess) return bail(MSR_ERR_NOMEM, "hipMalloc cand_hi", herr);
@@ -234,7 +237,7 @@ extern "C" int msr_create(const msr_config* cfg, msr_engine** out) {
 
 extern "C" int msr_destroy(msr_engine* e) {
     if (!e) return MSR_OK;
-    free_dev(e, e->chunk_doc); free_dev(e, e->emb_presplit); free_dev(e, e->row_meta); free_dev(e, e->inv_norm_own); free_dev(e, e->span_doc); free_dev(e, e->wspan_doc); free_dev(e, e->wspan12_doc); free_dev(e, e->qn); free_dev(e, e->qimg); free_dev(e, e->emb_bf16);
+    free_dev(e, e->chunk_doc); free_dev(e, e->emb_presplit); free_dev(e, e->row_meta); free_dev(e, e->inv_norm_own); free_dev(e, e->span_doc); free_dev(e, e->wspan_doc); free_dev(e, e->wspan12_doc); free_dev(e, e->qn); free_dev(e, e->rr_qn); free_dev(e, e->qimg); free_dev(e, e->emb_bf16);
     free_dev(e, e->score_rows); free_dev(e, e->bm_heavy_id); free_dev(e, e->bm_post); free_dev(e, e->bm_dense_id); free_dev(e, e->bm_dense); free_dev(e, e->bm_tile_off); free_dev(e, e->bm_cand_doc); free_dev(e, e->bm_cand_n); free_dev(e, e->sel.hist); free_dev(e, e->sel.state); free_dev(e, e->sel.cand_hi);
     free_dev(e, e->sel.cand_lo); free_dev(e, e->sel.cand_n); free_dev(e, e->rerank_cos); free_dev(e, e->rerank_meta);
     free_dev(e, e->bt_top_doc); free_dev(e, e->bt_top_score); free_dev(e, e->bt_top_n); free_dev(e, e->bt_cand_doc);
@@ -1035,28 +1038,56 @@ extern "C" int msr_dense_topk_bf16(msr_engine* e, const float* q, int32_t n_quer
     return MSR_OK;
 }
 
-extern "C" int msr_rerank_gather(msr_engine* e, const float* q, int32_t n_queries, const int32_t* cand_doc,
-                                 const int32_t* cand_n, int32_t max_cand, int32_t doc_base, int32_t row_base,
-                                 int32_t max_chunks, float* out_cos, int32_t* out_meta, void* stream) {
+static int rerank_gather_impl(msr_engine* e, const char* fn, const float* q, int32_t n_queries, const int32_t* cand_doc,
+                              const int32_t* cand_n, int32_t max_cand, int32_t doc_base, int32_t row_base, int32_t max_chunks,
+                              float* out_cos, int32_t* out_meta, int32_t q_per_block, int64_t block_stride, void* stream) {
     if (!e) return MSR_ERR_INVALID;
-    if (!e->have_chunks) return fail(e, MSR_ERR_NOT_BOUND, "msr_rerank_gather: chunks not bound");
-    if (!q || !cand_doc || !cand_n || !out_cos || !out_meta) return fail(e, MSR_ERR_INVALID, "msr_rerank_gather: null argument");
-    int rc = rerank_args_ok(e, "msr_rerank_gather", n_queries, max_cand, max_chunks);
+    if (!e->have_chunks) return fail(e, MSR_ERR_NOT_BOUND, "%s: chunks not bound", fn);
+    if (!q || !cand_doc || !cand_n || !out_cos || !out_meta) return fail(e, MSR_ERR_INVALID, "%s: null argument", fn);
+    int rc = rerank_args_ok(e, fn, n_queries, max_cand, max_chunks);
     if (rc) return rc;
     if (e->url_group && e->url_group_n != e->dense.n_docs)
-        return fail(e, MSR_ERR_INVALID, "msr_rerank_gather: doc meta bound for %lld docs, chunks for %lld",
+        return fail(e, MSR_ERR_INVALID, "%s: doc meta bound for %lld docs, chunks for %lld", fn,
                     (long long)e->url_group_n, (long long)e->dense.n_docs);
     if (n_queries == 0) return MSR_OK;
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(e, hipSetDevice(e->cfg.device));
-    for (int q0 = 0; q0 < n_queries; q0 += 128) {           // qn holds 128 normalised queries
-        const int nq = std::min(128, n_queries - q0);
-        HIP_TRY(e, msr_prep_queries(q + (int64_t)q0 * MSR_DIM, nq, e->qn, nq, st));
+    // ONE normalisation and ONE gather launch for up to max(max_queries, 128) queries (the scratch for the normalised queries)
+    const int cap = std::max(e->cfg.max_queries, 128);
+    for (int q0 = 0; q0 < n_queries; q0 += cap) {
+        const int nq = std::min(cap, n_queries - q0);
+        if (q0 % q_per_block != 0 && q_per_block < n_queries)
+            return fail(e, MSR_ERR_INVALID, "%s: max_queries must be a multiple of queries_per_block for calls this large", fn);
+        HIP_TRY(e, msr_prep_queries(q + (int64_t)q0 * MSR_DIM, nq, e->rr_qn, nq, st));
         const int64_t o = (int64_t)q0 * max_cand;
-        HIP_TRY(e, msr_rerank_gather(e->dense, e->url_group, e->qn, nq, cand_doc + o, cand_n + q0, max_cand, doc_base,
-                                     row_base, max_chunks, out_cos + o * MSR_RERANK_MAX_CHUNKS, out_meta + o * 3, st));
+        const bool blocked = q_per_block < n_queries;
+        float* co = blocked ? out_cos + (int64_t)(q0 / q_per_block) * block_stride : out_cos + o * MSR_RERANK_MAX_CHUNKS;
+        int32_t* mo = blocked ? out_meta + (int64_t)(q0 / q_per_block) * block_stride : out_meta + o * 3;
+        HIP_TRY(e, msr_rerank_gather(e->dense, e->url_group, e->rr_qn, nq, cand_doc + o, cand_n + q0, max_cand, doc_base,
+                                     row_base, max_chunks, co, mo, blocked ? q_per_block : nq, blocked ? block_stride : 0, st));
     }
     return MSR_OK;
+}
+
+extern "C" int msr_rerank_gather(msr_engine* e, const float* q, int32_t n_queries, const int32_t* cand_doc,
+                                 const int32_t* cand_n, int32_t max_cand, int32_t doc_base, int32_t row_base,
+                                 int32_t max_chunks, float* out_cos, int32_t* out_meta, void* stream) {
+    return rerank_gather_impl(e, "msr_rerank_gather", q, n_queries, cand_doc, cand_n, max_cand, doc_base, row_base, max_chunks,
+                              out_cos, out_meta, n_queries > 0 ? n_queries : 1, 0, stream);
+}
+
+extern "C" int msr_rerank_gather_blocks(msr_engine* e, const float* q, int32_t n_queries, const int32_t* cand_doc,
+                                        const int32_t* cand_n, int32_t max_cand, int32_t doc_base, int32_t row_base,
+                                        int32_t max_chunks, int32_t* out_blocks, int32_t queries_per_block,
+                                        int64_t block_words, void* stream) {
+    if (!e) return MSR_ERR_INVALID;
+    if (queries_per_block < 1 || block_words < (int64_t)queries_per_block * max_cand * (MSR_RERANK_MAX_CHUNKS + 3))
+        return fail(e, MSR_ERR_INVALID, "msr_rerank_gather_blocks: a block of %lld words cannot hold %d queries", (long long)block_words,
+                    queries_per_block);
+    // block b = [cos of its queries: qpb x max_cand x 10 | meta: qpb x max_cand x 3 | padding]
+    return rerank_gather_impl(e, "msr_rerank_gather_blocks", q, n_queries, cand_doc, cand_n, max_cand, doc_base, row_base,
+                              max_chunks, (float*)out_blocks, out_blocks + (int64_t)queries_per_block * max_cand * MSR_RERANK_MAX_CHUNKS,
+                              queries_per_block, block_words, stream);
 }
 
 extern "C" int msr_rerank_fuse(msr_engine* e, int32_t n_queries, const int32_t* cand_doc, const double* cand_bm25,
@@ -1099,7 +1130,7 @@ extern "C" int msr_rerank(msr_engine* e, const float* q, int32_t n_queries, cons
     if (!e) return MSR_ERR_INVALID;
     if (!params) return fail(e, MSR_ERR_INVALID, "msr_rerank: null params");
     // unsharded convenience: gather (this engine owns every document) + fuse, slice by slice
-    const int slice = 128;                                  // the gather scratch holds max(max_queries, 128) queries
+    const int slice = std::max(e->cfg.max_queries, 128);    // the gather scratch holds this many queries
     for (int q0 = 0; q0 < n_queries; q0 += slice) {
         const int nq = std::min(slice, n_queries - q0);
         const int64_t o = (int64_t)q0 * max_cand;

@@ -186,7 +186,9 @@ struct RerankParams {
 hipError_t msr_rerank_gather(const DenseIndex& ix, const int32_t* url_group, const float* qn, int nq,
                              const int32_t* cand_doc, const int32_t* cand_n, int max_cand, int doc_base,
                              int row_base, int max_chunks, float* cos_out /*[nq][max_cand][10]*/,
-                             int32_t* meta /*[nq][max_cand][3]*/, hipStream_t stream);
+                             int32_t* meta /*[nq][max_cand][3]*/, int q_per_block, int64_t block_stride, hipStream_t stream);
+// (q_per_block / block_stride: query q's rows start (q / q_per_block) * block_stride 32-bit words + (q % q_per_block) rows
+// into cos_out / meta -- the blocks of an all-to-all send buffer; one contiguous array: q_per_block >= nq, any stride)
 // (B) the float64 chain; needs no index.
 hipError_t msr_rerank_fuse_run(int nq, const int32_t* cand_doc, const double* cand_bm25, const int32_t* cand_n,
                                int max_cand, const RerankParams& p, const float* cos_in, const int32_t* meta,

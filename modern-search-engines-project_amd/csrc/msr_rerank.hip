@@ -37,9 +37,14 @@ __global__ __launch_bounds__(64) void rerank_cos_kernel(DenseIndex ix, const int
                                                          const int32_t* __restrict__ cand_doc,
                                                          const int32_t* __restrict__ cand_n, int max_cand,
                                                          int doc_base, int row_base, int max_chunks,
-                                                         float* __restrict__ cos_out, int32_t* __restrict__ meta) {
+                                                         float* __restrict__ cos_out, int32_t* __restrict__ meta,
+                                                         int q_per_block, int64_t block_stride) {
     // cand_doc holds GLOBAL document indices; this shard owns [doc_base, doc_base + n_docs).
+    // Output layout: query q's rows start (q / q_per_block) * block_stride words + (q % q_per_block) rows into cos_out / meta
+    // (one contiguous array: q_per_block >= the number of queries; the blocks of an all-to-all send buffer: see msretr.h).
     const int q = blockIdx.y, m0 = blockIdx.x * RC_SLOTS, lane = threadIdx.x;
+    cos_out += (int64_t)(q / q_per_block) * block_stride + (int64_t)(q % q_per_block) * max_cand * RR_MAXC;
+    meta += (int64_t)(q / q_per_block) * block_stride + (int64_t)(q % q_per_block) * max_cand * 3;
     int d_mine = -1;
     {
         const int m = m0 + lane;
@@ -48,8 +53,8 @@ __global__ __launch_bounds__(64) void rerank_cos_kernel(DenseIndex ix, const int
         const bool own = d_mine >= 0 && d_mine < ix.n_docs;
         if (!own) d_mine = -1;
         if (slot && !own) {                              // not a candidate, or owned by another shard
-            float* out = cos_out + ((int64_t)q * max_cand + m) * RR_MAXC;
-            int32_t* mt = meta + ((int64_t)q * max_cand + m) * 3;
+            float* out = cos_out + (int64_t)m * RR_MAXC;
+            int32_t* mt = meta + (int64_t)m * 3;
 #pragma unroll
             for (int i = 0; i < RR_MAXC; ++i) out[i] = 0.f;
             mt[0] = 0; mt[1] = 0; mt[2] = 0;
@@ -62,8 +67,8 @@ __global__ __launch_bounds__(64) void rerank_cos_kernel(DenseIndex ix, const int
     for (; todo != 0; todo &= todo - 1) {
         const int sl = __builtin_ctzll(todo);            // (wave-uniform)
         const int d = __builtin_amdgcn_readlane(d_mine, sl), m = m0 + sl;
-        float* out = cos_out + ((int64_t)q * max_cand + m) * RR_MAXC;
-        int32_t* mt = meta + ((int64_t)q * max_cand + m) * 3;
+        float* out = cos_out + (int64_t)m * RR_MAXC;
+        int32_t* mt = meta + (int64_t)m * 3;
         const int64_t ds = ix.doc_off[d];
         int64_t de = ix.doc_off[d + 1];
         if (ds + max_chunks < de) de = ds + max_chunks;
@@ -399,16 +404,17 @@ hipError_t msr_diversify_run(int nq, const int32_t* f_doc, const double* f_score
 
 hipError_t msr_rerank_gather(const DenseIndex& ix, const int32_t* url_group, const float* qn, int nq,
                              const int32_t* cand_doc, const int32_t* cand_n, int max_cand, int doc_base,
-                             int row_base, int max_chunks, float* cos_out, int32_t* meta, hipStream_t stream) {
+                             int row_base, int max_chunks, float* cos_out, int32_t* meta, int q_per_block,
+                             int64_t block_stride, hipStream_t stream) {
     if (nq <= 0) return hipSuccess;
-    if (max_cand <= 0 || max_cand > RR_MAXM || max_chunks <= 0 || max_chunks > RR_MAXC) return hipErrorInvalidValue;
+    if (max_cand <= 0 || max_cand > RR_MAXM || max_chunks <= 0 || max_chunks > RR_MAXC || q_per_block < 1) return hipErrorInvalidValue;
     dim3 grid((unsigned)((max_cand + RC_SLOTS - 1) / RC_SLOTS), (unsigned)nq);
     if (ix.layout == 1)
         rerank_cos_kernel<true><<<grid, 64, 0, stream>>>(ix, url_group, qn, cand_doc, cand_n, max_cand, doc_base,
-                                                         row_base, max_chunks, cos_out, meta);
+                                                         row_base, max_chunks, cos_out, meta, q_per_block, block_stride);
     else
         rerank_cos_kernel<false><<<grid, 64, 0, stream>>>(ix, url_group, qn, cand_doc, cand_n, max_cand, doc_base,
-                                                          row_base, max_chunks, cos_out, meta);
+                                                          row_base, max_chunks, cos_out, meta, q_per_block, block_stride);
     return hipGetLastError();
 }
 

@@ -223,14 +223,10 @@ class ShardedEngine:
         if rx is None:
             rx = ex.rerank[(k1, keep)] = _RerankExchange(self.world, Q, k1, keep, b_doc.device)
         Qs = rx.Qs
-        # a. my documents' halves of every query, written into the block of the rank that owns the query (the rows of a
-        #    short last block stay zero)
-        for o in range(self.world):
-            lo, hi = min(Q, o * Qs), min(Q, (o + 1) * Qs)
-            if hi > lo:
-                cv, mv = rx.send_views(o)
-                e.rerank_gather(qvec[lo:hi], b_doc[lo:hi], b_n[lo:hi], doc_base=self.doc_base, row_base=self.row_base,
-                                max_chunks=max_chunks, out=(cv[:hi - lo], mv[:hi - lo]))
+        # a. my documents' halves of every query, written into the block of the rank that owns the query: ONE gather launch
+        #    for all queries (the rows of a short last block stay zero)
+        e.rerank_gather_blocks(qvec, b_doc, b_n, rx.a2a_send.view(self.world, rx.block), Qs, doc_base=self.doc_base,
+                               row_base=self.row_base, max_chunks=max_chunks)
         # b. every half to the owner of its query
         dist.all_to_all_single(rx.a2a_recv, rx.a2a_send, group=self.group)
         # c. join + the float64 chain, for my queries only

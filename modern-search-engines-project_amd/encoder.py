@@ -27,8 +27,6 @@ from . import _abi
 HIDDEN, HEADS, LAYERS, INTER, VOCAB = 768, 12, 22, 1152, 50368
 GLOBAL_EVERY, LOCAL_WINDOW, THETA_GLOBAL, THETA_LOCAL, EPS = 3, 128, 160000.0, 10000.0, 1e-5
 MAX_SEQ = 128                                               # msr_enc_attention: tokens per sequence
-LINEAR_HIP_MAX_TOKENS = 1 << 30                             # msr_enc_linear for every batch (tools can lower it to compare
-#                                                             with the library GEMM, see _linear)
 
 
 def _ptr(t):
@@ -167,18 +165,9 @@ class QueryEncoder:
 
     def _linear(self, x, weight, y, resid=None):
         """y = x . weight^T (+ resid): msr_enc_linear, the HIP product on the exact-f32 matrix cores (K split over the waves of
-        a workgroup; single queries: weights streamed once; batches: 64 x 48 tiles, one workgroup per CU -- on a par with the
-        library GEMM at 1024 tokens, profiles/r03_enc_linear_shapes.md).  The library path (hipBLASLt through torch) only
-        remains as the comparison the tools run (LINEAR_HIP_MAX_TOKENS lowered by tools/encoder_bench.py)."""
+        a workgroup; single queries: weights streamed once; batches: 64 x 48 tiles, one workgroup per CU).  There is no other
+        implementation in the product; tools/encoder_bench.py swaps a library GEMM in for its comparison runs."""
         n_out, n_in = weight.shape
-        if x.shape[0] > LINEAR_HIP_MAX_TOKENS:
-            if resid is None:
-                torch.mm(x, weight.t(), out=y)
-            elif resid is y:
-                y.addmm_(x, weight.t())
-            else:
-                torch.addmm(resid, x, weight.t(), out=y)
-            return y
         self._check(self.lib.msr_enc_linear(_ptr(x), _ptr(weight), _ptr(resid), _ptr(y), int(x.shape[0]), int(n_out),
                                             int(n_in), self._stream()))
         return y

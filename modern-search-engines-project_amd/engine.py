@@ -65,6 +65,7 @@ class DeviceEngine:
         self.index = index
         self.device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
         self.max_k = int(max_k)
+        self.max_queries = int(max_queries)
         self.scan_layout = int(scan_layout)
         self.rerank_max_docs = int(rerank_max_docs)
         cfg = _abi.MsrConfig(C.sizeof(_abi.MsrConfig), self.device.index or 0, DIM, int(max_queries), int(max_k),
@@ -275,6 +276,19 @@ class DeviceEngine:
         self._check(self.lib.msr_rerank_gather(self.handle, _ptr(q), Q, _ptr(cand), _ptr(cn), M, int(doc_base),
                                                int(row_base), int(max_chunks), _ptr(cos), _ptr(meta), self._stream()))
         return cos, meta
+
+    def rerank_gather_blocks(self, qvec, cand_doc_global, cand_n, blocks, queries_per_block, doc_base=0, row_base=0, max_chunks=10):
+        """rerank_gather for ALL queries in one launch, written into `blocks` (int32 [n_blocks, block_words], contiguous: the
+        send buffer of the all-to-all): block b = [cos of queries b * qpb .. | their meta | padding] (msr_rerank_gather_blocks)."""
+        q = self._dev(qvec, torch.float32).reshape(-1, DIM)
+        cand = self._dev(cand_doc_global, torch.int32)
+        cn = self._dev(cand_n, torch.int32)
+        Q, M = int(cand.shape[0]), int(cand.shape[1])
+        assert blocks.is_contiguous() and blocks.dtype == torch.int32 and blocks.dim() == 2
+        assert int(blocks.shape[0]) * int(queries_per_block) >= Q
+        self._check(self.lib.msr_rerank_gather_blocks(self.handle, _ptr(q), Q, _ptr(cand), _ptr(cn), M, int(doc_base), int(row_base),
+                                                      int(max_chunks), _ptr(blocks), int(queries_per_block), int(blocks.shape[1]),
+                                                      self._stream()))
 
     def rerank_combine(self, cos_parts, meta_parts, nq):
         """Join of the gathered halves: cos_parts float32 [G, Qs, M, 10] and meta_parts int32 [G, Qs, M, 3] are views of ONE

@@ -89,6 +89,17 @@ class OracleEngine:
             return out
         return torch.as_tensor(cos), torch.as_tensor(meta)
 
+    def rerank_gather_blocks(self, qvec, cand_doc_global, cand_n, blocks, queries_per_block, doc_base=0, row_base=0, max_chunks=10):
+        """Stand-in for DeviceEngine.rerank_gather_blocks: block b = [cos of queries b * qpb .. | their meta | padding]."""
+        cos, meta = self.rerank_gather(qvec, cand_doc_global, cand_n, doc_base, row_base, max_chunks)
+        Q, M = cos.shape[0], cos.shape[1]
+        qpb = queries_per_block
+        for b in range(blocks.shape[0]):
+            lo, hi = min(Q, b * qpb), min(Q, (b + 1) * qpb)
+            if hi > lo:
+                blocks[b, :(hi - lo) * M * 10].copy_(cos[lo:hi].reshape(-1).view(torch.int32))
+                blocks[b, qpb * M * 10: qpb * M * 10 + (hi - lo) * M * 3].copy_(meta[lo:hi].reshape(-1))
+
     def rerank_fuse(self, cand_doc_global, cand_bm25, cand_n, cos, meta, smoothing=0.15, max_boost=0.1,
                     max_decay=0.05, max_chunks=10):
         cand, bm, cn, cos, meta = map(_np, (cand_doc_global, cand_bm25, cand_n, cos, meta))

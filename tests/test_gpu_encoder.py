@@ -51,8 +51,8 @@ def test_encoder_matches_transformers_modernbert(enc_world):
     # cosine between the two embeddings of every sequence: what the retriever consumes
     cos = torch.nn.functional.cosine_similarity(got, ref, dim=1)
     assert float(cos.min()) > 1 - 1e-6
-    # the batch above (400 tokens) takes the library GEMM for its products; single queries take msr_enc_linear: one per
-    # tile shape of that kernel (1, 17, 65, 128 tokens), same bar against transformers
+    # the batch above (400 tokens) runs msr_enc_linear's batch form (64 x 48 tiles); single queries its token-tile forms: one
+    # per tile shape of that kernel (1, 17, 65, 128 tokens), same bar against transformers
     for i in (0, 3, 5, 7):
         single = enc.encode([seqs[i]])[0]
         e1 = float((single - ref[i]).abs().max())

@@ -25,9 +25,23 @@ ap.add_argument("--hip-linear-max", type=int, default=-1,
                      "(default: msr_enc_linear always)")
 ap.add_argument("--no-hf", action="store_true", help="skip the transformers comparison (profiling runs)")
 a = ap.parse_args()
-import msretr.encoder as _enc_mod  # noqa: E402
 if a.hip_linear_max >= 0:
-    _enc_mod.LINEAR_HIP_MAX_TOKENS = a.hip_linear_max
+    # comparison runs only: batches of more than --hip-linear-max tokens take the library GEMM (hipBLASLt through torch) instead
+    # of msr_enc_linear.  The product module has no such branch; it is patched in here.
+    _hip_linear = QueryEncoder._linear
+
+    def _linear_or_library(self, x, weight, y, resid=None):
+        if x.shape[0] <= a.hip_linear_max:
+            return _hip_linear(self, x, weight, y, resid)
+        if resid is None:
+            torch.mm(x, weight.t(), out=y)
+        elif resid is y:
+            y.addmm_(x, weight.t())
+        else:
+            torch.addmm(resid, x, weight.t(), out=y)
+        return y
+
+    QueryEncoder._linear = _linear_or_library
 from transformers import ModernBertConfig, ModernBertModel  # noqa: E402
 torch.manual_seed(0)
 hf = ModernBertModel(ModernBertConfig(reference_compile=False, attn_implementation="eager")).eval().cuda()
