@@ -8,22 +8,28 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
+#include <thread>
+#include <vector>
+
 #include "../../include/msretr.h"
 
 namespace {
 
 // "%.3f" of a double, digit for digit what Python's format(x, ".3f") and glibc's printf give: both round the EXACT binary
-// value half-to-even at the third decimal.  x = m 2^e with a 53-bit integer m, so 1000 x = (1000 m) / 2^-e is an exact
-// 63-bit integer over a power of two: quotient, remainder and the half-way comparison are integer operations.
+// value half-to-even at the third decimal.  x = m / 2^k with a 53-bit integer m (read off the bits), so 1000 x = (1000 m) / 2^k
+// is an exact 63-bit integer over a power of two: quotient, remainder and the half-way comparison are integer operations.
 static inline int fmt3(double x, char* out) {
     const double ax = fabs(x);
     if (!(ax < 1.0e12)) return snprintf(out, 40, "%.3f", x);          // huge, inf, nan
     uint64_t v = 0;
     if (ax != 0.0) {
-        int ex;
-        const double fr = frexp(ax, &ex);                               // ax = fr 2^ex, fr in [0.5, 1)
-        const uint64_t M = (uint64_t)ldexp(fr, 53) * 1000u;             // < 2^63
-        const int k = 53 - ex;                                          // 1000 ax = M / 2^k
+        uint64_t bits;
+        memcpy(&bits, &ax, 8);
+        const int ef = (int)(bits >> 52);                               // biased exponent (sign is clear)
+        const uint64_t m = ef ? ((bits & ((1ull << 52) - 1)) | (1ull << 52)) : (bits & ((1ull << 52) - 1));
+        const int k = ef ? 1075 - ef : 1074;                            // ax = m / 2^k
+        const uint64_t M = m * 1000u;                                   // < 2^63: 1000 ax = M / 2^k
         if (k <= 0) {
             v = M << -k;                                                // (ax < 1e12: no overflow)
         } else if (k < 64) {
@@ -55,32 +61,21 @@ static inline int fmt_u(uint32_t v, char* out) {
 
 }  // namespace
 
-extern "C" int64_t msr_format_lines(const char* qnum_blob, const int64_t* qnum_off, int32_t n_queries, const int32_t* doc,
-                                    const double* score, const int32_t* n, int32_t stride, const char* url_blob,
-                                    const int64_t* url_off, int64_t n_docs, char* out, int64_t capacity) {
-    if (!qnum_blob || !qnum_off || !doc || !score || !n || !url_off || n_queries < 0 || stride < 0 || capacity < 0 || (capacity && !out))
-        return INT64_MIN;
-    // pass 1: an upper bound of the bytes (the formatted rank and score take at most 10 + 24 characters for ranks < 2^32 and
-    // |score| < 1e12; snprintf's output for anything larger is bounded by 40)
-    int64_t need = 0;
-    for (int32_t q = 0; q < n_queries; ++q) {
-        const int64_t ql = qnum_off[q + 1] - qnum_off[q];
-        const int32_t cnt = n[q] < 0 ? 0 : (n[q] > stride ? stride : n[q]);
-        for (int32_t r = 0; r < cnt; ++r) {
-            const int32_t d = doc[(int64_t)q * stride + r];
-            const int64_t ul = (d >= 0 && d < n_docs && url_blob) ? url_off[d + 1] - url_off[d] : 0;
-            need += ql + ul + 56;
-        }
-    }
-    if (need > capacity) return -need;
-    char* p = out;
-    for (int32_t q = 0; q < n_queries; ++q) {
+// format queries [q0, q1) into p (which has room for their upper bound); returns the end
+static char* format_range(const char* qnum_blob, const int64_t* qnum_off, int32_t q0, int32_t q1, const int32_t* doc,
+                          const double* score, const int32_t* n, int32_t stride, const char* url_blob, const int64_t* url_off,
+                          int64_t n_docs, char* p) {
+    for (int32_t q = q0; q < q1; ++q) {
         const char* qs = qnum_blob + qnum_off[q];
         const int64_t ql = qnum_off[q + 1] - qnum_off[q];
         const int32_t cnt = n[q] < 0 ? 0 : (n[q] > stride ? stride : n[q]);
         for (int32_t r = 0; r < cnt; ++r) {
             const int64_t i = (int64_t)q * stride + r;
             const int32_t d = doc[i];
+            // the URLs of a result list are scattered over the blob (tens of MB): fetch the offsets 8 results and the bytes 4
+            // results ahead, or every line costs two cache misses
+            if (r + 8 < cnt) { const int32_t d8 = doc[i + 8]; if (d8 >= 0 && d8 < n_docs) __builtin_prefetch(url_off + d8); }
+            if (r + 4 < cnt && url_blob) { const int32_t d4 = doc[i + 4]; if (d4 >= 0 && d4 < n_docs) __builtin_prefetch(url_blob + url_off[d4]); }
             memcpy(p, qs, (size_t)ql); p += ql;
             *p++ = '\t';
             p += fmt_u((uint32_t)(r + 1), p);
@@ -93,6 +88,60 @@ extern "C" int64_t msr_format_lines(const char* qnum_blob, const int64_t* qnum_o
             p += fmt3(score[i], p);
             *p++ = '\n';
         }
+    }
+    return p;
+}
+
+extern "C" int64_t msr_format_lines(const char* qnum_blob, const int64_t* qnum_off, int32_t n_queries, const int32_t* doc,
+                                    const double* score, const int32_t* n, int32_t stride, const char* url_blob,
+                                    const int64_t* url_off, int64_t n_docs, char* out, int64_t capacity) {
+    if (!qnum_blob || !qnum_off || !doc || !score || !n || !url_off || n_queries < 0 || stride < 0 || capacity < 0 || (capacity && !out))
+        return INT64_MIN;
+    // pass 1: an upper bound of the bytes per query, without touching the URL table (its entries are scattered: that would be
+    // a cache miss per line): rank and score take at most 10 + 24 characters (ranks < 2^32, |score| < 1e12; snprintf's output
+    // for anything larger is bounded by 40), a URL at most `max_url` bytes
+    int64_t max_url = 0;
+    {
+        static thread_local const int64_t* seen_off = nullptr;
+        static thread_local int64_t seen_n = -1, seen_max = 0;
+        if (seen_off != url_off || seen_n != n_docs) {                  // (one sequential pass per URL table, remembered)
+            int64_t m = 0;
+            if (url_blob) for (int64_t d = 0; d < n_docs; ++d) m = std::max(m, url_off[d + 1] - url_off[d]);
+            seen_off = url_off; seen_n = n_docs; seen_max = m;
+        }
+        max_url = seen_max;
+    }
+    std::vector<int64_t> bound((size_t)n_queries + 1, 0);
+    for (int32_t q = 0; q < n_queries; ++q) {
+        const int64_t ql = qnum_off[q + 1] - qnum_off[q];
+        const int32_t cnt = n[q] < 0 ? 0 : (n[q] > stride ? stride : n[q]);
+        bound[q + 1] = bound[q] + (int64_t)cnt * (ql + max_url + 56);
+    }
+    const int64_t need = bound[n_queries];
+    if (need > capacity) return -need;
+    // pass 2: contiguous ranges of queries on a few threads, each into the region its bound reserves, then closed up in order
+    int n_thr = (int)std::min<int64_t>(8, std::min<int64_t>((int64_t)std::thread::hardware_concurrency() / 2, need / (1024 * 1024) + 1));
+    if (n_thr < 1) n_thr = 1;
+    std::vector<int32_t> cut((size_t)n_thr + 1, 0);
+    for (int t = 1; t < n_thr; ++t)                                     // equal shares of the bound
+        cut[t] = (int32_t)(std::lower_bound(bound.begin(), bound.end(), need * t / n_thr) - bound.begin());
+    cut[n_thr] = n_queries;
+    for (int t = 1; t <= n_thr; ++t) cut[t] = std::max(cut[t], cut[t - 1]);
+    std::vector<char*> end((size_t)n_thr, nullptr);
+    auto work = [&](int t) {
+        end[t] = format_range(qnum_blob, qnum_off, cut[t], cut[t + 1], doc, score, n, stride, url_blob, url_off, n_docs,
+                              out + bound[cut[t]]);
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_thr; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto& th : pool) th.join();
+    char* p = end[0];
+    for (int t = 1; t < n_thr; ++t) {
+        const char* src = out + bound[cut[t]];
+        const int64_t len = end[t] - src;
+        if (p != src) memmove(p, src, (size_t)len);
+        p += len;
     }
     return (int64_t)(p - out);
 }

@@ -335,9 +335,12 @@ __device__ __forceinline__ uint32_t ord_key(float x) {
 __device__ __forceinline__ float ord_val(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
 
 // a 16-byte global load in the scalar-base + 32-bit lane-offset form: one register per row pointer instead of two
-template <int OFF>
+template <int OFF, bool NT = false>
 __device__ __forceinline__ void gload16s(f32x4& r, uint32_t voff, uint64_t sbase) {
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(r) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+    // NT: the non-temporal cache policy -- rows that are read once do not displace the query image (re-read by every
+    // workgroup for every tile) from the L2
+    if (NT) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(r) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(r) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
 }
 // A copy the compiler cannot see through: the fragment of a bf16 row IS the loaded register, and a plain copy would let the
 // register allocator rename the ring slots around the loop with moves of registers whose loads are still in flight (the
@@ -380,7 +383,7 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t u) {
 // then reads 1 KB = 8 whole cache lines of its own; on the row-major matrix it reads 64 of the 128 bytes of 16 lines, the
 // other halves follow in the next instruction and find their lines pending in the L1 (TCP_READ_TAGCONFLICT_STALL_CYCLES:
 // 23 % of the L1's cycles).
-template <bool EMIT, bool BF16, bool TILED = false>
+template <bool EMIT, bool BF16, bool TILED = false, bool NTL = false>
 __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args a) {
     // (A fragment-order copy of the bf16 image was measured too: 13.71 vs 13.97 ms per 1024 queries x 10 M rows, but 1.33 x
     // instead of 1.21 x the rows in HBM reads at 5 M rows and 7.9 GB more memory: not kept.  The addressing below stays general.)
@@ -504,12 +507,12 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
         for (int mi = 0; mi < NMI; ++mi) {
             if (TILED) {                                 // group 2 wr + mi of the tile, ring slot `slot` of the block at sb
                 const uint64_t b = sb + (uint64_t)((2 * wr + mi) * ((GF_KT / KPS) * 2048) + slot * 2048);
-                gload16s<0>(ring[slot][mi][0], v[0], b);
-                gload16s<1024>(ring[slot][mi][1], v[0], b);
+                gload16s<0, NTL>(ring[slot][mi][0], v[0], b);
+                gload16s<1024, NTL>(ring[slot][mi][1], v[0], b);
             } else {
                 const uint64_t b = BF16 ? sb + (uint64_t)(mi * 16 * ROWB) : sb;
-                gload16s<off>(ring[slot][mi][0], v[BF16 ? 0 : mi], b);
-                gload16s<off + 16>(ring[slot][mi][1], v[BF16 ? 0 : mi], b);
+                gload16s<off, NTL>(ring[slot][mi][0], v[BF16 ? 0 : mi], b);
+                gload16s<off + 16, NTL>(ring[slot][mi][1], v[BF16 ? 0 : mi], b);
             }
         }
     };
@@ -552,6 +555,9 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
         constexpr int slot = s4 / KPS, half = s4 % KPS;  // (bf16 rows: K step s4 = half `half` of slot s4 / 2)
         using SL = std::integral_constant<int, slot>;
         __builtin_amdgcn_sched_barrier(0);
+#ifdef MSR_DIAG
+        if (a.dbg & 32768) __builtin_amdgcn_s_setprio(3);   // timing experiment: the wave's memory section above its partner's MFMAs
+#endif
         if (half == 0) {
             if (BF16) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
@@ -575,6 +581,9 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
             if (last) load_rows(SL{}, bn, vn, std::integral_constant<int, slot * 128>{});
             else load_rows(SL{}, bp + (uint64_t)(kn * BLKB), vp, std::integral_constant<int, slot * 128>{});
         }
+#ifdef MSR_DIAG
+        if (a.dbg & 32768) __builtin_amdgcn_s_setprio(0);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         // (the lane's fragment offset is recomputed from a fresh lane id in every step -- 7 instructions beside 32 MFMAs --
         // so that it is not one more value held in a register across the whole kernel: the allocator has none to spare, and
@@ -897,15 +906,15 @@ hipError_t launch_stream_t(const GemmF32Args& a, int grid, hipStream_t stream) {
     gemm_stream_kernel<EMIT><<<grid, GF_THREADS, GS_LDS, stream>>>(a);
     return hipGetLastError();
 }
-template <bool EMIT, bool BF16, bool TILED = false>
+template <bool EMIT, bool BF16, bool TILED = false, bool NTL = false>
 hipError_t launch_stream256_t(const GemmF32Args& a, int grid, hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t err = hipFuncSetAttribute((const void*)gemm_stream256_kernel<EMIT, BF16, TILED>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
+        hipError_t err = hipFuncSetAttribute((const void*)gemm_stream256_kernel<EMIT, BF16, TILED, NTL>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
         if (err != hipSuccess) return err;
         attr_done = true;
     }
-    gemm_stream256_kernel<EMIT, BF16, TILED><<<grid, G2_THREADS, G2_LDS, stream>>>(a);
+    gemm_stream256_kernel<EMIT, BF16, TILED, NTL><<<grid, G2_THREADS, G2_LDS, stream>>>(a);
     return hipGetLastError();
 }
 
@@ -932,6 +941,10 @@ __global__ __launch_bounds__(256) void tile_rows_kernel(const char* __restrict__
 }
 // width: queries per pass (128 or 256; both kernels: 8 waves x 32 rows)
 hipError_t launch_f32(int width, bool emit, const GemmF32Args& a, int grid, hipStream_t stream, bool tiled = false) {
+#ifdef MSR_DIAG
+    if (width == 256 && tiled && (g_f32_dbg & 16384))       // timing experiment: non-temporal row loads
+        return emit ? launch_stream256_t<true, false, true, true>(a, grid, stream) : launch_stream256_t<false, false, true, true>(a, grid, stream);
+#endif
     if (width == 256 && tiled)
         return emit ? launch_stream256_t<true, false, true>(a, grid, stream) : launch_stream256_t<false, false, true>(a, grid, stream);
     if (width == 256) return emit ? launch_stream256_t<true, false>(a, grid, stream) : launch_stream256_t<false, false>(a, grid, stream);
@@ -944,6 +957,9 @@ void msr_gemm_f32_set_dbg(int v) { g_f32_dbg = v; }
 
 hipError_t msr_stream256_bf16_launch(bool emit, const StreamArgs& a, int grid, hipStream_t stream) {
     if (a.nt < 1 || (grid & 7) || (grid >> 3) < a.nt) return hipErrorInvalidValue;
+#ifdef MSR_DIAG
+    if (g_f32_dbg & 32768) { StreamArgs b = a; b.dbg |= 32768; return emit ? launch_stream256_t<true, true>(b, grid, stream) : launch_stream256_t<false, true>(b, grid, stream); }
+#endif
     return emit ? launch_stream256_t<true, true>(a, grid, stream) : launch_stream256_t<false, true>(a, grid, stream);
 }
 hipError_t msr_stream256_bf16_qimage(const float* qn, int nq, int n_groups, void* qimg, hipStream_t stream) {

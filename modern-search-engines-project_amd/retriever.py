@@ -36,6 +36,7 @@ class Retriever:
         self._ids = ids.cpu().numpy() if hasattr(ids, "cpu") else np.asarray(ids)
         self._domains_bound = False
         self._formatter = None
+        self._pinned = {}
 
     def _embed(self, query, query_embedding=None):
         if query_embedding is not None:
@@ -134,33 +135,84 @@ class Retriever:
             self.engine.bind_doc_domains(self._doc_domains())
             self._domains_bound = True
 
-    def final_lists(self, term_id_lists, query_vectors, top_k=TOP_K_RETRIEVAL, chunk=None):
-        """The whole live path for a batch, on the device: -> host arrays (doc index int32 [Q, S], new_similarity float64 [Q, S],
-        winning chunk row int32 [Q, S], n int32 [Q]); row q holds n[q] entries in final rank order (S = max n, normally the
-        reranker's top_k = 100).  term_id_lists: per query its term ids (repeats allowed, unknown < 0); query_vectors [Q, 768]."""
+    FINAL_COLS = 128           # columns of the final lists copied back per query (top_k = 100 + slack; a longer list -- more
+    #                            than top_k "high" domains -- makes that chunk come back in full)
+
+    def _enqueue_chunk(self, term_ids, qv, top_k, slot):
+        """Device work of one chunk + the asynchronous copy of its final rows into pinned host buffers.  Only enqueues."""
         import torch
         eng, cfg = self.engine, self.reranker.cfg
+        b = eng.bm25_topk(term_ids, k=top_k)
+        cos, meta = eng.rerank_gather(qv, b[0], b[2], max_chunks=RERANK_MAX_CHUNKS)
+        fused = eng.rerank_fuse(b[0], b[1], b[2], cos, meta, smoothing=cfg["smoothing"], max_chunks=RERANK_MAX_CHUNKS)
+        fin = eng.diversify(fused, top_k=int(cfg["top_k"]), diversification=bool(cfg.get("diversification", False)))
+        Qc, W = len(term_ids), min(self.FINAL_COLS, int(fin[0].shape[1]))
+        pin = self._pinned.get(slot)
+        if pin is None or pin[0].shape[0] < Qc or pin[0].shape[1] != W:
+            rows = max(Qc, 256)
+            pin = self._pinned[slot] = (torch.empty((rows, W), dtype=torch.int32, pin_memory=True),
+                                        torch.empty((rows, W), dtype=torch.float64, pin_memory=True),
+                                        torch.empty((rows, W), dtype=torch.int32, pin_memory=True),
+                                        torch.empty((rows,), dtype=torch.int32, pin_memory=True))
+        pin[0][:Qc].copy_(fin[0][:, :W], non_blocking=True)
+        pin[1][:Qc].copy_(fin[1][:, :W], non_blocking=True)
+        pin[2][:Qc].copy_(fin[3][:, :W], non_blocking=True)
+        pin[3][:Qc].copy_(fin[4], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(eng.device))
+        return fin, pin, ev, Qc, W
+
+    @staticmethod
+    def _collect_chunk(job):
+        """Wait for a chunk's copies -> (doc, score, chunk row, n) numpy arrays of that chunk (copies: the pinned buffers are
+        reused two chunks later)."""
+        fin, pin, ev, Qc, W = job
+        ev.synchronize()
+        n = pin[3][:Qc].numpy().copy()
+        S = int(n.max()) if Qc else 0
+        if S > W:                                            # (rare) a list longer than the copied columns: this chunk in full
+            return fin[0][:, :S].cpu().numpy(), fin[1][:, :S].cpu().numpy(), fin[3][:, :S].cpu().numpy(), n
+        return pin[0][:Qc, :S].numpy().copy(), pin[1][:Qc, :S].numpy().copy(), pin[2][:Qc, :S].numpy().copy(), n
+
+    def final_list_chunks(self, term_id_lists=None, query_vectors=None, top_k=TOP_K_RETRIEVAL, chunk=None, prepare=None,
+                          n_queries=None):
+        """The whole live path, chunk by chunk, on the device; yields (first query, doc index int32 [Qc, S], new_similarity
+        float64 [Qc, S], winning chunk row int32 [Qc, S], n int32 [Qc]) per chunk of queries, rows in final rank order.
+        Software-pipelined: while the GPU works on chunk i the host packs chunk i + 1 and the caller consumes chunk i - 1.
+        prepare(a, b) (optional, with n_queries) -> (term id lists, vectors) of queries a .. b, evaluated just before the chunk
+        is enqueued (text preprocessing inside the pipeline); otherwise term_id_lists / query_vectors hold all queries."""
+        import torch
+        eng = self.engine
         if top_k > eng.rerank_max_docs or top_k > eng.max_k:
             raise ValueError(f"top_k {top_k} exceeds the engine's max_k / rerank_max_docs ({eng.max_k} / {eng.rerank_max_docs})")
         self._ensure_response_tables()
-        Q = len(term_id_lists)
-        qv = eng._dev(np.asarray(query_vectors, np.float32) if not torch.is_tensor(query_vectors) else query_vectors, torch.float32).reshape(-1, 768)
+        Q = len(term_id_lists) if prepare is None else int(n_queries)
         step = int(chunk or max(256, eng.max_queries))
-        parts = []
-        for a in range(0, Q, step):                          # every call below only ENQUEUES: the host packs the next chunk's
-            b = eng.bm25_topk(term_id_lists[a:a + step], k=top_k)                     # terms while the GPU works on this one
-            cos, meta = eng.rerank_gather(qv[a:a + step], b[0], b[2], max_chunks=RERANK_MAX_CHUNKS)
-            fused = eng.rerank_fuse(b[0], b[1], b[2], cos, meta, smoothing=cfg["smoothing"], max_chunks=RERANK_MAX_CHUNKS)
-            parts.append(eng.diversify(fused, top_k=int(cfg["top_k"]), diversification=bool(cfg.get("diversification", False))))
+        pending = None
+        for i, a in enumerate(range(0, Q, step)):
+            b = min(Q, a + step)
+            ids, qv = prepare(a, b) if prepare is not None else (term_id_lists[a:b], query_vectors[a:b])
+            qv = eng._dev(np.asarray(qv, np.float32) if not torch.is_tensor(qv) else qv, torch.float32).reshape(-1, 768)
+            job = self._enqueue_chunk(ids, qv, top_k, i & 1)
+            if pending is not None:
+                yield (pending[0],) + self._collect_chunk(pending[1])
+            pending = (a, job)
+        if pending is not None:
+            yield (pending[0],) + self._collect_chunk(pending[1])
+
+    def final_lists(self, term_id_lists, query_vectors, top_k=TOP_K_RETRIEVAL, chunk=None):
+        """-> host arrays (doc index int32 [Q, S], new_similarity float64 [Q, S], winning chunk row int32 [Q, S], n int32 [Q]);
+        row q holds n[q] entries in final rank order (S = max n, normally the reranker's top_k = 100).  term_id_lists: per
+        query its term ids (repeats allowed, unknown < 0); query_vectors [Q, 768]."""
+        parts = list(self.final_list_chunks(term_id_lists, query_vectors, top_k, chunk))
         if not parts:
             z = np.zeros((0, 0), np.int32)
             return z, np.zeros((0, 0), np.float64), z, np.zeros(0, np.int32)
-        n = torch.cat([p[4] for p in parts]).cpu().numpy()   # (the one synchronisation of the batch)
-        S = int(n.max()) if len(n) else 0
-        doc = torch.cat([p[0][:, :S] for p in parts]).cpu().numpy()
-        score = torch.cat([p[1][:, :S] for p in parts]).cpu().numpy()
-        chunk_row = torch.cat([p[3][:, :S] for p in parts]).cpu().numpy()
-        return doc, score, chunk_row, n
+        S = max(p[1].shape[1] for p in parts)
+        pad = lambda x, fill: x if x.shape[1] == S else np.concatenate(
+            [x, np.full((x.shape[0], S - x.shape[1]), fill, x.dtype)], axis=1)
+        return (np.concatenate([pad(p[1], -1) for p in parts]), np.concatenate([pad(p[2], -np.inf) for p in parts]),
+                np.concatenate([pad(p[3], -1) for p in parts]), np.concatenate([p[4] for p in parts]))
 
     def _prepare(self, queries, query_embeddings, term_lists):
         processed = [preprocess_query(q) for q in queries]
@@ -206,10 +258,24 @@ class Retriever:
             self._formatter = LineFormatter(self.index.urls, self.index.n_docs)
         return BatchLines([qn for qn, _ in numbered_queries], doc, score, n, self.index.urls, self._formatter)
 
-    def batch_search_to_file(self, queries_path, out_path, query_embeddings=None, term_lists=None):
-        res = self.batch_search(read_queries_file(queries_path), query_embeddings, term_lists)
-        res.write(out_path)
-        return len(res)
+    def batch_search_to_file(self, queries_path, out_path, query_embeddings=None, term_lists=None, chunk=None):
+        """search_api.py:331-367: queries.txt -> one formatted line per result in out_path; -> number of lines.  The chunks of
+        the batch are pipelined: text preprocessing of chunk i + 1 and formatting / writing of chunk i - 1 run on the host
+        while the GPU ranks chunk i."""
+        nq = read_queries_file(queries_path)
+        if self._formatter is None:
+            self._formatter = LineFormatter(self.index.urls, self.index.n_docs)
+        texts, nums = [q for _, q in nq], [n for n, _ in nq]
+        sub = lambda x, a, b: None if x is None else x[a:b]
+
+        def prepare(a, b):
+            return self._prepare(texts[a:b], sub(query_embeddings, a, b), sub(term_lists, a, b))
+        total = 0
+        with open(out_path, "wb") as f:
+            for a, doc, score, _, n in self.final_list_chunks(top_k=TOP_K_RETRIEVAL, chunk=chunk, prepare=prepare, n_queries=len(nq)):
+                f.write(self._formatter.format(nums[a:a + len(n)], doc, score, n))
+                total += int(n.sum())
+        return total
 
 
 class BatchLines:

@@ -98,9 +98,11 @@ class LineFormatter:
         if enc:
             np.cumsum(np.fromiter((len(b) for b in enc), np.int64, n), out=self.off[1:])
         self.n_docs = n
+        self._buf = self._cbuf = None
 
     def format(self, query_nums, doc, score, n):
-        """query_nums: list of str; doc int32 [Q, S], score float64 [Q, S], n int32 [Q] (host arrays) -> bytes."""
+        """query_nums: list of str; doc int32 [Q, S], score float64 [Q, S], n int32 [Q] (host arrays) -> the lines as a
+        bytes-like view of the formatter's own buffer (valid until the next call; bytes(...) for a copy)."""
         import ctypes as C
 
         import numpy as np
@@ -118,9 +120,11 @@ class LineFormatter:
                 ptr(self.off), self.n_docs)
         need = -int(self._lib.msr_format_lines(*args, None, 0))
         if need <= 0:
-            return b""
-        buf = C.create_string_buffer(need)
-        got = int(self._lib.msr_format_lines(*args, buf, need))
+            return memoryview(b"")
+        if self._buf is None or len(self._buf) < need:         # one output buffer per formatter, grown when needed (a fresh
+            self._buf = bytearray(need + need // 4)             # bytearray of several MB costs more than filling it)
+            self._cbuf = (C.c_char * len(self._buf)).from_buffer(self._buf)
+        got = int(self._lib.msr_format_lines(*args, self._cbuf, len(self._buf)))
         if got < 0:
             raise RuntimeError(f"msr_format_lines failed ({got})")
-        return buf.raw[:got]
+        return memoryview(self._buf)[:got]

@@ -26,6 +26,7 @@ ap.add_argument("--k", type=int, default=100)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--check", type=int, default=128, help="queries compared with the exact path")
 ap.add_argument("--dbg", type=int, default=0, help="diagnostic build only: msr_tune(100, dbg) before the timing loops")
+ap.add_argument("--dbg-stream", type=int, default=0, help="diagnostic build only: msr_tune(101, v), the streaming kernel's switches")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 ix = synthetic_corpus(a.docs, n_chunks=a.chunks, device=dev, with_postings=False)
@@ -46,6 +47,8 @@ tie_ok = bool(((out[0][:a.check] == ex[0]) | ((out[1][:a.check] - ex[1]).abs() <
 print(json.dumps({"short_rows": n_bad, "max_abs_score_diff": d_err, "doc_agreement": agree, "near_tie_only": tie_ok}), flush=True)
 if a.dbg:
     e._check(e.lib.msr_tune(e.handle, 100, a.dbg))
+if a.dbg_stream:
+    e._check(e.lib.msr_tune(e.handle, 101, a.dbg_stream))
 for ver in (3,):
   o2 = e.dense_topk_batched(q, k=a.k)
   torch.cuda.synchronize()
