@@ -667,6 +667,9 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
             // DMAs are in flight; then everyone is done with this one
             if (BF16) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+#ifdef MSR_DIAG
+            if (!(a.dbg & 131072))                       // timing experiment (wrong results): no rendezvous at the end of a query block
+#endif
             wg_barrier();
             pb ^= 1;
             if (JOIN && kb == 0 && it > 0) flush_tmax(jt_prev, (it - 1) & 1);
@@ -688,6 +691,14 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
         //      the tile, query 128 wc + ni 16 + li16 of the group ----
         const int n_valid = row_end - row0;
         const int col_e = wc * 128 + (ln_e & 15);
+#ifdef MSR_DIAG
+        if (a.dbg & 65536) {                             // timing experiment (wrong results): no epilogue at all
+#pragma unroll
+            for (int ni = 0; ni < NNI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < NMI; ++mi) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        } else
+#endif
 #pragma unroll
         for (int ni = 0; ni < NNI; ++ni) {
             f32x4 v[NMI];
@@ -941,10 +952,16 @@ __global__ __launch_bounds__(256) void tile_rows_kernel(const char* __restrict__
 }
 // width: queries per pass (128 or 256; both kernels: 8 waves x 32 rows)
 hipError_t launch_f32(int width, bool emit, const GemmF32Args& a, int grid, hipStream_t stream, bool tiled = false) {
+    // One query group per launch: every row is read exactly once, by one wave -- loaded with the non-temporal policy, so that the
+    // 15 GB stream does not displace the 384 KB query image (re-read by every workgroup for every tile) from the L2s: 3.07 ->
+    // 2.94 ms per pass on one box (profiles/r04_stream256_experiments.md).  Several groups per launch share the rows through the
+    // L2 and keep the default policy.
+    bool ntl = width == 256 && tiled && a.nt == 1;
 #ifdef MSR_DIAG
-    if (width == 256 && tiled && (g_f32_dbg & 16384))       // timing experiment: non-temporal row loads
-        return emit ? launch_stream256_t<true, false, true, true>(a, grid, stream) : launch_stream256_t<false, false, true, true>(a, grid, stream);
+    if (g_f32_dbg & 16384) ntl = false;                     // timing experiment: default cache policy for the rows
 #endif
+    if (ntl)
+        return emit ? launch_stream256_t<true, false, true, true>(a, grid, stream) : launch_stream256_t<false, false, true, true>(a, grid, stream);
     if (width == 256 && tiled)
         return emit ? launch_stream256_t<true, false, true>(a, grid, stream) : launch_stream256_t<false, false, true>(a, grid, stream);
     if (width == 256) return emit ? launch_stream256_t<true, false>(a, grid, stream) : launch_stream256_t<false, false>(a, grid, stream);
@@ -958,7 +975,7 @@ void msr_gemm_f32_set_dbg(int v) { g_f32_dbg = v; }
 hipError_t msr_stream256_bf16_launch(bool emit, const StreamArgs& a, int grid, hipStream_t stream) {
     if (a.nt < 1 || (grid & 7) || (grid >> 3) < a.nt) return hipErrorInvalidValue;
 #ifdef MSR_DIAG
-    if (g_f32_dbg & 32768) { StreamArgs b = a; b.dbg |= 32768; return emit ? launch_stream256_t<true, true>(b, grid, stream) : launch_stream256_t<false, true>(b, grid, stream); }
+    if (g_f32_dbg & (32768 | 65536 | 131072)) { StreamArgs b = a; b.dbg |= g_f32_dbg & (32768 | 65536 | 131072); return emit ? launch_stream256_t<true, true>(b, grid, stream) : launch_stream256_t<false, true>(b, grid, stream); }
 #endif
     return emit ? launch_stream256_t<true, true>(a, grid, stream) : launch_stream256_t<false, true>(a, grid, stream);
 }

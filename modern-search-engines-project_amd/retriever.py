@@ -219,8 +219,11 @@ class Retriever:
         if term_lists is None:
             term_lists = [self.bm25._tokenize(q) for q in processed]
         ids = [self.index.term_ids(t) for t in term_lists]
-        qv = np.stack([self._embed(processed[i], None if query_embeddings is None else query_embeddings[i])
-                       for i in range(len(queries))]) if len(queries) else np.zeros((0, 768), np.float32)
+        if isinstance(query_embeddings, np.ndarray) and query_embeddings.ndim == 2:
+            qv = np.ascontiguousarray(query_embeddings, np.float32)             # (a matrix of vectors: taken as it is)
+        else:
+            qv = np.stack([self._embed(processed[i], None if query_embeddings is None else query_embeddings[i])
+                           for i in range(len(queries))]) if len(queries) else np.zeros((0, 768), np.float32)
         return ids, qv
 
     def search_batch(self, queries, top_k=TOP_K_RETRIEVAL, query_embeddings=None, term_lists=None, query_ids=None):
