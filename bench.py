@@ -301,7 +301,7 @@ def facade_bench(args, shard, eng, terms, qvec, n_queries=1024, single=20):
     used = sorted({int(t) for tl in terms[:n_queries] for t in tl})
     shard.vocab = {_term_name(t): t for t in used if t != 0}
     shard.vocab[CITY] = 0
-    rt = Retriever(indexer=eng)
+    rt = Retriever(indexer=eng, freeze_gc=True)      # (the corpus tables are permanent: no full collection walks them mid-batch)
     # (the engine was bound before the URL strings existed: every document is its own URL group, which is what these URLs
     # say too -- one page per document)
     texts = [" ".join(_term_name(t) for t in tl if t != 0) for tl in terms[:n_queries]]
@@ -316,13 +316,7 @@ def facade_bench(args, shard, eng, terms, qvec, n_queries=1024, single=20):
     nq = read_queries_file(qf)
     rt.batch_search(nq[:64], query_embeddings=embs[:64]).text()          # warm-up (binds the domain table, builds the URL blob)
     torch.cuda.synchronize()
-    times = []
-    for rep in range(3):
-        t1 = time.perf_counter()
-        n_lines = rt.batch_search_to_file(qf, of, query_embeddings=embs)
-        times.append(time.perf_counter() - t1)
-    total = min(times)
-    # where the host's time goes inside the pipelined call (wall time spent in each stage, one more run)
+    # timed runs, each with the wall time the host spends in every stage of the pipelined call; the fastest run is reported
     acc = {}
 
     def timed(obj, name, label):
@@ -340,12 +334,19 @@ def facade_bench(args, shard, eng, terms, qvec, n_queries=1024, single=20):
              (rt, "_enqueue_chunk", timed(rt, "_enqueue_chunk", "pack terms + H2D + enqueue kernels and copies")),
              (rt, "_collect_chunk", timed(rt, "_collect_chunk", "wait for a chunk's final rows (GPU not done yet) + copy out")),
              (rt._formatter, "format", timed(rt._formatter, "format", "native line formatting"))]
-    t1 = time.perf_counter()
-    rt.batch_search_to_file(qf, of, query_embeddings=embs)
-    acc["whole call"] = time.perf_counter() - t1
+    times, runs = [], []
+    for rep in range(7):
+        acc.clear()
+        t1 = time.perf_counter()
+        n_lines = rt.batch_search_to_file(qf, of, query_embeddings=embs)
+        times.append(time.perf_counter() - t1)
+        runs.append({k: 1e3 * v for k, v in acc.items()})
     for obj, name, fn in saved:
         setattr(obj, name, fn)
-    host_ms = {k: 1e3 * v for k, v in acc.items()}
+    total = min(times)
+    host_ms = runs[times.index(total)]
+    host_ms["whole call"] = 1e3 * total
+    host_ms["all runs, whole call"] = [round(1e3 * t, 2) for t in times]
     # the same stages one after the other, not pipelined
     t1 = time.perf_counter()
     idl, qv = rt._prepare([q for _, q in nq], embs, None)

@@ -22,7 +22,7 @@ RERANK_MAX_CHUNKS = 10     # reranker_api.py:58
 
 
 class Retriever:
-    def __init__(self, embedder=None, indexer=None, db_path=None, tokenizer=None, device=0, **engine_kw):
+    def __init__(self, embedder=None, indexer=None, db_path=None, tokenizer=None, device=0, freeze_gc=False, **engine_kw):
         if isinstance(indexer, DeviceEngine):
             self.engine = indexer
         else:
@@ -37,6 +37,13 @@ class Retriever:
         self._domains_bound = False
         self._formatter = None
         self._pinned = {}
+        if freeze_gc:
+            # The corpus side of a retriever is millions of long-lived Python objects (URL / title / text strings, the id maps):
+            # every full garbage collection walks them -- tens of milliseconds, in the middle of a 10 ms batch.  They never
+            # die, so they are moved to the permanent generation (gc.freeze), as a long-running server would do after start-up.
+            import gc
+            gc.collect()
+            gc.freeze()
 
     def _embed(self, query, query_embedding=None):
         if query_embedding is not None:
