@@ -129,6 +129,7 @@ class ShardedEngine:
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         self._ex = {}
         self._side = None                                 # second stream for the dense stage's finish (one-GPU path)
+        self.use_tail_stream = True
 
     # ------------------------------------------------------------------ exchange helpers
     def _exchange(self, Q, k1, k2, device):
@@ -191,7 +192,7 @@ class ShardedEngine:
         # One GPU, rerank wanted: the dense stage's finish (small launches behind the pass over the matrix) goes to a second
         # stream and runs beside the rerank gather of the same batch, which does not depend on it (msr_dense_topk_tail)
         side = None
-        if (self.world == 1 and rerank and not dense_batched and self.doc_base == 0 and self.row_base == 0     # (no index arithmetic
+        if (self.use_tail_stream and self.world == 1 and rerank and not dense_batched and self.doc_base == 0 and self.row_base == 0     # (no index arithmetic
                 and getattr(getattr(e, "device", None), "type", "") == "cuda"):                                  # on the outputs before the join)
             if self._side is None:
                 self._side = torch.cuda.Stream(e.device)

@@ -498,6 +498,16 @@ def test_streaming_pass_last_tile_with_a_partly_filled_fragment(mods):
         g2 = [x.cpu().numpy() for x in got]
         assert g2[0][3, 0] == n_docs - 1 and g2[2][3, 0] == C - 1 and abs(g2[1][3, 0] - 1.0) <= 1e-5
         assert all(np.array_equal(a_[:100], b_) for a_, b_ in zip(g2, g))          # (exact f32 rescoring: the kernels agree bit for bit)
+        owned_with_copy = eng.owned_bytes()
+        assert eng.row_copy_state() == "built" and owned_with_copy > C * 768 * 4    # the handle owns the copy and says so
+        eng.close()
+        # ... and with the copy declined (MSR_CFG_NO_ROW_COPY; also what a failed allocation of the copy falls back to): the
+        # same kernel reads the caller's row-major matrix, clamping the row index at the end of the matrix -- the same bits
+        eng = mods["DeviceEngine"](ix, max_queries=256, max_k=100, rerank_max_docs=0, row_copy=False)
+        assert eng.scan_width() == 256 and eng.row_copy_state() == "declined"
+        assert owned_with_copy - eng.owned_bytes() >= C * 768 * 4                    # ... and is that much lighter without it
+        g3 = [x.cpu().numpy() for x in eng.dense_topk(q2, k=100)]
+        assert eng.dense_path() == 256 and all(np.array_equal(a_, b_) for a_, b_ in zip(g3, g2))
         eng.close()
 
 
