@@ -391,7 +391,9 @@ def facade_bench(args, shard, eng, terms, qvec, n_queries=1024, single=20):
                    "everything included",
             "queries": n_queries, "value": n_queries / total, "unit": "queries/sec", "ms_per_batch": 1e3 * total,
             "lines_written": int(n_lines), "results_per_query": float(n.mean()),
-            "pipelined": "chunks of 256 queries: the host prepares chunk i + 1 and formats / writes chunk i - 1 while the GPU ranks chunk i",
+            "pipelined": "chunks of 256 queries, three stages side by side: the calling thread prepares and enqueues chunk i + 1, the GPU "
+                         "ranks chunk i, a second host thread collects, formats (native code) and writes chunk i - 1; the stage times "
+                         "below are wall time per stage summed over the chunks, on whichever thread ran them",
             "host_ms_inside_the_pipelined_call": host_ms,
             "stage_ms_unpipelined": {"read + preprocess + tokenise + term ids + vectors": 1e3 * (t2 - t1),
                              "device path incl. packing, H2D, D2H of the final rows": 1e3 * (t3 - t2),

@@ -195,7 +195,9 @@ class ShardedEngine:
         if (self.use_tail_stream and self.world == 1 and rerank and not dense_batched and self.doc_base == 0 and self.row_base == 0     # (no index arithmetic
                 and getattr(getattr(e, "device", None), "type", "") == "cuda"):                                  # on the outputs before the join)
             if self._side is None:
-                self._side = torch.cuda.Stream(e.device)
+                # (high priority: the tail is a chain of small dependent launches; at the default priority each of them queues
+                # behind the 32 k one-wave workgroups of the gather it runs beside, and the chain takes longer than it saves)
+                self._side = torch.cuda.Stream(e.device, priority=-1)
             side = self._side
         if side is not None:
             d_doc, d_score, d_chunk, d_n = e.dense_topk(qvec, k=k2, max_chunks_per_doc=max_chunks_per_doc, tail_stream=side)

@@ -269,23 +269,36 @@ class Retriever:
         return BatchLines([qn for qn, _ in numbered_queries], doc, score, n, self.index.urls, self._formatter)
 
     def batch_search_to_file(self, queries_path, out_path, query_embeddings=None, term_lists=None, chunk=None):
-        """search_api.py:331-367: queries.txt -> one formatted line per result in out_path; -> number of lines.  The chunks of
-        the batch are pipelined: text preprocessing of chunk i + 1 and formatting / writing of chunk i - 1 run on the host
-        while the GPU ranks chunk i."""
+        """search_api.py:331-367: queries.txt -> one formatted line per result in out_path; -> number of lines.  Three things
+        run side by side, chunk by chunk: this thread preprocesses / tokenises chunk i + 1 and enqueues it, the GPU ranks
+        chunk i, a second host thread waits for chunk i - 1's final rows, formats them (native code, outside the interpreter
+        lock) and writes them."""
+        from concurrent.futures import ThreadPoolExecutor
         nq = read_queries_file(queries_path)
         if self._formatter is None:
             self._formatter = LineFormatter(self.index.urls, self.index.n_docs)
+        eng = self.engine
+        if TOP_K_RETRIEVAL > eng.rerank_max_docs or TOP_K_RETRIEVAL > eng.max_k:
+            raise ValueError(f"the batch path needs max_k / rerank_max_docs >= {TOP_K_RETRIEVAL}")
+        self._ensure_response_tables()
         texts, nums = [q for _, q in nq], [n for n, _ in nq]
         sub = lambda x, a, b: None if x is None else x[a:b]
-
-        def prepare(a, b):
-            return self._prepare(texts[a:b], sub(query_embeddings, a, b), sub(term_lists, a, b))
-        total = 0
-        with open(out_path, "wb") as f:
-            for a, doc, score, _, n in self.final_list_chunks(top_k=TOP_K_RETRIEVAL, chunk=chunk, prepare=prepare, n_queries=len(nq)):
+        step = int(chunk or max(256, eng.max_queries))
+        import torch
+        with open(out_path, "wb") as f, ThreadPoolExecutor(max_workers=1) as pool:
+            def consume(a, job):
+                doc, score, _, n = self._collect_chunk(job)
                 f.write(self._formatter.format(nums[a:a + len(n)], doc, score, n))
-                total += int(n.sum())
-        return total
+                return int(n.sum())
+            futs = []
+            for i, a in enumerate(range(0, len(nq), step)):
+                b = min(len(nq), a + step)
+                if i >= 2:
+                    futs[i - 2].result()                      # its pinned buffers (slot i & 1) are free again
+                ids, qv = self._prepare(texts[a:b], sub(query_embeddings, a, b), sub(term_lists, a, b))
+                qv = eng._dev(qv, torch.float32).reshape(-1, 768)
+                futs.append(pool.submit(consume, a, self._enqueue_chunk(ids, qv, TOP_K_RETRIEVAL, i & 1)))
+            return sum(ft.result() for ft in futs)
 
 
 class BatchLines:
