@@ -474,8 +474,6 @@ def main():
                     help="time the variant that starts from token ids (QueryEncoder -> hybrid step) even with --no-variants")
     ap.add_argument("--facade", action="store_true",
                     help="time the drop-in API (Retriever.batch_search_to_file / Retriever.search) even with --no-variants")
-    ap.add_argument("--no-tail-stream", action="store_true",
-                    help="A/B: the dense stage's finish on the main stream (msr_dense_topk) instead of beside the rerank gather")
     ap.add_argument("--latency-queries", type=int, default=20)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--same-device", action="store_true",
@@ -522,7 +520,6 @@ def main():
     eng = DeviceEngine(shard, device=local_rank, max_queries=max(Q, 1), max_k=max(args.k1, args.k2),
                        rerank_max_docs=args.k1, scan_layout=args.scan_layout, scan_variant=args.scan_variant)
     se = ShardedEngine(eng, shard.doc_base, shard.row_base)
-    se.use_tail_stream = not args.no_tail_stream
     if args.workload != "bm25" and args.dense_mode == "bf16":
         eng.enable_bf16()
     batches = []

@@ -162,18 +162,6 @@ int msr_bm25_topk(msr_engine* e, const int32_t* q_term_off, const int32_t* q_ter
 int msr_dense_topk(msr_engine* e, const float* q, int32_t n_queries, int32_t k, int32_t max_chunks_per_doc,
                    int32_t* out_doc, float* out_score, int32_t* out_chunk, int32_t* out_n, void* stream);
 
-/* msr_dense_topk with its finish on a second stream.  The call has two parts: the pass(es) over the embedding matrix (HBM-bound,
- * every CU busy) and a tail of small launches behind the last pass (tile-maximum selects, candidate lists, exact f32 rescoring,
- * final sort: ~0.3 ms per 256 queries in which the GPU is mostly idle).  Here the tail is enqueued on `tail_stream`, which waits
- * for the pass through an engine-owned event, so that whatever the caller enqueues next on `stream` (the rerank gather of the
- * same batch, msretr/distributed.py) runs beside it.  The OUTPUTS ARE VALID ONCE tail_stream HAS DRAINED: the caller joins the
- * two streams (an event recorded on tail_stream, waited for on stream) before it reads them.  The engine's other entry points
- * that share scratch with the tail (msr_bm25_topk, msr_dense_topk*) wait for a pending tail themselves.  Calls that do not take
- * the streaming pass (<= 64 queries, corpora without row tiles) run entirely on `stream`, as msr_dense_topk does. */
-int msr_dense_topk_tail(msr_engine* e, const float* q, int32_t n_queries, int32_t k, int32_t max_chunks_per_doc,
-                        int32_t* out_doc, float* out_score, int32_t* out_chunk, int32_t* out_n, void* stream,
-                        void* tail_stream);
-
 /* Batched variant of msr_dense_topk for throughput (BASELINE config 5).  Candidates come from a bf16 image of the
  * NORMALISED rows (v_mfma_f32_16x16x32_bf16, f32 accumulation), whose scores carry a proven error bound; every document
  * within twice that bound of the k-th approximate score is re-scored in f32 from the f32 rows, so the final top-k is

@@ -33,17 +33,6 @@
 
 namespace {
 
-// a 16-byte load of a row piece.  (Diagnostic build: the non-temporal policy, for the A/B of round 4 -- rows are read once.)
-template <typename V>
-__device__ __forceinline__ V ks_row_load(const V* p) {
-#ifdef MSR_DIAG
-    return __builtin_nontemporal_load(p);
-#else
-    return *p;
-#endif
-}
-
-
 template <int QB, int MODE, int RING_DOCS = MSR_WIDE_RING, int NWAVES = 8> struct KsCfg {
     static constexpr int WAVES = NWAVES;                             // K-split ways; waves 0..7 also reduce and write
     static constexpr int THREADS = WAVES * 64;
@@ -216,7 +205,7 @@ __global__ __launch_bounds__(NWAVES * 64) void dense_ksplit_kernel(DenseIndex ix
         for (int b = 0; b < NBUF - 1; ++b) {
             const f32x4* p = row_ptr(g0 + b);
 #pragma unroll
-            for (int j = 0; j < NLU; ++j) A[b][j] = ks_row_load(p + j * 4);
+            for (int j = 0; j < NLU; ++j) A[b][j] = p[j * 4];
             load_meta(g0 + b, mtr[b]);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -230,7 +219,7 @@ __global__ __launch_bounds__(NWAVES * 64) void dense_ksplit_kernel(DenseIndex ix
                 {
                     const f32x4* pn = row_ptr(grp + NBUF - 1);
 #pragma unroll
-                    for (int j = 0; j < NLU; ++j) A[nx][j] = ks_row_load(pn + j * 4);
+                    for (int j = 0; j < NLU; ++j) A[nx][j] = pn[j * 4];
                     load_meta(grp + NBUF - 1, mtr[nx]);
                 }
                 if (pw && grp > g0) red_load((int)((grp - 1 - g0) & 1));        // unit u - 1: complete since barrier u - 1

@@ -81,8 +81,6 @@ struct msr_engine {
     void* bf_row_meta = nullptr;       // {document, 1.0f} per row for the K-split bf16 sweeps
     DenseIndex dense_bf16{};           // `dense` with the unit-row image, its inverse norms and row meta
     int n_cus = 256;
-    hipEvent_t ev_fork = nullptr, ev_tail = nullptr;   // msr_dense_topk_tail: pass -> tail stream, and "the tail of the previous call is done"
-    bool tail_pending = false;
     std::unordered_map<void*, size_t> owned;   // engine-owned device allocations (msr_owned_bytes)
     int row_copy_state = 0;            // fragment-order copy of the rows: 0 not wanted / not applicable, 1 built, 2 declined by
                                        // msr_config.flags, 3 allocation failed (the row-major instantiation of the kernel runs)
@@ -233,16 +231,12 @@ extern "C" int msr_create(const msr_config* cfg, msr_engine** out) {
             if ((herr = hipEventCreate(&e->ev_start[w][j])) != hipSuccess) return bail(MSR_ERR_HIP, "hipEventCreate", herr);
             if ((herr = hipEventCreate(&e->ev_stop[w][j])) != hipSuccess) return bail(MSR_ERR_HIP, "hipEventCreate", herr);
         }
-    if ((herr = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming)) != hipSuccess) return bail(MSR_ERR_HIP, "hipEventCreate", herr);
-    if ((herr = hipEventCreateWithFlags(&e->ev_tail, hipEventDisableTiming)) != hipSuccess) return bail(MSR_ERR_HIP, "hipEventCreate", herr);
     *out = e;
     return MSR_OK;
 }
 
 extern "C" int msr_destroy(msr_engine* e) {
     if (!e) return MSR_OK;
-    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
-    if (e->ev_tail) (void)hipEventDestroy(e->ev_tail);
     free_dev(e, e->chunk_doc); free_dev(e, e->emb_presplit); free_dev(e, e->row_meta); free_dev(e, e->inv_norm_own); free_dev(e, e->span_doc); free_dev(e, e->wspan_doc); free_dev(e, e->wspan12_doc); free_dev(e, e->qn); free_dev(e, e->rr_qn); free_dev(e, e->qimg); free_dev(e, e->emb_bf16);
     free_dev(e, e->score_rows); free_dev(e, e->bm_heavy_id); free_dev(e, e->bm_post); free_dev(e, e->bm_dense_id); free_dev(e, e->bm_dense); free_dev(e, e->bm_tile_off); free_dev(e, e->bm_cand_doc); free_dev(e, e->bm_cand_n); free_dev(e, e->sel.hist); free_dev(e, e->sel.state); free_dev(e, e->sel.cand_hi);
     free_dev(e, e->sel.cand_lo); free_dev(e, e->sel.cand_n); free_dev(e, e->rerank_cos); free_dev(e, e->rerank_meta);
@@ -256,16 +250,6 @@ extern "C" int msr_destroy(msr_engine* e) {
             if (e->ev_stop[w][j]) (void)hipEventDestroy(e->ev_stop[w][j]);
         }
     delete e;
-    return MSR_OK;
-}
-
-// The finish of an msr_dense_topk_tail call may still be running on its tail stream; it works on scratch (select state, score
-// rows) that other entry points use as well: they wait for it first (a no-op once the caller has joined the streams).
-static int join_tail(msr_engine* e, hipStream_t st) {
-    if (e->tail_pending) {
-        HIP_TRY(e, hipStreamWaitEvent(st, e->ev_tail, 0));
-        e->tail_pending = false;
-    }
     return MSR_OK;
 }
 
@@ -776,10 +760,6 @@ extern "C" int msr_bm25_topk(msr_engine* e, const int32_t* q_term_off, const int
     if (n_queries == 0) return MSR_OK;
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(e, hipSetDevice(e->cfg.device));
-    {
-        int rcj = join_tail(e, st);
-        if (rcj) return rcj;
-    }
     const int slice = e->cfg.max_queries;
     const int64_t N = e->bm25.n_docs;
     for (int q0 = 0; q0 < n_queries; q0 += slice) {
@@ -803,24 +783,8 @@ extern "C" int msr_bm25_topk(msr_engine* e, const int32_t* q_term_off, const int
     return MSR_OK;
 }
 
-static int dense_topk_impl(msr_engine* e, const float* q, int32_t n_queries, int32_t k, int32_t max_chunks_per_doc,
-                           int32_t* out_doc, float* out_score, int32_t* out_chunk, int32_t* out_n, void* stream, void* tail_stream);
-
 extern "C" int msr_dense_topk(msr_engine* e, const float* q, int32_t n_queries, int32_t k, int32_t max_chunks_per_doc,
                               int32_t* out_doc, float* out_score, int32_t* out_chunk, int32_t* out_n, void* stream) {
-    return dense_topk_impl(e, q, n_queries, k, max_chunks_per_doc, out_doc, out_score, out_chunk, out_n, stream, nullptr);
-}
-
-extern "C" int msr_dense_topk_tail(msr_engine* e, const float* q, int32_t n_queries, int32_t k, int32_t max_chunks_per_doc,
-                                   int32_t* out_doc, float* out_score, int32_t* out_chunk, int32_t* out_n, void* stream,
-                                   void* tail_stream) {
-    if (e && (!tail_stream || tail_stream == stream))
-        return fail(e, MSR_ERR_INVALID, "msr_dense_topk_tail: tail_stream must be a second stream");
-    return dense_topk_impl(e, q, n_queries, k, max_chunks_per_doc, out_doc, out_score, out_chunk, out_n, stream, tail_stream);
-}
-
-static int dense_topk_impl(msr_engine* e, const float* q, int32_t n_queries, int32_t k, int32_t max_chunks_per_doc,
-                           int32_t* out_doc, float* out_score, int32_t* out_chunk, int32_t* out_n, void* stream, void* tail_stream) {
     if (!e) return MSR_ERR_INVALID;
     if (!e->have_chunks) return fail(e, MSR_ERR_NOT_BOUND, "msr_dense_topk: chunks not bound");
     if (n_queries < 0 || k < 1 || k > e->cfg.max_k || max_chunks_per_doc < 0 || !q || !out_doc || !out_score || !out_n)
@@ -834,12 +798,6 @@ static int dense_topk_impl(msr_engine* e, const float* q, int32_t n_queries, int
                       e->dense.wide_ok && max_chunks_per_doc == 0;
     const bool gemm = wide && e->gf_ok && e->dense.variant == 14 && e->gf.n_tiles >= 2 * k;
     const int64_t N = e->dense.n_docs;
-    hipStream_t tl = (hipStream_t)tail_stream;
-    // the scratch of this path is also what the tail of an earlier msr_dense_topk_tail call works on: wait for that tail
-    {
-        int rcj = join_tail(e, st);
-        if (rcj) return rcj;
-    }
     e->last_dense_width = gemm && n_queries > 64 ? 0 : (wide ? 64 : 32);       // (the streaming path reports its own width below)
     // sweeps for queries [q0, q0 + cnt): `gate` non-null = fallback launches that only do work when *gate != 0
     auto sweeps = [&](int q0, int cnt, const int32_t* gate) -> int {
@@ -886,13 +844,9 @@ static int dense_topk_impl(msr_engine* e, const float* q, int32_t n_queries, int
                 ev[2] = e->ev_start[0][e->ev_count[0]]; ev[3] = e->ev_stop[0][e->ev_count[0]];
             }
             int width = 0;
-            // (only the LAST chunk of a call forks its tail: an earlier chunk's scratch is reused by the next chunk's pass)
-            hipStream_t fin = tl && q0 + nq >= n_queries ? tl : nullptr;
             HIP_TRY(e, msr_gemm_f32_topk(e->gf, e->dense, e->gf_qn, nq, k, out_doc + (int64_t)q0 * k,
                                          out_score + (int64_t)q0 * k, out_chunk ? out_chunk + (int64_t)q0 * k : nullptr,
-                                         out_n + q0, e->gf_gate, timed ? ev : nullptr, &width, st, fin, e->ev_fork));
-            hipStream_t st_main = st;
-            if (fin) st = fin;                          // the gated fallback below follows the finish on the tail stream
+                                         out_n + q0, e->gf_gate, timed ? ev : nullptr, &width, st));
             e->last_dense_width = std::max(e->last_dense_width, width);
             if (timed) { e->ev_count[0]++; e->ev_count[3]++; }
             // A query whose entries overflowed (huge tie groups, a zero vector) raised the gate word of its 64-query slice: that
@@ -911,11 +865,6 @@ static int dense_topk_impl(msr_engine* e, const float* q, int32_t n_queries, int
                 if (out_chunk)
                     HIP_TRY(e, msr_best_chunk(ix, e->gf_qn, nq, k, 0, out_doc + (int64_t)q0 * k, out_n + q0,
                                               out_chunk + (int64_t)q0 * k, st));
-            }
-            if (fin) {
-                HIP_TRY(e, hipEventRecord(e->ev_tail, fin));
-                e->tail_pending = true;
-                st = st_main;
             }
             q0 += nq;
         } else {
@@ -1029,10 +978,6 @@ extern "C" int msr_dense_topk_bf16(msr_engine* e, const float* q, int32_t n_quer
     if (n_queries == 0) return MSR_OK;
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(e, hipSetDevice(e->cfg.device));
-    {
-        int rcj = join_tail(e, st);
-        if (rcj) return rcj;
-    }
     const int64_t N = e->dense.n_docs;
     // candidate margin: 2 eps_q from the measured rounding errors of the image and of each query (msr_batch.hip)
     // More than 128 queries: the tiled GEMM (msr_gemm.hip), GM_SLICE queries per pair of passes.  It needs whole

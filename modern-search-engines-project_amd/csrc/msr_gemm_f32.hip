@@ -1017,8 +1017,7 @@ hipError_t msr_f16_row_error(const float* emb, const float* inv_norm, int64_t n_
 // the first group.  *width_out (nullable): queries per pass of the kernel that ran.
 hipError_t msr_gemm_f32_topk(const GemmF32Index& g, const DenseIndex& ix, const float* qn, int nq, int k,
                              int32_t* out_doc, float* out_score, int32_t* out_chunk,
-                             int32_t* out_n, int32_t* gate, hipEvent_t* ev, int* width_out, hipStream_t stream,
-                             hipStream_t tail, hipEvent_t fork_ev) {
+                             int32_t* out_n, int32_t* gate, hipEvent_t* ev, int* width_out, hipStream_t stream) {
     const int W = nq > 128 ? 256 : 128;                 // queries per pass
     const int waves = 8;                                // waves per workgroup = emission buffers per workgroup (both kernels)
     const int G = (nq + W - 1) / W;
@@ -1072,14 +1071,6 @@ hipError_t msr_gemm_f32_topk(const GemmF32Index& g, const DenseIndex& ix, const 
         if (ev && gi == 0 && (err = hipEventRecord(ev[2], stream)) != hipSuccess) return err;
         if ((err = launch_f32(W, true, a, grid, stream, tiled)) != hipSuccess) return err;
         if (ev && gi == 0 && (err = hipEventRecord(ev[3], stream)) != hipSuccess) return err;
-        // Everything behind the LAST pass over the rows -- the transposition of its tile maxima, the tighter thresholds,
-        // bucketing, candidate lists, exact rescoring, final sort: small, latency-bound launches -- may run on a second
-        // stream (`tail`), beside whatever the caller enqueues next on `stream` (the BM25 stage of the same batch)
-        if (tail && gi + NT >= G) {
-            if ((err = hipEventRecord(fork_ev, stream)) != hipSuccess) return err;
-            if ((err = hipStreamWaitEvent(tail, fork_ev, 0)) != hipSuccess) return err;
-            stream = tail;
-        }
         if ((err = msr_gemm_tmax(g.tmax_t, g.n_tiles, waves, W * a.nt, g.tmax + (size_t)gi * W * g.tmax_stride, g.tmax_stride, stream)) != hipSuccess) return err;
     }
     if ((err = msr_gemm_kth(g.tmax, g.n_tiles, g.tmax_stride, nq, W * G, k, margin, g.thr2, nullptr, stream)) != hipSuccess) return err;

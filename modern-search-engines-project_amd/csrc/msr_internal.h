@@ -306,9 +306,7 @@ hipError_t msr_pad_inv_norm(const float* inv, int64_t n, int64_t n_pad, float* o
 // pass (0, 1) and the emit pass (2, 3).
 hipError_t msr_gemm_f32_topk(const GemmF32Index& g, const DenseIndex& ix, const float* qn, int nq, int k,
                              int32_t* out_doc, float* out_score, int32_t* out_chunk,
-                             int32_t* out_n, int32_t* gate, hipEvent_t* ev, int* width_out, hipStream_t stream,
-                             hipStream_t tail = nullptr, hipEvent_t fork_ev = nullptr);
-// (tail: optional second stream for everything behind the last pass over the rows; it waits for the pass through fork_ev)
+                             int32_t* out_n, int32_t* gate, hipEvent_t* ev, int* width_out, hipStream_t stream);
 
 // ---- K5: batched bf16 candidate scan finished exactly in f32 (msr_batch.hip) -----------------------
 // exact f32 rescoring + final sort of candidate lists that are already filled (cand_n zeroed on return)

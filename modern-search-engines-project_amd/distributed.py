@@ -128,8 +128,6 @@ class ShardedEngine:
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         self._ex = {}
-        self._side = None                                 # second stream for the dense stage's finish (one-GPU path)
-        self.use_tail_stream = True
 
     # ------------------------------------------------------------------ exchange helpers
     def _exchange(self, Q, k1, k2, device):
@@ -189,21 +187,8 @@ class ShardedEngine:
         lists to return (None: all k1; the reranker facade's diversification wants them all, a top-100 service k2)."""
         e = self.engine
         b_doc, b_score, b_n = e.bm25_topk(term_lists, k=k1, min_score=min_score, packed=packed)
-        # One GPU, rerank wanted: the dense stage's finish (small launches behind the pass over the matrix) goes to a second
-        # stream and runs beside the rerank gather of the same batch, which does not depend on it (msr_dense_topk_tail)
-        side = None
-        if (self.use_tail_stream and self.world == 1 and rerank and not dense_batched and self.doc_base == 0 and self.row_base == 0     # (no index arithmetic
-                and getattr(getattr(e, "device", None), "type", "") == "cuda"):                                  # on the outputs before the join)
-            if self._side is None:
-                # (high priority: the tail is a chain of small dependent launches; at the default priority each of them queues
-                # behind the 32 k one-wave workgroups of the gather it runs beside, and the chain takes longer than it saves)
-                self._side = torch.cuda.Stream(e.device, priority=-1)
-            side = self._side
-        if side is not None:
-            d_doc, d_score, d_chunk, d_n = e.dense_topk(qvec, k=k2, max_chunks_per_doc=max_chunks_per_doc, tail_stream=side)
-        else:
-            dense = e.dense_topk_batched if dense_batched else e.dense_topk
-            d_doc, d_score, d_chunk, d_n = dense(qvec, k=k2, max_chunks_per_doc=max_chunks_per_doc)
+        dense = e.dense_topk_batched if dense_batched else e.dense_topk
+        d_doc, d_score, d_chunk, d_n = dense(qvec, k=k2, max_chunks_per_doc=max_chunks_per_doc)
         Q = int(b_doc.shape[0])
         if self.world > 1:
             ex = self._exchange(Q, k1, k2, b_doc.device)
@@ -233,8 +218,6 @@ class ShardedEngine:
             cos, meta = e.rerank_gather(qvec, b_doc, b_n, doc_base=self.doc_base, row_base=self.row_base, max_chunks=max_chunks)
             r = e.rerank_fuse(b_doc, b_score, b_n, cos, meta, **rerank_params)
             out["rerank"] = r if keep == k1 else self._truncate(r, keep)
-            if side is not None:
-                torch.cuda.current_stream(e.device).wait_stream(side)       # the dense results are valid behind this join
             return out
         rx = ex.rerank.get((k1, keep))
         if rx is None:

@@ -202,24 +202,16 @@ class DeviceEngine:
         return out_doc, out_score, out_n
 
     # ------------------------------------------------------------------ stage 2 (full scan)
-    def dense_topk(self, qvec, k=100, max_chunks_per_doc=0, want_chunk=True, tail_stream=None):
-        """qvec float32 [Q, 768] (not normalised) -> (doc [Q,k] i32, score [Q,k] f32, chunk row [Q,k] i32, n [Q]).
-        tail_stream (a torch.cuda.Stream other than the current one): msr_dense_topk_tail -- the finish behind the pass over the
-        matrix runs on that stream, beside what the caller enqueues next on the current one; the outputs are valid once the
-        caller has joined the streams (torch.cuda.current_stream().wait_stream(tail_stream))."""
+    def dense_topk(self, qvec, k=100, max_chunks_per_doc=0, want_chunk=True):
+        """qvec float32 [Q, 768] (not normalised) -> (doc [Q,k] i32, score [Q,k] f32, chunk row [Q,k] i32, n [Q])."""
         q = self._dev(qvec, torch.float32).reshape(-1, DIM)
         Q = int(q.shape[0])
         out_doc = torch.empty((Q, k), dtype=torch.int32, device=self.device)
         out_score = torch.empty((Q, k), dtype=torch.float32, device=self.device)
         out_chunk = torch.empty((Q, k), dtype=torch.int32, device=self.device) if want_chunk else None
         out_n = torch.empty((Q,), dtype=torch.int32, device=self.device)
-        if tail_stream is not None:
-            self._check(self.lib.msr_dense_topk_tail(self.handle, _ptr(q), Q, k, int(max_chunks_per_doc), _ptr(out_doc),
-                                                     _ptr(out_score), _ptr(out_chunk), _ptr(out_n), self._stream(),
-                                                     C.c_void_p(tail_stream.cuda_stream)))
-        else:
-            self._check(self.lib.msr_dense_topk(self.handle, _ptr(q), Q, k, int(max_chunks_per_doc), _ptr(out_doc),
-                                                _ptr(out_score), _ptr(out_chunk), _ptr(out_n), self._stream()))
+        self._check(self.lib.msr_dense_topk(self.handle, _ptr(q), Q, k, int(max_chunks_per_doc), _ptr(out_doc),
+                                            _ptr(out_score), _ptr(out_chunk), _ptr(out_n), self._stream()))
         return out_doc, out_score, out_chunk, out_n
 
     def enable_bf16(self):

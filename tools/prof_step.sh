@@ -9,7 +9,12 @@ python3 tools/summarize_prof.py stats $(ls $O/${T}_prof/*/*kernel_stats.csv) $(l
 python3 - "$(ls $O/${T}_prof/*/*kernel_trace.csv)" $O/${T}_trace.csv <<'PY'
 import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
-keep = rows[-400:]
+dur = lambda r: int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+starts = [i for i, r in enumerate(rows) if "bm25_taat" in r["Kernel_Name"]]
+longest = max(dur(rows[i]) for i in starts)
+big = [i for i in starts if dur(rows[i]) > 0.5 * longest]          # the batched (timed) steps
+a, b = big[len(big) // 2], big[min(len(big) - 1, len(big) // 2 + 2)]   # two consecutive timed steps
+keep = rows[a:b]
 t0 = int(keep[0]["Start_Timestamp"])
 with open(sys.argv[2], "w") as f:
     f.write("start_us,end_us,queue,kernel\n")
