@@ -79,8 +79,9 @@ __global__ __launch_bounds__(64) void rerank_cos_kernel(DenseIndex ix, const int
             mt[2] = (int32_t)ds + row_base;                  // global row of the document's first chunk
         }
         if (lane >= (int)(de - ds) && lane < RR_MAXC) out[lane] = 0.f;
-        for (int64_t c = ds; c < de; ++c) {
-            f32x4 a, b, e;
+        // two rows in flight per wave: the loads of row c + 1 are issued before row c is reduced (a document's rows are
+        // consecutive: 6 KB per pair)
+        auto load_row = [&](int64_t c, f32x4& a, f32x4& b, f32x4& e2) {
             if (TILED) {
                 const f32x4* base = (const f32x4*)(ix.emb + (size_t)(c >> 4) * (16 * MSR_DIM));
                 const int i = (int)(c & 15);
@@ -88,16 +89,31 @@ __global__ __launch_bounds__(64) void rerank_cos_kernel(DenseIndex ix, const int
                 const int v0 = lane, v1 = lane + 64, v2 = lane + 128;
                 a = base[(v0 >> 2) * 64 + (v0 & 3) * 16 + i];
                 b = base[(v1 >> 2) * 64 + (v1 & 3) * 16 + i];
-                e = base[(v2 >> 2) * 64 + (v2 & 3) * 16 + i];
+                e2 = base[(v2 >> 2) * 64 + (v2 & 3) * 16 + i];
             } else {
                 const f32x4* p = (const f32x4*)(ix.emb + (size_t)c * MSR_DIM);
-                a = p[lane]; b = p[lane + 64]; e = p[lane + 128];
+                a = p[lane]; b = p[lane + 64]; e2 = p[lane + 128];
             }
+        };
+        auto dot_row = [&](const f32x4& a, const f32x4& b, const f32x4& e2) {
             float s = a.x * qa.x + a.y * qa.y + a.z * qa.z + a.w * qa.w;
             s += b.x * qb.x + b.y * qb.y + b.z * qb.z + b.w * qb.w;
-            s += e.x * qc.x + e.y * qc.y + e.z * qc.z + e.w * qc.w;
+            s += e2.x * qc.x + e2.y * qc.y + e2.z * qc.z + e2.w * qc.w;
             for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            if (lane == 0) out[c - ds] = s * ix.inv_norm[c];
+            return s;
+        };
+        f32x4 a0, b0, e0, a1, b1, e1;
+        if (ds < de) load_row(ds, a0, b0, e0);
+        for (int64_t c = ds; c < de; c += 2) {
+            const bool two = c + 1 < de;                     // (wave-uniform)
+            if (two) load_row(c + 1, a1, b1, e1);
+            const float s0 = dot_row(a0, b0, e0);
+            if (c + 2 < de) load_row(c + 2, a0, b0, e0);
+            if (lane == 0) out[c - ds] = s0 * ix.inv_norm[c];
+            if (two) {
+                const float s1 = dot_row(a1, b1, e1);
+                if (lane == 0) out[c + 1 - ds] = s1 * ix.inv_norm[c + 1];
+            }
         }
     }
 }
