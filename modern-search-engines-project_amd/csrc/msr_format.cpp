@@ -120,7 +120,7 @@ extern "C" int64_t msr_format_lines(const char* qnum_blob, const int64_t* qnum_o
     const int64_t need = bound[n_queries];
     if (need > capacity) return -need;
     // pass 2: contiguous ranges of queries on a few threads, each into the region its bound reserves, then closed up in order
-    int n_thr = (int)std::min<int64_t>(8, std::min<int64_t>((int64_t)std::thread::hardware_concurrency() / 2, need / (384 * 1024) + 1));
+    int n_thr = (int)std::min<int64_t>(4, std::min<int64_t>((int64_t)std::thread::hardware_concurrency() / 2, need / (384 * 1024) + 1));
     if (n_thr < 1) n_thr = 1;
     std::vector<int32_t> cut((size_t)n_thr + 1, 0);
     for (int t = 1; t < n_thr; ++t)                                     // equal shares of the bound

@@ -273,7 +273,7 @@ class Retriever:
         run side by side, chunk by chunk: this thread preprocesses / tokenises chunk i + 1 and enqueues it, the GPU ranks
         chunk i, a second host thread waits for chunk i - 1's final rows, formats them (native code, outside the interpreter
         lock) and writes them."""
-        from concurrent.futures import ThreadPoolExecutor
+        import sys
         nq = read_queries_file(queries_path)
         if self._formatter is None:
             self._formatter = LineFormatter(self.index.urls, self.index.n_docs)
@@ -284,7 +284,19 @@ class Retriever:
         texts, nums = [q for _, q in nq], [n for n, _ in nq]
         sub = lambda x, a, b: None if x is None else x[a:b]
         step = int(chunk or max(256, eng.max_queries))
+        # two threads hand the interpreter lock back and forth every fraction of a millisecond here; the default switch interval
+        # (5 ms) is longer than a whole chunk takes
+        old_switch = sys.getswitchinterval()
+        sys.setswitchinterval(1e-4)
+        try:
+            return self._batch_to_file(nq, texts, nums, sub, step, out_path, query_embeddings, term_lists)
+        finally:
+            sys.setswitchinterval(old_switch)
+
+    def _batch_to_file(self, nq, texts, nums, sub, step, out_path, query_embeddings, term_lists):
+        from concurrent.futures import ThreadPoolExecutor
         import torch
+        eng = self.engine
         with open(out_path, "wb") as f, ThreadPoolExecutor(max_workers=1) as pool:
             def consume(a, job):
                 doc, score, _, n = self._collect_chunk(job)
