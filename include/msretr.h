@@ -162,6 +162,27 @@ int msr_bm25_topk(msr_engine* e, const int32_t* q_term_off, const int32_t* q_ter
 int msr_dense_topk(msr_engine* e, const float* q, int32_t n_queries, int32_t k, int32_t max_chunks_per_doc,
                    int32_t* out_doc, float* out_score, int32_t* out_chunk, int32_t* out_n, void* stream);
 
+/* msr_dense_topk in two halves, for a doc-sharded index: between them the caller exchanges ONE float per query across the
+ * shards (msretr/distributed.py: an all-reduce MIN over RCCL), after which every shard rescores only the documents that can
+ * be in the top-k of the WHOLE corpus instead of its own top-k -- 1 / shards of the exact-f32 rescoring per rank.
+ *   msr_dense_split_max(e, k): most queries one begin / end pair takes (0: this engine cannot split -- corpus without row
+ *     tiles, fewer than 2 k tiles -- use msr_dense_topk).  Pairs take MORE than 64 queries.
+ *   msr_dense_topk_begin: the passes over this shard's rows and the thresholds of its own tile maxima.  out_part[q] f32
+ *     [n_queries] (device) <- a cosine that k_part documents of THIS shard are guaranteed to reach EXACTLY (their filter
+ *     scores minus the measured error margin); -inf when the shard has fewer than k_part row tiles.  With
+ *     k_part = ceil(k / shards), the minimum of out_part[q] over all shards is a lower bound of the k-th exact cosine of the
+ *     whole corpus: shards x k_part >= k documents reach it.
+ *   msr_dense_topk_end: bound [n_queries] (device; NULL: none) = that minimum.  Candidates whose filter score lies below
+ *     bound - margin cannot be in the global top-k and are dropped before the candidate lists and the exact rescoring.  Output
+ *     as msr_dense_topk, except that out_n[q] may be < k: the shard returns every document it can contribute to the global
+ *     top-k (merge the shards' lists with msr_merge_topk_payload as usual; the merged list is the unsharded one, bit for bit).
+ * One begin may be pending per engine; the matching end must follow with the same n_queries and k. */
+int msr_dense_split_max(const msr_engine* e, int32_t k);
+int msr_dense_topk_begin(msr_engine* e, const float* q, int32_t n_queries, int32_t k, int32_t k_part, float* out_part,
+                         void* stream);
+int msr_dense_topk_end(msr_engine* e, int32_t n_queries, int32_t k, const float* bound, int32_t* out_doc, float* out_score,
+                       int32_t* out_chunk, int32_t* out_n, void* stream);
+
 /* Batched variant of msr_dense_topk for throughput (BASELINE config 5).  Candidates come from a bf16 image of the
  * NORMALISED rows (v_mfma_f32_16x16x32_bf16, f32 accumulation), whose scores carry a proven error bound; every document
  * within twice that bound of the k-th approximate score is re-scored in f32 from the f32 rows, so the final top-k is

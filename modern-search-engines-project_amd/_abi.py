@@ -57,6 +57,9 @@ _SIGNATURES = {
     "msr_interleave_rows": (C.c_int, [_P, _P, C.c_int64, _P, _P]),
     "msr_bm25_topk": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_double, _P, _P, _P, _P]),
     "msr_dense_topk": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
+    "msr_dense_split_max": (C.c_int, [_P, C.c_int32]),
+    "msr_dense_topk_begin": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    "msr_dense_topk_end": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "msr_enable_bf16": (C.c_int, [_P, _P]),
     "msr_dense_topk_bf16": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
     "msr_rerank": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.c_int32, C.POINTER(MsrRerankParams), _P, _P, _P,

@@ -82,6 +82,7 @@ struct msr_engine {
     DenseIndex dense_bf16{};           // `dense` with the unit-row image, its inverse norms and row meta
     int n_cus = 256;
     std::unordered_map<void*, size_t> owned;   // engine-owned device allocations (msr_owned_bytes)
+    int split_pending = 0;             // queries of an msr_dense_topk_begin whose msr_dense_topk_end has not come yet
     int row_copy_state = 0;            // fragment-order copy of the rows: 0 not wanted / not applicable, 1 built, 2 declined by
                                        // msr_config.flags, 3 allocation failed (the row-major instantiation of the kernel runs)
     int last_dense_width = 0;          // queries per pass over the matrix of the most recent msr_dense_topk call (msr_dense_path)
@@ -783,6 +784,74 @@ extern "C" int msr_bm25_topk(msr_engine* e, const int32_t* q_term_off, const int
     return MSR_OK;
 }
 
+// A query whose entries overflowed in the streaming pass (huge tie groups, a zero vector) raised the gate word of its 64-query
+// slice: that slice once more on the sweeps, which handle any input.  One scan per slice, gated on its word, into its own score
+// rows; then ONE select and ONE best-chunk pass over all rows of the call, in which a query takes part only if its slice's word
+// is up.  When no gate is up (the normal case) all these launches return at once.  Queries: e->gf_qn (normalised, nq of them).
+static int dense_gated_fallback(msr_engine* e, int nq, int k, int32_t* out_doc, float* out_score, int32_t* out_chunk,
+                                int32_t* out_n, hipStream_t st) {
+    const int64_t N = e->dense.n_docs;
+    DenseIndex ix = e->dense;
+    ix.gate = e->gf_gate;
+    HIP_TRY(e, msr_dense_scan_slices(ix, e->gf_qn, nq, (float*)e->score_rows, e->gf_fb_qimg, st));
+    SelScratch sel = e->sel;
+    sel.gate = e->gf_gate; sel.gate_per64 = 1;
+    HIP_TRY(e, msr_select_topk(32, e->score_rows, N, e->dense.score_stride, nq, k, sel, out_doc, out_score, out_n, st));
+    ix.gate = e->gf_gate; ix.gate_per64 = 1;
+    if (out_chunk) HIP_TRY(e, msr_best_chunk(ix, e->gf_qn, nq, k, 0, out_doc, out_n, out_chunk, st));
+    return MSR_OK;
+}
+
+static bool dense_stream_ok(const msr_engine* e, int k) {
+    const bool wide = (e->dense.variant == 2 || e->dense.variant == 14 || e->dense.variant == 15) && e->dense.layout == 0 &&
+                      e->dense.wide_ok;
+    return wide && e->gf_ok && e->dense.variant == 14 && e->gf.n_tiles >= 2 * k;
+}
+
+extern "C" int msr_dense_split_max(const msr_engine* e, int32_t k) {
+    if (!e || !e->have_chunks || k < 1 || k > e->cfg.max_k || !dense_stream_ok(e, k)) return 0;
+    return e->gf.max_groups >= 2 ? (e->gf.max_groups & ~1) * 128 : 128;
+}
+
+extern "C" int msr_dense_topk_begin(msr_engine* e, const float* q, int32_t n_queries, int32_t k, int32_t k_part, float* out_part,
+                                    void* stream) {
+    if (!e) return MSR_ERR_INVALID;
+    if (!e->have_chunks) return fail(e, MSR_ERR_NOT_BOUND, "msr_dense_topk_begin: chunks not bound");
+    const int cap = msr_dense_split_max(e, k);
+    if (!q || !out_part || k_part < 1 || k_part > k || n_queries <= 64 || n_queries > cap)
+        return fail(e, MSR_ERR_INVALID, "msr_dense_topk_begin: needs 64 < n_queries <= msr_dense_split_max() = %d, 1 <= k_part <= k (got %d, %d, %d)",
+                    cap, n_queries, k_part, k);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, msr_prep_queries(q, n_queries, e->gf_qn, (n_queries + 63) / 64 * 64, st));
+    HIP_TRY(e, hipMemsetAsync(e->gf_gate, 0, 16 * 4, st));
+    hipEvent_t ev[4];
+    const bool timed = e->timing && e->ev_count[0] < msr_engine::EV_RING && e->ev_count[3] < msr_engine::EV_RING;
+    if (timed) {
+        ev[0] = e->ev_start[3][e->ev_count[3]]; ev[1] = e->ev_stop[3][e->ev_count[3]];
+        ev[2] = e->ev_start[0][e->ev_count[0]]; ev[3] = e->ev_stop[0][e->ev_count[0]];
+    }
+    int width = 0;
+    HIP_TRY(e, msr_gemm_f32_pass(e->gf, e->dense, e->gf_qn, n_queries, k, k_part, out_part, timed ? ev : nullptr, &width, st));
+    e->last_dense_width = width;
+    if (timed) { e->ev_count[0]++; e->ev_count[3]++; }
+    e->split_pending = n_queries;
+    return MSR_OK;
+}
+
+extern "C" int msr_dense_topk_end(msr_engine* e, int32_t n_queries, int32_t k, const float* bound, int32_t* out_doc,
+                                  float* out_score, int32_t* out_chunk, int32_t* out_n, void* stream) {
+    if (!e) return MSR_ERR_INVALID;
+    if (e->split_pending != n_queries || n_queries <= 0)
+        return fail(e, MSR_ERR_INVALID, "msr_dense_topk_end: no matching msr_dense_topk_begin (pending %d, got %d)", e->split_pending, n_queries);
+    if (!out_doc || !out_score || !out_n || k < 1 || k > e->cfg.max_k) return fail(e, MSR_ERR_INVALID, "msr_dense_topk_end: bad argument");
+    e->split_pending = 0;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, msr_gemm_f32_finish(e->gf, e->dense, e->gf_qn, n_queries, k, bound, out_doc, out_score, out_chunk, out_n, e->gf_gate, st));
+    return dense_gated_fallback(e, n_queries, k, out_doc, out_score, out_chunk, out_n, st);
+}
+
 extern "C" int msr_dense_topk(msr_engine* e, const float* q, int32_t n_queries, int32_t k, int32_t max_chunks_per_doc,
                               int32_t* out_doc, float* out_score, int32_t* out_chunk, int32_t* out_n, void* stream) {
     if (!e) return MSR_ERR_INVALID;
@@ -849,22 +918,10 @@ extern "C" int msr_dense_topk(msr_engine* e, const float* q, int32_t n_queries, 
                                          out_n + q0, e->gf_gate, timed ? ev : nullptr, &width, st));
             e->last_dense_width = std::max(e->last_dense_width, width);
             if (timed) { e->ev_count[0]++; e->ev_count[3]++; }
-            // A query whose entries overflowed (huge tie groups, a zero vector) raised the gate word of its 64-query slice: that
-            // slice once more on the sweeps, which handle any input.  One scan per slice, gated on its word, into its own score
-            // rows; then ONE select and ONE best-chunk pass over all rows of the call, in which a query takes part only if its
-            // slice's word is up.  When no gate is up (the normal case) all these launches return at once.
             {
-                DenseIndex ix = e->dense;
-                ix.gate = e->gf_gate;
-                HIP_TRY(e, msr_dense_scan_slices(ix, e->gf_qn, nq, (float*)e->score_rows, e->gf_fb_qimg, st));
-                SelScratch sel = e->sel;
-                sel.gate = e->gf_gate; sel.gate_per64 = 1;
-                HIP_TRY(e, msr_select_topk(32, e->score_rows, N, e->dense.score_stride, nq, k, sel, out_doc + (int64_t)q0 * k,
-                                           out_score + (int64_t)q0 * k, out_n + q0, st));
-                ix.gate = e->gf_gate; ix.gate_per64 = 1;
-                if (out_chunk)
-                    HIP_TRY(e, msr_best_chunk(ix, e->gf_qn, nq, k, 0, out_doc + (int64_t)q0 * k, out_n + q0,
-                                              out_chunk + (int64_t)q0 * k, st));
+                int rcf = dense_gated_fallback(e, nq, k, out_doc + (int64_t)q0 * k, out_score + (int64_t)q0 * k,
+                                               out_chunk ? out_chunk + (int64_t)q0 * k : nullptr, out_n + q0, st);
+                if (rcf) return rcf;
             }
             q0 += nq;
         } else {

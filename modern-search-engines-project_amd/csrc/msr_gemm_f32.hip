@@ -1015,9 +1015,8 @@ hipError_t msr_f16_row_error(const float* emb, const float* inv_norm, int64_t n_
 // qn: [nq][768] normalised queries.  gate[s] != 0 (one word per 64 queries, zero on entry) when a query of slice s overflowed
 // (the caller falls back for that slice).  ev (nullable): events around the sample pass (0, 1) and the emit pass (2, 3) of
 // the first group.  *width_out (nullable): queries per pass of the kernel that ran.
-hipError_t msr_gemm_f32_topk(const GemmF32Index& g, const DenseIndex& ix, const float* qn, int nq, int k,
-                             int32_t* out_doc, float* out_score, int32_t* out_chunk,
-                             int32_t* out_n, int32_t* gate, hipEvent_t* ev, int* width_out, hipStream_t stream) {
+hipError_t msr_gemm_f32_pass(const GemmF32Index& g, const DenseIndex& ix, const float* qn, int nq, int k, int k_part,
+                             float* out_part, hipEvent_t* ev, int* width_out, hipStream_t stream) {
     const int W = nq > 128 ? 256 : 128;                 // queries per pass
     const int waves = 8;                                // waves per workgroup = emission buffers per workgroup (both kernels)
     const int G = (nq + W - 1) / W;
@@ -1074,10 +1073,47 @@ hipError_t msr_gemm_f32_topk(const GemmF32Index& g, const DenseIndex& ix, const 
         if ((err = msr_gemm_tmax(g.tmax_t, g.n_tiles, waves, W * a.nt, g.tmax + (size_t)gi * W * g.tmax_stride, g.tmax_stride, stream)) != hipSuccess) return err;
     }
     if ((err = msr_gemm_kth(g.tmax, g.n_tiles, g.tmax_stride, nq, W * G, k, margin, g.thr2, nullptr, stream)) != hipSuccess) return err;
-    if ((err = msr_gemm_bucket(g.wvbuf, a.wv_cap, g.wv_count, grid * waves, g.thr2, g.pairs, g.pair_n, stream)) != hipSuccess) return err;
+    // (sharded callers: what this shard can vouch for towards the k-th score over all shards, see msr_internal.h)
+    if (out_part && (err = msr_gemm_kth(g.tmax, g.n_tiles, g.tmax_stride, nq, nq, k_part, margin, out_part, nullptr, stream,
+                                        -__builtin_inff())) != hipSuccess) return err;
+    return hipSuccess;
+}
+
+namespace {
+// thr2[q] = max(thr2[q], bound[q] - margin[q]): the threshold of this shard's own tile maxima, raised to what all shards together
+// guarantee for the k-th score
+__global__ __launch_bounds__(256) void raise_thr_kernel(float* __restrict__ thr2, const float* __restrict__ bound,
+                                                         const float* __restrict__ margin, int nq) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    const float b = bound[q] - margin[q];
+    if (b > thr2[q]) thr2[q] = b;                           // (NaN / -inf bounds leave the local threshold alone)
+}
+}  // namespace
+
+hipError_t msr_gemm_f32_finish(const GemmF32Index& g, const DenseIndex& ix, const float* qn, int nq, int k, const float* bound,
+                               int32_t* out_doc, float* out_score, int32_t* out_chunk, int32_t* out_n, int32_t* gate,
+                               hipStream_t stream) {
+    const int waves = 8, grid = g.n_cus;
+    const int wv_cap = g.wv_cap * (8 / waves);
+    if (nq <= 0 || k < 1) return hipErrorInvalidValue;
+    hipError_t err;
+    if (bound) {
+        raise_thr_kernel<<<(nq + 255) / 256, 256, 0, stream>>>(g.thr2, bound, g.margin, nq);
+        if ((err = hipGetLastError()) != hipSuccess) return err;
+    }
+    if ((err = msr_gemm_bucket(g.wvbuf, wv_cap, g.wv_count, grid * waves, g.thr2, g.pairs, g.pair_n, stream)) != hipSuccess) return err;
     gemm_f32_cand_kernel<<<nq, 1024, 0, stream>>>((const int2*)g.pairs, g.pair_n, ix.chunk_doc, ix.n_chunks, g.wv_count, grid * waves,
-                                                  a.wv_cap, g.flag, g.cand_doc, g.cand_n, gate);
+                                                  wv_cap, g.flag, g.cand_doc, g.cand_n, gate);
     if ((err = hipGetLastError()) != hipSuccess) return err;
     return msr_batch_rescore(ix, qn, nq, k, 0, g.cand_doc, g.cand_score, g.cand_chunk, g.cand_n, out_doc, out_score, out_chunk,
                              out_n, stream);
+}
+
+hipError_t msr_gemm_f32_topk(const GemmF32Index& g, const DenseIndex& ix, const float* qn, int nq, int k,
+                             int32_t* out_doc, float* out_score, int32_t* out_chunk,
+                             int32_t* out_n, int32_t* gate, hipEvent_t* ev, int* width_out, hipStream_t stream) {
+    hipError_t err = msr_gemm_f32_pass(g, ix, qn, nq, k, k, nullptr, ev, width_out, stream);
+    if (err != hipSuccess) return err;
+    return msr_gemm_f32_finish(g, ix, qn, nq, k, nullptr, out_doc, out_score, out_chunk, out_n, gate, stream);
 }

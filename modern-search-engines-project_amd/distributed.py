@@ -160,6 +160,32 @@ class ShardedEngine:
             res.append(lst)
         return res
 
+    def _dense(self, qvec, k, max_chunks_per_doc, dense_batched):
+        """This shard's dense top-k.  With several shards and an engine that can split the call (DeviceEngine.dense_begin /
+        dense_end) the shards first agree on a lower bound of the k-th cosine of the WHOLE corpus -- every shard vouches for
+        ceil(k / world) of its own documents, ONE all-reduce MIN of a float per query -- and each then rescores in exact f32
+        only what can be in the global top-k: 1 / world of the rescoring a rank otherwise does for its own top-k, for nothing.
+        The lists come back shorter than k; merged they are the unsharded list, bit for bit."""
+        e = self.engine
+        Q = int(qvec.shape[0]) if hasattr(qvec, "shape") else len(qvec)
+        split = 0
+        if self.world > 1 and not dense_batched and max_chunks_per_doc == 0 and hasattr(e, "dense_split_max"):
+            split = e.dense_split_max(k)
+        if split <= 0 or Q <= 64:
+            dense = e.dense_topk_batched if dense_batched else e.dense_topk
+            return dense(qvec, k=k, max_chunks_per_doc=max_chunks_per_doc)
+        k_part = (k + self.world - 1) // self.world
+        outs = []
+        for a in range(0, Q, split):
+            b = min(Q, a + split)
+            if b - a <= 64:                                   # (a short last piece: the sweeps, no split)
+                outs.append(e.dense_topk(qvec[a:b], k=k))
+                continue
+            part = e.dense_begin(qvec[a:b], k=k, k_part=k_part)
+            dist.all_reduce(part, op=dist.ReduceOp.MIN, group=self.group)
+            outs.append(e.dense_end(b - a, k=k, bound=part))
+        return tuple(torch.cat([o[j] for o in outs]) for j in range(4)) if len(outs) > 1 else outs[0]
+
     @staticmethod
     def _truncate(fused, keep):
         """rerank_keep: the first `keep` columns of the fused lists, with the COUNT clamped to match (a caller iterating
@@ -187,8 +213,7 @@ class ShardedEngine:
         lists to return (None: all k1; the reranker facade's diversification wants them all, a top-100 service k2)."""
         e = self.engine
         b_doc, b_score, b_n = e.bm25_topk(term_lists, k=k1, min_score=min_score, packed=packed)
-        dense = e.dense_topk_batched if dense_batched else e.dense_topk
-        d_doc, d_score, d_chunk, d_n = dense(qvec, k=k2, max_chunks_per_doc=max_chunks_per_doc)
+        d_doc, d_score, d_chunk, d_n = self._dense(qvec, k2, max_chunks_per_doc, dense_batched)
         Q = int(b_doc.shape[0])
         if self.world > 1:
             ex = self._exchange(Q, k1, k2, b_doc.device)

@@ -214,6 +214,31 @@ class DeviceEngine:
                                             _ptr(out_score), _ptr(out_chunk), _ptr(out_n), self._stream()))
         return out_doc, out_score, out_chunk, out_n
 
+    def dense_split_max(self, k=100):
+        """Most queries one dense_begin / dense_end pair takes (0: this engine cannot split the dense call)."""
+        return int(self.lib.msr_dense_split_max(self.handle, int(k)))
+
+    def dense_begin(self, qvec, k=100, k_part=None):
+        """First half of dense_topk for a doc-sharded index (msr_dense_topk_begin): -> part float32 [Q] (device): a cosine that
+        k_part documents of this shard reach exactly.  The caller takes the minimum over the shards (k_part = ceil(k / shards))
+        and hands it to dense_end."""
+        q = self._dev(qvec, torch.float32).reshape(-1, DIM)
+        Q = int(q.shape[0])
+        part = torch.empty((Q,), dtype=torch.float32, device=self.device)
+        self._check(self.lib.msr_dense_topk_begin(self.handle, _ptr(q), Q, int(k), int(k_part or k), _ptr(part), self._stream()))
+        return part
+
+    def dense_end(self, Q, k=100, bound=None, want_chunk=True):
+        """Second half (msr_dense_topk_end): bound float32 [Q] (device) or None -> (doc, score, chunk row, n) as dense_topk; with
+        a bound n may be < k -- every document this shard can contribute to the global top-k."""
+        out_doc = torch.empty((Q, k), dtype=torch.int32, device=self.device)
+        out_score = torch.empty((Q, k), dtype=torch.float32, device=self.device)
+        out_chunk = torch.empty((Q, k), dtype=torch.int32, device=self.device) if want_chunk else None
+        out_n = torch.empty((Q,), dtype=torch.int32, device=self.device)
+        self._check(self.lib.msr_dense_topk_end(self.handle, int(Q), int(k), _ptr(bound), _ptr(out_doc), _ptr(out_score),
+                                                _ptr(out_chunk), _ptr(out_n), self._stream()))
+        return out_doc, out_score, out_chunk, out_n
+
     def enable_bf16(self):
         """Build the bf16 copy of the embeddings used by dense_topk_batched (+7.7 GB at 5 M chunks)."""
         self._check(self.lib.msr_enable_bf16(self.handle, self._stream()))
