@@ -1290,3 +1290,66 @@ def test_diversify_kernel_matches_reference(mods):
             exp = rr.hybrid_diversification(items, top_k=top_k) if div else items[:top_k]
             assert got == [(e["doc_id"], e["similarity_score"]) for e in exp], (trial, div)
     eng.close()
+
+
+def test_split_dense_call_with_a_cross_shard_bound_equals_unsharded(mods):
+    """msr_dense_topk_begin / _end (the dense stage of a doc-sharded run): three shard engines on one GPU each vouch for
+    ceil(k / 3) of their own documents, the minimum over the shards bounds the k-th cosine of the whole corpus from below, and
+    every shard rescores only what can be in the global top-k.  The shards' lists are SHORTER than k; merged they are the
+    unsharded engine's list bit for bit (documents, exact f32 scores, arg-max chunks) -- for planted near-duplicates, an exact
+    hit, random directions, k = 100 and k = 10; a shard that holds none of a query's top documents contributes (almost) nothing."""
+    rng = np.random.default_rng(123)
+    n_docs = 90000
+    n = rng.integers(1, 9, size=n_docs)
+    doc_off = np.zeros(n_docs + 1, np.int64); doc_off[1:] = np.cumsum(n)
+    C = int(doc_off[-1])
+    emb_t = torch.randn((C, 768), generator=torch.Generator().manual_seed(9))
+    emb_t /= emb_t.norm(dim=1, keepdim=True)
+    emb = emb_t.numpy()
+    ix = mods["CorpusIndex"](doc_ids=np.arange(n_docs, dtype=np.int64), doc_off=doc_off.astype(np.int32),
+                             chunk_ids=np.arange(C, dtype=np.int64), emb=emb, total_docs=n_docs)
+    Q = 200
+    q = rng.standard_normal((Q, 768)).astype(np.float32) * rng.uniform(0.5, 12, size=(Q, 1)).astype(np.float32)
+    q[0] = emb[12345] * 3.0                                    # exact hit (first shard)
+    q[1:60] = emb[rng.integers(0, C, 59)] + 0.4 * q[1:60] / np.linalg.norm(q[1:60], axis=1, keepdims=True)
+    q[60] = emb[C - 1] * 0.5                                   # exact hit in the LAST shard's last tile
+    full = mods["DeviceEngine"](ix, max_queries=256, max_k=100, rerank_max_docs=0)
+    world = 3
+    shards = [ix.shard(r, world) for r in range(world)]
+    engs = [mods["DeviceEngine"](s_, max_queries=256, max_k=100, rerank_max_docs=0) for s_ in shards]
+    glob = lambda t, base: torch.where(t >= 0, t + base, t)
+    for k in (100, 10):
+        ref = full.dense_topk(q, k=k)
+        assert all(e.dense_split_max(k) >= Q for e in engs)
+        parts = [e.dense_begin(q, k=k, k_part=(k + world - 1) // world) for e in engs]
+        bound = torch.stack(parts).min(dim=0).values
+        outs = [e.dense_end(Q, k=k, bound=bound) for e in engs]
+        assert all(int(o[3].max()) <= k for o in outs) and sum(int(o[3].sum()) for o in outs) < 0.8 * world * Q * k   # shorter lists
+        assert all(bool((o[3] >= 0).all()) for o in outs)
+        # payload merge (the arg-max chunk travels with its document), as the sharded engine does after the all-gather
+        docs = torch.stack([glob(o[0], s_.doc_base) for o, s_ in zip(outs, shards)])
+        chunks = torch.stack([glob(o[2], s_.row_base) for o, s_ in zip(outs, shards)])
+        m_doc, m_score, m_n = engs[0].merge_topk(docs, torch.stack([o[1] for o in outs]), torch.stack([o[3] for o in outs]), k)
+        assert torch.equal(m_n, ref[3]) and torch.equal(m_doc, ref[0]) and torch.equal(m_score, ref[1])
+        # the winning chunk of every merged document, looked up in the shard lists
+        look = {}
+        for g in range(world):
+            d_, c_, n_ = docs[g].cpu().numpy(), chunks[g].cpu().numpy(), outs[g][3].cpu().numpy()
+            for qi in (0, 1, 60, 199):
+                for j in range(n_[qi]):
+                    look[(qi, int(d_[qi, j]))] = int(c_[qi, j])
+        rd, rc = ref[0].cpu().numpy(), ref[2].cpu().numpy()
+        for qi in (0, 1, 60, 199):
+            assert [look[(qi, int(d))] for d in rd[qi]] == rc[qi].tolist()
+        # without a bound the halves are the plain call
+        p0 = engs[0].dense_begin(q, k=k, k_part=k)
+        plain = engs[0].dense_end(Q, k=k, bound=None)
+        whole = engs[0].dense_topk(q, k=k)
+        assert all(torch.equal(a_, b_) for a_, b_ in zip(plain, whole))
+    # misuse is refused, with a reason
+    with pytest.raises(mods["msretr"].MsrError):
+        engs[0].dense_end(Q, k=100)                             # no begin pending
+    with pytest.raises(mods["msretr"].MsrError):
+        engs[0].dense_begin(q[:10], k=100)                      # <= 64 queries: the sweeps, not the streaming pass
+    for e in engs + [full]:
+        e.close()
