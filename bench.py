@@ -766,9 +766,9 @@ def main():
     ok = True
     if "dense" in out:
         d_doc, d_score, d_chunk, d_n = out["dense"]
-        full = bool((d_n == args.k2).all().item()) if args.emulate_ranks <= 1 else bool((d_n > 0).all().item())   # (an emulated rank
-        #                                                  returns only what it can contribute to the node's top-k: fewer than k2)
-        ok = ok and full and bool((torch.diff(torch.nan_to_num(d_score, neginf=-1e30), dim=1) <= 0).all().item())
+        lists_ok = bool((d_n == args.k2).all().item()) if args.emulate_ranks <= 1 else bool((d_n > 0).all().item())   # (an emulated
+        #                                             rank returns only what it can contribute to the node's top-k: fewer than k2)
+        ok = ok and lists_ok and bool((torch.diff(torch.nan_to_num(d_score, neginf=-1e30), dim=1) <= 0).all().item())
     if "bm25" in out:
         ok = ok and bool((out["bm25"][2] > 0).all().item())
     if "rerank" in out:
