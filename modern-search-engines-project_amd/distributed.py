@@ -171,14 +171,15 @@ class ShardedEngine:
         split = 0
         if self.world > 1 and not dense_batched and max_chunks_per_doc == 0 and hasattr(e, "dense_split_max"):
             split = e.dense_split_max(k)
-        if split <= 0 or Q <= 64:
+        min_q = getattr(e, "dense_split_min", 65)             # (the device engine splits calls of more than 64 queries)
+        if split <= 0 or Q < min_q:
             dense = e.dense_topk_batched if dense_batched else e.dense_topk
             return dense(qvec, k=k, max_chunks_per_doc=max_chunks_per_doc)
         k_part = (k + self.world - 1) // self.world
         outs = []
         for a in range(0, Q, split):
             b = min(Q, a + split)
-            if b - a <= 64:                                   # (a short last piece: the sweeps, no split)
+            if b - a < min_q:                                 # (a short last piece: the sweeps, no split)
                 outs.append(e.dense_topk(qvec[a:b], k=k))
                 continue
             part = e.dense_begin(qvec[a:b], k=k, k_part=k_part)

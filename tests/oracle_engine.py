@@ -37,6 +37,31 @@ class OracleEngine:
             doc[i, :len(a)], sc[i, :len(a)], ch[i, :len(a)], n[i] = a, b, c, len(a)
         return torch.as_tensor(doc), torch.as_tensor(sc), torch.as_tensor(ch), torch.as_tensor(n)
 
+    # the two halves of the dense call (DeviceEngine.dense_begin / dense_end): the stand-in vouches for the EXACT score of its
+    # k_part-th best document and afterwards returns only the documents at or above the bound the shards agreed on
+    dense_split_min = 1
+
+    def dense_split_max(self, k=100):
+        return 1 << 20
+
+    def dense_begin(self, qvec, k=100, k_part=None):
+        self.begin_calls = getattr(self, "begin_calls", 0) + 1
+        self._pending = self.dense_topk(qvec, k=k)
+        _, sc, _, n = [_np(x) for x in self._pending]
+        kp = int(k_part or k)
+        part = np.where(n >= kp, sc[:, kp - 1], -np.inf).astype(np.float32)
+        return torch.as_tensor(part)
+
+    def dense_end(self, Q, k=100, bound=None, want_chunk=True):
+        doc, sc, ch, n = [_np(x).copy() for x in self._pending]
+        assert len(doc) == Q
+        if bound is not None:
+            b = _np(bound)
+            for q in range(Q):
+                keep = int((sc[q, :n[q]] >= b[q]).sum())           # (the list is sorted: a prefix)
+                doc[q, keep:], sc[q, keep:], ch[q, keep:], n[q] = -1, -np.inf, -1, keep
+        return torch.as_tensor(doc), torch.as_tensor(sc), torch.as_tensor(ch), torch.as_tensor(n)
+
     def merge_topk(self, docs, scores, ns, k):
         docs, scores, ns = _np(docs), _np(scores), _np(ns)
         G, Q = docs.shape[:2]

@@ -43,6 +43,7 @@ def _run(rank, world, port, ret, snap_dir=None):
         se = ShardedEngine(OracleEngine(sh), sh.doc_base, sh.row_base)
         assert se.world == world and se.rank == rank
         out = se.search([sh.term_ids(t) for t in terms], qvec, k1=200, k2=50)
+        assert se.engine.begin_calls == 1                  # the dense stage went through begin / all-reduce MIN / end
         res = {k: [x.numpy() for x in v] for k, v in out.items()}
         cut = se.search([sh.term_ids(t) for t in terms], qvec, k1=200, k2=50, rerank_keep=20)
         res["rerank_cut"] = [x.numpy() for x in cut["rerank"]]
