@@ -65,10 +65,8 @@ def main():
     queries = read_queries_file(qfile) if qfile else [(str(i + 1), q) for i, q in enumerate(DEFAULT_QUERIES)]
     ix = synthetic_crawl()
     rt = Retriever(embedder=fake_encoder(), indexer=ix, tokenizer=simple_tokenize, max_queries=8, max_k=1000)
-    res = rt.batch_search(queries)
-    with open(out, "w", encoding="utf-8") as f:
-        for r in res:
-            f.write(r["formatted_line"] + "\n")
+    res = rt.batch_search(queries)                  # the reference's `results` list (dicts built on access) ...
+    res.write(out)                                  # ... and all formatted lines in one native call
     print(f"{len(queries)} queries -> {len(res)} result lines in {out}")
     rt.engine.close()
 
