@@ -578,8 +578,13 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
         }
         // rows of the same step of the NEXT block: of this tile, or (a tile's last block) of the next tile's first block
         if (half == KPS - 1) {                           // (the slot's last K step: everything has been taken out of it)
+#ifdef MSR_DIAG
+            if (!(a.dbg & 262144))                       // timing experiment (wrong results): no row loads behind the prologue
+#endif
+            {
             if (last) load_rows(SL{}, bn, vn, std::integral_constant<int, slot * 128>{});
             else load_rows(SL{}, bp + (uint64_t)(kn * BLKB), vp, std::integral_constant<int, slot * 128>{});
+            }
         }
 #ifdef MSR_DIAG
         if (a.dbg & 32768) __builtin_amdgcn_s_setprio(0);
@@ -658,6 +663,9 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
         for (int kb = 0; kb < NKB; ++kb) {
             const bool last = kb == NKB - 1;
             const int kn = last ? 0 : kb + 1;
+#ifdef MSR_DIAG
+            if (!(a.dbg & 524288))                       // timing experiment (wrong results): the query image is staged once
+#endif
             stage_b(kn, pb ^ 1);                         // the next query block (the image repeats for every tile)
             step(std::integral_constant<int, 0>{}, kn, last);
             step(std::integral_constant<int, 1>{}, kn, last);
@@ -977,7 +985,7 @@ void msr_gemm_f32_set_dbg(int v) { g_f32_dbg = v; }
 hipError_t msr_stream256_bf16_launch(bool emit, const StreamArgs& a, int grid, hipStream_t stream) {
     if (a.nt < 1 || (grid & 7) || (grid >> 3) < a.nt) return hipErrorInvalidValue;
 #ifdef MSR_DIAG
-    if (g_f32_dbg & (32768 | 65536 | 131072)) { StreamArgs b = a; b.dbg |= g_f32_dbg & (32768 | 65536 | 131072); return emit ? launch_stream256_t<true, true>(b, grid, stream) : launch_stream256_t<false, true>(b, grid, stream); }
+    if (g_f32_dbg & (32768 | 65536 | 131072 | 262144 | 524288)) { StreamArgs b = a; b.dbg |= g_f32_dbg & (32768 | 65536 | 131072 | 262144 | 524288); return emit ? launch_stream256_t<true, true>(b, grid, stream) : launch_stream256_t<false, true>(b, grid, stream); }
 #endif
     return emit ? launch_stream256_t<true, true>(a, grid, stream) : launch_stream256_t<false, true>(a, grid, stream);
 }
