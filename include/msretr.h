@@ -227,12 +227,13 @@ int msr_diversify(msr_engine* e, int32_t n_queries, const int32_t* fused_doc, co
 /* HOST function (every pointer is host memory; no device is touched): the batch result lines of search_api.py:290,
  * "{query_num}\t{rank}\t{url}\t{score:.3f}\n", for n_queries final lists in one call.  Query q's number is the bytes
  * qnum_blob[qnum_off[q] .. qnum_off[q+1]); its list is doc / score [q * stride .. + n[q]) (rank = position + 1); the URL of
- * document d is url_blob[url_off[d] .. url_off[d+1]) (UTF-8; d outside [0, n_docs): empty).  The score is printed exactly as
+ * document d is url_blob[url_off[d] .. url_off[d+1]) (UTF-8; d outside [0, n_docs): empty); max_url_len = the longest URL in
+ * bytes (sizes the output without touching the table; <= 0: computed here, one pass over url_off).  The score is printed exactly as
  * Python's format(score, ".3f").  Returns the bytes written; if `capacity` is below the function's upper bound of them nothing
  * is written and the result is -(that bound) (call with capacity 0 to size the buffer); INT64_MIN for a bad argument. */
 int64_t msr_format_lines(const char* qnum_blob, const int64_t* qnum_off, int32_t n_queries, const int32_t* doc,
                          const double* score, const int32_t* n, int32_t stride, const char* url_blob, const int64_t* url_off,
-                         int64_t n_docs, char* out, int64_t capacity);
+                         int64_t n_docs, int64_t max_url_len, char* out, int64_t capacity);
 
 /* The two halves of msr_rerank, for a doc-sharded index (the reference-exact hybrid needs a
  * second exchange).  cand_doc holds GLOBAL document indices and is identical on every rank.

@@ -67,7 +67,7 @@ _SIGNATURES = {
     "msr_bind_doc_domains": (C.c_int, [_P, _P, C.c_int64, _P]),
     "msr_diversify": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_double, C.c_int32, _P, _P, _P, _P,
                                 _P, _P]),
-    "msr_format_lines": (C.c_int64, [_P, _P, C.c_int32, _P, _P, _P, C.c_int32, _P, _P, C.c_int64, _P, C.c_int64]),
+    "msr_format_lines": (C.c_int64, [_P, _P, C.c_int32, _P, _P, _P, C.c_int32, _P, _P, C.c_int64, C.c_int64, _P, C.c_int64]),
     "msr_rerank_gather": (C.c_int, [_P, _P, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     "msr_rerank_gather_blocks": (C.c_int, [_P, _P, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32,
                                            C.c_int64, _P]),

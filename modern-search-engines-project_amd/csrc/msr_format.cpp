@@ -64,7 +64,7 @@ static inline int fmt_u(uint32_t v, char* out) {
 // format queries [q0, q1) into p (which has room for their upper bound); returns the end
 static char* format_range(const char* qnum_blob, const int64_t* qnum_off, int32_t q0, int32_t q1, const int32_t* doc,
                           const double* score, const int32_t* n, int32_t stride, const char* url_blob, const int64_t* url_off,
-                          int64_t n_docs, char* p) {
+                          int64_t n_docs, int64_t max_url, char* p) {
     for (int32_t q = q0; q < q1; ++q) {
         const char* qs = qnum_blob + qnum_off[q];
         const int64_t ql = qnum_off[q + 1] - qnum_off[q];
@@ -81,8 +81,9 @@ static char* format_range(const char* qnum_blob, const int64_t* qnum_off, int32_
             p += fmt_u((uint32_t)(r + 1), p);
             *p++ = '\t';
             if (d >= 0 && d < n_docs && url_blob) {
-                const int64_t ul = url_off[d + 1] - url_off[d];
-                memcpy(p, url_blob + url_off[d], (size_t)ul); p += ul;
+                int64_t ul = url_off[d + 1] - url_off[d];
+                if (ul > max_url) ul = max_url;                         // (a wrong max_url_len must not overrun the buffer)
+                if (ul > 0) { memcpy(p, url_blob + url_off[d], (size_t)ul); p += ul; }
             }
             *p++ = '\t';
             p += fmt3(score[i], p);
@@ -94,22 +95,17 @@ static char* format_range(const char* qnum_blob, const int64_t* qnum_off, int32_
 
 extern "C" int64_t msr_format_lines(const char* qnum_blob, const int64_t* qnum_off, int32_t n_queries, const int32_t* doc,
                                     const double* score, const int32_t* n, int32_t stride, const char* url_blob,
-                                    const int64_t* url_off, int64_t n_docs, char* out, int64_t capacity) {
+                                    const int64_t* url_off, int64_t n_docs, int64_t max_url_len, char* out, int64_t capacity) {
     if (!qnum_blob || !qnum_off || !doc || !score || !n || !url_off || n_queries < 0 || stride < 0 || capacity < 0 || (capacity && !out))
         return INT64_MIN;
     // pass 1: an upper bound of the bytes per query, without touching the URL table (its entries are scattered: that would be
     // a cache miss per line): rank and score take at most 10 + 24 characters (ranks < 2^32, |score| < 1e12; snprintf's output
-    // for anything larger is bounded by 40), a URL at most `max_url` bytes
-    int64_t max_url = 0;
-    {
-        static thread_local const int64_t* seen_off = nullptr;
-        static thread_local int64_t seen_n = -1, seen_max = 0;
-        if (seen_off != url_off || seen_n != n_docs) {                  // (one sequential pass per URL table, remembered)
-            int64_t m = 0;
-            if (url_blob) for (int64_t d = 0; d < n_docs; ++d) m = std::max(m, url_off[d + 1] - url_off[d]);
-            seen_off = url_off; seen_n = n_docs; seen_max = m;
-        }
-        max_url = seen_max;
+    // for anything larger is bounded by 40), a URL at most `max_url` bytes (the caller's max_url_len; a URL longer than
+    // that is cut to it rather than written past its line's share of the buffer)
+    int64_t max_url = max_url_len;
+    if (max_url <= 0) {                                                 // (not given: one sequential pass over the offsets)
+        max_url = 0;
+        if (url_blob) for (int64_t d = 0; d < n_docs; ++d) max_url = std::max(max_url, url_off[d + 1] - url_off[d]);
     }
     std::vector<int64_t> bound((size_t)n_queries + 1, 0);
     for (int32_t q = 0; q < n_queries; ++q) {
@@ -129,7 +125,7 @@ extern "C" int64_t msr_format_lines(const char* qnum_blob, const int64_t* qnum_o
     for (int t = 1; t <= n_thr; ++t) cut[t] = std::max(cut[t], cut[t - 1]);
     std::vector<char*> end((size_t)n_thr, nullptr);
     auto work = [&](int t) {
-        end[t] = format_range(qnum_blob, qnum_off, cut[t], cut[t + 1], doc, score, n, stride, url_blob, url_off, n_docs,
+        end[t] = format_range(qnum_blob, qnum_off, cut[t], cut[t + 1], doc, score, n, stride, url_blob, url_off, n_docs, max_url,
                               out + bound[cut[t]]);
     };
     std::vector<std::thread> pool;

@@ -98,6 +98,7 @@ class LineFormatter:
         if enc:
             np.cumsum(np.fromiter((len(b) for b in enc), np.int64, n), out=self.off[1:])
         self.n_docs = n
+        self.max_url = int(np.diff(self.off).max()) if n else 0
         self._buf = self._cbuf = None
 
     def format(self, query_nums, doc, score, n):
@@ -117,7 +118,7 @@ class LineFormatter:
             np.cumsum(np.fromiter((len(b) for b in qb), np.int64, Q), out=qoff[1:])
         ptr = lambda a: C.c_void_p(a.ctypes.data)
         args = (C.c_char_p(qblob), ptr(qoff), Q, ptr(doc), ptr(score), ptr(n), int(doc.shape[1]), C.c_char_p(self.blob),
-                ptr(self.off), self.n_docs)
+                ptr(self.off), self.n_docs, max(1, self.max_url))
         need = -int(self._lib.msr_format_lines(*args, None, 0))
         if need <= 0:
             return memoryview(b"")
