@@ -817,6 +817,7 @@ extern "C" int msr_dense_topk_begin(msr_engine* e, const float* q, int32_t n_que
                                     void* stream) {
     if (!e) return MSR_ERR_INVALID;
     if (!e->have_chunks) return fail(e, MSR_ERR_NOT_BOUND, "msr_dense_topk_begin: chunks not bound");
+    if (e->split_pending) return fail(e, MSR_ERR_INVALID, "msr_dense_topk_begin: the previous begin has not been ended");
     const int cap = msr_dense_split_max(e, k);
     if (!q || !out_part || k_part < 1 || k_part > k || n_queries <= 64 || n_queries > cap)
         return fail(e, MSR_ERR_INVALID, "msr_dense_topk_begin: needs 64 < n_queries <= msr_dense_split_max() = %d, 1 <= k_part <= k (got %d, %d, %d)",
@@ -856,6 +857,8 @@ extern "C" int msr_dense_topk(msr_engine* e, const float* q, int32_t n_queries, 
                               int32_t* out_doc, float* out_score, int32_t* out_chunk, int32_t* out_n, void* stream) {
     if (!e) return MSR_ERR_INVALID;
     if (!e->have_chunks) return fail(e, MSR_ERR_NOT_BOUND, "msr_dense_topk: chunks not bound");
+    if (e->split_pending)
+        return fail(e, MSR_ERR_INVALID, "msr_dense_topk: an msr_dense_topk_begin is pending (its scratch is in use): call msr_dense_topk_end first");
     if (n_queries < 0 || k < 1 || k > e->cfg.max_k || max_chunks_per_doc < 0 || !q || !out_doc || !out_score || !out_n)
         return fail(e, MSR_ERR_INVALID, "msr_dense_topk: bad argument (k=%d, max_k=%d)", k, e->cfg.max_k);
     if (n_queries == 0) return MSR_OK;
