@@ -1351,5 +1351,11 @@ def test_split_dense_call_with_a_cross_shard_bound_equals_unsharded(mods):
         engs[0].dense_end(Q, k=100)                             # no begin pending
     with pytest.raises(mods["msretr"].MsrError):
         engs[0].dense_begin(q[:10], k=100)                      # <= 64 queries: the sweeps, not the streaming pass
+    engs[0].dense_begin(q, k=100)
+    with pytest.raises(mods["msretr"].MsrError):
+        engs[0].dense_topk(q, k=100)                            # the pending begin's scratch is in use
+    with pytest.raises(mods["msretr"].MsrError):
+        engs[0].dense_begin(q, k=100)
+    assert int(engs[0].dense_end(Q, k=100)[3].min()) == 100     # ... and the pair still completes
     for e in engs + [full]:
         e.close()
