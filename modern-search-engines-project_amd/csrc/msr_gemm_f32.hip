@@ -432,6 +432,25 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
     const int q_base = a.q_base + grp * 256;
     float* thr_lds = (float*)(smem + 2 * G2_BLK);
     if (EMIT && tid < 256) thr_lds[tid] = a.thr[grp * 256 + tid];
+    // f32 rows: the lane's 16 emission thresholds (queries ni 16 + lane & 15) stay in 8 registers for the whole kernel, as f16
+    // pairs rounded DOWN (a lower threshold only emits a few more entries; the final bound is applied in f32 later).  Read
+    // from LDS they cost the epilogue one LDS round trip per 16 queries -- 16 per tile and wave, on its critical path.
+    // (bf16 rows: no registers to spare, 250 of 256 in use; there the next threshold is requested one block of queries ahead.)
+    constexpr bool THR_REGS = EMIT && !BF16;
+    uint32_t thr_h[THR_REGS ? NNI / 2 : 1];
+    if (THR_REGS) {
+        auto down_h = [](float x) -> uint32_t {             // largest f16 <= x (inf stays inf; NaN stays NaN: never emits)
+            _Float16 h = (_Float16)x;
+            uint16_t b = __builtin_bit_cast(uint16_t, h);
+            if ((float)h > x) b = (b & 0x8000u) ? (uint16_t)(b + 1) : (b == 0 ? (uint16_t)0x8001u : (uint16_t)(b - 1));
+            return b;
+        };
+#pragma unroll
+        for (int j = 0; j < NNI / 2; ++j) {
+            const float lo = a.thr[grp * 256 + (2 * j) * 16 + li16], hi = a.thr[grp * 256 + (2 * j + 1) * 16 + li16];
+            thr_h[j] = down_h(lo) | (down_h(hi) << 16);
+        }
+    }
     // Tile maxima, bf16 rows (1024 queries per pass: eight rows of maxima per tile would be 640 MB of writes per pass): the
     // eight waves' maxima of a (tile, query) are joined in LDS (atomic max on order-preserving keys; two sets, by tile
     // parity) and written as ONE row of 256 per tile -- after the first barrier of the NEXT tile, which every wave passes
@@ -699,6 +718,8 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
         //      the tile, query 128 wc + ni 16 + li16 of the group ----
         const int n_valid = row_end - row0;
         const int col_e = wc * 128 + (ln_e & 15);
+        float thr_nx = (EMIT && !THR_REGS) ? thr_lds[col_e] : 0.f;        // (bf16 rows: the threshold of the NEXT 16 queries is
+        //                                                                    requested while this block's maxima are computed)
 #ifdef MSR_DIAG
         if (a.dbg & 65536) {                             // timing experiment (wrong results): no epilogue at all
 #pragma unroll
@@ -711,6 +732,8 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
         for (int ni = 0; ni < NNI; ++ni) {
             f32x4 v[NMI];
             float cmax = NEG_INF;
+            const float thr_cur = thr_nx;
+            if (EMIT && !THR_REGS && ni + 1 < NNI) thr_nx = thr_lds[(ni + 1) * 16 + col_e];
 #pragma unroll
             for (int mi = 0; mi < NMI; ++mi) {
                 const int blk = wr * WROWS + mi * 16;
@@ -725,7 +748,9 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
                 acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
             if (EMIT) {
-                const float thr = thr_lds[ni * 16 + col_e];
+                float thr;
+                if (THR_REGS) thr = (float)__builtin_bit_cast(_Float16, (uint16_t)(ni & 1 ? thr_h[ni >> 1] >> 16 : thr_h[ni >> 1] & 0xffffu));
+                else thr = thr_cur;
                 if (__ballot(cmax >= thr) != 0) {
                     const int q = q_base + ni * 16 + col_e;
 #pragma unroll

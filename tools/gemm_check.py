@@ -16,6 +16,8 @@ from msretr.engine import DeviceEngine  # noqa: E402
 
 if os.environ.get("MSR_DIAG_LIB"):       # timing experiments (--dbg) only exist in the -DMSR_DIAG build
     _abi.LIB_PATH = build_library(diag=True)
+if os.environ.get("MSR_LIB_PATH"):       # A/B against another build of the library (e.g. the previous commit's)
+    _abi.LIB_PATH = os.environ["MSR_LIB_PATH"]
 from msretr.synthetic import synthetic_corpus  # noqa: E402
 
 ap = argparse.ArgumentParser()
