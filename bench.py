@@ -574,15 +574,16 @@ def main():
             # rank's own value: the emulated shards are statistically alike), end with the bound; lists shorter than k2
             split = eng.dense_split_max(args.k2)
             if split > 0 and nq > 64:
-                parts = []
+                d = (torch.empty((nq, args.k2), dtype=torch.int32, device=dev), torch.empty((nq, args.k2), dtype=torch.float32, device=dev),
+                     torch.empty((nq, args.k2), dtype=torch.int32, device=dev), torch.empty((nq,), dtype=torch.int32, device=dev))
                 for a0 in range(0, nq, split):
                     a1 = min(nq, a0 + split)
                     if a1 - a0 <= 64:
-                        parts.append(eng.dense_topk(qv[a0:a1], k=args.k2))
+                        for dst, src in zip(d, eng.dense_topk(qv[a0:a1], k=args.k2)):
+                            dst[a0:a1].copy_(src)
                     else:
                         bound = eng.dense_begin(qv[a0:a1], k=args.k2, k_part=(args.k2 + NE - 1) // NE)
-                        parts.append(eng.dense_end(a1 - a0, k=args.k2, bound=bound))
-                d = tuple(torch.cat([p[j] for p in parts]) for j in range(4)) if len(parts) > 1 else parts[0]
+                        eng.dense_end(a1 - a0, k=args.k2, bound=bound, out=tuple(t[a0:a1] for t in d))
             else:
                 d = eng.dense_topk(qv, k=args.k2)
             # the two merges of NE gathered lists (stand-in operands: NE copies of the local lists)

@@ -77,6 +77,9 @@ __global__ __launch_bounds__(BT_THREADS) void rescore_kernel(DenseIndex ix, cons
     const int q = blockIdx.y, lane = threadIdx.x & 63;
     int cnt = cand_n[q];
     if (cnt > MSR_SEL_CAP) cnt = MSR_SEL_CAP;
+    // (a wave without a candidate leaves before it loads the query: with a node-wide bound a shard keeps ~20 candidates per
+    // query, and 2048 queries x 256 waves each fetching 3 KB of query for nothing were most of this kernel's time)
+    if ((int)(blockIdx.x * (BT_THREADS / 64) + (threadIdx.x >> 6)) >= cnt) return;
     const f32x4* q4 = (const f32x4*)(qn + (size_t)q * MSR_DIM);
     const f32x4 qa = q4[lane], qb = q4[lane + 64], qc = q4[lane + 128];
     for (int slot = blockIdx.x * (BT_THREADS / 64) + (threadIdx.x >> 6); slot < cnt;

@@ -176,16 +176,23 @@ class ShardedEngine:
             dense = e.dense_topk_batched if dense_batched else e.dense_topk
             return dense(qvec, k=k, max_chunks_per_doc=max_chunks_per_doc)
         k_part = (k + self.world - 1) // self.world
-        outs = []
-        for a in range(0, Q, split):
+        if Q <= split:
+            part = e.dense_begin(qvec, k=k, k_part=k_part)
+            dist.all_reduce(part, op=dist.ReduceOp.MIN, group=self.group)
+            return e.dense_end(Q, k=k, bound=part)
+        dev = getattr(e, "device", None) or (qvec.device if torch.is_tensor(qvec) else None)
+        res = (torch.empty((Q, k), dtype=torch.int32, device=dev), torch.empty((Q, k), dtype=torch.float32, device=dev),
+               torch.empty((Q, k), dtype=torch.int32, device=dev), torch.empty((Q,), dtype=torch.int32, device=dev))
+        for a in range(0, Q, split):                          # pieces of the call write straight into their rows of the result
             b = min(Q, a + split)
             if b - a < min_q:                                 # (a short last piece: the sweeps, no split)
-                outs.append(e.dense_topk(qvec[a:b], k=k))
+                for dst, src in zip(res, e.dense_topk(qvec[a:b], k=k)):
+                    dst[a:b].copy_(src)
                 continue
             part = e.dense_begin(qvec[a:b], k=k, k_part=k_part)
             dist.all_reduce(part, op=dist.ReduceOp.MIN, group=self.group)
-            outs.append(e.dense_end(b - a, k=k, bound=part))
-        return tuple(torch.cat([o[j] for o in outs]) for j in range(4)) if len(outs) > 1 else outs[0]
+            e.dense_end(b - a, k=k, bound=part, out=tuple(t[a:b] for t in res))
+        return res
 
     @staticmethod
     def _truncate(fused, keep):

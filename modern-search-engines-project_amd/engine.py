@@ -228,13 +228,18 @@ class DeviceEngine:
         self._check(self.lib.msr_dense_topk_begin(self.handle, _ptr(q), Q, int(k), int(k_part or k), _ptr(part), self._stream()))
         return part
 
-    def dense_end(self, Q, k=100, bound=None, want_chunk=True):
+    def dense_end(self, Q, k=100, bound=None, want_chunk=True, out=None):
         """Second half (msr_dense_topk_end): bound float32 [Q] (device) or None -> (doc, score, chunk row, n) as dense_topk; with
-        a bound n may be < k -- every document this shard can contribute to the global top-k."""
-        out_doc = torch.empty((Q, k), dtype=torch.int32, device=self.device)
-        out_score = torch.empty((Q, k), dtype=torch.float32, device=self.device)
-        out_chunk = torch.empty((Q, k), dtype=torch.int32, device=self.device) if want_chunk else None
-        out_n = torch.empty((Q,), dtype=torch.int32, device=self.device)
+        a bound n may be < k -- every document this shard can contribute to the global top-k.  out: optional (doc, score,
+        chunk, n) contiguous tensors of those shapes to write into (row slices of a larger result)."""
+        if out is not None:
+            out_doc, out_score, out_chunk, out_n = out
+            assert tuple(out_doc.shape) == (Q, k) and out_doc.is_contiguous() and out_score.is_contiguous() and out_n.is_contiguous()
+        else:
+            out_doc = torch.empty((Q, k), dtype=torch.int32, device=self.device)
+            out_score = torch.empty((Q, k), dtype=torch.float32, device=self.device)
+            out_chunk = torch.empty((Q, k), dtype=torch.int32, device=self.device) if want_chunk else None
+            out_n = torch.empty((Q,), dtype=torch.int32, device=self.device)
         self._check(self.lib.msr_dense_topk_end(self.handle, int(Q), int(k), _ptr(bound), _ptr(out_doc), _ptr(out_score),
                                                 _ptr(out_chunk), _ptr(out_n), self._stream()))
         return out_doc, out_score, out_chunk, out_n

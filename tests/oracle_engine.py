@@ -52,7 +52,7 @@ class OracleEngine:
         part = np.where(n >= kp, sc[:, kp - 1], -np.inf).astype(np.float32)
         return torch.as_tensor(part)
 
-    def dense_end(self, Q, k=100, bound=None, want_chunk=True):
+    def dense_end(self, Q, k=100, bound=None, want_chunk=True, out=None):
         doc, sc, ch, n = [_np(x).copy() for x in self._pending]
         assert len(doc) == Q
         if bound is not None:
@@ -60,7 +60,12 @@ class OracleEngine:
             for q in range(Q):
                 keep = int((sc[q, :n[q]] >= b[q]).sum())           # (the list is sorted: a prefix)
                 doc[q, keep:], sc[q, keep:], ch[q, keep:], n[q] = -1, -np.inf, -1, keep
-        return torch.as_tensor(doc), torch.as_tensor(sc), torch.as_tensor(ch), torch.as_tensor(n)
+        res = torch.as_tensor(doc), torch.as_tensor(sc), torch.as_tensor(ch), torch.as_tensor(n)
+        if out is not None:
+            for dst, src in zip(out, res):
+                dst.copy_(src)
+            return out
+        return res
 
     def merge_topk(self, docs, scores, ns, k):
         docs, scores, ns = _np(docs), _np(scores), _np(ns)
