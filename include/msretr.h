@@ -173,7 +173,7 @@ int msr_dense_topk(msr_engine* e, const float* q, int32_t n_queries, int32_t k, 
  *     k_part = ceil(k / shards), the minimum of out_part[q] over all shards is a lower bound of the k-th exact cosine of the
  *     whole corpus: shards x k_part >= k documents reach it.
  *   msr_dense_topk_end: bound [n_queries] (device; NULL: none) = that minimum.  Candidates whose filter score lies below
- *     bound - margin cannot be in the global top-k and are dropped before the candidate lists and the exact rescoring.  Output
+ *     bound - (half the filter's measured error margin) cannot be in the global top-k and are dropped before the candidate lists and the exact rescoring.  Output
  *     as msr_dense_topk, except that out_n[q] may be < k: the shard returns every document it can contribute to the global
  *     top-k (merge the shards' lists with msr_merge_topk_payload as usual; the merged list is the unsharded one, bit for bit).
  * One begin may be pending per engine; the matching end must follow with the same n_queries and k. */

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void gemm_tmax_kernel(const float* __restrict_
 // thr = +inf and flag[q] = 1 (the caller treats the query as overflowed).  Rows q >= nq (padding): +inf, flag 0.
 __global__ __launch_bounds__(1024) void gemm_kth_kernel(const float* __restrict__ tmax, int n, int stride, int nq, int k,
                                                          const float* __restrict__ margin, float* __restrict__ thr,
-                                                         int32_t* __restrict__ flag, float short_val) {
+                                                         int32_t* __restrict__ flag, float short_val, float margin_scale) {
     __shared__ uint32_t hist[2048];
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t s_bin, s_kk, s_hit;
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(1024) void gemm_kth_kernel(const float* __restrict_
         __syncthreads();
     }
     if (t == 0) {
-        thr[q] = short_row ? short_val : msr_unord32(prefix) - (margin ? margin[q] : 0.0f);
+        thr[q] = short_row ? short_val : msr_unord32(prefix) - (margin ? margin_scale * margin[q] : 0.0f);
         if (flag) flag[q] = short_row ? 1 : 0;
     }
 }
@@ -320,9 +320,9 @@ hipError_t msr_gemm_tmax(const float* tmax_t, int n_j, int parts, int nq_pad, fl
     return hipGetLastError();
 }
 hipError_t msr_gemm_kth(const float* tmax, int n, int stride, int nq, int nq_pad, int k, const float* margin, float* thr,
-                        int32_t* flag, hipStream_t stream, float short_val) {
+                        int32_t* flag, hipStream_t stream, float short_val, float margin_scale) {
     if (nq_pad <= 0) return hipSuccess;
-    gemm_kth_kernel<<<nq_pad, 1024, 0, stream>>>(tmax, n, stride, nq, k, margin, thr, flag, short_val);
+    gemm_kth_kernel<<<nq_pad, 1024, 0, stream>>>(tmax, n, stride, nq, k, margin, thr, flag, short_val, margin_scale);
     return hipGetLastError();
 }
 hipError_t msr_gemm_bucket(const void* wvbuf, int wv_cap, const int32_t* wv_count, int n_waves, const float* thr2,
@@ -363,14 +363,14 @@ hipError_t msr_gemm_candidates(const GemmIndex& g, const DenseIndex& ix, const f
         if ((err = msr_stream256_bf16_launch(false, a, grid, stream)) != hipSuccess) return err;
         if (ev && (err = hipEventRecord(ev[1], stream)) != hipSuccess) return err;
         gemm_tmax_kernel<<<dim3((n_s + 31) / 32, nq_pad / 32), 256, 0, stream>>>(g.tmax_t, n_s, 1, nq_pad, (float*)g.tmax, g.tmax_stride);
-        gemm_kth_kernel<<<nq_pad, 1024, 0, stream>>>((const float*)g.tmax, n_s, g.tmax_stride, nq, k, margin, g.thr, g.flag, __builtin_inff());
+        gemm_kth_kernel<<<nq_pad, 1024, 0, stream>>>((const float*)g.tmax, n_s, g.tmax_stride, nq, k, margin, g.thr, g.flag, __builtin_inff(), 1.0f);
         a.t_first = 0; a.t_stride = 1; a.t_count = g.n_tiles;
         a.thr = g.thr; a.wvbuf = g.wgbuf; a.wv_cap = g.wv_cap; a.wv_count = g.wv_count;
         if (ev && (err = hipEventRecord(ev[2], stream)) != hipSuccess) return err;
         if ((err = msr_stream256_bf16_launch(true, a, grid, stream)) != hipSuccess) return err;
         if (ev && (err = hipEventRecord(ev[3], stream)) != hipSuccess) return err;
         gemm_tmax_kernel<<<dim3((g.n_tiles + 31) / 32, nq_pad / 32), 256, 0, stream>>>(g.tmax_t, g.n_tiles, 1, nq_pad, (float*)g.tmax, g.tmax_stride);
-        gemm_kth_kernel<<<nq_pad, 1024, 0, stream>>>((const float*)g.tmax, g.n_tiles, g.tmax_stride, nq, k, margin, g.thr2, nullptr, __builtin_inff());
+        gemm_kth_kernel<<<nq_pad, 1024, 0, stream>>>((const float*)g.tmax, g.n_tiles, g.tmax_stride, nq, k, margin, g.thr2, nullptr, __builtin_inff(), 1.0f);
     }
     // ---- finish: bucket, per-document maxima, candidates ----
     gemm_bucket_kernel<<<dim3(2, (unsigned)grid * 8), 256, 0, stream>>>((const int4*)g.wgbuf, g.wv_cap, g.wv_count, g.thr2,

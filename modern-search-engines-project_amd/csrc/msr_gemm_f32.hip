@@ -1108,18 +1108,18 @@ hipError_t msr_gemm_f32_pass(const GemmF32Index& g, const DenseIndex& ix, const 
     if ((err = msr_gemm_kth(g.tmax, g.n_tiles, g.tmax_stride, nq, W * G, k, margin, g.thr2, nullptr, stream)) != hipSuccess) return err;
     // (sharded callers: what this shard can vouch for towards the k-th score over all shards, see msr_internal.h)
     if (out_part && (err = msr_gemm_kth(g.tmax, g.n_tiles, g.tmax_stride, nq, nq, k_part, margin, out_part, nullptr, stream,
-                                        -__builtin_inff())) != hipSuccess) return err;
+                                        -__builtin_inff(), 0.5f)) != hipSuccess) return err;
     return hipSuccess;
 }
 
 namespace {
-// thr2[q] = max(thr2[q], bound[q] - margin[q]): the threshold of this shard's own tile maxima, raised to what all shards together
-// guarantee for the k-th score
+// thr2[q] = max(thr2[q], bound[q] - margin[q] / 2): the threshold of this shard's own tile maxima, raised to what all shards
+// together guarantee for the k-th score (bound is in exact-cosine space; a filter score is within margin / 2 of the exact one)
 __global__ __launch_bounds__(256) void raise_thr_kernel(float* __restrict__ thr2, const float* __restrict__ bound,
                                                          const float* __restrict__ margin, int nq) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= nq) return;
-    const float b = bound[q] - margin[q];
+    const float b = bound[q] - 0.5f * margin[q];
     if (b > thr2[q]) thr2[q] = b;                           // (NaN / -inf bounds leave the local threshold alone)
 }
 }  // namespace

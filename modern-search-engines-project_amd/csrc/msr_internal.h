@@ -229,8 +229,9 @@ int msr_gemm_pair_cap();
 hipError_t msr_gemm_tmax(const float* tmax_t, int n_j, int parts, int nq_pad, float* out, int out_stride, hipStream_t stream);
 // thr[q] = k-th largest valid value of row q of tmax ([nq][stride], n values per row) - margin[q]; one launch
 hipError_t msr_gemm_kth(const float* tmax, int n, int stride, int nq, int nq_pad, int k, const float* margin, float* thr,
-                        int32_t* flag, hipStream_t stream, float short_val = __builtin_inff());
-// (short_val: what thr[q] becomes when row q holds fewer than k valid values -- and for the padding rows q >= nq)
+                        int32_t* flag, hipStream_t stream, float short_val = __builtin_inff(), float margin_scale = 1.0f);
+// (short_val: what thr[q] becomes when row q holds fewer than k valid values -- and for the padding rows q >= nq;
+// margin_scale: thr = k-th value - margin_scale * margin[q])
 hipError_t msr_gemm_bucket(const void* wvbuf, int wv_cap, const int32_t* wv_count, int n_waves, const float* thr2,
                            void* pairs, int32_t* pair_n, hipStream_t stream);
 void msr_bm25_set_dbg(int v);       // honoured by -DMSR_DIAG builds only
@@ -309,10 +310,11 @@ hipError_t msr_gemm_f32_topk(const GemmF32Index& g, const DenseIndex& ix, const 
                              int32_t* out_doc, float* out_score, int32_t* out_chunk,
                              int32_t* out_n, int32_t* gate, hipEvent_t* ev, int* width_out, hipStream_t stream);
 // The same in two halves, for a doc-sharded index (msr_dense_topk_begin / _end).  _pass: everything up to the thresholds of
-// this shard's own tile maxima; out_part[q] (nullable) <- (k_part-th largest tile maximum of query q) - margin[q], -inf when
-// the shard has fewer than k_part row tiles: k_part documents of this shard have EXACT cosines >= that value.  _finish:
-// bound (nullable, [nq]): a lower bound of the exact k-th cosine over ALL shards (the minimum over the shards of their
-// out_part with k_part = ceil(k / shards)); entries below bound - margin cannot be in the global top-k and are dropped before
+// this shard's own tile maxima; out_part[q] (nullable) <- (k_part-th largest tile maximum of query q) - margin[q] / 2, -inf
+// when the shard has fewer than k_part row tiles: k_part documents of this shard have EXACT cosines >= that value (a filter
+// score is within eps = margin / 2 - 5e-5 of the exact cosine).  _finish: bound (nullable, [nq]): a lower bound A of the
+// exact k-th cosine over ALL shards (the minimum over the shards of their out_part with k_part = ceil(k / shards)); a
+// document of the global top-k has exact cosine >= A, so filter score >= A - eps: entries below bound - margin / 2 are dropped before
 // bucketing, candidate lists and exact rescoring -- the shard then returns fewer than k documents, all it can contribute.
 hipError_t msr_gemm_f32_pass(const GemmF32Index& g, const DenseIndex& ix, const float* qn, int nq, int k, int k_part,
                              float* out_part, hipEvent_t* ev, int* width_out, hipStream_t stream);
