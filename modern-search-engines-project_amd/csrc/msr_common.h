@@ -9,6 +9,7 @@
 __host__ __device__ __forceinline__ uint32_t msr_ord32(float f) {
     uint32_t u;
     __builtin_memcpy(&u, &f, 4);
+    if (f == 0.0f) u = 0;                    // -0.0 == 0.0 in the reference's sort: one key (ties go by index)
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 __host__ __device__ __forceinline__ float msr_unord32(uint32_t u) {
@@ -20,6 +21,7 @@ __host__ __device__ __forceinline__ float msr_unord32(uint32_t u) {
 __host__ __device__ __forceinline__ uint64_t msr_ord64(double d) {
     uint64_t u;
     __builtin_memcpy(&u, &d, 8);
+    if (d == 0.0) u = 0;                     // (as above)
     return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
 }
 __host__ __device__ __forceinline__ double msr_unord64(uint64_t u) {

@@ -57,7 +57,7 @@ template <> struct ScoreTraits<double> {
 // h, appends that digit to the resolved prefix and updates the counters.  `suf` is LDS scratch of
 // SCAN_THREADS + 1 words, `S_sh` an LDS copy of the state that every thread reads back.
 template <int SB>
-__device__ void select_step(const uint32_t* h, uint32_t* suf, SelState* S_sh, int digit, int k) {
+__device__ void select_step(const uint32_t* h, uint32_t* suf, SelState* S_sh, int digit, int k, int* superset_out = nullptr) {
     const int t = threadIdx.x;
     uint32_t local = h[4 * t] + h[4 * t + 1] + h[4 * t + 2] + h[4 * t + 3];
     suf[t] = local;
@@ -96,6 +96,7 @@ __device__ void select_step(const uint32_t* h, uint32_t* suf, SelState* S_sh, in
         N.n_sel = k;
         const uint32_t superset = (uint32_t)N.n_above + h[b];
         if (superset <= MSR_SEL_CAP || digit == KeyCfg<SB>::ND - 1) N.done = 1;
+        if (superset_out) *superset_out = (int)superset;
         *S_sh = N;
     }
     __syncthreads();
@@ -304,8 +305,22 @@ __device__ __forceinline__ bool key_less(uint64_t ah, uint32_t al, uint64_t bh, 
     return ah < bh || (ah == bh && al < bl);
 }
 
+// Between two stages of a compare-exchange network whose partner distance is <= 64 no workgroup barrier is needed: thread
+// t's pair of such a stage lies in the 128-element block of the 64 consecutive pair indices its wave holds (the same block
+// in every such stage), and a wave's LDS operations execute in order.  Only the compiler has to be kept from moving LDS
+// accesses across the stage boundary.
+__device__ __forceinline__ void stage_sync(int j, int j_next) {
+    if (j <= 64 && j_next <= 64) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+}
+
 template <int THREADS>
 __device__ void bitonic_desc(uint64_t* khi, uint32_t* klo, int P) {
+    static_assert(THREADS % 64 == 0, "whole waves");
     for (int kk = 2; kk <= P; kk <<= 1) {
         for (int j = kk >> 1; j > 0; j >>= 1) {
             for (int idx = threadIdx.x; idx < (P >> 1); idx += THREADS) {
@@ -320,9 +335,10 @@ __device__ void bitonic_desc(uint64_t* khi, uint32_t* klo, int P) {
                     khi[i] = bh; klo[i] = bl; khi[p] = ah; klo[p] = al;
                 }
             }
-            __syncthreads();
+            stage_sync(j, j > 1 ? j >> 1 : kk);                  // (the stage after j = 1 is the next level's first: j = kk)
         }
     }
+    __syncthreads();
 }
 
 // One workgroup per query: exact sort of the candidates and output.  If the two streaming passes did not
@@ -358,9 +374,56 @@ __global__ __launch_bounds__(SCAN_THREADS) void sel_final_kernel(const T* __rest
     if (S_sh.done) {
         cnt = cand_n[q];
         if (cnt > MSR_SEL_CAP) cnt = MSR_SEL_CAP;
-        for (int i = t; i < cnt; i += SCAN_THREADS) {
-            khi[i] = cand_hi[(int64_t)q * MSR_SEL_CAP + i];
-            klo[i] = cand_lo[(int64_t)q * MSR_SEL_CAP + i];
+        const uint64_t* ch = cand_hi + (int64_t)q * MSR_SEL_CAP;
+        const uint32_t* cl = cand_lo + (int64_t)q * MSR_SEL_CAP;
+        int Pk = 64;
+        while (Pk < k) Pk <<= 1;
+        if (cnt <= Pk) {
+            for (int i = t; i < cnt; i += SCAN_THREADS) { khi[i] = ch[i]; klo[i] = cl[i]; }
+        } else {
+            // More candidates than the sort needs slots for k (the bin of the k-th key at 24 resolved bits holds a few dozen
+            // elements: 1000 + 30 candidates would be sorted as 2048): resolve further digits HERE, on the candidates (L2-resident,
+            // <= 48 KB), until they fit the next power of two above k -- the sort is 2.4 x shorter at 1024 than at 2048 entries.
+            uint32_t* h = (uint32_t*)khi;                        // (the key array is not loaded yet)
+            int d = 0;
+            for (; d < KeyCfg<SB>::ND; ++d) {                    // first digit that is not resolved
+                int part, shift, width;
+                digit_pos<SB>(d, part, shift, width);
+                if (!(part == 0 ? (S_sh.mask_hi >> shift) & 1 : (S_sh.mask_lo >> shift) & 1)) break;
+            }
+            int cur = cnt;
+            for (; cur > Pk && d < KeyCfg<SB>::ND; ++d) {
+                for (int b = t; b < MSR_SEL_BINS; b += SCAN_THREADS) h[b] = 0;
+                __syncthreads();
+                const SelState S = S_sh;
+                int part, shift, width;
+                digit_pos<SB>(d, part, shift, width);
+                const uint32_t wmask = (1u << width) - 1u;
+                for (int i = t; i < cnt; i += SCAN_THREADS) {
+                    const uint64_t a = ch[i];
+                    const uint32_t b = cl[i];
+                    if ((a & S.mask_hi) != S.pref_hi || (b & S.mask_lo) != S.pref_lo) continue;
+                    atomicAdd(&h[part == 0 ? (uint32_t)(a >> shift) & wmask : (b >> shift) & wmask], 1u);
+                }
+                __syncthreads();
+                select_step<SB>(h, suf, &S_sh, d, k, &s_cnt);
+                cur = s_cnt;
+                __syncthreads();
+            }
+            if (t == 0) s_cnt = 0;
+            __syncthreads();
+            const SelState S = S_sh;
+            for (int i = t; i < cnt; i += SCAN_THREADS) {
+                const uint64_t a = ch[i];
+                const uint32_t b = cl[i];
+                const uint64_t mh = a & S.mask_hi;
+                if (mh > S.pref_hi || (mh == S.pref_hi && (b & S.mask_lo) >= S.pref_lo)) {
+                    const int pos = atomicAdd(&s_cnt, 1);
+                    khi[pos] = a; klo[pos] = b;                  // (a subset of the cnt <= MSR_SEL_CAP candidates)
+                }
+            }
+            __syncthreads();
+            cnt = s_cnt;
         }
     } else {
         uint32_t* h = (uint32_t*)khi;                            // the histogram lives in the (still unused) key array
@@ -446,27 +509,6 @@ hipError_t select_impl(const T* scores, int64_t n, int64_t stride, RowView view,
 }
 
 // ---- merge of per-shard lists ---------------------------------------------------------------------
-// (hi, lo) keys with a 32-bit payload that travels with its key (the arg-max chunk row of a dense result)
-template <int THREADS>
-__device__ void bitonic_desc_pay(uint64_t* khi, uint32_t* klo, int32_t* pay, int P) {
-    for (int kk = 2; kk <= P; kk <<= 1) {
-        for (int j = kk >> 1; j > 0; j >>= 1) {
-            for (int idx = threadIdx.x; idx < (P >> 1); idx += THREADS) {
-                const int i = ((idx & ~(j - 1)) << 1) | (idx & (j - 1));
-                const int p = i | j;
-                const bool desc = (i & kk) == 0;
-                const uint64_t ah = khi[i], bh = khi[p];
-                const uint32_t al = klo[i], bl = klo[p];
-                if (desc ? key_less(ah, al, bh, bl) : key_less(bh, bl, ah, al)) {
-                    khi[i] = bh; klo[i] = bl; khi[p] = ah; klo[p] = al;
-                    const int32_t t = pay[i]; pay[i] = pay[p]; pay[p] = t;
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
 // Merge of n_parts lists of <= k records, EACH SORTED by (score descending, index ascending) -- what every *_topk entry
 // point returns -- into the k best.  One workgroup per query.  The lists sit side by side in LDS (Pk = k rounded up to a power
 // of two entries each, missing lists and tails filled with the smallest key) and are reduced pairwise: the element-wise
@@ -481,9 +523,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void merge_kernel(const int32_t* __re
                                                               int64_t pstride, int nq, int k, int32_t* __restrict__ out_doc,
                                                               T* __restrict__ out_score,
                                                               int32_t* __restrict__ out_n,
-                                                              int32_t* __restrict__ out_pay) {
+                                                              int32_t* __restrict__ out_pay, int only_left_over) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int q = blockIdx.x;
+    if (only_left_over && out_n[q] != -1) return;                 // merge_rank_kernel has written this query's result
     int lg = 6;
     while ((1 << lg) < k) ++lg;
     const int Pk = 1 << lg;                                       // entries per list
@@ -526,14 +569,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void merge_kernel(const int32_t* __re
         if (in_pay) pay[i] = v;
     }
     __syncthreads();
-    auto less = [&](int x, int y) { return khi[x] < khi[y] || (khi[x] == khi[y] && klo[x] < klo[y]); };
     for (int step = 1; step < NP; step <<= 1) {                   // lists a = 2 m step and b = a + step -> a
         const int n_pairs = NP / (2 * step);
         for (int idx = threadIdx.x; idx < (n_pairs << lg); idx += SCAN_THREADS) {
             const int m = idx >> lg, i = idx & (Pk - 1);
             const int ai = ((2 * m * step) << lg) + i, bi = ((2 * m * step + step) << lg) + (Pk - 1 - i);
-            if (less(ai, bi)) {
-                khi[ai] = khi[bi]; klo[ai] = klo[bi];
+            const uint64_t ah = khi[ai], bh = khi[bi];
+            const uint32_t al = klo[ai], bl = klo[bi];
+            if (key_less(ah, al, bh, bl)) {
+                khi[ai] = bh; klo[ai] = bl;
                 if (in_pay) pay[ai] = pay[bi];
             }
         }
@@ -542,13 +586,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void merge_kernel(const int32_t* __re
             for (int idx = threadIdx.x; idx < (n_pairs << (lg - 1)); idx += SCAN_THREADS) {
                 const int m = idx >> (lg - 1), t = idx & ((Pk >> 1) - 1);
                 const int a0 = ((2 * m * step) << lg) + (((t & ~(j - 1)) << 1) | (t & (j - 1))), b0 = a0 + j;
-                if (less(a0, b0)) {
-                    const uint64_t h = khi[a0]; khi[a0] = khi[b0]; khi[b0] = h;
-                    const uint32_t l = klo[a0]; klo[a0] = klo[b0]; klo[b0] = l;
+                const uint64_t ah = khi[a0], bh = khi[b0];
+                const uint32_t al = klo[a0], bl = klo[b0];
+                if (key_less(ah, al, bh, bl)) {
+                    khi[a0] = bh; khi[b0] = ah; klo[a0] = bl; klo[b0] = al;
                     if (in_pay) { const int32_t v = pay[a0]; pay[a0] = pay[b0]; pay[b0] = v; }
                 }
             }
-            __syncthreads();
+            stage_sync(j, j > 1 ? j >> 1 : Pk);                   // (after j = 1: the next round's maximum stage, or the output)
         }
     }
     const int n_sel = n_valid < k ? n_valid : k;
@@ -559,6 +604,169 @@ __global__ __launch_bounds__(SCAN_THREADS) void merge_kernel(const int32_t* __re
         if (out_pay) out_pay[(int64_t)q * k + i] = ok && in_pay ? pay[i] : -1;
     }
     if (threadIdx.x == 0) out_n[q] = n_sel;
+}
+
+// The merge most calls take.  Of N sorted lists of <= k records only a prefix of each can reach the k best: with `quota` =
+// ceil(k / lists that hold at least that many), the smallest of those lists' quota-th keys -- the CUT -- has at least k keys at
+// or above it, so nothing below it is wanted (8 lists of 1000 from statistically alike shards: ~130-200 records of each, 1.2 k
+// of the 8 k).  The prefixes (<= MRG_CAP / lists records each) are staged in LDS and every record finds its place in the output
+// by counting: its index in its own list + for every other list the number of keys above it (binary search; on equal keys --
+// the same document in two lists -- the lower list number goes first).  No compare-exchange network, no barrier after the
+// staging.  A query whose prefixes do not fit (lists from very unlike shards), or with an invalid score in them, is left to
+// the merge tree below: out_n[q] = -1 is the message.
+constexpr int MRG_THREADS = 512;
+constexpr int MRG_CAP = 2048;
+constexpr int MRG_MAX_PARTS = 64;
+
+template <typename T>
+__global__ __launch_bounds__(MRG_THREADS) void merge_rank_kernel(const int32_t* __restrict__ in_doc,
+                                                                  const T* __restrict__ in_score,
+                                                                  const int32_t* __restrict__ in_n,
+                                                                  const int32_t* __restrict__ in_pay, int n_parts,
+                                                                  int64_t pstride, int nq, int k, int32_t* __restrict__ out_doc,
+                                                                  T* __restrict__ out_score, int32_t* __restrict__ out_n,
+                                                                  int32_t* __restrict__ out_pay) {
+    __shared__ uint64_t khi[MRG_CAP];
+    __shared__ uint32_t klo[MRG_CAP];
+    __shared__ int32_t pay[MRG_CAP];
+    __shared__ int s_c[MRG_MAX_PARTS], s_len[MRG_MAX_PARTS];
+    __shared__ int s_quota, s_flag;
+    const int q = blockIdx.x, t = threadIdx.x;
+    int lgS = 11, NP = 1;
+    while (NP < n_parts) { NP <<= 1; --lgS; }
+    const int SPEC = 1 << lgS;                                    // staged records per list
+    auto part = [&](const auto* base, int p, int64_t elems) {
+        typedef decltype(base) PT;
+        return pstride ? (PT)((const char*)base + (int64_t)p * pstride) : base + (int64_t)p * elems;
+    };
+    // ONE round trip to memory: every thread asks for its list's count and its records at once (a list is k records long
+    // whatever its count: what lies behind the count is masked afterwards)
+    if (t == 0) s_flag = 0;
+    if (t < MRG_MAX_PARTS) s_c[t] = 0;
+    __syncthreads();
+    constexpr int PER = MRG_CAP / MRG_THREADS;                     // staged records per thread: all requested before any is used
+    int c_[PER], d_[PER], pv_[PER];
+    T sc_[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = t + j * MRG_THREADS, p = i >> lgS, r = i & (SPEC - 1);
+        const bool in = p < n_parts && r < k;
+        const int64_t off = (int64_t)q * k + (in ? r : 0);
+        const int pp = in ? p : 0;
+        c_[j] = in ? part(in_n, pp, nq)[q] : 0;
+        sc_[j] = part(in_score, pp, (int64_t)nq * k)[off];
+        d_[j] = part(in_doc, pp, (int64_t)nq * k)[off];
+        pv_[j] = in_pay ? part(in_pay, pp, (int64_t)nq * k)[off] : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = t + j * MRG_THREADS, p = i >> lgS, r = i & (SPEC - 1);
+        uint64_t h = 0; uint32_t l = 0; int32_t v = -1;
+        const int c = c_[j] < 0 ? 0 : (c_[j] > k ? k : c_[j]);
+        if (p < n_parts && r == 0) s_c[p] = c;
+        if (r < c) {                                              // (c = 0 for the slots outside the lists)
+            if (msr_valid(sc_[j])) { h = ScoreTraits<T>::ord(sc_[j]); l = ~(uint32_t)d_[j]; v = pv_[j]; }
+            else s_flag = 1;
+        }
+        khi[i] = h; klo[i] = l; pay[i] = v;
+    }
+    __syncthreads();
+    if (t == 0) {                                                 // quota: ceil(k / #lists with at least quota records), fixed point
+        int n_long = n_parts, quota = 0;
+        for (int it = 0; it <= n_parts && n_long > 0; ++it) {
+            quota = (k + n_long - 1) / n_long;
+            int m = 0;
+            for (int p = 0; p < n_parts; ++p) m += s_c[p] >= quota;
+            if (m == n_long) break;
+            n_long = m;
+        }
+        s_quota = n_long > 0 ? quota : 0;                         // 0: no cut (fewer than k records in all, or nearly)
+        if (s_quota > SPEC) s_flag = 1;                           // (the long lists' wanted prefixes are longer than what is staged)
+    }
+    __syncthreads();
+    const int quota = s_quota;
+    // records of list p with key > (or, with_equal, >=) the given key, among its first n
+    auto count_above = [&](int p, int n, uint64_t kh, uint32_t kl, bool with_equal) {
+        int lo = 0, hi = n;
+        const int base = p << lgS;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            const uint64_t mh = khi[base + mid];
+            const uint32_t ml = klo[base + mid];
+            const bool above = mh > kh || (mh == kh && (with_equal ? ml >= kl : ml > kl));
+            if (above) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    if (t < MRG_MAX_PARTS && !s_flag) {
+        int len = 0;
+        if (t < n_parts) {
+            const int c = s_c[t], staged = c < SPEC ? c : SPEC;
+            len = staged;
+            if (quota > 0) {
+                uint64_t ch = ~(uint64_t)0; uint32_t cl = ~0u;    // the cut: smallest quota-th key of the long lists
+                for (int p = 0; p < n_parts; ++p) {
+                    const int at = (p << lgS) + quota - 1;
+                    if (s_c[p] >= quota && key_less(khi[at], klo[at], ch, cl)) { ch = khi[at]; cl = klo[at]; }
+                }
+                len = count_above(t, staged, ch, cl, true);
+            }
+            if (len == SPEC && c > SPEC) s_flag = 1;              // the wanted prefix may be longer than what is staged
+        }
+        s_len[t] = len;
+    }
+    __syncthreads();
+    if (s_flag) {
+        if (t == 0) out_n[q] = -1;
+        return;
+    }
+    int total = 0;
+    for (int p = 0; p < n_parts; ++p) total += s_len[p];
+    const int n_sel = total < k ? total : k;
+    // record e of the `total` kept ones = record r of list p; its rank: r + what the other lists hold above it.  The searches
+    // in four other lists run side by side (independent LDS round trips).
+    for (int e = t; e < total; e += MRG_THREADS) {
+        int p = 0, r = e;
+        while (r >= s_len[p]) { r -= s_len[p]; ++p; }
+        const int i = (p << lgS) + r;
+        const uint64_t kh = khi[i];
+        const uint32_t kl = klo[i];
+        int rank = r;
+        for (int o0 = 0; o0 < n_parts; o0 += 4) {
+            int lo[4], hi[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int o = o0 + u;
+                lo[u] = 0;
+                hi[u] = o < n_parts && o != p ? s_len[o] : 0;
+            }
+            for (int st = 0; st <= lgS; ++st) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (lo[u] < hi[u]) {
+                        const int mid = (lo[u] + hi[u]) >> 1, at = ((o0 + u) << lgS) + mid;
+                        const uint64_t mh = khi[at];
+                        const uint32_t ml = klo[at];
+                        const bool above = mh > kh || (mh == kh && (o0 + u < p ? ml >= kl : ml > kl));
+                        if (above) lo[u] = mid + 1; else hi[u] = mid;
+                    }
+                }
+            }
+            rank += lo[0] + lo[1] + lo[2] + lo[3];
+        }
+        if (rank < k) {
+            const bool ok = !(kh == 0 && kl == 0);
+            out_doc[(int64_t)q * k + rank] = ok ? (int32_t)~kl : -1;
+            out_score[(int64_t)q * k + rank] = ok ? ScoreTraits<T>::unord(kh) : ScoreTraits<T>::neg_inf();
+            if (out_pay) out_pay[(int64_t)q * k + rank] = ok && in_pay ? pay[i] : -1;
+        }
+    }
+    for (int i = n_sel + t; i < k; i += MRG_THREADS) {
+        out_doc[(int64_t)q * k + i] = -1;
+        out_score[(int64_t)q * k + i] = ScoreTraits<T>::neg_inf();
+        if (out_pay) out_pay[(int64_t)q * k + i] = -1;
+    }
+    if (t == 0) out_n[q] = n_sel;
 }
 
 }  // namespace
@@ -589,16 +797,24 @@ hipError_t msr_merge_lists(int score_bits, const int32_t* in_doc, const void* in
     while (NP < n_parts) NP <<= 1;
     const size_t lds = (size_t)NP * Pk * (in_pay ? 16 : 12);
     if (lds > 150 * 1024) return hipErrorInvalidValue;
+    // the counting merge for every query it can take (out_n[q] = -1 where it cannot), the merge tree for the rest
+    const int fast = n_parts <= MRG_MAX_PARTS && n_parts > 1;
     if (score_bits == 32) {
+        if (fast)
+            merge_rank_kernel<float><<<nq, MRG_THREADS, 0, stream>>>(in_doc, (const float*)in_score, in_n, in_pay, n_parts,
+                                                                     part_stride_bytes, nq, k, out_doc, (float*)out_score, out_n, out_pay);
         if (lds > 48 * 1024)
             (void)hipFuncSetAttribute((const void*)merge_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         merge_kernel<float><<<nq, SCAN_THREADS, lds, stream>>>(in_doc, (const float*)in_score, in_n, in_pay, n_parts,
-                                                               part_stride_bytes, nq, k, out_doc, (float*)out_score, out_n, out_pay);
+                                                               part_stride_bytes, nq, k, out_doc, (float*)out_score, out_n, out_pay, fast);
     } else {
+        if (fast)
+            merge_rank_kernel<double><<<nq, MRG_THREADS, 0, stream>>>(in_doc, (const double*)in_score, in_n, in_pay, n_parts,
+                                                                      part_stride_bytes, nq, k, out_doc, (double*)out_score, out_n, out_pay);
         if (lds > 48 * 1024)
             (void)hipFuncSetAttribute((const void*)merge_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         merge_kernel<double><<<nq, SCAN_THREADS, lds, stream>>>(in_doc, (const double*)in_score, in_n, in_pay, n_parts,
-                                                                part_stride_bytes, nq, k, out_doc, (double*)out_score, out_n, out_pay);
+                                                                part_stride_bytes, nq, k, out_doc, (double*)out_score, out_n, out_pay, fast);
     }
     return hipGetLastError();
 }

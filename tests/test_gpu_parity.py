@@ -737,13 +737,26 @@ def test_merge_topk(mods, bits):
                              post_tf=np.ones(1, np.int32), idf=np.ones(1, np.float32), avgdl=1.0, total_docs=4)
     eng = mods["DeviceEngine"](ix, max_queries=2, max_k=16)
     dt = np.float32 if bits == 32 else np.float64
-    for G_, Q, k in ((2, 3, 10), (8, 5, 100), (8, 2, 1000), (1, 1, 1), (3, 4, 100), (5, 2, 37), (6, 3, 1000)):   # (the kernel is a
-        # merge tree over power-of-two list counts and lengths: odd part counts and ks exercise its phantom lists and tails)
+    # Two kernels share the work (msr_topk.hip): the counting merge over the lists' prefixes above a cut, and the merge tree
+    # (power-of-two list counts and lengths: odd part counts and ks exercise its phantom lists and tails) for the queries whose
+    # prefixes do not fit.  "random": list lengths 0 .. k, many exact ties; "full": every list k long, scores alike (the
+    # counting merge takes these); "skewed": one list holds nearly all of the best (left to the tree).
+    for G_, Q, k, shape in ((2, 3, 10, "random"), (8, 5, 100, "random"), (8, 2, 1000, "random"), (1, 1, 1, "random"),
+                            (3, 4, 100, "random"), (5, 2, 37, "random"), (6, 3, 1000, "random"), (8, 3, 1000, "full"),
+                            (2, 2, 1000, "full"), (4, 3, 100, "full"), (8, 3, 1000, "skewed"), (3, 2, 700, "skewed"),
+                            (16, 2, 500, "full"), (64, 2, 100, "full")):
         docs = np.full((G_, Q, k), -1, np.int32); sc = np.full((G_, Q, k), -np.inf, dt); ns = np.zeros((G_, Q), np.int32)
         for g in range(G_):
             for qi in range(Q):
-                m = int(rng.integers(0, k + 1))
-                s = np.sort(rng.integers(0, 50, size=m).astype(dt) / 7)[::-1]     # many exact ties
+                m = int(rng.integers(0, k + 1)) if shape == "random" else k
+                if shape == "random":
+                    s = np.sort(rng.integers(0, 50, size=m).astype(dt) / 7)[::-1]     # many exact ties
+                elif shape == "full":
+                    s = np.sort(rng.standard_normal(m).astype(dt))[::-1]
+                    if qi == 1:
+                        s = np.round(s, 1)                                            # ties across and inside the lists
+                else:
+                    s = np.sort((rng.standard_normal(m) + (6.0 if g == 1 else 0.0)).astype(dt))[::-1]
                 d = rng.choice(np.arange(g * 100000, (g + 1) * 100000), size=m, replace=False).astype(np.int32)
                 o = np.lexsort((d, -s.astype(np.float64)))
                 docs[g, qi, :m], sc[g, qi, :m], ns[g, qi] = d[o], s[o], m
