@@ -564,7 +564,12 @@ def main():
         from msretr.distributed import _RerankExchange
         NE = args.emulate_ranks
         rx = _RerankExchange(NE, Q, args.k1, args.k2, dev)
-        slot = torch.arange(args.k1, device=dev).unsqueeze(0)
+        plan = rx.records()
+        # the merged candidate lists of an NE-way run: slot m of every list belongs to shard m % NE (shard 0 = this engine:
+        # global index = local index + (m % NE) * documents per shard), so this rank owns 1 / NE of every query's candidates
+        slot_shard = (torch.arange(args.k1, device=dev) % NE).to(torch.int32).unsqueeze(0)
+        e_bounds = (torch.arange(NE + 1, dtype=torch.int64) * shard.n_docs).to(torch.int32).to(dev)
+        e_src = torch.arange(NE, dtype=torch.int32, device=dev).view(NE, 1)
 
         def step(i, one=None):                          # noqa: F811  (replaces the step above)
             packed, qv = one if one is not None else batches[i % len(batches)]
@@ -592,12 +597,23 @@ def main():
             eng.merge_topk(rep(d[0]), rep(d[1]), rep(d[3]), args.k2)
             if nq != Q:                                  # (the single-query latency loop: local stages only)
                 return {"bm25": b, "dense": d}
-            cand = torch.where(slot % NE == 0, b[0], torch.full_like(b[0], -1))   # a rank owns 1 / NE of the merged candidates
-            eng.rerank_gather_blocks(qv, cand, b[2], rx.a2a_send.view(NE, rx.block), rx.Qs)      # one launch, all destination blocks
-            rx.a2a_recv.copy_(rx.a2a_send)               # (where the all-to-all would be)
-            cp, mp = rx.recv_parts()
-            cos, meta = eng.rerank_combine(cp, mp, rx.Qs)
-            r = eng.rerank_fuse(b[0][:rx.Qs], b[1][:rx.Qs], b[2][:rx.Qs], cos, meta)
+            # the rerank exchange in its compact form (distributed.py): count who owns what, the N x N matrix to the host (in
+            # the real run that copy is made before the dense stage and read here; the emulation keeps the wait where it is
+            # cheapest to reason about: right here, unhidden), records of the owned slots, scatter, fuse for Qs queries
+            cand = torch.where(b[0] >= 0, b[0] + slot_shard * shard.n_docs, b[0])
+            eng.rerank_plan(cand, b[2], e_bounds, 0, rx.Qs, plan)
+            plan.to_host()
+            eng.rerank_gather_records(qv, cand, b[2], plan, rx.rec_send)          # one launch, all destinations
+            send_splits, recv_splits = plan.splits(0)
+            # where the all-to-all would be: what arrives is as large as the plan says; its content -- source g's records for
+            # MY queries -- is stood in for by this rank's own records for them, the slots moved to source g's slots
+            c = min(recv_splits) // 16
+            got = rx.rec_recv[:NE * c * 16].view(NE, c, 16)
+            got.copy_(rx.rec_send[:c * 16].view(1, c, 16).expand(NE, c, 16))
+            got[:, :, 0] += e_src
+            got[:, :, 2] += e_src * shard.n_docs            # (and its URL group: the owner's documents are other documents)
+            cos, meta = eng.rerank_scatter(rx.rec_recv, plan, 0, rx.Qs, args.k1)
+            r = eng.rerank_fuse(cand[:rx.Qs], b[1][:rx.Qs], b[2][:rx.Qs], cos, meta)
             return {"bm25": b, "dense": d, "rerank": r}
 
     def fence():
@@ -787,7 +803,14 @@ def main():
     if "bm25" in out:
         ok = ok and bool((out["bm25"][2] > 0).all().item())
     if "rerank" in out:
-        ok = ok and bool((out["rerank"][4] > 0).all().item())
+        if args.emulate_ranks > 1:                    # (the stand-in for the received records is not aligned query by query:
+            #                                           a short list at the end of a source's region may get another query's slots)
+            ok = ok and float((out["rerank"][4] > 0).float().mean().item()) >= 0.98
+        else:
+            ok = ok and bool((out["rerank"][4] > 0).all().item())
+    if not ok:                                        # say which list failed
+        log("outputs_sane false:", {k: [int((v[-1 if k == "dense" else 2 if k == "bm25" else 4] <= 0).sum().item()), len(v[0])]
+                                    for k, v in out.items()})
 
     verified = None
     if args.verify and world > 1:

@@ -272,6 +272,34 @@ int msr_rerank_combine(msr_engine* e, const float* cos_parts, const int32_t* met
                        int64_t part_stride_bytes, int32_t n_queries, int32_t max_cand, float* out_cos,
                        int32_t* out_meta, void* stream);
 
+/* The COMPACT form of that exchange (round 4; msretr/distributed.py uses it by default).  A rank of an N-way run owns ~1/N of a
+ * query's candidates, so the blocks of msr_rerank_gather_blocks are mostly zero words (52 KB per query and rank at max_cand =
+ * 1000).  Here a rank sends one RECORD of 16 words per candidate slot it owns -- [slot, rows, url_group + 2, first row,
+ * cos x 10 (float bits), query, 0] -- and every rank can size the exchange without talking to anyone: the merged candidate
+ * lists are replicated and the shards are document ranges (shard s owns shard_bounds[s] <= doc < shard_bounds[s + 1], device
+ * array of n_shards + 1), so
+ *   msr_rerank_plan counts, for ALL shards, counts[s][q] = candidates of query q that shard s owns, and derives from it
+ *     send_base[q] / send_blk[q][ceil(max_cand / 8)]: the record number of the first owned slot of query q / of each block of
+ *       8 slots within the query, in THIS rank's send buffer (records ordered by query, then slot: the records for the
+ *       queries of rank o -- queries [o * queries_per_shard, (o + 1) * queries_per_shard) -- are contiguous),
+ *     recv_off[s][j]: the record number, in the receive buffer, of the first record source s sends for my j-th query,
+ *     pair[s][o]: records source s sends to rank o -- the split sizes of the all-to-all (x 16 words), which the host reads;
+ *   msr_rerank_gather_records is msr_rerank_gather writing those records (nothing for slots of other shards);
+ *   msr_rerank_scatter puts the received records of my queries [first_query, first_query + n_my_queries) into the dense
+ *     out_cos [n_my_queries][max_cand][10] / out_meta [..][3] msr_rerank_fuse reads (zeroed first: a slot nobody owns stays
+ *     "no document").  The result equals msr_rerank_combine over the dense halves, bit for bit.
+ * All arrays are device pointers.  No reference counterpart (reranker_api.py:27-63 fetches all rows from one database). */
+int msr_rerank_plan(msr_engine* e, int32_t n_queries, const int32_t* cand_doc, const int32_t* cand_n, int32_t max_cand,
+                    const int32_t* shard_bounds, int32_t n_shards, int32_t my_shard, int32_t queries_per_shard,
+                    int32_t* counts, int32_t* send_base, int32_t* send_blk, int32_t* recv_off, int32_t* pair, void* stream);
+int msr_rerank_gather_records(msr_engine* e, const float* q, int32_t n_queries, const int32_t* cand_doc,
+                              const int32_t* cand_n, int32_t max_cand, int32_t doc_base, int32_t row_base,
+                              int32_t max_chunks, const int32_t* send_base, const int32_t* send_blk, int32_t* out_records,
+                              void* stream);
+int msr_rerank_scatter(msr_engine* e, const int32_t* records, const int32_t* counts, const int32_t* recv_off,
+                       int32_t n_shards, int32_t n_queries, int32_t queries_per_shard, int32_t first_query,
+                       int32_t n_my_queries, int32_t max_cand, float* out_cos, int32_t* out_meta, void* stream);
+
 /* Merge n_parts per-shard top-k lists (the payload of the RCCL all-gather) into the global top-k.
  * in_doc [n_parts][n_queries][k] i32 GLOBAL doc indices, in_score same shape (score_bits = 32: f32,
  * 64: f64), in_n [n_parts][n_queries].  Order: score desc, doc index asc -- identical on every rank.

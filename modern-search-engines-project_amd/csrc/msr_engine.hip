@@ -1100,10 +1100,11 @@ extern "C" int msr_dense_topk_bf16(msr_engine* e, const float* q, int32_t n_quer
 
 static int rerank_gather_impl(msr_engine* e, const char* fn, const float* q, int32_t n_queries, const int32_t* cand_doc,
                               const int32_t* cand_n, int32_t max_cand, int32_t doc_base, int32_t row_base, int32_t max_chunks,
-                              float* out_cos, int32_t* out_meta, int32_t q_per_block, int64_t block_stride, void* stream) {
+                              float* out_cos, int32_t* out_meta, int32_t q_per_block, int64_t block_stride, void* stream,
+                              const RerankRecords* rec = nullptr) {
     if (!e) return MSR_ERR_INVALID;
     if (!e->have_chunks) return fail(e, MSR_ERR_NOT_BOUND, "%s: chunks not bound", fn);
-    if (!q || !cand_doc || !cand_n || !out_cos || !out_meta) return fail(e, MSR_ERR_INVALID, "%s: null argument", fn);
+    if (!q || !cand_doc || !cand_n || (!rec && (!out_cos || !out_meta))) return fail(e, MSR_ERR_INVALID, "%s: null argument", fn);
     int rc = rerank_args_ok(e, fn, n_queries, max_cand, max_chunks);
     if (rc) return rc;
     if (e->url_group && e->url_group_n != e->dense.n_docs)
@@ -1123,8 +1124,10 @@ static int rerank_gather_impl(msr_engine* e, const char* fn, const float* q, int
         const bool blocked = q_per_block < n_queries;
         float* co = blocked ? out_cos + (int64_t)(q0 / q_per_block) * block_stride : out_cos + o * MSR_RERANK_MAX_CHUNKS;
         int32_t* mo = blocked ? out_meta + (int64_t)(q0 / q_per_block) * block_stride : out_meta + o * 3;
+        RerankRecords rr{nullptr, nullptr, nullptr};
+        if (rec) rr = RerankRecords{rec->out, rec->q_base + q0, rec->blk_off + (int64_t)q0 * ((max_cand + 7) / 8)};
         HIP_TRY(e, msr_rerank_gather(e->dense, e->url_group, e->rr_qn, nq, cand_doc + o, cand_n + q0, max_cand, doc_base,
-                                     row_base, max_chunks, co, mo, blocked ? q_per_block : nq, blocked ? block_stride : 0, st));
+                                     row_base, max_chunks, co, mo, blocked ? q_per_block : nq, blocked ? block_stride : 0, rr, st));
     }
     return MSR_OK;
 }
@@ -1148,6 +1151,50 @@ extern "C" int msr_rerank_gather_blocks(msr_engine* e, const float* q, int32_t n
     return rerank_gather_impl(e, "msr_rerank_gather_blocks", q, n_queries, cand_doc, cand_n, max_cand, doc_base, row_base,
                               max_chunks, (float*)out_blocks, out_blocks + (int64_t)queries_per_block * max_cand * MSR_RERANK_MAX_CHUNKS,
                               queries_per_block, block_words, stream);
+}
+
+extern "C" int msr_rerank_plan(msr_engine* e, int32_t n_queries, const int32_t* cand_doc, const int32_t* cand_n,
+                               int32_t max_cand, const int32_t* shard_bounds, int32_t n_shards, int32_t my_shard,
+                               int32_t queries_per_shard, int32_t* counts, int32_t* send_base, int32_t* send_blk,
+                               int32_t* recv_off, int32_t* pair, void* stream) {
+    if (!e) return MSR_ERR_INVALID;
+    if (!cand_doc || !cand_n || !shard_bounds || !counts || !send_base || !send_blk || !recv_off || !pair || n_queries < 0 ||
+        max_cand < 1 || max_cand > 1024 || n_shards < 1 || n_shards > 64 || my_shard < 0 || my_shard >= n_shards ||
+        queries_per_shard < 1 || (int64_t)queries_per_shard * n_shards < n_queries)
+        return fail(e, MSR_ERR_INVALID, "msr_rerank_plan: bad argument (n_shards=%d, my_shard=%d, queries_per_shard=%d)", n_shards,
+                    my_shard, queries_per_shard);
+    if (n_queries == 0) return MSR_OK;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, msr_rerank_plan_run(n_queries, cand_doc, cand_n, max_cand, shard_bounds, n_shards, my_shard, queries_per_shard,
+                                   counts, send_base, send_blk, recv_off, pair, (hipStream_t)stream));
+    return MSR_OK;
+}
+
+extern "C" int msr_rerank_gather_records(msr_engine* e, const float* q, int32_t n_queries, const int32_t* cand_doc,
+                                         const int32_t* cand_n, int32_t max_cand, int32_t doc_base, int32_t row_base,
+                                         int32_t max_chunks, const int32_t* send_base, const int32_t* send_blk,
+                                         int32_t* out_records, void* stream) {
+    if (!e) return MSR_ERR_INVALID;
+    if (!send_base || !send_blk || !out_records) return fail(e, MSR_ERR_INVALID, "msr_rerank_gather_records: null argument");
+    const RerankRecords rec{out_records, send_base, send_blk};
+    return rerank_gather_impl(e, "msr_rerank_gather_records", q, n_queries, cand_doc, cand_n, max_cand, doc_base, row_base,
+                              max_chunks, nullptr, nullptr, n_queries > 0 ? n_queries : 1, 0, stream, &rec);
+}
+
+extern "C" int msr_rerank_scatter(msr_engine* e, const int32_t* records, const int32_t* counts, const int32_t* recv_off,
+                                  int32_t n_shards, int32_t n_queries, int32_t queries_per_shard, int32_t first_query,
+                                  int32_t n_my_queries, int32_t max_cand, float* out_cos, int32_t* out_meta, void* stream) {
+    if (!e) return MSR_ERR_INVALID;
+    if (!records || !counts || !recv_off || !out_cos || !out_meta || n_shards < 1 || n_shards > 64 || max_cand < 1 ||
+        max_cand > 1024 || n_my_queries < 0 || n_my_queries > queries_per_shard || first_query < 0 ||
+        first_query + n_my_queries > n_queries)
+        return fail(e, MSR_ERR_INVALID, "msr_rerank_scatter: bad argument (n_shards=%d, first_query=%d, n_my_queries=%d)", n_shards,
+                    first_query, n_my_queries);
+    if (n_my_queries == 0) return MSR_OK;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, msr_rerank_scatter_run(records, counts, recv_off, n_shards, n_queries, queries_per_shard, first_query,
+                                      n_my_queries, max_cand, out_cos, out_meta, (hipStream_t)stream));
+    return MSR_OK;
 }
 
 extern "C" int msr_rerank_fuse(msr_engine* e, int32_t n_queries, const int32_t* cand_doc, const double* cand_bm25,

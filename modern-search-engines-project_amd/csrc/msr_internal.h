@@ -182,11 +182,29 @@ struct RerankParams {
     double smoothing, max_boost, max_decay;
     int32_t max_chunks;
 };
+// The compact form of (A)'s output (sharded runs): a record of MSR_RERANK_RECORD_WORDS words per OWNED slot, at record number
+// q_base[q] + blk_off[q][slot / 8] + (owned slots before it in its block of 8).  out == nullptr: the dense arrays.
+#define MSR_RERANK_RECORD_WORDS 16
+struct RerankRecords {
+    int32_t* out;
+    const int32_t* q_base;
+    const int32_t* blk_off;
+};
 // (A) cosines + (rows, url group, first row) of the candidates this shard owns; zeros for the others.
 hipError_t msr_rerank_gather(const DenseIndex& ix, const int32_t* url_group, const float* qn, int nq,
                              const int32_t* cand_doc, const int32_t* cand_n, int max_cand, int doc_base,
                              int row_base, int max_chunks, float* cos_out /*[nq][max_cand][10]*/,
-                             int32_t* meta /*[nq][max_cand][3]*/, int q_per_block, int64_t block_stride, hipStream_t stream);
+                             int32_t* meta /*[nq][max_cand][3]*/, int q_per_block, int64_t block_stride,
+                             const RerankRecords& rec, hipStream_t stream);
+// counts[s][q]: candidates of query q that shard s owns (bounds[s] <= doc < bounds[s + 1]); send_base / blk_off: see
+// RerankRecords (for shard `my`); recv_off[s][j]: first record of (source s, query my * qps + j) in the receive buffer of an
+// all-to-all whose (source, destination) blocks hold pair[s][o] records
+hipError_t msr_rerank_plan_run(int nq, const int32_t* cand_doc, const int32_t* cand_n, int max_cand, const int32_t* bounds,
+                               int n_shards, int my, int qps, int32_t* counts, int32_t* send_base, int32_t* blk_off,
+                               int32_t* recv_off, int32_t* pair, hipStream_t stream);
+hipError_t msr_rerank_scatter_run(const int32_t* records, const int32_t* counts, const int32_t* recv_off, int n_shards, int nq,
+                                  int qps, int q_first, int n_mine, int max_cand, float* cos_out, int32_t* meta_out,
+                                  hipStream_t stream);
 // (q_per_block / block_stride: query q's rows start (q / q_per_block) * block_stride 32-bit words + (q % q_per_block) rows
 // into cos_out / meta -- the blocks of an all-to-all send buffer; one contiguous array: q_per_block >= nq, any stride)
 // (B) the float64 chain; needs no index.

@@ -38,11 +38,14 @@ __global__ __launch_bounds__(64) void rerank_cos_kernel(DenseIndex ix, const int
                                                          const int32_t* __restrict__ cand_n, int max_cand,
                                                          int doc_base, int row_base, int max_chunks,
                                                          float* __restrict__ cos_out, int32_t* __restrict__ meta,
-                                                         int q_per_block, int64_t block_stride) {
+                                                         int q_per_block, int64_t block_stride, RerankRecords rec) {
     // cand_doc holds GLOBAL document indices; this shard owns [doc_base, doc_base + n_docs).
     // Output layout: query q's rows start (q / q_per_block) * block_stride words + (q % q_per_block) rows into cos_out / meta
     // (one contiguous array: q_per_block >= the number of queries; the blocks of an all-to-all send buffer: see msretr.h).
+    // RECORDS (rec.out != null): nothing is written for the slots this shard does not own; an owned slot becomes a 16-word
+    // record [slot, rows, url group + 2, first row, cos x 10, query, 0] at the place rerank_plan_kernel counted out for it.
     const int q = blockIdx.y, m0 = blockIdx.x * RC_SLOTS, lane = threadIdx.x;
+    const bool records = rec.out != nullptr;
     cos_out += (int64_t)(q / q_per_block) * block_stride + (int64_t)(q % q_per_block) * max_cand * RR_MAXC;
     meta += (int64_t)(q / q_per_block) * block_stride + (int64_t)(q % q_per_block) * max_cand * 3;
     int d_mine = -1;
@@ -52,7 +55,7 @@ __global__ __launch_bounds__(64) void rerank_cos_kernel(DenseIndex ix, const int
         if (slot && m < cand_n[q]) d_mine = cand_doc[(int64_t)q * max_cand + m] - doc_base;
         const bool own = d_mine >= 0 && d_mine < ix.n_docs;
         if (!own) d_mine = -1;
-        if (slot && !own) {                              // not a candidate, or owned by another shard
+        if (slot && !own && !records) {                  // not a candidate, or owned by another shard
             float* out = cos_out + (int64_t)m * RR_MAXC;
             int32_t* mt = meta + (int64_t)m * 3;
 #pragma unroll
@@ -62,6 +65,10 @@ __global__ __launch_bounds__(64) void rerank_cos_kernel(DenseIndex ix, const int
     }
     unsigned long long todo = __ballot(d_mine >= 0);
     if (todo == 0) return;
+    const unsigned long long mine_all = todo;
+    int32_t* rec0 = nullptr;
+    if (records)
+        rec0 = rec.out + ((int64_t)rec.q_base[q] + rec.blk_off[(int64_t)q * gridDim.x + blockIdx.x]) * MSR_RERANK_RECORD_WORDS;
     const f32x4* q4 = (const f32x4*)(qn + (size_t)q * MSR_DIM);
     const f32x4 qa = q4[lane], qb = q4[lane + 64], qc = q4[lane + 128];
     for (; todo != 0; todo &= todo - 1) {
@@ -69,6 +76,12 @@ __global__ __launch_bounds__(64) void rerank_cos_kernel(DenseIndex ix, const int
         const int d = __builtin_amdgcn_readlane(d_mine, sl), m = m0 + sl;
         float* out = cos_out + (int64_t)m * RR_MAXC;
         int32_t* mt = meta + (int64_t)m * 3;
+        if (records) {
+            int32_t* r = rec0 + (int64_t)__builtin_popcountll(mine_all & ((1ull << sl) - 1)) * MSR_RERANK_RECORD_WORDS;
+            out = (float*)(r + 4);
+            mt = r + 1;
+            if (lane == 0) { r[0] = m; r[14] = q; r[15] = 0; }
+        }
         const int64_t ds = ix.doc_off[d];
         int64_t de = ix.doc_off[d + 1];
         if (ds + max_chunks < de) de = ds + max_chunks;
@@ -405,7 +418,158 @@ __global__ __launch_bounds__(DV_THREADS) void diversify_kernel(
     if (tid == 0) out_n[q] = n_out;
 }
 
+// ---- the sharded rerank's compact exchange ------------------------------------------------------------------------------
+// A rank of an N-way run owns ~1/N of a query's candidates: the dense halves of msr_rerank_gather_blocks are 13 words per
+// SLOT, mostly zeros.  Compact: a 16-word record per OWNED slot, variable counts -- which every rank can work out for every
+// (source, query) without talking to anyone, because the merged candidate lists are replicated and the shards are document
+// ranges.  rerank_plan_kernel counts, rerank_offsets_kernel turns the counts into the places of the records in the send and
+// receive buffers and into the N x N matrix of records per (source, destination) the host sizes the all-to-all with.
+constexpr int RP_THREADS = 256;
+__global__ __launch_bounds__(RP_THREADS) void rerank_plan_kernel(const int32_t* __restrict__ cand_doc,
+                                                                  const int32_t* __restrict__ cand_n, int max_cand,
+                                                                  const int32_t* __restrict__ bounds, int n_shards, int my,
+                                                                  int nq, int32_t* __restrict__ counts,
+                                                                  int32_t* __restrict__ blk_off) {
+    __shared__ int s_cnt[64];
+    __shared__ int s_blk[RR_MAXM / RC_SLOTS + 1];
+    const int q = blockIdx.x, t = threadIdx.x;
+    const int n_blk = (max_cand + RC_SLOTS - 1) / RC_SLOTS;
+    if (t < 64) s_cnt[t] = 0;
+    __syncthreads();
+    int n = cand_n[q];
+    if (n > max_cand) n = max_cand;
+    const int lo_my = bounds[my], hi_my = bounds[my + 1];
+    for (int m0 = 0; m0 < n_blk * RC_SLOTS; m0 += RP_THREADS) {           // (whole waves: the ballot below)
+        const int m = m0 + t;
+        int owner = -1;
+        const int d = m < n ? cand_doc[(int64_t)q * max_cand + m] : -1;
+        if (d >= bounds[0] && d < bounds[n_shards]) {
+            int a = 0, b = n_shards;                                       // bounds[a] <= d < bounds[b]
+            while (b - a > 1) {
+                const int c = (a + b) >> 1;
+                if (d >= bounds[c]) a = c; else b = c;
+            }
+            owner = a;
+        }
+        if (owner >= 0) atomicAdd(&s_cnt[owner], 1);
+        const unsigned long long mine = __ballot(d >= lo_my && d < hi_my);
+        if ((t & (RC_SLOTS - 1)) == 0 && m < n_blk * RC_SLOTS)
+            s_blk[m / RC_SLOTS] = __builtin_popcountll((mine >> (t & 63)) & ((1ull << RC_SLOTS) - 1));
+    }
+    __syncthreads();
+    if (t < n_shards) counts[(int64_t)t * nq + q] = s_cnt[t];
+    if (t == 0) {                                                          // <= 128 blocks: a serial prefix in LDS
+        int acc = 0;
+        for (int b = 0; b < n_blk; ++b) { const int c = s_blk[b]; s_blk[b] = acc; acc += c; }
+    }
+    __syncthreads();
+    for (int b = t; b < n_blk; b += RP_THREADS) blk_off[(int64_t)q * n_blk + b] = s_blk[b];
+}
+
+constexpr int RO_THREADS = 1024;
+// exclusive prefix of in[0 .. n) + base -> out, by one workgroup
+__device__ void block_excl_scan(const int32_t* __restrict__ in, int n, int base, int32_t* __restrict__ out, int* sh) {
+    const int t = threadIdx.x, per = (n + RO_THREADS - 1) / RO_THREADS;
+    const int a = t * per < n ? t * per : n, b = a + per < n ? a + per : n;
+    int sum = 0;
+    for (int i = a; i < b; ++i) sum += in[i];
+    sh[t] = sum;
+    __syncthreads();
+    for (int o = 1; o < RO_THREADS; o <<= 1) {
+        const int v = t >= o ? sh[t - o] : 0;
+        __syncthreads();
+        sh[t] += v;
+        __syncthreads();
+    }
+    int acc = base + sh[t] - sum;
+    for (int i = a; i < b; ++i) { out[i] = acc; acc += in[i]; }
+    __syncthreads();
+}
+// sum of in[0 .. n) by ONE wave (every lane gets it)
+__device__ __forceinline__ int wave_sum(const int32_t* __restrict__ in, int n) {
+    int sum = 0;
+    for (int i = threadIdx.x & 63; i < n; i += 64) sum += in[i];
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    return sum;
+}
+// block s < n_shards: the places of source s' records for MY queries in the receive buffer; block n_shards: the places of my
+// records in the send buffer; block n_shards + 1: pair[s][o] = records source s has for the queries of rank o (a wave per
+// pair, no barrier).
+__global__ __launch_bounds__(RO_THREADS) void rerank_offsets_kernel(const int32_t* __restrict__ counts, int n_shards, int my,
+                                                                     int nq, int qps, int32_t* __restrict__ send_base,
+                                                                     int32_t* __restrict__ recv_off,
+                                                                     int32_t* __restrict__ pair) {
+    __shared__ int sh[RO_THREADS];
+    __shared__ int s_base[64];
+    const int b = blockIdx.x, w = threadIdx.x >> 6;
+    const int lo = my * qps < nq ? my * qps : nq, hi = lo + qps < nq ? lo + qps : nq;
+    if (b < n_shards) {
+        for (int s = w; s < b; s += RO_THREADS / 64) {                     // what the sources before b send me
+            const int v = wave_sum(counts + (int64_t)s * nq + lo, hi - lo);
+            if ((threadIdx.x & 63) == 0) s_base[s] = v;
+        }
+        __syncthreads();
+        int base = 0;
+        for (int s = 0; s < b; ++s) base += s_base[s];
+        block_excl_scan(counts + (int64_t)b * nq + lo, hi - lo, base, recv_off + (int64_t)b * qps, sh);
+    } else if (b == n_shards) {
+        block_excl_scan(counts + (int64_t)my * nq, nq, 0, send_base, sh);
+    } else {
+        for (int p = w; p < n_shards * n_shards; p += RO_THREADS / 64) {
+            const int s = p / n_shards, o = p - s * n_shards;
+            const int a0 = o * qps < nq ? o * qps : nq, a1 = a0 + qps < nq ? a0 + qps : nq;
+            const int v = wave_sum(counts + (int64_t)s * nq + a0, a1 - a0);
+            if ((threadIdx.x & 63) == 0) pair[p] = v;
+        }
+    }
+}
+
+// The receiving side: the records of (source s, my query j) go to their slots of the dense arrays the fuse kernel reads
+// (zeroed beforehand: a slot nobody owns stays "no document").  One workgroup per (query, source).
+__global__ __launch_bounds__(256) void rerank_scatter_kernel(const int32_t* __restrict__ records,
+                                                              const int32_t* __restrict__ counts,
+                                                              const int32_t* __restrict__ recv_off, int nq, int qps, int q_first,
+                                                              int max_cand, float* __restrict__ cos_out,
+                                                              int32_t* __restrict__ meta_out) {
+    const int j = blockIdx.x, s = blockIdx.y;
+    const int cnt = counts[(int64_t)s * nq + q_first + j];
+    const int32_t* rec = records + (int64_t)recv_off[(int64_t)s * qps + j] * MSR_RERANK_RECORD_WORDS;
+    for (int i = threadIdx.x; i < cnt * 13; i += 256) {
+        const int r = i / 13, w = i - 13 * r;
+        const int32_t* rr = rec + (int64_t)r * MSR_RERANK_RECORD_WORDS;
+        const int slot = rr[0];
+        if (slot < 0 || slot >= max_cand) continue;                       // (never, with records this library wrote)
+        if (w < 3) meta_out[((int64_t)j * max_cand + slot) * 3 + w] = rr[1 + w];
+        else cos_out[((int64_t)j * max_cand + slot) * RR_MAXC + (w - 3)] = __int_as_float(rr[4 + (w - 3)]);
+    }
+}
+
 }  // namespace
+
+hipError_t msr_rerank_plan_run(int nq, const int32_t* cand_doc, const int32_t* cand_n, int max_cand, const int32_t* bounds,
+                               int n_shards, int my, int qps, int32_t* counts, int32_t* send_base, int32_t* blk_off,
+                               int32_t* recv_off, int32_t* pair, hipStream_t stream) {
+    if (nq <= 0) return hipSuccess;
+    if (max_cand <= 0 || max_cand > RR_MAXM || n_shards < 1 || n_shards > 64 || my < 0 || my >= n_shards || qps < 1)
+        return hipErrorInvalidValue;
+    rerank_plan_kernel<<<nq, RP_THREADS, 0, stream>>>(cand_doc, cand_n, max_cand, bounds, n_shards, my, nq, counts, blk_off);
+    rerank_offsets_kernel<<<n_shards + 2, RO_THREADS, 0, stream>>>(counts, n_shards, my, nq, qps, send_base, recv_off, pair);
+    return hipGetLastError();
+}
+
+hipError_t msr_rerank_scatter_run(const int32_t* records, const int32_t* counts, const int32_t* recv_off, int n_shards, int nq,
+                                  int qps, int q_first, int n_mine, int max_cand, float* cos_out, int32_t* meta_out,
+                                  hipStream_t stream) {
+    if (n_mine <= 0) return hipSuccess;
+    if (max_cand <= 0 || max_cand > RR_MAXM || n_shards < 1 || n_shards > 64) return hipErrorInvalidValue;
+    hipError_t err = hipMemsetAsync(cos_out, 0, (size_t)n_mine * max_cand * RR_MAXC * 4, stream);
+    if (err != hipSuccess) return err;
+    err = hipMemsetAsync(meta_out, 0, (size_t)n_mine * max_cand * 3 * 4, stream);
+    if (err != hipSuccess) return err;
+    rerank_scatter_kernel<<<dim3((unsigned)n_mine, (unsigned)n_shards), 256, 0, stream>>>(records, counts, recv_off, nq, qps,
+                                                                                           q_first, max_cand, cos_out, meta_out);
+    return hipGetLastError();
+}
 
 hipError_t msr_diversify_run(int nq, const int32_t* f_doc, const double* f_score, const double* f_orig, const int32_t* f_chunk,
                              const int32_t* f_n, int max_cand, const int32_t* doc_domain, int64_t n_domain_docs, int top_k,
@@ -421,16 +585,16 @@ hipError_t msr_diversify_run(int nq, const int32_t* f_doc, const double* f_score
 hipError_t msr_rerank_gather(const DenseIndex& ix, const int32_t* url_group, const float* qn, int nq,
                              const int32_t* cand_doc, const int32_t* cand_n, int max_cand, int doc_base,
                              int row_base, int max_chunks, float* cos_out, int32_t* meta, int q_per_block,
-                             int64_t block_stride, hipStream_t stream) {
+                             int64_t block_stride, const RerankRecords& rec, hipStream_t stream) {
     if (nq <= 0) return hipSuccess;
     if (max_cand <= 0 || max_cand > RR_MAXM || max_chunks <= 0 || max_chunks > RR_MAXC || q_per_block < 1) return hipErrorInvalidValue;
     dim3 grid((unsigned)((max_cand + RC_SLOTS - 1) / RC_SLOTS), (unsigned)nq);
     if (ix.layout == 1)
         rerank_cos_kernel<true><<<grid, 64, 0, stream>>>(ix, url_group, qn, cand_doc, cand_n, max_cand, doc_base,
-                                                         row_base, max_chunks, cos_out, meta, q_per_block, block_stride);
+                                                         row_base, max_chunks, cos_out, meta, q_per_block, block_stride, rec);
     else
         rerank_cos_kernel<false><<<grid, 64, 0, stream>>>(ix, url_group, qn, cand_doc, cand_n, max_cand, doc_base,
-                                                          row_base, max_chunks, cos_out, meta, q_per_block, block_stride);
+                                                          row_base, max_chunks, cos_out, meta, q_per_block, block_stride, rec);
     return hipGetLastError();
 }
 

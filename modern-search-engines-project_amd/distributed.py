@@ -4,20 +4,25 @@ The corpus is cut into contiguous ranges of the dense document index (balanced b
 CorpusIndex.shard).  Global statistics (idf, avgdl) are replicated, so a shard's BM25 scores are bit-equal
 to the unsharded ones.  Per query batch:
 
-  1. every rank: BM25 top-k1 and dense top-k2 over its shard                 (msr_bm25_topk / msr_dense_topk)
-  2. ONE all-gather of the packed per-shard lists (k1*(4+8) + k2*(4+4+4) bytes per query), send and receive buffers
-     allocated once per batch shape
-  3. every rank: the same deterministic merge (score desc, doc index asc), reading the gathered records in place; the
-     arg-max chunk row of a dense entry rides along as the merge payload          (msr_merge_topk_payload)
-  4. reference-exact rerank of the GLOBAL stage-1 candidates, sharded BY QUERY for everything that is not tied to the
+  1. every rank: BM25 top-k1 over its shard (msr_bm25_topk); ONE all-gather of the packed lists (k1 * (4 + 8) bytes per
+     query; send and receive buffers allocated once per batch shape); every rank: the same deterministic merge (score desc,
+     doc index asc), reading the gathered records in place (msr_merge_topk_payload).  The merged candidate lists are
+     replicated and the shards are document ranges, so every rank can now COUNT who owns which candidate
+     (msr_rerank_plan); the N x N matrix of counts goes to the host beside step 2.
+  2. every rank: dense top-k2 over its shard, the shards agreeing on a bound first (one all-reduce MIN of a float per
+     query, see _dense); ONE all-gather of the lists (k2 * 12 bytes per query), merge; the arg-max chunk row of a dense
+     entry rides along as the merge payload.
+  3. reference-exact rerank of the GLOBAL stage-1 candidates, sharded BY QUERY for everything that is not tied to the
      documents: rank r owns queries [r Qs, (r + 1) Qs), Qs = ceil(Q / world).
-       a. every rank computes the cosines / meta of the candidates it owns, for all queries (msr_rerank_gather), straight
-          into the send buffer of
-       b. ONE all-to-all: the half of query q goes to the rank that owns q (xGMI is point to point: every link carries
-          1 / world of a rank's buffer at the same time -- an all-reduce of the same words moved twice the bytes around a
-          ring and left every rank with all queries);
-       c. the owner joins the `world` halves (bitwise OR: exactly one rank wrote non-zero words per candidate,
-          msr_rerank_combine) and runs the float64 chain for ITS queries only (msr_rerank_fuse: 1 / world of the work);
+       a. every rank computes the cosines / meta of the candidates it owns, for all queries, as 16-word RECORDS of the owned
+          slots only (msr_rerank_gather_records), straight into the send buffer of
+       b. ONE all-to-all with the split sizes of step 1's matrix (the host waits for that copy here -- it was made before
+          the dense stage ran, so the wait is over before it starts): the records of query q go to the rank that owns q
+          (xGMI is point to point: every link carries its pair's records at the same time).  1 / world of the dense form's
+          bytes (52 KB per query and rank at k1 = 1000, mostly zero words; `a2a="blocks"` keeps that form:
+          msr_rerank_gather_blocks + msr_rerank_combine);
+       c. the owner scatters the records into the dense arrays (msr_rerank_scatter) and runs the float64 chain for ITS
+          queries only (msr_rerank_fuse: 1 / world of the work);
        d. ONE all-gather of the fused lists (rerank_keep entries per query) gives every rank the result.
 
 No embedding or posting ever crosses a link: only k records per query do.  The reference has no counterpart
@@ -27,19 +32,21 @@ import torch
 import torch.distributed as dist
 
 
-_SEGS = (("b_doc", torch.int32, "k1"), ("b_score", torch.float64, "k1"), ("b_n", torch.int32, None),
-         ("d_doc", torch.int32, "k2"), ("d_score", torch.float32, "k2"), ("d_chunk", torch.int32, "k2"),
-         ("d_n", torch.int32, None))
+_SEGS_B = (("b_doc", torch.int32, "k1"), ("b_score", torch.float64, "k1"), ("b_n", torch.int32, None))
+_SEGS_D = (("d_doc", torch.int32, "k2"), ("d_score", torch.float32, "k2"), ("d_chunk", torch.int32, "k2"),
+           ("d_n", torch.int32, None))
+_SEGS = _SEGS_B + _SEGS_D
 
 
 class _Exchange:
-    """The record one rank contributes to the all-gather -- [b_doc | b_score | b_n | d_doc | d_score | d_chunk | d_n], every
-    segment 8-byte aligned -- and the receive buffer [world][record], allocated ONCE per (Q, k1, k2, device).  The merge
-    kernels read the gathered segments in place (msr_merge_topk_payload with part_stride_bytes = len(record))."""
+    """The record one rank contributes to an all-gather -- [b_doc | b_score | b_n] after stage 1, [d_doc | d_score | d_chunk |
+    d_n] after stage 2, every segment 8-byte aligned -- and the receive buffer [world][record], allocated ONCE per (Q, k1,
+    k2, device).  The merge kernels read the gathered segments in place (msr_merge_topk_payload with part_stride_bytes =
+    len(record))."""
 
-    def __init__(self, world, Q, k1, k2, device):
+    def __init__(self, world, Q, k1, k2, device, segs=_SEGS):
         self.off, o = {}, 0
-        for name, dt, kk in _SEGS:
+        for name, dt, kk in segs:
             n = Q * (k1 if kk == "k1" else k2 if kk == "k2" else 1)
             self.off[name] = (o, n, dt)
             o += (n * torch.empty(0, dtype=dt).element_size() + 7) // 8 * 8
@@ -67,6 +74,34 @@ _FUSED = (("doc", torch.int32, True), ("score", torch.float64, True), ("orig", t
           ("chunk", torch.int32, True), ("n", torch.int32, False), ("rows", torch.int32, False))
 
 
+RECORD_WORDS = 16          # msretr.h: [slot, rows, url group + 2, first row, cos x 10, query, 0]
+
+
+class _RerankPlan:
+    """What msr_rerank_plan fills (device, int32) + the host copy of the N x N matrix the all-to-all is sized with."""
+
+    def __init__(self, world, Q, Qs, M, device):
+        z = lambda *shape: torch.zeros(shape, dtype=torch.int32, device=device)
+        self.counts, self.send_base, self.send_blk = z(world, Q), z(Q), z(Q, (M + 7) // 8)
+        self.recv_off, self.pair = z(world, Qs), z(world, world)
+        cuda = torch.device(device).type == "cuda"
+        self.pair_host = torch.zeros((world, world), dtype=torch.int32, pin_memory=cuda)
+        self.event = torch.cuda.Event() if cuda else None
+
+    def to_host(self):
+        """Enqueue the copy of `pair` to the host (nothing waits here)."""
+        self.pair_host.copy_(self.pair, non_blocking=True)
+        if self.event is not None:
+            self.event.record()
+
+    def splits(self, rank):
+        """-> (send split sizes, receive split sizes) in 32-bit words; waits for the copy enqueued by to_host."""
+        if self.event is not None:
+            self.event.synchronize()
+        m = self.pair_host.tolist()
+        return [m[rank][o] * RECORD_WORDS for o in range(len(m))], [m[g][rank] * RECORD_WORDS for g in range(len(m))]
+
+
 class _RerankExchange:
     """Buffers of the query-sharded rerank, allocated once per (Q, M, keep, device).
     a2a_send / a2a_recv: int32 [world][block]; block o of the send buffer holds this rank's halves of the queries rank o owns,
@@ -89,6 +124,17 @@ class _RerankExchange:
         self.record = o
         self.out_send = torch.zeros(o, dtype=torch.uint8, device=device)
         self.out_recv = torch.zeros(world * o, dtype=torch.uint8, device=device)
+        self.device = device
+        self.plan = self.rec_send = self.rec_recv = None
+
+    def records(self):
+        """The buffers of the compact form, allocated at first use for the worst case: every candidate of every query in THIS
+        shard on the way out (Q x M records), every slot of my queries owned by somebody on the way in (Qs x M)."""
+        if self.plan is None:
+            self.plan = _RerankPlan(self.world, self.Q, self.Qs, self.M, self.device)
+            self.rec_send = torch.zeros(self.Q * self.M * RECORD_WORDS, dtype=torch.int32, device=self.device)
+            self.rec_recv = torch.zeros(self.Qs * self.M * RECORD_WORDS, dtype=torch.int32, device=self.device)
+        return self.plan
 
     def send_views(self, o):
         """(cos float32 [Qs, M, 10], meta int32 [Qs, M, 3]) of block o of the send buffer."""
@@ -120,7 +166,9 @@ class ShardedEngine:
     merge_gathered, rerank_gather, rerank_fuse -- the CPU tests pass an oracle-backed stand-in to exercise the exchange
     logic under gloo)."""
 
-    def __init__(self, engine, doc_base, row_base, group=None):
+    def __init__(self, engine, doc_base, row_base, group=None, a2a="records"):
+        """a2a: "records" (the compact rerank exchange; needs an engine with rerank_plan and shards that are consecutive
+        document ranges in rank order -- otherwise "blocks" is used) or "blocks" (dense halves)."""
         self.engine = engine
         self.doc_base = int(doc_base)
         self.row_base = int(row_base)
@@ -128,13 +176,32 @@ class ShardedEngine:
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         self._ex = {}
+        assert a2a in ("records", "blocks")
+        self.a2a = a2a
+        self._bounds = None
 
     # ------------------------------------------------------------------ exchange helpers
     def _exchange(self, Q, k1, k2, device):
+        """-> (stage-1 exchange, stage-2 exchange) for this batch shape."""
         key = (Q, k1, k2, str(device), self.world)
         if key not in self._ex:
-            self._ex[key] = _Exchange(self.world, Q, k1, k2, device)
+            self._ex[key] = (_Exchange(self.world, Q, k1, k2, device, _SEGS_B), _Exchange(self.world, Q, k1, k2, device, _SEGS_D))
         return self._ex[key]
+
+    def _shard_bounds(self, device):
+        """Device int32 [world + 1]: shard g owns global documents bounds[g] <= doc < bounds[g + 1] -- ONE small all-gather,
+        once.  None when the shards are not consecutive ranges in rank order, or the engine cannot tell its document count
+        (then the rerank exchange keeps its dense form)."""
+        if self._bounds is None:
+            n = getattr(getattr(self.engine, "index", None), "n_docs", None)
+            mine = torch.tensor([self.doc_base, self.doc_base + int(n) if n is not None else -1], dtype=torch.int64, device=device)
+            every = torch.empty(self.world * 2, dtype=torch.int64, device=device)
+            dist.all_gather_into_tensor(every, mine, group=self.group)
+            every = every.view(self.world, 2).cpu()
+            ok = bool((every[:, 1] >= every[:, 0]).all()) and bool((every[1:, 0] == every[:-1, 1]).all())
+            b = torch.cat([every[:, 0], every[-1:, 1]]).to(torch.int32).to(device) if ok and int(every[-1, 1]) < 2 ** 31 else None
+            self._bounds = (b,)
+        return self._bounds[0]
 
     def _allgather_bytes(self, parts):
         """parts: list of tensors -> list (per rank) of lists of tensors with the same shapes/dtypes.  One collective:
@@ -220,53 +287,75 @@ class ShardedEngine:
         and chunk rows are GLOBAL indices; every rank returns the same tensors.  rerank_keep: entries per query of the fused
         lists to return (None: all k1; the reranker facade's diversification wants them all, a top-100 service k2)."""
         e = self.engine
+        keep = k1 if rerank_keep is None else min(int(rerank_keep), k1)
+        max_chunks = rerank_params.get("max_chunks", 10)
         b_doc, b_score, b_n = e.bm25_topk(term_lists, k=k1, min_score=min_score, packed=packed)
-        d_doc, d_score, d_chunk, d_n = self._dense(qvec, k2, max_chunks_per_doc, dense_batched)
         Q = int(b_doc.shape[0])
+        rx = plan = None
         if self.world > 1:
-            ex = self._exchange(Q, k1, k2, b_doc.device)
-            # this rank's record: local indices -> global, written straight into the preallocated send buffer
+            ex, ex_d = self._exchange(Q, k1, k2, b_doc.device)
+            # stage 1: this rank's record (local indices -> global, written straight into the preallocated send buffer), ONE
+            # all-gather, the identical deterministic merge on every rank, reading the gathered records in place
             self._globalise_into(ex.out("b_doc"), b_doc, self.doc_base)
             ex.out("b_score").copy_(b_score)
             ex.out("b_n").copy_(b_n)
-            self._globalise_into(ex.out("d_doc"), d_doc, self.doc_base)
-            ex.out("d_score").copy_(d_score)
-            self._globalise_into(ex.out("d_chunk"), d_chunk, self.row_base)
-            ex.out("d_n").copy_(d_n)
-            dist.all_gather_into_tensor(ex.recv, ex.send, group=self.group)          # THE collective of stage 1 + 2
-            # identical deterministic merge on every rank, reading the gathered records in place; the arg-max chunk of a
-            # dense entry travels with it as the merge payload
+            dist.all_gather_into_tensor(ex.recv, ex.send, group=self.group)
             b_doc, b_score, b_n, _ = e.merge_gathered(ex, "b_doc", "b_score", "b_n", None, k1)
-            d_doc, d_score, d_n, d_chunk = e.merge_gathered(ex, "d_doc", "d_score", "d_n", "d_chunk", k2)
+            if rerank:
+                rx = ex.rerank.get((k1, keep))
+                if rx is None:
+                    rx = ex.rerank[(k1, keep)] = _RerankExchange(self.world, Q, k1, keep, b_doc.device)
+                bounds = self._shard_bounds(b_doc.device) if self.a2a == "records" and hasattr(e, "rerank_plan") else None
+                if bounds is not None:
+                    # who owns which candidate: counted now, copied to the host while stage 2 runs
+                    plan = rx.records()
+                    e.rerank_plan(b_doc, b_n, bounds, self.rank, rx.Qs, plan)
+                    plan.to_host()
         else:
             b_doc = self._globalise(b_doc, self.doc_base)
+        d_doc, d_score, d_chunk, d_n = self._dense(qvec, k2, max_chunks_per_doc, dense_batched)
+        if self.world > 1:
+            # stage 2: the same; the arg-max chunk of a dense entry travels with it as the merge payload
+            self._globalise_into(ex_d.out("d_doc"), d_doc, self.doc_base)
+            ex_d.out("d_score").copy_(d_score)
+            self._globalise_into(ex_d.out("d_chunk"), d_chunk, self.row_base)
+            ex_d.out("d_n").copy_(d_n)
+            dist.all_gather_into_tensor(ex_d.recv, ex_d.send, group=self.group)
+            d_doc, d_score, d_n, d_chunk = e.merge_gathered(ex_d, "d_doc", "d_score", "d_n", "d_chunk", k2)
+        else:
             d_doc = self._globalise(d_doc, self.doc_base)
             d_chunk = self._globalise(d_chunk, self.row_base)
         out = dict(bm25=(b_doc, b_score, b_n), dense=(d_doc, d_score, d_chunk, d_n))
         if not rerank:
             return out
-        keep = k1 if rerank_keep is None else min(int(rerank_keep), k1)
-        max_chunks = rerank_params.get("max_chunks", 10)
         if self.world == 1:
             cos, meta = e.rerank_gather(qvec, b_doc, b_n, doc_base=self.doc_base, row_base=self.row_base, max_chunks=max_chunks)
             r = e.rerank_fuse(b_doc, b_score, b_n, cos, meta, **rerank_params)
             out["rerank"] = r if keep == k1 else self._truncate(r, keep)
             return out
-        rx = ex.rerank.get((k1, keep))
-        if rx is None:
-            rx = ex.rerank[(k1, keep)] = _RerankExchange(self.world, Q, k1, keep, b_doc.device)
         Qs = rx.Qs
-        # a. my documents' halves of every query, written into the block of the rank that owns the query: ONE gather launch
-        #    for all queries (the rows of a short last block stay zero)
-        e.rerank_gather_blocks(qvec, b_doc, b_n, rx.a2a_send.view(self.world, rx.block), Qs, doc_base=self.doc_base,
-                               row_base=self.row_base, max_chunks=max_chunks)
-        # b. every half to the owner of its query
-        dist.all_to_all_single(rx.a2a_recv, rx.a2a_send, group=self.group)
-        # c. join + the float64 chain, for my queries only
         lo, hi = min(Q, self.rank * Qs), min(Q, (self.rank + 1) * Qs)
+        if plan is not None:
+            # a. my documents' records of every query, ordered by the rank that owns the query: ONE gather launch
+            e.rerank_gather_records(qvec, b_doc, b_n, plan, rx.rec_send, doc_base=self.doc_base, row_base=self.row_base,
+                                    max_chunks=max_chunks)
+            # b. every record to the owner of its query (the host reads the split sizes here: copied before stage 2 ran)
+            send_splits, recv_splits = plan.splits(self.rank)
+            dist.all_to_all_single(rx.rec_recv[:sum(recv_splits)], rx.rec_send[:sum(send_splits)], recv_splits, send_splits,
+                                   group=self.group)
+        else:
+            # a. / b. the dense form: my documents' halves of every query, written into the block of the rank that owns the
+            #    query (the rows of a short last block stay zero), every half to the owner of its query
+            e.rerank_gather_blocks(qvec, b_doc, b_n, rx.a2a_send.view(self.world, rx.block), Qs, doc_base=self.doc_base,
+                                   row_base=self.row_base, max_chunks=max_chunks)
+            dist.all_to_all_single(rx.a2a_recv, rx.a2a_send, group=self.group)
+        # c. join + the float64 chain, for my queries only
         if hi > lo:
-            cp, mp = rx.recv_parts()
-            cos, meta = e.rerank_combine(cp, mp, hi - lo)
+            if plan is not None:
+                cos, meta = e.rerank_scatter(rx.rec_recv, plan, lo, hi - lo, k1)
+            else:
+                cp, mp = rx.recv_parts()
+                cos, meta = e.rerank_combine(cp, mp, hi - lo)
             fused = e.rerank_fuse(b_doc[lo:hi], b_score[lo:hi], b_n[lo:hi], cos, meta, **rerank_params)
             if keep < k1:
                 fused = self._truncate(fused, keep)

@@ -334,6 +334,42 @@ class DeviceEngine:
                                                 _ptr(cos), _ptr(meta), self._stream()))
         return cos, meta
 
+    # -- the compact form of the rerank exchange (msretr.h: msr_rerank_plan / _gather_records / _scatter)
+    def rerank_plan(self, cand_doc_global, cand_n, shard_bounds, my_shard, queries_per_shard, plan):
+        """Fills `plan` (distributed._RerankPlan: counts [N, Q], send_base [Q], send_blk [Q, ceil(M / 8)], recv_off [N, Qs],
+        pair [N, N], all int32 on the device) for the merged candidate lists cand_doc_global [Q, M] / cand_n [Q]."""
+        cand = self._dev(cand_doc_global, torch.int32)
+        cn = self._dev(cand_n, torch.int32)
+        Q, M = int(cand.shape[0]), int(cand.shape[1])
+        N = int(shard_bounds.numel()) - 1
+        assert tuple(plan.counts.shape) == (N, Q) and tuple(plan.send_blk.shape) == (Q, (M + 7) // 8)
+        assert tuple(plan.recv_off.shape) == (N, int(queries_per_shard)) and tuple(plan.pair.shape) == (N, N)
+        self._check(self.lib.msr_rerank_plan(self.handle, Q, _ptr(cand), _ptr(cn), M, _ptr(shard_bounds), N, int(my_shard),
+                                             int(queries_per_shard), _ptr(plan.counts), _ptr(plan.send_base), _ptr(plan.send_blk),
+                                             _ptr(plan.recv_off), _ptr(plan.pair), self._stream()))
+
+    def rerank_gather_records(self, qvec, cand_doc_global, cand_n, plan, records, doc_base=0, row_base=0, max_chunks=10):
+        """rerank_gather for ALL queries in one launch, as 16-word records of the slots this shard owns, at the places `plan`
+        holds (records: int32, at least sum(plan.pair[my]) * 16 words)."""
+        q = self._dev(qvec, torch.float32).reshape(-1, DIM)
+        cand = self._dev(cand_doc_global, torch.int32)
+        cn = self._dev(cand_n, torch.int32)
+        Q, M = int(cand.shape[0]), int(cand.shape[1])
+        assert records.is_contiguous() and records.dtype == torch.int32
+        self._check(self.lib.msr_rerank_gather_records(self.handle, _ptr(q), Q, _ptr(cand), _ptr(cn), M, int(doc_base), int(row_base),
+                                                       int(max_chunks), _ptr(plan.send_base), _ptr(plan.send_blk), _ptr(records),
+                                                       self._stream()))
+
+    def rerank_scatter(self, records, plan, first_query, nq, M):
+        """The received records of my queries [first_query, first_query + nq) -> (cos [nq, M, 10], meta [nq, M, 3])."""
+        N, Q = int(plan.counts.shape[0]), int(plan.counts.shape[1])
+        cos = torch.empty((nq, M, _abi.MSR_RERANK_MAX_CHUNKS), dtype=torch.float32, device=self.device)
+        meta = torch.empty((nq, M, 3), dtype=torch.int32, device=self.device)
+        self._check(self.lib.msr_rerank_scatter(self.handle, _ptr(records), _ptr(plan.counts), _ptr(plan.recv_off), N, Q,
+                                                int(plan.recv_off.shape[1]), int(first_query), int(nq), int(M), _ptr(cos), _ptr(meta),
+                                                self._stream()))
+        return cos, meta
+
     def rerank_fuse(self, cand_doc_global, cand_bm25, cand_n, cos, meta, **params):
         p = dict(RERANK_DEFAULTS)
         p.update(params)

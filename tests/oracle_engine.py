@@ -130,6 +130,58 @@ class OracleEngine:
                 blocks[b, :(hi - lo) * M * 10].copy_(cos[lo:hi].reshape(-1).view(torch.int32))
                 blocks[b, qpb * M * 10: qpb * M * 10 + (hi - lo) * M * 3].copy_(meta[lo:hi].reshape(-1))
 
+    # the compact exchange (DeviceEngine.rerank_plan / rerank_gather_records / rerank_scatter; msretr.h)
+    def rerank_plan(self, cand_doc_global, cand_n, shard_bounds, my_shard, queries_per_shard, plan):
+        cand, cn, bounds = _np(cand_doc_global).astype(np.int64), _np(cand_n), _np(shard_bounds).astype(np.int64)
+        Q, M = cand.shape
+        N, qps = len(bounds) - 1, int(queries_per_shard)
+        valid = (np.arange(M)[None, :] < cn[:, None]) & (cand >= bounds[0]) & (cand < bounds[-1])
+        owner = np.where(valid, np.searchsorted(bounds, cand, side="right") - 1, -1)
+        counts = np.stack([(owner == s).sum(axis=1) for s in range(N)]).astype(np.int32)
+        mine = np.zeros((Q, (M + 7) // 8 * 8), np.int64)
+        mine[:, :M] = owner == my_shard
+        per_blk = mine.reshape(Q, -1, 8).sum(axis=2)
+        lo, hi = min(Q, my_shard * qps), min(Q, (my_shard + 1) * qps)
+        pair = np.array([[counts[s, min(Q, o * qps):min(Q, (o + 1) * qps)].sum() for o in range(N)] for s in range(N)], np.int32)
+        recv_off = np.zeros((N, qps), np.int32)
+        base = 0
+        for s in range(N):
+            c = counts[s, lo:hi]
+            recv_off[s, :hi - lo] = base + np.cumsum(c) - c
+            base += int(c.sum())
+        plan.counts.copy_(torch.as_tensor(counts))
+        plan.send_base.copy_(torch.as_tensor((np.cumsum(counts[my_shard]) - counts[my_shard]).astype(np.int32)))
+        plan.send_blk.copy_(torch.as_tensor((np.cumsum(per_blk, axis=1) - per_blk).astype(np.int32)))
+        plan.recv_off.copy_(torch.as_tensor(recv_off))
+        plan.pair.copy_(torch.as_tensor(pair))
+
+    def rerank_gather_records(self, qvec, cand_doc_global, cand_n, plan, records, doc_base=0, row_base=0, max_chunks=10):
+        cos, meta = [_np(x) for x in self.rerank_gather(qvec, cand_doc_global, cand_n, doc_base, row_base, max_chunks)]
+        cand, cn = _np(cand_doc_global), _np(cand_n)
+        Q, M = cand.shape
+        N = len(self.doc_off) - 1
+        rec = _np(records).reshape(-1, 16)
+        base = _np(plan.send_base)
+        for q in range(Q):
+            r = int(base[q])
+            for m in range(min(int(cn[q]), M)):
+                if 0 <= cand[q, m] - doc_base < N:
+                    rec[r, 0], rec[r, 1:4], rec[r, 14], rec[r, 15] = m, meta[q, m], q, 0
+                    rec[r, 4:14] = cos[q, m].view(np.int32)
+                    r += 1
+        records.copy_(torch.as_tensor(rec.reshape(-1)))
+
+    def rerank_scatter(self, records, plan, first_query, nq, M):
+        rec, counts, off = _np(records).reshape(-1, 16), _np(plan.counts), _np(plan.recv_off)
+        cos = np.zeros((nq, M, 10), np.float32); meta = np.zeros((nq, M, 3), np.int32)
+        for s in range(counts.shape[0]):
+            for j in range(nq):
+                for r in rec[off[s, j]: off[s, j] + counts[s, first_query + j]]:
+                    assert r[14] == first_query + j, "a record of another query"
+                    meta[j, r[0]] = r[1:4]
+                    cos[j, r[0]] = r[4:14].view(np.float32)
+        return torch.as_tensor(cos), torch.as_tensor(meta)
+
     def rerank_fuse(self, cand_doc_global, cand_bm25, cand_n, cos, meta, smoothing=0.15, max_boost=0.1,
                     max_decay=0.05, max_chunks=10):
         cand, bm, cn, cos, meta = map(_np, (cand_doc_global, cand_bm25, cand_n, cos, meta))

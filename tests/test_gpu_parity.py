@@ -1372,3 +1372,78 @@ def test_split_dense_call_with_a_cross_shard_bound_equals_unsharded(mods):
     assert int(engs[0].dense_end(Q, k=100)[3].min()) == 100     # ... and the pair still completes
     for e in engs + [full]:
         e.close()
+
+
+def test_compact_rerank_exchange_equals_the_dense_halves(mods):
+    """msr_rerank_plan / _gather_records / _scatter against msr_rerank_gather_blocks / _combine: three shard engines on one GPU,
+    candidate lists with documents of every shard, absent documents (-1, out of range), short lists and an empty one; the
+    all-to-all is done by hand from the plan's N x N matrix.  Every rank's (cos, meta) of ITS queries must equal the join of
+    the dense halves bit for bit, the counts must equal a numpy count, and the records a rank receives must all be for its own
+    queries."""
+    from msretr.distributed import RECORD_WORDS, _RerankPlan
+    rng = np.random.default_rng(77)
+    n_docs = 30000
+    n = rng.integers(1, 13, size=n_docs)                      # (some documents have more than 10 chunks: the first 10 take part)
+    doc_off = np.zeros(n_docs + 1, np.int64); doc_off[1:] = np.cumsum(n)
+    C = int(doc_off[-1])
+    emb = torch.randn((C, 768), generator=torch.Generator().manual_seed(4)).numpy()
+    ix = mods["CorpusIndex"](doc_ids=np.arange(n_docs, dtype=np.int64), doc_off=doc_off.astype(np.int32),
+                             chunk_ids=np.arange(C, dtype=np.int64), emb=emb, total_docs=n_docs)
+    world, Q, M = 3, 11, 203                                   # (Q not a multiple of world, M not a multiple of 8)
+    Qs = (Q + world - 1) // world
+    shards = [ix.shard(r, world) for r in range(world)]
+    engs = [mods["DeviceEngine"](s_, max_queries=16, max_k=16, rerank_max_docs=256) for s_ in shards]
+    bounds = torch.tensor([s_.doc_base for s_ in shards] + [n_docs], dtype=torch.int32).cuda()
+    cand = np.stack([rng.choice(n_docs, size=M, replace=False) for _ in range(Q)]).astype(np.int32)
+    cand[0, :40] = np.arange(40) + shards[1].doc_base           # a run of one shard's documents (whole blocks of 8 owned)
+    cand[1, ::3] = -1                                           # absent documents
+    cand[2, 5] = n_docs + 7                                     # out of every shard's range
+    cn = np.full(Q, M, np.int32); cn[3] = 17; cn[4] = 0; cn[5] = 1
+    q = rng.standard_normal((Q, 768)).astype(np.float32) * 3
+    cand_t, cn_t = torch.as_tensor(cand).cuda(), torch.as_tensor(cn).cuda()
+    # the dense form, as distributed.py's a2a="blocks" runs it
+    block = (Qs * M * 13 + 3) // 4 * 4
+    sends = []
+    for e, s_ in zip(engs, shards):
+        buf = torch.zeros((world, block), dtype=torch.int32, device="cuda")
+        e.rerank_gather_blocks(q, cand_t, cn_t, buf, Qs, doc_base=s_.doc_base, row_base=s_.row_base)
+        sends.append(buf)
+    # the compact form
+    plans, recs = [], []
+    for r, (e, s_) in enumerate(zip(engs, shards)):
+        plan = _RerankPlan(world, Q, Qs, M, "cuda")
+        e.rerank_plan(cand_t, cn_t, bounds, r, Qs, plan)
+        rec = torch.full((Q * M * RECORD_WORDS,), -7, dtype=torch.int32, device="cuda")
+        e.rerank_gather_records(q, cand_t, cn_t, plan, rec, doc_base=s_.doc_base, row_base=s_.row_base)
+        plans.append(plan); recs.append(rec)
+    torch.cuda.synchronize()
+    own = np.full((Q, M), -1)
+    b = bounds.cpu().numpy()
+    for qi in range(Q):
+        for m in range(cn[qi]):
+            d = cand[qi, m]
+            if b[0] <= d < b[-1]:
+                own[qi, m] = np.searchsorted(b, d, side="right") - 1
+    counts = np.stack([(own == s_).sum(axis=1) for s_ in range(world)])
+    pair = np.array([[counts[s_, o * Qs:(o + 1) * Qs].sum() for o in range(world)] for s_ in range(world)])
+    for plan in plans:
+        assert np.array_equal(plan.counts.cpu().numpy(), counts) and np.array_equal(plan.pair.cpu().numpy(), pair)
+    for r in range(world):
+        lo, hi = min(Q, r * Qs), min(Q, (r + 1) * Qs)
+        # what the all-to-all delivers to rank r: source g's records for r's queries, sources in order
+        got = []
+        for g in range(world):
+            first = int(pair[g, :r].sum())
+            got.append(recs[g][first * RECORD_WORDS:(first + int(pair[g, r])) * RECORD_WORDS])
+        recv = torch.cat(got + [torch.zeros(8 * RECORD_WORDS, dtype=torch.int32, device="cuda")])
+        rv = recv[:int(pair[:, r].sum()) * RECORD_WORDS].view(-1, RECORD_WORDS).cpu().numpy()
+        assert ((rv[:, 14] >= lo) & (rv[:, 14] < hi)).all() and (rv[:, 0] >= 0).all() and (rv[:, 0] < M).all()
+        cos, meta = engs[r].rerank_scatter(recv, plans[r], lo, hi - lo, M)
+        parts = torch.stack([s_[r] for s_ in sends])                                    # [world][block]: the dense halves for r
+        cp = parts[:, :Qs * M * 10].view(torch.float32).view(world, Qs, M, 10)
+        mp = parts[:, Qs * M * 10:Qs * M * 13].view(world, Qs, M, 3)
+        ref_cos, ref_meta = engs[r].rerank_combine(cp, mp, hi - lo)
+        assert torch.equal(meta, ref_meta)
+        assert torch.equal(cos.view(torch.int32), ref_cos.view(torch.int32))
+    for e in engs:
+        e.close()

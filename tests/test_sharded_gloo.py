@@ -44,7 +44,10 @@ def _run(rank, world, port, ret, snap_dir=None):
         assert se.world == world and se.rank == rank
         out = se.search([sh.term_ids(t) for t in terms], qvec, k1=200, k2=50)
         assert se.engine.begin_calls == 1                  # the dense stage went through begin / all-reduce MIN / end
+        assert se._bounds[0] is not None                   # ... and the rerank exchange took its compact form (records)
         res = {k: [x.numpy() for x in v] for k, v in out.items()}
+        dense_form = ShardedEngine(se.engine, sh.doc_base, sh.row_base, a2a="blocks")
+        res["rerank_blocks"] = [x.numpy() for x in dense_form.search([sh.term_ids(t) for t in terms], qvec, k1=200, k2=50)["rerank"]]
         cut = se.search([sh.term_ids(t) for t in terms], qvec, k1=200, k2=50, rerank_keep=20)
         res["rerank_cut"] = [x.numpy() for x in cut["rerank"]]
         ret[rank] = res
@@ -71,8 +74,8 @@ def test_two_rank_sharded_equals_unsharded(via_snapshot, tmp_path):
     ref = {k: [x.numpy() for x in v] for k, v in ref.items()}
     for r in range(world):
         got = ret[r]
-        for key in ("bm25", "dense", "rerank"):
-            for a, b in zip(got[key], ref[key]):
+        for key in ("bm25", "dense", "rerank", "rerank_blocks"):            # (rerank_blocks: the dense form of the exchange)
+            for a, b in zip(got[key], ref[key.replace("_blocks", "")]):
                 assert a.shape == b.shape and np.array_equal(a, b), (r, key)
         # rerank_keep < k1: lists AND counts are cut (a caller iterating range(n[q]) stays inside the rows it was given)
         cut = got["rerank_cut"]
