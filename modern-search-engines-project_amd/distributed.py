@@ -227,13 +227,16 @@ class ShardedEngine:
             res.append(lst)
         return res
 
-    def _dense(self, qvec, k, max_chunks_per_doc, dense_batched):
+    def _dense(self, qvec, k, max_chunks_per_doc, dense_batched, beside=None):
         """This shard's dense top-k.  With several shards and an engine that can split the call (DeviceEngine.dense_begin /
         dense_end) the shards first agree on a lower bound of the k-th cosine of the WHOLE corpus -- every shard vouches for
         ceil(k / world) of its own documents, ONE all-reduce MIN of a float per query -- and each then rescores in exact f32
         only what can be in the global top-k: 1 / world of the rescoring a rank otherwise does for its own top-k, for nothing.
-        The lists come back shorter than k; merged they are the unsharded list, bit for bit."""
+        The lists come back shorter than k; merged they are the unsharded list, bit for bit.
+        beside: called once, right after the stage's long pass over the shard has been enqueued (before the first collective
+        of this stage) -- search() finishes stage 1's exchange there, so that its all-gather runs beside that pass."""
         e = self.engine
+        beside = beside or (lambda: None)
         Q = int(qvec.shape[0]) if hasattr(qvec, "shape") else len(qvec)
         split = 0
         if self.world > 1 and not dense_batched and max_chunks_per_doc == 0 and hasattr(e, "dense_split_max"):
@@ -241,10 +244,13 @@ class ShardedEngine:
         min_q = getattr(e, "dense_split_min", 65)             # (the device engine splits calls of more than 64 queries)
         if split <= 0 or Q < min_q:
             dense = e.dense_topk_batched if dense_batched else e.dense_topk
-            return dense(qvec, k=k, max_chunks_per_doc=max_chunks_per_doc)
+            res = dense(qvec, k=k, max_chunks_per_doc=max_chunks_per_doc)
+            beside()
+            return res
         k_part = (k + self.world - 1) // self.world
         if Q <= split:
             part = e.dense_begin(qvec, k=k, k_part=k_part)
+            beside()
             dist.all_reduce(part, op=dist.ReduceOp.MIN, group=self.group)
             return e.dense_end(Q, k=k, bound=part)
         dev = getattr(e, "device", None) or (qvec.device if torch.is_tensor(qvec) else None)
@@ -257,6 +263,8 @@ class ShardedEngine:
                     dst[a:b].copy_(src)
                 continue
             part = e.dense_begin(qvec[a:b], k=k, k_part=k_part)
+            if a == 0:
+                beside()
             dist.all_reduce(part, op=dist.ReduceOp.MIN, group=self.group)
             e.dense_end(b - a, k=k, bound=part, out=tuple(t[a:b] for t in res))
         return res
@@ -299,22 +307,31 @@ class ShardedEngine:
             self._globalise_into(ex.out("b_doc"), b_doc, self.doc_base)
             ex.out("b_score").copy_(b_score)
             ex.out("b_n").copy_(b_n)
-            dist.all_gather_into_tensor(ex.recv, ex.send, group=self.group)
-            b_doc, b_score, b_n, _ = e.merge_gathered(ex, "b_doc", "b_score", "b_n", None, k1)
+            # (asynchronous: the collective runs on the backend's own stream beside what is enqueued next -- stage 2's pass over
+            # the shard; stage 1 is finished from inside _dense, right behind that pass)
+            gathering = dist.all_gather_into_tensor(ex.recv, ex.send, group=self.group, async_op=True)
             if rerank:
                 rx = ex.rerank.get((k1, keep))
                 if rx is None:
                     rx = ex.rerank[(k1, keep)] = _RerankExchange(self.world, Q, k1, keep, b_doc.device)
-                bounds = self._shard_bounds(b_doc.device) if self.a2a == "records" and hasattr(e, "rerank_plan") else None
+            bounds = self._shard_bounds(b_doc.device) if rerank and self.a2a == "records" and hasattr(e, "rerank_plan") else None
+            stage1 = {}
+
+            def finish_stage1():
+                gathering.wait()
+                stage1["lists"] = e.merge_gathered(ex, "b_doc", "b_score", "b_n", None, k1)[:3]
                 if bounds is not None:
-                    # who owns which candidate: counted now, copied to the host while stage 2 runs
-                    plan = rx.records()
-                    e.rerank_plan(b_doc, b_n, bounds, self.rank, rx.Qs, plan)
-                    plan.to_host()
+                    # who owns which candidate: counted now, copied to the host while the rest of stage 2 runs
+                    stage1["plan"] = rx.records()
+                    e.rerank_plan(stage1["lists"][0], stage1["lists"][2], bounds, self.rank, rx.Qs, stage1["plan"])
+                    stage1["plan"].to_host()
         else:
             b_doc = self._globalise(b_doc, self.doc_base)
-        d_doc, d_score, d_chunk, d_n = self._dense(qvec, k2, max_chunks_per_doc, dense_batched)
+            finish_stage1 = None
+        d_doc, d_score, d_chunk, d_n = self._dense(qvec, k2, max_chunks_per_doc, dense_batched, beside=finish_stage1)
         if self.world > 1:
+            b_doc, b_score, b_n = stage1["lists"]
+            plan = stage1.get("plan")
             # stage 2: the same; the arg-max chunk of a dense entry travels with it as the merge payload
             self._globalise_into(ex_d.out("d_doc"), d_doc, self.doc_base)
             ex_d.out("d_score").copy_(d_score)
