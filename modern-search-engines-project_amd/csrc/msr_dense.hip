@@ -425,19 +425,22 @@ template <bool TILED>
 __global__ __launch_bounds__(64) void best_chunk_kernel(DenseIndex ix, const float* __restrict__ qn, int k,
                                                          int max_chunks, const int32_t* __restrict__ out_doc,
                                                          const int32_t* __restrict__ out_n,
-                                                         int32_t* __restrict__ out_chunk) {
-    const int q = blockIdx.y, r = blockIdx.x, lane = threadIdx.x;
+                                                         int32_t* __restrict__ out_chunk, int per_wave) {
+    // (per_wave > 1: the gated fallback launch, which almost never has work -- a sixteenth of the waves to start and retire)
+    const int q = blockIdx.y, lane = threadIdx.x;
     if (ix.gate && ix.gate[ix.gate_per64 ? q >> 6 : 0] == 0) return;
+    float qv[12];
+    for (int j = 0; j < 12; ++j) qv[j] = qn[(size_t)q * MSR_DIM + lane + 64 * j];
+    const int r_end = (int)(blockIdx.x + 1) * per_wave < k ? (int)(blockIdx.x + 1) * per_wave : k;
+    for (int r = blockIdx.x * per_wave; r < r_end; ++r) {
     if (r >= out_n[q]) {
         if (lane == 0) out_chunk[(int64_t)q * k + r] = -1;
-        return;
+        continue;
     }
     const int d = out_doc[(int64_t)q * k + r];
     const int64_t ds = ix.doc_off[d];
     int64_t de = ix.doc_off[d + 1];
     if (max_chunks > 0 && ds + max_chunks < de) de = ds + max_chunks;
-    float qv[12];
-    for (int j = 0; j < 12; ++j) qv[j] = qn[(size_t)q * MSR_DIM + lane + 64 * j];
     float best = -__builtin_inff();
     int64_t arg = -1;
     for (int64_t c = ds; c < de; ++c) {
@@ -458,6 +461,7 @@ __global__ __launch_bounds__(64) void best_chunk_kernel(DenseIndex ix, const flo
         if (s > best) { best = s; arg = c; }
     }
     if (lane == 0) out_chunk[(int64_t)q * k + r] = (int32_t)arg;
+    }
 }
 
 // Diagnostic build only (-DMSR_DIAG, tools/ab_scan.py): MSR_SCAN_DEBUG bit 0 drops the score-row stores for timing
@@ -632,10 +636,11 @@ hipError_t msr_interleave(const float* src, int64_t n_rows, float* dst, hipStrea
 hipError_t msr_best_chunk(const DenseIndex& ix, const float* qn, int nq, int k, int max_chunks,
                           const int32_t* out_doc, const int32_t* out_n, int32_t* out_chunk, hipStream_t stream) {
     if (nq <= 0 || k <= 0) return hipSuccess;
-    dim3 grid((unsigned)k, (unsigned)nq);
+    const int per_wave = ix.gate ? 16 : 1;
+    dim3 grid((unsigned)((k + per_wave - 1) / per_wave), (unsigned)nq);
     if (ix.layout == 1)
-        best_chunk_kernel<true><<<grid, 64, 0, stream>>>(ix, qn, k, max_chunks, out_doc, out_n, out_chunk);
+        best_chunk_kernel<true><<<grid, 64, 0, stream>>>(ix, qn, k, max_chunks, out_doc, out_n, out_chunk, per_wave);
     else
-        best_chunk_kernel<false><<<grid, 64, 0, stream>>>(ix, qn, k, max_chunks, out_doc, out_n, out_chunk);
+        best_chunk_kernel<false><<<grid, 64, 0, stream>>>(ix, qn, k, max_chunks, out_doc, out_n, out_chunk, per_wave);
     return hipGetLastError();
 }

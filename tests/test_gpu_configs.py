@@ -83,8 +83,18 @@ _RCCL_CHILD = textwrap.dedent("""
     ok_reduce = torch.equal(buf, ref)
     t = torch.tensor([1.25], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX); dist.barrier()
+    # the calls of ShardedEngine.search in the forms it uses them: an asynchronous all-gather waited for later, an
+    # all-reduce MIN of floats, an all-to-all with split sizes on slices of preallocated int32 buffers
+    src = torch.arange(4096, dtype=torch.uint8, device=dev); dst = torch.zeros(4096, dtype=torch.uint8, device=dev)
+    work = dist.all_gather_into_tensor(dst, src, async_op=True)
+    mn = torch.tensor([0.5, -1.0], device=dev); dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+    work.wait()
+    send = torch.arange(64 * 16, dtype=torch.int32, device=dev); recv = torch.zeros(80 * 16, dtype=torch.int32, device=dev)
+    dist.all_to_all_single(recv[:37 * 16], send[:37 * 16], [37 * 16], [37 * 16])
+    torch.cuda.synchronize()
+    ok_forms = torch.equal(dst, src) and mn.tolist() == [0.5, -1.0] and torch.equal(recv[:37 * 16], send[:37 * 16]) and int(recv[37 * 16:].abs().sum()) == 0
     loaded = [l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l or "libnccl" in l]
-    print(json.dumps({"gather": bool(ok_gather), "reduce": bool(ok_reduce), "max": float(t.item()),
+    print(json.dumps({"gather": bool(ok_gather), "reduce": bool(ok_reduce), "max": float(t.item()), "forms": bool(ok_forms),
                       "backend": dist.get_backend(), "lib": sorted(set(loaded))[:2]}))
     dist.destroy_process_group()
 """)
@@ -96,5 +106,5 @@ def test_rccl_one_rank_smoke():
     r = subprocess.run([sys.executable, "-c", _RCCL_CHILD % ROOT], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert out["backend"] == "nccl" and out["gather"] and out["reduce"] and out["max"] == 1.25
+    assert out["backend"] == "nccl" and out["gather"] and out["reduce"] and out["max"] == 1.25 and out["forms"]
     assert out["lib"], "librccl was not mapped into the process"
