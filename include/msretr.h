@@ -284,8 +284,11 @@ int msr_rerank_combine(msr_engine* e, const float* cos_parts, const int32_t* met
  *       queries of rank o -- queries [o * queries_per_shard, (o + 1) * queries_per_shard) -- are contiguous),
  *     recv_off[s][j]: the record number, in the receive buffer, of the first record source s sends for my j-th query,
  *     pair[s][o]: records source s sends to rank o -- the split sizes of the all-to-all (x 16 words), which the host reads;
- *   msr_rerank_gather_records is msr_rerank_gather writing those records (nothing for slots of other shards);
- *   msr_rerank_scatter puts the received records of my queries [first_query, first_query + n_my_queries) into the dense
+ *   msr_rerank_gather_records is msr_rerank_gather writing those records (nothing for slots of other shards; out_records
+ *     holds capacity_records records -- n_queries * max_cand is always enough -- and a record whose number is not below that
+ *     is not written);
+ *   msr_rerank_scatter puts the received records (a buffer of capacity_records records: nothing past it is read) of my
+ *     queries [first_query, first_query + n_my_queries) into the dense
  *     out_cos [n_my_queries][max_cand][10] / out_meta [..][3] msr_rerank_fuse reads (zeroed first: a slot nobody owns stays
  *     "no document").  The result equals msr_rerank_combine over the dense halves, bit for bit.
  * All arrays are device pointers.  No reference counterpart (reranker_api.py:27-63 fetches all rows from one database). */
@@ -295,10 +298,11 @@ int msr_rerank_plan(msr_engine* e, int32_t n_queries, const int32_t* cand_doc, c
 int msr_rerank_gather_records(msr_engine* e, const float* q, int32_t n_queries, const int32_t* cand_doc,
                               const int32_t* cand_n, int32_t max_cand, int32_t doc_base, int32_t row_base,
                               int32_t max_chunks, const int32_t* send_base, const int32_t* send_blk, int32_t* out_records,
-                              void* stream);
-int msr_rerank_scatter(msr_engine* e, const int32_t* records, const int32_t* counts, const int32_t* recv_off,
-                       int32_t n_shards, int32_t n_queries, int32_t queries_per_shard, int32_t first_query,
-                       int32_t n_my_queries, int32_t max_cand, float* out_cos, int32_t* out_meta, void* stream);
+                              int64_t capacity_records, void* stream);
+int msr_rerank_scatter(msr_engine* e, const int32_t* records, int64_t capacity_records, const int32_t* counts,
+                       const int32_t* recv_off, int32_t n_shards, int32_t n_queries, int32_t queries_per_shard,
+                       int32_t first_query, int32_t n_my_queries, int32_t max_cand, float* out_cos, int32_t* out_meta,
+                       void* stream);
 
 /* Merge n_parts per-shard top-k lists (the payload of the RCCL all-gather) into the global top-k.
  * in_doc [n_parts][n_queries][k] i32 GLOBAL doc indices, in_score same shape (score_bits = 32: f32,

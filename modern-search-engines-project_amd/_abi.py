@@ -75,8 +75,9 @@ _SIGNATURES = {
                                   _P, _P, _P, _P, _P]),
     "msr_rerank_combine": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P]),
     "msr_rerank_plan": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P]),
-    "msr_rerank_gather_records": (C.c_int, [_P, _P, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
-    "msr_rerank_scatter": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
+    "msr_rerank_gather_records": (C.c_int, [_P, _P, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int64,
+                                            _P]),
+    "msr_rerank_scatter": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     "msr_merge_topk": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "msr_merge_topk_payload": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P,
                                          _P, _P]),

@@ -1124,8 +1124,8 @@ static int rerank_gather_impl(msr_engine* e, const char* fn, const float* q, int
         const bool blocked = q_per_block < n_queries;
         float* co = blocked ? out_cos + (int64_t)(q0 / q_per_block) * block_stride : out_cos + o * MSR_RERANK_MAX_CHUNKS;
         int32_t* mo = blocked ? out_meta + (int64_t)(q0 / q_per_block) * block_stride : out_meta + o * 3;
-        RerankRecords rr{nullptr, nullptr, nullptr};
-        if (rec) rr = RerankRecords{rec->out, rec->q_base + q0, rec->blk_off + (int64_t)q0 * ((max_cand + 7) / 8)};
+        RerankRecords rr{nullptr, nullptr, nullptr, 0};
+        if (rec) rr = RerankRecords{rec->out, rec->q_base + q0, rec->blk_off + (int64_t)q0 * ((max_cand + 7) / 8), rec->capacity};
         HIP_TRY(e, msr_rerank_gather(e->dense, e->url_group, e->rr_qn, nq, cand_doc + o, cand_n + q0, max_cand, doc_base,
                                      row_base, max_chunks, co, mo, blocked ? q_per_block : nq, blocked ? block_stride : 0, rr, st));
     }
@@ -1173,26 +1173,28 @@ extern "C" int msr_rerank_plan(msr_engine* e, int32_t n_queries, const int32_t* 
 extern "C" int msr_rerank_gather_records(msr_engine* e, const float* q, int32_t n_queries, const int32_t* cand_doc,
                                          const int32_t* cand_n, int32_t max_cand, int32_t doc_base, int32_t row_base,
                                          int32_t max_chunks, const int32_t* send_base, const int32_t* send_blk,
-                                         int32_t* out_records, void* stream) {
+                                         int32_t* out_records, int64_t capacity_records, void* stream) {
     if (!e) return MSR_ERR_INVALID;
-    if (!send_base || !send_blk || !out_records) return fail(e, MSR_ERR_INVALID, "msr_rerank_gather_records: null argument");
-    const RerankRecords rec{out_records, send_base, send_blk};
+    if (!send_base || !send_blk || !out_records || capacity_records < 0)
+        return fail(e, MSR_ERR_INVALID, "msr_rerank_gather_records: bad argument");
+    const RerankRecords rec{out_records, send_base, send_blk, capacity_records};
     return rerank_gather_impl(e, "msr_rerank_gather_records", q, n_queries, cand_doc, cand_n, max_cand, doc_base, row_base,
                               max_chunks, nullptr, nullptr, n_queries > 0 ? n_queries : 1, 0, stream, &rec);
 }
 
-extern "C" int msr_rerank_scatter(msr_engine* e, const int32_t* records, const int32_t* counts, const int32_t* recv_off,
-                                  int32_t n_shards, int32_t n_queries, int32_t queries_per_shard, int32_t first_query,
-                                  int32_t n_my_queries, int32_t max_cand, float* out_cos, int32_t* out_meta, void* stream) {
+extern "C" int msr_rerank_scatter(msr_engine* e, const int32_t* records, int64_t capacity_records, const int32_t* counts,
+                                  const int32_t* recv_off, int32_t n_shards, int32_t n_queries, int32_t queries_per_shard,
+                                  int32_t first_query, int32_t n_my_queries, int32_t max_cand, float* out_cos, int32_t* out_meta,
+                                  void* stream) {
     if (!e) return MSR_ERR_INVALID;
-    if (!records || !counts || !recv_off || !out_cos || !out_meta || n_shards < 1 || n_shards > 64 || max_cand < 1 ||
+    if (!records || capacity_records < 0 || !counts || !recv_off || !out_cos || !out_meta || n_shards < 1 || n_shards > 64 || max_cand < 1 ||
         max_cand > 1024 || n_my_queries < 0 || n_my_queries > queries_per_shard || first_query < 0 ||
         first_query + n_my_queries > n_queries)
         return fail(e, MSR_ERR_INVALID, "msr_rerank_scatter: bad argument (n_shards=%d, first_query=%d, n_my_queries=%d)", n_shards,
                     first_query, n_my_queries);
     if (n_my_queries == 0) return MSR_OK;
     HIP_TRY(e, hipSetDevice(e->cfg.device));
-    HIP_TRY(e, msr_rerank_scatter_run(records, counts, recv_off, n_shards, n_queries, queries_per_shard, first_query,
+    HIP_TRY(e, msr_rerank_scatter_run(records, capacity_records, counts, recv_off, n_shards, n_queries, queries_per_shard, first_query,
                                       n_my_queries, max_cand, out_cos, out_meta, (hipStream_t)stream));
     return MSR_OK;
 }

@@ -189,6 +189,7 @@ struct RerankRecords {
     int32_t* out;
     const int32_t* q_base;
     const int32_t* blk_off;
+    int64_t capacity;            // records `out` holds: a record at or past it is dropped (a caller's sizing error must not write outside)
 };
 // (A) cosines + (rows, url group, first row) of the candidates this shard owns; zeros for the others.
 hipError_t msr_rerank_gather(const DenseIndex& ix, const int32_t* url_group, const float* qn, int nq,
@@ -202,7 +203,7 @@ hipError_t msr_rerank_gather(const DenseIndex& ix, const int32_t* url_group, con
 hipError_t msr_rerank_plan_run(int nq, const int32_t* cand_doc, const int32_t* cand_n, int max_cand, const int32_t* bounds,
                                int n_shards, int my, int qps, int32_t* counts, int32_t* send_base, int32_t* blk_off,
                                int32_t* recv_off, int32_t* pair, hipStream_t stream);
-hipError_t msr_rerank_scatter_run(const int32_t* records, const int32_t* counts, const int32_t* recv_off, int n_shards, int nq,
+hipError_t msr_rerank_scatter_run(const int32_t* records, int64_t capacity, const int32_t* counts, const int32_t* recv_off, int n_shards, int nq,
                                   int qps, int q_first, int n_mine, int max_cand, float* cos_out, int32_t* meta_out,
                                   hipStream_t stream);
 // (q_per_block / block_stride: query q's rows start (q / q_per_block) * block_stride 32-bit words + (q % q_per_block) rows

@@ -66,9 +66,8 @@ __global__ __launch_bounds__(64) void rerank_cos_kernel(DenseIndex ix, const int
     unsigned long long todo = __ballot(d_mine >= 0);
     if (todo == 0) return;
     const unsigned long long mine_all = todo;
-    int32_t* rec0 = nullptr;
-    if (records)
-        rec0 = rec.out + ((int64_t)rec.q_base[q] + rec.blk_off[(int64_t)q * gridDim.x + blockIdx.x]) * MSR_RERANK_RECORD_WORDS;
+    int64_t rec_first = 0;
+    if (records) rec_first = (int64_t)rec.q_base[q] + rec.blk_off[(int64_t)q * gridDim.x + blockIdx.x];
     const f32x4* q4 = (const f32x4*)(qn + (size_t)q * MSR_DIM);
     const f32x4 qa = q4[lane], qb = q4[lane + 64], qc = q4[lane + 128];
     for (; todo != 0; todo &= todo - 1) {
@@ -77,7 +76,9 @@ __global__ __launch_bounds__(64) void rerank_cos_kernel(DenseIndex ix, const int
         float* out = cos_out + (int64_t)m * RR_MAXC;
         int32_t* mt = meta + (int64_t)m * 3;
         if (records) {
-            int32_t* r = rec0 + (int64_t)__builtin_popcountll(mine_all & ((1ull << sl) - 1)) * MSR_RERANK_RECORD_WORDS;
+            const int64_t at = rec_first + __builtin_popcountll(mine_all & ((1ull << sl) - 1));
+            if (at < 0 || at >= rec.capacity) continue;      // (wave-uniform)
+            int32_t* r = rec.out + at * MSR_RERANK_RECORD_WORDS;
             out = (float*)(r + 4);
             mt = r + 1;
             if (lane == 0) { r[0] = m; r[14] = q; r[15] = 0; }
@@ -526,14 +527,17 @@ __global__ __launch_bounds__(RO_THREADS) void rerank_offsets_kernel(const int32_
 
 // The receiving side: the records of (source s, my query j) go to their slots of the dense arrays the fuse kernel reads
 // (zeroed beforehand: a slot nobody owns stays "no document").  One workgroup per (query, source).
-__global__ __launch_bounds__(256) void rerank_scatter_kernel(const int32_t* __restrict__ records,
+__global__ __launch_bounds__(256) void rerank_scatter_kernel(const int32_t* __restrict__ records, int64_t capacity,
                                                               const int32_t* __restrict__ counts,
                                                               const int32_t* __restrict__ recv_off, int nq, int qps, int q_first,
                                                               int max_cand, float* __restrict__ cos_out,
                                                               int32_t* __restrict__ meta_out) {
     const int j = blockIdx.x, s = blockIdx.y;
-    const int cnt = counts[(int64_t)s * nq + q_first + j];
-    const int32_t* rec = records + (int64_t)recv_off[(int64_t)s * qps + j] * MSR_RERANK_RECORD_WORDS;
+    int cnt = counts[(int64_t)s * nq + q_first + j];
+    const int64_t first = recv_off[(int64_t)s * qps + j];
+    if (first < 0 || first >= capacity) return;
+    if (first + cnt > capacity) cnt = (int)(capacity - first);
+    const int32_t* rec = records + first * MSR_RERANK_RECORD_WORDS;
     for (int i = threadIdx.x; i < cnt * 13; i += 256) {
         const int r = i / 13, w = i - 13 * r;
         const int32_t* rr = rec + (int64_t)r * MSR_RERANK_RECORD_WORDS;
@@ -557,7 +561,7 @@ hipError_t msr_rerank_plan_run(int nq, const int32_t* cand_doc, const int32_t* c
     return hipGetLastError();
 }
 
-hipError_t msr_rerank_scatter_run(const int32_t* records, const int32_t* counts, const int32_t* recv_off, int n_shards, int nq,
+hipError_t msr_rerank_scatter_run(const int32_t* records, int64_t capacity, const int32_t* counts, const int32_t* recv_off, int n_shards, int nq,
                                   int qps, int q_first, int n_mine, int max_cand, float* cos_out, int32_t* meta_out,
                                   hipStream_t stream) {
     if (n_mine <= 0) return hipSuccess;
@@ -566,7 +570,7 @@ hipError_t msr_rerank_scatter_run(const int32_t* records, const int32_t* counts,
     if (err != hipSuccess) return err;
     err = hipMemsetAsync(meta_out, 0, (size_t)n_mine * max_cand * 3 * 4, stream);
     if (err != hipSuccess) return err;
-    rerank_scatter_kernel<<<dim3((unsigned)n_mine, (unsigned)n_shards), 256, 0, stream>>>(records, counts, recv_off, nq, qps,
+    rerank_scatter_kernel<<<dim3((unsigned)n_mine, (unsigned)n_shards), 256, 0, stream>>>(records, capacity, counts, recv_off, nq, qps,
                                                                                            q_first, max_cand, cos_out, meta_out);
     return hipGetLastError();
 }

@@ -358,14 +358,14 @@ class DeviceEngine:
         assert records.is_contiguous() and records.dtype == torch.int32
         self._check(self.lib.msr_rerank_gather_records(self.handle, _ptr(q), Q, _ptr(cand), _ptr(cn), M, int(doc_base), int(row_base),
                                                        int(max_chunks), _ptr(plan.send_base), _ptr(plan.send_blk), _ptr(records),
-                                                       self._stream()))
+                                                       int(records.numel()) // 16, self._stream()))
 
     def rerank_scatter(self, records, plan, first_query, nq, M):
         """The received records of my queries [first_query, first_query + nq) -> (cos [nq, M, 10], meta [nq, M, 3])."""
         N, Q = int(plan.counts.shape[0]), int(plan.counts.shape[1])
         cos = torch.empty((nq, M, _abi.MSR_RERANK_MAX_CHUNKS), dtype=torch.float32, device=self.device)
         meta = torch.empty((nq, M, 3), dtype=torch.int32, device=self.device)
-        self._check(self.lib.msr_rerank_scatter(self.handle, _ptr(records), _ptr(plan.counts), _ptr(plan.recv_off), N, Q,
+        self._check(self.lib.msr_rerank_scatter(self.handle, _ptr(records), int(records.numel()) // 16, _ptr(plan.counts), _ptr(plan.recv_off), N, Q,
                                                 int(plan.recv_off.shape[1]), int(first_query), int(nq), int(M), _ptr(cos), _ptr(meta),
                                                 self._stream()))
         return cos, meta
