@@ -570,6 +570,7 @@ def main():
         slot_shard = (torch.arange(args.k1, device=dev) % NE).to(torch.int32).unsqueeze(0)
         e_bounds = (torch.arange(NE + 1, dtype=torch.int64) * shard.n_docs).to(torch.int32).to(dev)
         e_src = torch.arange(NE, dtype=torch.int32, device=dev).view(NE, 1)
+        e_gathered = {}
 
         def step(i, one=None):                          # noqa: F811  (replaces the step above)
             packed, qv = one if one is not None else batches[i % len(batches)]
@@ -591,10 +592,18 @@ def main():
                         eng.dense_end(a1 - a0, k=args.k2, bound=bound, out=tuple(t[a0:a1] for t in d))
             else:
                 d = eng.dense_topk(qv, k=args.k2)
-            # the two merges of NE gathered lists (stand-in operands: NE copies of the local lists)
-            rep = lambda t: t.unsqueeze(0).expand(NE, *t.shape).contiguous()
-            eng.merge_topk(rep(b[0]), rep(b[1]), rep(b[2]), args.k1)
-            eng.merge_topk(rep(d[0]), rep(d[1]), rep(d[3]), args.k2)
+            # the two merges of NE gathered lists.  Stand-in operands: NE copies of the local lists of the FIRST step of this
+            # shape, made once -- in the real step the gathered buffer is filled by the collective, not by this GPU's CUs;
+            # what the real step does on the GPU before its all-gathers, writing its lists into the send buffers, is done here too
+            if nq not in e_gathered:
+                rep = lambda t: t.unsqueeze(0).expand(NE, *t.shape).contiguous()
+                e_gathered[nq] = ((rep(b[0]), rep(b[1]), rep(b[2])), (rep(d[0]), rep(d[1]), rep(d[3])),
+                                  [torch.empty_like(t) for t in (b[0], b[1], b[2], d[0], d[1], d[2], d[3])])
+            g_b, g_d, send = e_gathered[nq]
+            for dst, src in zip(send, b + d):
+                dst.copy_(src)
+            eng.merge_topk(*g_b, args.k1)
+            eng.merge_topk(*g_d, args.k2)
             if nq != Q:                                  # (the single-query latency loop: local stages only)
                 return {"bm25": b, "dense": d}
             # the rerank exchange in its compact form (distributed.py): count who owns what, the N x N matrix to the host (in
