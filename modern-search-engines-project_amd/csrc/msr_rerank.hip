@@ -16,6 +16,7 @@
 // zeros), and that rank runs (B) for its share of the queries.
 #include "msr_common.h"
 #include "msr_internal.h"
+#include "msr_sort.h"
 
 namespace {
 
@@ -132,29 +133,6 @@ __global__ __launch_bounds__(64) void rerank_cos_kernel(DenseIndex ix, const int
     }
 }
 
-// Bitonic sort of (hi, lo) keys with a 32-bit payload; ascending if ASC else descending.
-template <bool ASC>
-__device__ void bitonic_kv(uint64_t* khi, uint32_t* klo, uint32_t* val, int P) {
-    for (int kk = 2; kk <= P; kk <<= 1) {
-        for (int j = kk >> 1; j > 0; j >>= 1) {
-            for (int idx = threadIdx.x; idx < (P >> 1); idx += RR_THREADS) {
-                const int i = ((idx & ~(j - 1)) << 1) | (idx & (j - 1));
-                const int p = i | j;
-                const bool up = ((i & kk) == 0) == ASC;          // this pair must end ascending
-                const uint64_t ah = khi[i], bh = khi[p];
-                const uint32_t al = klo[i], bl = klo[p];
-                const bool a_gt_b = ah > bh || (ah == bh && al > bl);
-                const bool a_lt_b = ah < bh || (ah == bh && al < bl);
-                if (up ? a_gt_b : a_lt_b) {
-                    khi[i] = bh; klo[i] = bl; khi[p] = ah; klo[p] = al;
-                    const uint32_t t = val[i]; val[i] = val[p]; val[p] = t;
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
 __device__ __forceinline__ double block_reduce(double v, bool is_min, double* red) {
     // red: LDS scratch of RR_THREADS/64 doubles
     for (int o = 32; o > 0; o >>= 1) {
@@ -210,7 +188,7 @@ __global__ __launch_bounds__(RR_THREADS) void rerank_fuse_kernel(
     }
     if (tid < 2) cnt[tid] = 0;
     __syncthreads();
-    bitonic_kv<true>(khi, klo, val, P);
+    msr_sort::bitonic_sort<RR_THREADS, true>(khi, klo, val, P, true);
 
     // 2. keep = first of its URL group, has at least one chunk row
     double cmin = __builtin_inf(), cmax = -__builtin_inf(), bmin = __builtin_inf(), bmax = -__builtin_inf();
@@ -279,7 +257,7 @@ __global__ __launch_bounds__(RR_THREADS) void rerank_fuse_kernel(
     }
     __syncthreads();
     // 4. order by (score desc, doc asc)
-    bitonic_kv<false>(khi, klo, val, P);
+    msr_sort::bitonic_sort<RR_THREADS, true>(khi, klo, val, P, false);
     const int n_keep = cnt[1];
     for (int i = tid; i < max_cand; i += RR_THREADS) {
         const int64_t o = (int64_t)q * max_cand + i;

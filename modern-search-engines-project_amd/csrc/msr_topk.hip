@@ -11,6 +11,18 @@
 // final kernel.  Every pass is a streaming read of the score row: HBM-bound.
 #include "msr_common.h"
 #include "msr_internal.h"
+#include "msr_sort.h"
+
+#ifdef MSR_DIAG
+// diagnostic build: phase timestamps of sel_final_kernel's workgroup 0 (s_memtime ticks), read by msr_debug_sel_final
+__device__ unsigned long long msr_dbg_ts[16];
+extern "C" int msr_debug_sel_final(unsigned long long* out16) {
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(msr_dbg_ts), sizeof(unsigned long long) * 16);
+}
+#define DBG_TS(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) msr_dbg_ts[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define DBG_TS(i) do { } while (0)
+#endif
 
 namespace {
 
@@ -305,41 +317,7 @@ __device__ __forceinline__ bool key_less(uint64_t ah, uint32_t al, uint64_t bh, 
     return ah < bh || (ah == bh && al < bl);
 }
 
-// Between two stages of a compare-exchange network whose partner distance is <= 64 no workgroup barrier is needed: thread
-// t's pair of such a stage lies in the 128-element block of the 64 consecutive pair indices its wave holds (the same block
-// in every such stage), and a wave's LDS operations execute in order.  Only the compiler has to be kept from moving LDS
-// accesses across the stage boundary.
-__device__ __forceinline__ void stage_sync(int j, int j_next) {
-    if (j <= 64 && j_next <= 64) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-    } else {
-        __syncthreads();
-    }
-}
-
-template <int THREADS>
-__device__ void bitonic_desc(uint64_t* khi, uint32_t* klo, int P) {
-    static_assert(THREADS % 64 == 0, "whole waves");
-    for (int kk = 2; kk <= P; kk <<= 1) {
-        for (int j = kk >> 1; j > 0; j >>= 1) {
-            for (int idx = threadIdx.x; idx < (P >> 1); idx += THREADS) {
-                const int i = ((idx & ~(j - 1)) << 1) | (idx & (j - 1));
-                const int p = i | j;
-                const bool desc = (i & kk) == 0;
-                const uint64_t ah = khi[i], bh = khi[p];
-                const uint32_t al = klo[i], bl = klo[p];
-                const bool a_lt_b = key_less(ah, al, bh, bl);
-                const bool b_lt_a = key_less(bh, bl, ah, al);
-                if (desc ? a_lt_b : b_lt_a) {
-                    khi[i] = bh; klo[i] = bl; khi[p] = ah; klo[p] = al;
-                }
-            }
-            stage_sync(j, j > 1 ? j >> 1 : kk);                  // (the stage after j = 1 is the next level's first: j = kk)
-        }
-    }
-    __syncthreads();
-}
+using msr_sort::stage_sync;
 
 // One workgroup per query: exact sort of the candidates and output.  If the two streaming passes did not
 // resolve the query (state not done), this workgroup finishes the radix select on its own over the score
@@ -368,9 +346,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void sel_final_kernel(const T* __rest
     const int32_t* irow = view.idx ? view.idx + (int64_t)q * stride : nullptr;
     int n_sg = 1, sg0 = 0;
     part_segments(view, 0, 1, sg0, n_sg);                        // (this workgroup walks every segment of the row)
+    DBG_TS(0);
     if (t == 0) S_sh = st[q];
     __syncthreads();
     int cnt;
+    DBG_TS(1);
     if (S_sh.done) {
         cnt = cand_n[q];
         if (cnt > MSR_SEL_CAP) cnt = MSR_SEL_CAP;
@@ -410,6 +390,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void sel_final_kernel(const T* __rest
                 cur = s_cnt;
                 __syncthreads();
             }
+            DBG_TS(2);
             if (t == 0) s_cnt = 0;
             __syncthreads();
             const SelState S = S_sh;
@@ -470,9 +451,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void sel_final_kernel(const T* __rest
     int P = 64;
     while (P < cnt) P <<= 1;
     __syncthreads();
+    DBG_TS(3);
     for (int i = cnt + t; i < P; i += SCAN_THREADS) { khi[i] = 0; klo[i] = 0; }
     __syncthreads();
-    bitonic_desc<SCAN_THREADS>(khi, klo, P);
+    msr_sort::bitonic_sort<SCAN_THREADS, false>(khi, klo, nullptr, P, false);
+    DBG_TS(4);
     int n_sel = S_sh.n_sel;
     if (n_sel > cnt) n_sel = cnt;
     for (int i = t; i < k; i += SCAN_THREADS) {
@@ -484,6 +467,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void sel_final_kernel(const T* __rest
         out_n[q] = n_sel;
         cand_n[q] = 0;                                           // invariant: zero between calls
     }
+    DBG_TS(5);
+#ifdef MSR_DIAG
+    if (blockIdx.x == 0 && t == 0) { msr_dbg_ts[6] = (unsigned long long)cnt; msr_dbg_ts[7] = (unsigned long long)P; }
+#endif
 }
 
 template <typename T>
