@@ -3,8 +3,10 @@
 * configs[1]: BM25 top-100, synthetic 100 k-doc postings resident in HBM, 1024 queries in ONE call (the L3-resident,
   49-tile regime that the 600 / 2 500 / 30 000 / 1 M-document tests only bracket), bitwise against the C oracle.
 * a 1-rank RCCL smoke: torch.distributed backend "nccl" IS RCCL on ROCm.  world_size = 1 still loads librccl and runs the
-  two collectives of the sharded path (uint8 all_gather_into_tensor of the packed lists, int32 SUM all_reduce of raw
-  cosine bits) on their real dtypes, so the first 8-GPU run is not the first execution of that code.
+  collectives of the sharded path in the forms it uses them (uint8 all_gather_into_tensor of the packed lists, also
+  asynchronous and waited for later; all_reduce MIN of floats; int32 all_to_all_single with split sizes on slices of
+  preallocated buffers; the int32 SUM all_reduce of raw cosine bits round 2 used), so the first 8-GPU run is not the
+  first execution of those calls.
 """
 import json
 import os
