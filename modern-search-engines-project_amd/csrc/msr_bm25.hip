@@ -542,6 +542,38 @@ hipError_t msr_bm25_validate(const Bm25Index& ix, int32_t* flag, hipStream_t str
 
 int msr_bm25_max_segments(int64_t n_docs) { return (int)((n_docs + BM25_TILE - 1) / BM25_TILE); }
 
+// An upper bound of every score of a query, as the 20-bit key prefix (sign, exponent, 8 mantissa bits of the order-preserving
+// key) the select's window pass anchors its 4096 bins to: U = (k1 + 1) * sum over the query's terms with positive idf of
+// idf * qtf (a tf_component is below k1 + 1), a little raised; out[q] = prefix(U) - 4094, i.e. U falls into bin 4094 and bin
+// 4095 stays empty unless the bound is wrong -- which the select notices (it then takes its general path).
+__global__ __launch_bounds__(256) void bm25_window_kernel(Bm25Index ix, const int32_t* __restrict__ q_term_off,
+                                                           const int32_t* __restrict__ q_terms,
+                                                           const int32_t* __restrict__ q_qtf, int q_first, int nq,
+                                                           uint64_t* __restrict__ out) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    const int t0 = q_term_off[q_first + q];
+    int nt = q_term_off[q_first + q + 1] - t0;
+    if (nt > BM25_MAX_TERMS) nt = BM25_MAX_TERMS;
+    double u = 0.0;
+    for (int j = 0; j < nt; ++j) {
+        const int32_t t = q_terms[t0 + j];
+        if (t < 0 || t >= ix.n_terms) continue;
+        const double w = (double)ix.idf[t] * (double)q_qtf[t0 + j];
+        if (w > 0.0) u += w;
+    }
+    u = u * (ix.k1 + 1.0) * 1.0000001 + 1e-300;
+    const uint64_t pre = msr_ord64(u) >> 44;
+    out[q] = pre > 4094 ? pre - 4094 : 0;
+}
+
+hipError_t msr_bm25_window(const Bm25Index& ix, const int32_t* q_term_off, const int32_t* q_terms, const int32_t* q_qtf,
+                           int q_first, int nq, uint64_t* out, hipStream_t stream) {
+    if (nq <= 0) return hipSuccess;
+    bm25_window_kernel<<<(unsigned)((nq + 255) / 256), 256, 0, stream>>>(ix, q_term_off, q_terms, q_qtf, q_first, nq, out);
+    return hipGetLastError();
+}
+
 hipError_t msr_bm25_scores(const Bm25Index& ix, const int32_t* q_term_off, const int32_t* q_terms,
                            const int32_t* q_qtf, int q_first, int nq, double min_score, double* cand_score,
                            int32_t* cand_doc, int32_t* seg_n, int* n_seg, int64_t* seg_stride, hipStream_t stream) {

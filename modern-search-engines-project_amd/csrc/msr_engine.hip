@@ -46,6 +46,7 @@ struct msr_engine {
     uint32_t* bm_tile_off = nullptr;
     int32_t* bm_cand_doc = nullptr;    // max_queries rows of n_docs i32: document of each BM25 candidate
     int32_t* bm_cand_n = nullptr;      // [max_queries][tiles] candidates per (query, segment) of the candidate rows
+    uint64_t* bm_win = nullptr;        // [max_queries] anchor of the select's window pass (msr_bm25_window)
     size_t bm_cand_bytes = 0;
     SelScratch sel{};
     float* rerank_cos = nullptr;
@@ -239,7 +240,7 @@ extern "C" int msr_create(const msr_config* cfg, msr_engine** out) {
 extern "C" int msr_destroy(msr_engine* e) {
     if (!e) return MSR_OK;
     free_dev(e, e->chunk_doc); free_dev(e, e->emb_presplit); free_dev(e, e->row_meta); free_dev(e, e->inv_norm_own); free_dev(e, e->span_doc); free_dev(e, e->wspan_doc); free_dev(e, e->wspan12_doc); free_dev(e, e->qn); free_dev(e, e->rr_qn); free_dev(e, e->qimg); free_dev(e, e->emb_bf16);
-    free_dev(e, e->score_rows); free_dev(e, e->bm_heavy_id); free_dev(e, e->bm_post); free_dev(e, e->bm_dense_id); free_dev(e, e->bm_dense); free_dev(e, e->bm_tile_off); free_dev(e, e->bm_cand_doc); free_dev(e, e->bm_cand_n); free_dev(e, e->sel.hist); free_dev(e, e->sel.state); free_dev(e, e->sel.cand_hi);
+    free_dev(e, e->score_rows); free_dev(e, e->bm_heavy_id); free_dev(e, e->bm_post); free_dev(e, e->bm_dense_id); free_dev(e, e->bm_dense); free_dev(e, e->bm_tile_off); free_dev(e, e->bm_cand_doc); free_dev(e, e->bm_cand_n); free_dev(e, e->bm_win); free_dev(e, e->sel.hist); free_dev(e, e->sel.state); free_dev(e, e->sel.cand_hi);
     free_dev(e, e->sel.cand_lo); free_dev(e, e->sel.cand_n); free_dev(e, e->rerank_cos); free_dev(e, e->rerank_meta);
     free_dev(e, e->bt_top_doc); free_dev(e, e->bt_top_score); free_dev(e, e->bt_top_n); free_dev(e, e->bt_cand_doc);
     free_dev(e, e->bt_cand_score); free_dev(e, e->bt_cand_chunk); free_dev(e, e->bt_cand_n);
@@ -295,6 +296,9 @@ extern "C" int msr_bind_postings(msr_engine* e, const int64_t* term_off, int64_t
             e->bm_cand_bytes = need;
         }
         free_dev(e, e->bm_cand_n); e->bm_cand_n = nullptr;
+        free_dev(e, e->bm_win); e->bm_win = nullptr;
+        if ((herr = eng_malloc(e, (void**)&e->bm_win, (size_t)e->cfg.max_queries * sizeof(uint64_t))) != hipSuccess)
+            return fail(e, MSR_ERR_NOMEM, "msr_bind_postings: %s", hipGetErrorString(herr));
         if ((herr = eng_malloc(e, (void**)&e->bm_cand_n, (size_t)e->cfg.max_queries * msr_bm25_max_segments(n_docs) * sizeof(int32_t))) != hipSuccess)
             return fail(e, MSR_ERR_NOMEM, "BM25 candidate counts: %s", hipGetErrorString(herr));
 
@@ -778,8 +782,15 @@ extern "C" int msr_bm25_topk(msr_engine* e, const int32_t* q_term_off, const int
             HIP_TRY(e, hipEventRecord(e->ev_stop[1][e->ev_count[1]], st));
             e->ev_count[1]++;
         }
+        // scores >= min_score >= 0 lie in a window of 16 octaves below a bound known from the query alone: one histogram
+        // pass instead of two (a negative min_score keeps the general two)
+        const uint64_t* win = nullptr;
+        if (min_score >= 0.0) {
+            HIP_TRY(e, msr_bm25_window(e->bm25, q_term_off, q_terms, q_qtf, q0, nq, e->bm_win, st));
+            win = e->bm_win;
+        }
         HIP_TRY(e, msr_select_topk_list((const double*)e->score_rows, e->bm_cand_doc, e->bm_cand_n, n_seg, seg_stride, N, nq, k,
-                                        e->sel, o_doc, o_score, out_n + q0, st));
+                                        e->sel, o_doc, o_score, out_n + q0, st, win));
     }
     return MSR_OK;
 }

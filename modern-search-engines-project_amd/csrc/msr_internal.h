@@ -38,9 +38,13 @@ hipError_t msr_select_topk(int score_bits, const void* scores, int64_t n, int64_
 
 // The same over segmented LISTS: row q (stride elements apart) is cut into n_seg segments seg_stride elements apart; segment s
 // holds counts[q * n_seg + s] pairs (scores, idx) in any order, from its first position on.
+// win_base (nullable, [nq]): the first histogram pass takes a WINDOW of the 20-bit key prefixes (sign, exponent, 8 mantissa
+// bits) instead of the first 12-bit digit -- bin = clamp(prefix - win_base[q], 0, 4095) -- and resolves 20 bits at once: one
+// streaming pass instead of two when an upper bound of the scores is known (msr_bm25_window); a k-th key in bin 0 or 4095
+// (the bound was wrong, or the k-th score is 2^-15 of it) sends the query down the general in-kernel path: exact either way.
 hipError_t msr_select_topk_list(const double* scores, const int32_t* idx, const int32_t* counts, int n_seg, int64_t seg_stride,
                                 int64_t stride, int nq, int k, const SelScratch& sc, int32_t* out_doc,
-                                double* out_score, int32_t* out_n, hipStream_t stream);
+                                double* out_score, int32_t* out_n, hipStream_t stream, const uint64_t* win_base = nullptr);
 
 // Merge lists: in_* [n_parts][nq][k]; see msretr.h msr_merge_topk.  in_pay / out_pay (nullable): a 32-bit payload per entry
 // that travels with it (the arg-max chunk row of a dense result).  part_stride_bytes != 0: part p of EVERY input array starts
@@ -102,6 +106,8 @@ hipError_t msr_bm25_build_skip(const Bm25Index& ix, const int32_t* heavy_terms, 
 // a span of tiles); segment s holds seg_n[q * n_seg + s] pairs from position s * seg_stride on, in no particular order.
 // Every count is written by the kernel (no initialisation, no atomics).  seg_n: msr_bm25_max_segments(n_docs) words per query.
 int msr_bm25_max_segments(int64_t n_docs);
+hipError_t msr_bm25_window(const Bm25Index& ix, const int32_t* q_term_off, const int32_t* q_terms, const int32_t* q_qtf,
+                           int q_first, int nq, uint64_t* out /*[nq]: see msr_select_topk_list*/, hipStream_t stream);
 hipError_t msr_bm25_scores(const Bm25Index& ix, const int32_t* q_term_off, const int32_t* q_terms,
                            const int32_t* q_qtf, int q_first, int nq, double min_score, double* cand_score,
                            int32_t* cand_doc, int32_t* seg_n, int* n_seg, int64_t* seg_stride, hipStream_t stream);

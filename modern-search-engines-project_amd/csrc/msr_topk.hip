@@ -28,6 +28,7 @@ namespace {
 
 constexpr int SEL_THREADS = 256;
 constexpr int SCAN_THREADS = 1024;
+constexpr int WIN_SHIFT = 44;                      // the window pass bins 20-bit prefixes of a 64-bit key (msr_internal.h)
 
 template <int SB> struct KeyCfg {
     static constexpr int NS = (SB + 11) / 12;      // digits in the score part
@@ -68,8 +69,10 @@ template <> struct ScoreTraits<double> {
 // them must call it).  Finds the bin that holds the S.k_rem-th largest element among the elements counted in
 // h, appends that digit to the resolved prefix and updates the counters.  `suf` is LDS scratch of
 // SCAN_THREADS + 1 words, `S_sh` an LDS copy of the state that every thread reads back.
+// digit = -1: the window pass (h counts the 20-bit prefixes win_base .. win_base + 4095, both ends clamped).
 template <int SB>
-__device__ void select_step(const uint32_t* h, uint32_t* suf, SelState* S_sh, int digit, int k, int* superset_out = nullptr) {
+__device__ void select_step(const uint32_t* h, uint32_t* suf, SelState* S_sh, int digit, int k, int* superset_out = nullptr,
+                            uint64_t win_base = 0) {
     const int t = threadIdx.x;
     uint32_t local = h[4 * t] + h[4 * t + 1] + h[4 * t + 2] + h[4 * t + 3];
     suf[t] = local;
@@ -84,7 +87,7 @@ __device__ void select_step(const uint32_t* h, uint32_t* suf, SelState* S_sh, in
     const SelState S = *S_sh;
     const uint32_t total = suf[0];
     __syncthreads();
-    if (digit == 0 && total <= (uint32_t)S.k_rem) {              // fewer valid elements than k: take all
+    if (digit <= 0 && total <= (uint32_t)S.k_rem) {              // fewer valid elements than k: take all
         if (t == 0) { S_sh->done = 1; S_sh->n_sel = (int32_t)total; }
         __syncthreads();
         return;
@@ -97,17 +100,29 @@ __device__ void select_step(const uint32_t* h, uint32_t* suf, SelState* S_sh, in
             if (above + h[b] >= need) break;
             above += h[b];
         }
-        int part, shift, width;
-        digit_pos<SB>(digit, part, shift, width);
-        const uint64_t wmask = ((uint64_t)1 << width) - 1;
         SelState N = S;
-        if (part == 0) { N.pref_hi |= (uint64_t)b << shift; N.mask_hi |= wmask << shift; }
-        else { N.pref_lo |= (uint32_t)b << shift; N.mask_lo |= (uint32_t)(wmask << shift); }
-        N.n_above += (int32_t)above;
-        N.k_rem -= (int32_t)above;
+        const uint32_t superset = (uint32_t)S.n_above + above + h[b];
         N.n_sel = k;
-        const uint32_t superset = (uint32_t)N.n_above + h[b];
-        if (superset <= MSR_SEL_CAP || digit == KeyCfg<SB>::ND - 1) N.done = 1;
+        if (digit < 0) {
+            if (b == 0 || b == MSR_SEL_BINS - 1) {               // a clamped bin: no prefix is known -- the general path, from scratch
+                N.done = 0;
+            } else {
+                N.pref_hi = (win_base + (uint64_t)b) << WIN_SHIFT;
+                N.mask_hi = ~(uint64_t)0 << WIN_SHIFT;
+                N.n_above += (int32_t)above;
+                N.k_rem -= (int32_t)above;
+                if (superset <= MSR_SEL_CAP) N.done = 1;
+            }
+        } else {
+            int part, shift, width;
+            digit_pos<SB>(digit, part, shift, width);
+            const uint64_t wmask = ((uint64_t)1 << width) - 1;
+            if (part == 0) { N.pref_hi |= (uint64_t)b << shift; N.mask_hi |= wmask << shift; }
+            else { N.pref_lo |= (uint32_t)b << shift; N.mask_lo |= (uint32_t)(wmask << shift); }
+            N.n_above += (int32_t)above;
+            N.k_rem -= (int32_t)above;
+            if (superset <= MSR_SEL_CAP || digit == KeyCfg<SB>::ND - 1) N.done = 1;
+        }
         if (superset_out) *superset_out = (int)superset;
         *S_sh = N;
     }
@@ -131,7 +146,9 @@ struct RowView {
     const int32_t* counts;   // null: every row has n elements
     int32_t n_seg;           // lists: segments per row (dense: unused)
     int64_t seg_stride;      // lists: elements between the starts of consecutive segments
+    const uint64_t* win_base;  // non-null (64-bit scores only): pass -1 bins the 20-bit key prefixes, see msr_internal.h
 };
+
 __device__ __forceinline__ int64_t row_index(const int32_t* idx_row, int64_t i) { return idx_row ? idx_row[i] : i; }
 // Work split: part `part` of `parts` takes a contiguous range of a dense row, or whole segments of a list.
 __device__ __forceinline__ void part_segments(const RowView& v, int part, int parts, int& s_first, int& s_last) {
@@ -171,8 +188,10 @@ __global__ __launch_bounds__(SEL_THREADS) void sel_hist_kernel(const T* __restri
     __shared__ uint32_t h[MSR_SEL_BINS];
     for (int b = threadIdx.x; b < MSR_SEL_BINS; b += SEL_THREADS) h[b] = 0;
     __syncthreads();
+    const bool window = digit < 0;
+    const int64_t wbase = window ? (int64_t)view.win_base[q] : 0;
     int part, shift, width;
-    digit_pos<SB>(digit, part, shift, width);
+    digit_pos<SB>(window ? 0 : digit, part, shift, width);
     const uint32_t wmask = (1u << width) - 1u;
     const T* row = scores + (int64_t)q * stride;
     const int32_t* irow = view.idx ? view.idx + (int64_t)q * stride : nullptr;
@@ -196,7 +215,11 @@ __global__ __launch_bounds__(SEL_THREADS) void sel_hist_kernel(const T* __restri
                 uint64_t khi; uint32_t klo;
                 if (!key_of(v[u], ix[u], khi, klo)) continue;
                 if ((khi & S.mask_hi) != S.pref_hi || (klo & S.mask_lo) != S.pref_lo) continue;
-                const uint32_t dg = part == 0 ? (uint32_t)(khi >> shift) & wmask : (klo >> shift) & wmask;
+                uint32_t dg = part == 0 ? (uint32_t)(khi >> shift) & wmask : (klo >> shift) & wmask;
+                if (window) {
+                    const int64_t b = (int64_t)(khi >> WIN_SHIFT) - wbase;
+                    dg = b < 0 ? 0u : (b > MSR_SEL_BINS - 1 ? (uint32_t)(MSR_SEL_BINS - 1) : (uint32_t)b);
+                }
                 atomicAdd(&h[dg], 1u);
             }
         }
@@ -211,14 +234,15 @@ __global__ __launch_bounds__(SEL_THREADS) void sel_hist_kernel(const T* __restri
 template <int SB>
 __global__ __launch_bounds__(SCAN_THREADS) void sel_scan_kernel(SelState* __restrict__ st,
                                                                  uint32_t* __restrict__ hist, int digit, int k,
-                                                                 const int32_t* __restrict__ gate, int gate_per64) {
+                                                                 const int32_t* __restrict__ gate, int gate_per64,
+                                                                 const uint64_t* __restrict__ win_base) {
     if (gate && gate[gate_per64 ? (int)blockIdx.x >> 6 : 0] == 0) return;
     __shared__ uint32_t h[MSR_SEL_BINS];
     __shared__ uint32_t suf[SCAN_THREADS + 1];
     __shared__ SelState S_sh;
     const int q = blockIdx.x, t = threadIdx.x;
     if (t == 0) {
-        if (digit == 0) {
+        if (digit <= 0) {
             SelState S;
             S.pref_hi = S.mask_hi = 0; S.pref_lo = S.mask_lo = 0;
             S.k_rem = k; S.n_above = 0; S.done = 0; S.n_sel = 0;
@@ -235,7 +259,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void sel_scan_kernel(SelState* __rest
         gh[4 * t + j] = 0;
     }
     __syncthreads();
-    select_step<SB>(h, suf, &S_sh, digit, k);
+    select_step<SB>(h, suf, &S_sh, digit, k, nullptr, digit < 0 ? win_base[q] : 0);
     if (t == 0) st[q] = S_sh;
 }
 
@@ -408,7 +432,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void sel_final_kernel(const T* __rest
         }
     } else {
         uint32_t* h = (uint32_t*)khi;                            // the histogram lives in the (still unused) key array
-        for (int d = 2; d < KeyCfg<SB>::ND; ++d) {
+        int d0 = 0;
+        for (; d0 < KeyCfg<SB>::ND; ++d0) {                      // first digit that is not (fully) resolved: 2 after the two
+            int part, shift, width;                              // streaming passes, 1 after a window pass, 0 if that gave up
+            digit_pos<SB>(d0, part, shift, width);
+            if (!(part == 0 ? (S_sh.mask_hi >> shift) & 1 : (S_sh.mask_lo >> shift) & 1)) break;
+        }
+        for (int d = d0; d < KeyCfg<SB>::ND; ++d) {
             for (int b = t; b < MSR_SEL_BINS; b += SCAN_THREADS) h[b] = 0;
             __syncthreads();
             const SelState S = S_sh;
@@ -483,10 +513,12 @@ hipError_t select_impl(const T* scores, int64_t n, int64_t stride, RowView view,
     if (parts > max_parts) parts = max_parts;
     if (parts < 1) parts = 1;
     dim3 grid((unsigned)parts, (unsigned)nq);
-    // two streaming histogram passes (24 key bits), one compaction, one exact sort: 6 launches
-    for (int d = 0; d < 2; ++d) {
+    // two streaming histogram passes (24 key bits) -- or ONE over a window of 20-bit prefixes --, one compaction, one exact
+    // sort: 6 (4) launches
+    const bool window = SB == 64 && view.win_base != nullptr;
+    for (int d = window ? -1 : 0; d < (window ? 0 : 2); ++d) {
         sel_hist_kernel<T><<<grid, SEL_THREADS, 0, stream>>>(scores, n, stride, view, d, sc.state, sc.hist, sc.gate, sc.gate_per64);
-        sel_scan_kernel<SB><<<nq, SCAN_THREADS, 0, stream>>>(sc.state, sc.hist, d, k, sc.gate, sc.gate_per64);
+        sel_scan_kernel<SB><<<nq, SCAN_THREADS, 0, stream>>>(sc.state, sc.hist, d, k, sc.gate, sc.gate_per64, view.win_base);
     }
     sel_compact_kernel<T><<<grid, SEL_THREADS, 0, stream>>>(scores, n, stride, view, sc.state, sc.cand_hi, sc.cand_lo,
                                                              sc.cand_n, sc.gate, sc.gate_per64);
@@ -761,7 +793,7 @@ __global__ __launch_bounds__(MRG_THREADS) void merge_rank_kernel(const int32_t* 
 hipError_t msr_select_topk(int score_bits, const void* scores, int64_t n, int64_t stride, int nq, int k,
                            const SelScratch& sc, int32_t* out_doc, void* out_score, int32_t* out_n,
                            hipStream_t stream) {
-    const RowView dense{nullptr, nullptr, 1, 0};
+    const RowView dense{nullptr, nullptr, 1, 0, nullptr};
     if (score_bits == 32)
         return select_impl<float>((const float*)scores, n, stride, dense, nq, k, sc, out_doc, (float*)out_score, out_n, stream);
     return select_impl<double>((const double*)scores, n, stride, dense, nq, k, sc, out_doc, (double*)out_score, out_n, stream);
@@ -769,9 +801,9 @@ hipError_t msr_select_topk(int score_bits, const void* scores, int64_t n, int64_
 
 hipError_t msr_select_topk_list(const double* scores, const int32_t* idx, const int32_t* counts, int n_seg, int64_t seg_stride,
                                 int64_t stride, int nq, int k, const SelScratch& sc, int32_t* out_doc,
-                                double* out_score, int32_t* out_n, hipStream_t stream) {
+                                double* out_score, int32_t* out_n, hipStream_t stream, const uint64_t* win_base) {
     if (n_seg < 1 || !counts || !idx) return hipErrorInvalidValue;
-    const RowView list{idx, counts, n_seg, seg_stride};
+    const RowView list{idx, counts, n_seg, seg_stride, win_base};
     return select_impl<double>(scores, stride, stride, list, nq, k, sc, out_doc, out_score, out_n, stream);
 }
 
