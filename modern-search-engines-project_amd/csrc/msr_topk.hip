@@ -194,7 +194,10 @@ __global__ __launch_bounds__(SEL_THREADS) void sel_hist_kernel(const T* __restri
     digit_pos<SB>(window ? 0 : digit, part, shift, width);
     const uint32_t wmask = (1u << width) - 1u;
     const T* row = scores + (int64_t)q * stride;
-    const int32_t* irow = view.idx ? view.idx + (int64_t)q * stride : nullptr;
+    // (a pass over the score part of the key with no index bits resolved does not look at the index: a list's 4 bytes of
+    // index per element are then not loaded -- a third of the pass' bytes)
+    const bool need_index = part != 0 || S.mask_lo != 0;
+    const int32_t* irow = view.idx && need_index ? view.idx + (int64_t)q * stride : nullptr;
     int s_first, s_last;
     part_segments(view, (int)blockIdx.x, (int)gridDim.x, s_first, s_last);
     for (int sg = s_first; sg < s_last; ++sg) {
