@@ -484,6 +484,8 @@ def main():
                     help="ONE GPU does the per-rank GPU work of an N-GPU step (run with 1/N of --docs/--chunks and N times the "
                          "queries): local stages, the merges of N gathered lists, the rerank gather of the 1/N of the candidates "
                          "a rank owns, the join of N halves and the fuse of 1/N of the queries; no collective is executed")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="also time the steps with stage 1 of the next batch overlapped with the tail of this one (variant_pipelined)")
     ap.add_argument("--with-encoder", action="store_true",
                     help="time the variant that starts from token ids (QueryEncoder -> hybrid step) even with --no-variants")
     ap.add_argument("--facade", action="store_true",
@@ -668,6 +670,65 @@ def main():
             if rep:
                 lat.append(time.perf_counter() - t1)
     p50_ms = 1e3 * float(np.median(lat)) if lat else None
+
+    # The same steps with the stages of CONSECUTIVE batches overlapped (one GPU, `--pipelined` only: measured at +1.8 %, 59.0 ->
+    # 60.1 k queries/s on one box -- the latency-bound BM25 stage and the gather both want every wave slot of the chip, side by
+    # side each takes about twice as long; profiles/r04_stream256_experiments.md 3b): stage 1 of
+    # batch i + 1 (BM25 + its select: latency-bound, 0.55 ms) runs on a second stream, with its own engine (its own scratch),
+    # beside what follows the dense pass of batch i (finish chain, rerank gather, fuse: 1.1 ms) -- it is released by an event
+    # behind that pass (msr_dense_topk_begin), so the HBM-bound pass itself keeps the whole chip.  Same kernels, same
+    # results; reported NEXT TO the headline.
+    pipelined = None
+    if args.workload == "hybrid" and args.dense_mode == "f32" and world == 1 and args.emulate_ranks <= 1 and Q > 64 \
+            and args.pipelined and eng.dense_split_max(args.k2) >= Q:
+        try:
+            from msretr.engine import DeviceEngine as _DE
+            eng_b = _DE(_without_emb(shard), device=local_rank, max_queries=Q, max_k=args.k1, rerank_max_docs=0)
+            s_b = torch.cuda.Stream(device=dev)
+            main = torch.cuda.current_stream(dev)
+
+            def stage1(i):                                   # -> (lists, event) ; enqueued on the second stream
+                with torch.cuda.stream(s_b):
+                    b = eng_b.bm25_topk(None, k=args.k1, packed=batches[i % len(batches)][0])
+                    ev = torch.cuda.Event()
+                    ev.record(s_b)
+                for t_ in b:                                 # (allocated on the second stream, read on the main one)
+                    t_.record_stream(main)
+                return b, ev
+
+            def run(n, first):
+                pend = stage1(first)
+                for i in range(first, first + n):
+                    qv = batches[i % len(batches)][1]
+                    b, ev = pend
+                    eng.dense_begin(qv, k=args.k2, k_part=args.k2)          # the passes over the rows
+                    behind = torch.cuda.Event()
+                    behind.record(main)
+                    s_b.wait_event(behind)                                   # stage 1 of the next batch: behind the pass
+                    pend = stage1(i + 1)
+                    d = eng.dense_end(Q, k=args.k2, bound=None)
+                    main.wait_event(ev)
+                    cos, meta = eng.rerank_gather(qv, b[0], b[2])
+                    r = eng.rerank_fuse(b[0], b[1], b[2], cos, meta)
+                main.wait_stream(s_b)                                        # (the look-ahead stage 1 of the batch after the last)
+                return {"bm25": b, "dense": d, "rerank": r}
+            run(2, 0)
+            fence()
+            tp = time.perf_counter()
+            pout = run(args.steps, args.warmup)
+            fence()
+            p_el = time.perf_counter() - tp
+            last = (args.warmup + args.steps - 1) % len(batches)
+            ref = se.search(None, batches[last][1], k1=args.k1, k2=args.k2, packed=batches[last][0])
+            same = all(bool(torch.equal(x, y)) for key in ("bm25", "dense", "rerank") for x, y in zip(pout[key], ref[key]))
+            pipelined = {"what": "stage 1 (BM25 + select) of batch i + 1 on a second stream and engine beside the finish chain, rerank "
+                                 "gather and fuse of batch i; released by an event behind the dense pass",
+                         "value": Q * args.steps / p_el, "unit": "queries/sec",
+                         "ms_per_step": 1e3 * p_el / args.steps, "equals_default_path_bitwise": same,
+                         "note": "the timed region holds steps + 1 BM25 stages (the look-ahead of the batch after the last)"}
+            eng_b.close()
+        except Exception as ex:
+            pipelined = {"error": repr(ex)}
 
     # The same steps with the dense stage on the batched path (bf16 candidates: a sweep per 128 queries, the tiled GEMM for more, + exact f32
     # rescoring; final scores and top-100 are those of the default path up to f32 rounding).  Reported NEXT TO the
@@ -938,6 +999,8 @@ def main():
             line["metric"] += f" [per-rank GPU work of a {args.emulate_ranks}-GPU step on ONE GPU: no collectives executed]"
         if verified is not None:
             line["sharded_equals_unsharded"] = verified
+        if pipelined is not None:
+            line["variant_pipelined"] = pipelined
         if variant is not None:
             line["variant_bf16_candidates"] = variant
         if exact is not None:
