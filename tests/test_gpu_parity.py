@@ -140,6 +140,38 @@ def test_bm25_many_tiles_common_rare_and_tied_terms(mods):
     eng.close()
 
 
+def test_bm25_select_window_pass_and_its_fallbacks(mods):
+    """The BM25 select's first pass histograms a window of 16 octaves below a bound of the query's scores.  Scores far below it
+    (a term whose idf is 1e-7 of another's: the k-th score falls into the clamped lowest bin), scores spread over 30 octaves,
+    a bound that is loose by orders of magnitude (high query term frequencies on terms most documents lack), and a negative
+    min_score (the general two-pass path) -- all bit for bit against the oracle, k below, at and above the strong documents."""
+    rng = np.random.default_rng(31)
+    N = 6000
+    doc_len = rng.integers(5, 400, size=N).astype(np.int32)
+    lists = [np.sort(rng.choice(N, size=12, replace=False)),           # term 0: strong, rare
+             np.sort(rng.choice(N, size=4500, replace=False)),         # term 1: idf 1e-7 of term 0's
+             np.sort(rng.choice(N, size=3000, replace=False)),         # term 2: in between
+             np.arange(N)]                                             # term 3: every document, tiny idf
+    idf = np.array([6.0, 6e-7, 2e-3, 3e-9], np.float32)
+    term_off = np.zeros(len(lists) + 1, np.int64); term_off[1:] = np.cumsum([len(l) for l in lists])
+    post_doc = np.concatenate(lists).astype(np.int32)
+    post_tf = rng.integers(1, 9, size=len(post_doc)).astype(np.int32)
+    ix = mods["CorpusIndex"](doc_ids=np.arange(N, dtype=np.int64), doc_len=doc_len, term_off=term_off, post_doc=post_doc,
+                             post_tf=post_tf, idf=idf, avgdl=float(doc_len.mean()), total_docs=N)
+    z = {k: (getattr(ix, k).cpu().numpy() if torch.is_tensor(getattr(ix, k)) else getattr(ix, k))
+         for k in ("doc_ids", "doc_len", "term_off", "post_doc", "post_tf", "idf")}
+    z["avgdl"] = ix.avgdl
+    terms = [[0, 1], [0, 1, 2, 3], [1], [3], [0], [0] * 40 + [3], [2, 3, 3, 3], []]
+    eng = mods["DeviceEngine"](ix, max_queries=8, max_k=1000)
+    for k, ms in ((5, 0.0), (12, 0.0), (100, 0.0), (1000, 0.0), (1000, 1e-8), (100, -1.0)):
+        doc, score, n = [x.cpu().numpy() for x in eng.bm25_topk(terms, k=k, min_score=ms)]
+        for i, t in enumerate(terms):
+            oi, os_ = mods["bm25_ref"].topk(z, t, k, ms)
+            assert n[i] == len(oi), (i, k, ms)
+            assert doc[i, :n[i]].tolist() == oi.tolist() and score[i, :n[i]].tolist() == os_.tolist(), (i, k, ms)
+    eng.close()
+
+
 def test_bm25_negative_idf_terms_are_looked_up_in_query_order(mods):
     """The scoring kernel does not stream the long lists with negative idf (min_score >= 0): their contributions are looked up
     in dense tables for the documents the other terms touch, and must enter every sum at the term's position in the query.
