@@ -5,10 +5,13 @@
 // is what Python's stable sort produces on candidates that arrive in ascending doc_id (:445).
 //
 // Key = (orderable(score), ~index): all keys of a row are distinct, so "the k largest keys" is a unique
-// set.  Two streaming passes resolve the top 24 key bits with LDS histograms (12 bits each); the elements at
-// or above the resolved prefix (<= MSR_SEL_CAP in every non-degenerate case) are compacted and one
-// workgroup sorts them exactly.  Tie groups too large for that are finished digit by digit inside the
-// final kernel.  Every pass is a streaming read of the score row: HBM-bound.
+// set.  Two streaming passes resolve the top 24 key bits with LDS histograms (12 bits each) -- or, for BM25 lists whose
+// scores are bounded from the query alone, ONE pass over a window of 4096 consecutive 20-bit prefixes (msr_internal.h) --;
+// the elements at or above the resolved prefix (<= MSR_SEL_CAP in every non-degenerate case) are compacted and one
+// workgroup resolves further digits on them until they fit the next power of two above k, then sorts them exactly.  Tie
+// groups too large for that are finished digit by digit inside the final kernel.  Every pass is a streaming read of the
+// score row.  Merges of sorted lists (the shards' lists after an all-gather): merge_rank_kernel (counting, over the lists'
+// prefixes above a cut) with merge_kernel (a merge tree) behind it for what it declines.
 #include "msr_common.h"
 #include "msr_internal.h"
 #include "msr_sort.h"
