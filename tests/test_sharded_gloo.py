@@ -1,6 +1,7 @@
-"""N > 1 path on CPU: two gloo ranks, each with its document shard, must reproduce the unsharded result
-exactly (bm25 + dense lists after the all-gather + merge; rerank after the integer-SUM all-reduce of the raw bits).  The compute
-is the oracle (tests/oracle_engine.py); what is under test is msretr.distributed + CorpusIndex.shard."""
+"""N > 1 path on CPU: two (and three) gloo ranks, each with its document shard, must reproduce the unsharded result
+exactly (bm25 + dense lists after their all-gathers + merges; rerank after the all-to-all of the owned slots' records, and in
+its dense form).  The compute is the oracle (tests/oracle_engine.py); what is under test is msretr.distributed +
+CorpusIndex.shard."""
 import os
 import sys
 
@@ -87,6 +88,49 @@ def test_two_rank_sharded_equals_unsharded(via_snapshot, tmp_path):
     for key in ("bm25", "dense", "rerank"):
         for a, b in zip(ret[0][key], ret[1][key]):
             assert np.array_equal(a, b)
+
+
+def _run_few(rank, world, port, ret):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from msretr.distributed import ShardedEngine
+        from oracle_engine import OracleEngine
+        ix, terms, qvec = _corpus()
+        sh = ix.shard(rank, world)
+        se = ShardedEngine(OracleEngine(sh), sh.doc_base, sh.row_base)
+        res = {}
+        for nq in (2, 4):                                   # 2 queries on 3 ranks: the last rank fuses none; 4: a ragged last block
+            out = se.search([sh.term_ids(t) for t in terms[:nq]], qvec[:nq], k1=120, k2=30)
+            res[nq] = {k: [x.numpy() for x in v] for k, v in out.items()}
+        assert se._bounds[0] is not None
+        ret[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_three_ranks_with_fewer_queries_than_ranks_and_a_ragged_block():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from msretr.distributed import ShardedEngine
+    from oracle_engine import OracleEngine
+    world = 3
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_run_few, args=(world, 30000 + os.getpid() % 900, ret), nprocs=world, join=True)
+    ix, terms, qvec = _corpus()
+    for nq in (2, 4):
+        ref = ShardedEngine(OracleEngine(ix), 0, 0).search([ix.term_ids(t) for t in terms[:nq]], qvec[:nq], k1=120, k2=30)
+        ref = {k: [x.numpy() for x in v] for k, v in ref.items()}
+        for r in range(world):
+            for key in ("bm25", "dense", "rerank"):
+                for j, (a, b) in enumerate(zip(ret[r][nq][key], ref[key])):
+                    if key == "dense" and j == 1:            # (the stand-in's scores come out of a BLAS product whose blocking
+                        #                                      follows the matrix shape: a shard's differ from the whole corpus' in the last bit)
+                        assert a.shape == b.shape and np.allclose(a, b, rtol=0, atol=2e-6), (r, nq, key)
+                    else:
+                        assert a.shape == b.shape and np.array_equal(a, b), (r, nq, key, j)
 
 
 def test_shard_partition_is_exact():
