@@ -68,6 +68,7 @@ struct msr_engine {
     uint32_t* gf_err = nullptr; float* gf_margin = nullptr; int32_t* gf_cand_doc = nullptr; float* gf_cand_score = nullptr;
     int32_t* gf_cand_chunk = nullptr; int32_t* gf_cand_n = nullptr; float* gf_qn = nullptr; void* gf_fb_qimg = nullptr;
     void* gf_emb_tiled = nullptr;     // fragment-order copy of the f32 rows (256-query streaming pass)
+    void* gf_emb_f16 = nullptr;       // row-major f16 image of the rows (launches of several 256-query groups)
     int32_t* tile_trow = nullptr;     // [n_tiles] first row of each tile in those copies
     int64_t n_trows = 0;
     // batched path as a tiled GEMM (msr_gemm.hip): unit-row bf16 image + tile table + scratch for GM_SLICE queries per pass
@@ -146,6 +147,7 @@ static void free_gf(msr_engine* e) {
     free_dev(e, e->gf_cand_chunk); free_dev(e, e->gf_cand_n); free_dev(e, e->gf_qn); e->gf_qn = nullptr;
     free_dev(e, e->gf_fb_qimg); e->gf_fb_qimg = nullptr;
     free_dev(e, e->gf_emb_tiled); e->gf_emb_tiled = nullptr;
+    free_dev(e, e->gf_emb_f16); e->gf_emb_f16 = nullptr;
     e->gf_err = nullptr; e->gf_margin = nullptr; e->gf_cand_doc = nullptr; e->gf_cand_score = nullptr; e->gf_cand_chunk = nullptr;
     e->gf_cand_n = nullptr;
     e->tile_row = nullptr; e->gf_inv_pad = nullptr; e->gf_qimg = nullptr; e->gf_tmax_t = nullptr; e->gf_tmax = nullptr;
@@ -645,10 +647,25 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
                 e->row_copy_state = 1;
             }
         }
+        // Launches of SEVERAL 256-query groups (engines for >= 512 queries per call: the batched steps, a rank of a sharded
+        // run) are bound by the matrix pipes and the vector issue beside them; every group converts the same f32 rows to f16
+        // again.  They read an f16 image of the rows instead -- the very values the pass converts in registers (round to
+        // nearest, not normalised): same products, same candidates, same results; 1536 B per row.  Declined with the other
+        // copy (MSR_CFG_NO_ROW_COPY) or when the allocation fails: those launches then convert as before.
+        if (max_nt >= 2 && !(e->cfg.flags & MSR_CFG_NO_ROW_COPY)) {
+            const size_t img_rows = (size_t)n_chunks + 512;
+            if ((herr = alloc(&e->gf_emb_f16, img_rows * MSR_DIM * 2)) != hipSuccess) {
+                (void)hipGetLastError();
+                e->gf_emb_f16 = nullptr;
+            } else {
+                HIP_TRY(e, msr_f16_rows(emb, n_chunks, (int64_t)img_rows, e->gf_emb_f16, st));
+            }
+        }
         e->gf = GemmF32Index{e->tile_row, n_tiles, e->n_cus, groups, e->gf_inv_pad, e->gf_qimg, e->gf_tmax_t, e->gf_tmax, stride,
                              e->gf_thr, e->gf_thr2, e->gf_flag, e->gf_wvbuf,
                              GF_WV_CAP, e->gf_wv_count, e->gf_pairs, e->gf_pair_n, e->gf_err, e->gf_margin, e->gf_cand_doc,
-                             e->gf_cand_score, e->gf_cand_chunk, e->gf_cand_n, max_nt, e->gf_emb_tiled, e->gf_emb_tiled ? e->tile_trow : nullptr};
+                             e->gf_cand_score, e->gf_cand_chunk, e->gf_cand_n, max_nt, e->gf_emb_tiled,
+                             e->gf_emb_tiled ? e->tile_trow : nullptr, e->gf_emb_f16};
         e->gf_ok = true;
     }
     e->have_chunks = true;

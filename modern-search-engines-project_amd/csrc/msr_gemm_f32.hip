@@ -383,8 +383,13 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t u) {
 // then reads 1 KB = 8 whole cache lines of its own; on the row-major matrix it reads 64 of the 128 bytes of 16 lines, the
 // other halves follow in the next instruction and find their lines pending in the L1 (TCP_READ_TAGCONFLICT_STALL_CYCLES:
 // 23 % of the L1's cycles).
-template <bool EMIT, bool BF16, bool TILED = false, bool NTL = false>
+// F16I = true (with BF16 = true, which stands for the data path of a row-major 16-bit image): the image holds the f32 rows
+// AS THE f32 PASS CONVERTS THEM (f16, round to nearest, not normalised) -- the products, thresholds, margins and emitted entries
+// are those of the f32 rows' pass bit for bit; only the conversion is not done again by every query group of a launch.  f16
+// matrix instructions, the rows' inverse norms in the epilogue and per-wave tile maxima as on the f32 rows.
+template <bool EMIT, bool BF16, bool TILED = false, bool NTL = false, bool F16I = false>
 __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args a) {
+    static_assert(!F16I || (BF16 && !TILED && !NTL), "the f16 image takes the 16-bit image's data path");
     // (A fragment-order copy of the bf16 image was measured too: 13.71 vs 13.97 ms per 1024 queries x 10 M rows, but 1.33 x
     // instead of 1.21 x the rows in HBM reads at 5 M rows and 7.9 GB more memory: not kept.  The addressing below stays general.)
     static_assert(!(BF16 && TILED), "the fragment-order copy exists for the f32 rows only");
@@ -456,7 +461,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
     // parity) and written as ONE row of 256 per tile -- after the first barrier of the NEXT tile, which every wave passes
     // only with its epilogue behind it.  f32 rows (160 MB per 256-query pass, 1 % of its traffic): every wave stores its own
     // row as before -- the join costs the pass 1.3 % and saves the transposing kernel the same.
-    constexpr bool JOIN = BF16;
+    constexpr bool JOIN = BF16 && !F16I;
     uint32_t* tmx = (uint32_t*)(smem + G2_TMX);
     if (JOIN) tmx[tid] = 0u;                            // (512 threads, 2 x 256 keys; 0 orders below every float)
     auto flush_tmax = [&](int tile_j, int par) {        // wave w: queries 32 w .. + 31 of the tile whose maxima sit in set par
@@ -591,7 +596,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
             af[mi] = BF16 ? take16(ring[slot][mi][half]) : cvt_f16_rtn(ring[slot][mi][0], ring[slot][mi][1]);
 #pragma unroll
         for (int mi = 0; mi < NMI; ++mi) asm volatile("" :: "v"(af[mi]));     // (taken out of the slot before it is reloaded)
-        if (!BF16 && s4 == 1 && last) {                  // this tile's inverse norms (uniform branch), retired by later waits
+        if ((!BF16 || F16I) && s4 == 1 && last) {        // this tile's inverse norms (uniform branch), retired by later waits
             const char* src = uniform_ptr((const char*)(a.inv_pad + (size_t)row0 + w * 32));
             __builtin_amdgcn_global_load_lds((glb_void*)(src + (uint32_t)(fresh_lane() * 4)), (lds_void*)inv_lds, 4, 0, 0);
         }
@@ -662,7 +667,8 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
             asm volatile("" : "+v"(bh[f & 3]));
 #pragma unroll
             for (int mi = 0; mi < NMI; ++mi)
-                acc[mi][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                acc[mi][f] = F16I ? __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bh[f & 3], acc[mi][f], 0, 0, 0)
+                                  : __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                     __builtin_bit_cast(bf16x8, af[mi]), __builtin_bit_cast(bf16x8, bh[f & 3]), acc[mi][f], 0, 0, 0);
             if (f + 4 < NNI) lds_read16<(f + 4) * 1024>(bh[f & 3], la);
             else if (s4 + 1 < G2_NB) lds_read16<G2_STEP + (f + 4 - NNI) * 1024>(bh[f & 3], la);
@@ -709,8 +715,11 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
         const int ln_e = (int)fresh_lane();
         const int lg_e = ln_e >> 4;
         f32x4 inv4[NMI];
-        if (!BF16) {
-            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        if (!BF16 || F16I) {
+            // (16-bit image: the DMA is older than the 8 row loads of the block's steps 1 and 3, which the block's last wait left
+            // in flight at most)
+            if (F16I) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
 #pragma unroll
             for (int mi = 0; mi < NMI; ++mi) inv4[mi] = *(const f32x4*)(inv_lds + mi * 16 + 4 * lg_e);
         }
@@ -737,7 +746,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
 #pragma unroll
             for (int mi = 0; mi < NMI; ++mi) {
                 const int blk = wr * WROWS + mi * 16;
-                if (BF16) v[mi] = acc[mi][ni];          // unit rows: the cosine as it is
+                if (BF16 && !F16I) v[mi] = acc[mi][ni]; // unit rows: the cosine as it is
                 else v[mi] = acc[mi][ni] * inv4[mi];    // cosine = <e, q^> / ||e||
                 if (blk + 16 > n_valid) {               // (wave-uniform: only a tile's last, partly filled fragment -- or one wholly
 #pragma unroll                                          // behind the tile -- pays for the per-row test)
@@ -801,7 +810,8 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
 }
 
 // query image of the 256-query kernel: [kt 24][q 256][physical chunk c' 4] x 16 B, group blockIdx.y = queries 256 g .. + 255
-template <bool BF16>
+// BF16: the K order of the 16-bit image's data path; TOBF16: bf16 elements (else f16)
+template <bool BF16, bool TOBF16 = BF16>
 __global__ __launch_bounds__(256) void build_qimg2_kernel(const float* __restrict__ qn, int nq, f16x8* __restrict__ qimg) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= GF_KT * 256 * 4) return;
@@ -814,7 +824,7 @@ __global__ __launch_bounds__(256) void build_qimg2_kernel(const float* __restric
         // f16 image: chunk c of K step kt = K elements 32 kt + 8 c ..; bf16 image: the kernel takes K steps 2 p and 2 p + 1
         // from the lower / upper 16 bytes of the 32 bytes a lane loads at lg * 32 of a row's 128-byte line
         const float* src = qn + (size_t)q * MSR_DIM + (BF16 ? 64 * (kt >> 1) + 16 * c + 8 * (kt & 1) : 32 * kt + 8 * c);
-        if (BF16) {
+        if (TOBF16) {
             bf16x8 b;
 #pragma unroll
             for (int j = 0; j < 8; ++j) b[j] = (__bf16)src[j];
@@ -952,16 +962,34 @@ hipError_t launch_stream_t(const GemmF32Args& a, int grid, hipStream_t stream) {
     gemm_stream_kernel<EMIT><<<grid, GF_THREADS, GS_LDS, stream>>>(a);
     return hipGetLastError();
 }
-template <bool EMIT, bool BF16, bool TILED = false, bool NTL = false>
+template <bool EMIT, bool BF16, bool TILED = false, bool NTL = false, bool F16I = false>
 hipError_t launch_stream256_t(const GemmF32Args& a, int grid, hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t err = hipFuncSetAttribute((const void*)gemm_stream256_kernel<EMIT, BF16, TILED, NTL>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
+        hipError_t err = hipFuncSetAttribute((const void*)gemm_stream256_kernel<EMIT, BF16, TILED, NTL, F16I>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
         if (err != hipSuccess) return err;
         attr_done = true;
     }
-    gemm_stream256_kernel<EMIT, BF16, TILED, NTL><<<grid, G2_THREADS, G2_LDS, stream>>>(a);
+    gemm_stream256_kernel<EMIT, BF16, TILED, NTL, F16I><<<grid, G2_THREADS, G2_LDS, stream>>>(a);
     return hipGetLastError();
+}
+
+// dst[r] = f16(src[r]) (round to nearest: what the f32 rows' pass does in registers) for r < n_rows, zero rows up to n_pad
+__global__ __launch_bounds__(256) void f16_rows_kernel(const float* __restrict__ src, int64_t n_rows, int64_t n_pad,
+                                                        f16x8* __restrict__ dst) {
+    const int64_t n8 = n_pad * (MSR_DIM / 8), stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {
+        const int64_t r = i / (MSR_DIM / 8);
+        f16x8 h;
+        if (r < n_rows) {
+            const float* p = src + i * 8;
+            h = cvt_f16_rtn(*(const f32x4*)p, *(const f32x4*)(p + 4));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) h[j] = (_Float16)0.f;
+        }
+        dst[i] = h;
+    }
 }
 
 // The fragment-order copy of the f32 rows (see gemm_stream256_kernel, TILED): one workgroup per tile; piece (lane, half) of
@@ -986,7 +1014,11 @@ __global__ __launch_bounds__(256) void tile_rows_kernel(const char* __restrict__
     }
 }
 // width: queries per pass (128 or 256; both kernels: 8 waves x 32 rows)
-hipError_t launch_f32(int width, bool emit, const GemmF32Args& a, int grid, hipStream_t stream, bool tiled = false) {
+hipError_t launch_f32(int width, bool emit, const GemmF32Args& a, int grid, hipStream_t stream, bool tiled = false,
+                      bool image16 = false) {
+    if (image16)
+        return emit ? launch_stream256_t<true, true, false, false, true>(a, grid, stream)
+                    : launch_stream256_t<false, true, false, false, true>(a, grid, stream);
     // One query group per launch: every row is read exactly once, by one wave -- loaded with the non-temporal policy, so that the
     // 15 GB stream does not displace the 384 KB query image (re-read by every workgroup for every tile) from the L2s: 3.07 ->
     // 2.94 ms per pass on one box (profiles/r04_stream256_experiments.md).  Several groups per launch share the rows through the
@@ -1027,6 +1059,12 @@ hipError_t msr_tile_rows(const float* emb, const int32_t* tile_row, const int32_
 }
 
 
+hipError_t msr_f16_rows(const float* emb, int64_t n_rows, int64_t n_pad, void* out, hipStream_t stream) {
+    if (n_pad <= 0) return hipSuccess;
+    f16_rows_kernel<<<8192, 256, 0, stream>>>(emb, n_rows, n_pad, (f16x8*)out);
+    return hipGetLastError();
+}
+
 hipError_t msr_pad_inv_norm(const float* inv, int64_t n, int64_t n_pad, float* out, hipStream_t stream) {
     if (n_pad <= 0) return hipSuccess;
     pad_inv_kernel<<<(unsigned)((n_pad + 255) / 256), 256, 0, stream>>>(inv, n, n_pad, out);
@@ -1056,7 +1094,17 @@ hipError_t msr_gemm_f32_pass(const GemmF32Index& g, const DenseIndex& ix, const 
     if (nq <= 0 || G * W > 128 * g.max_groups || k < 1 || g.n_tiles < 2 * k) return hipErrorInvalidValue;
     if (width_out) *width_out = W;
     hipError_t err;
-    if (W == 256) build_qimg2_kernel<false><<<dim3((GF_KT * 256 * 4 + 255) / 256, G), 256, 0, stream>>>(qn, nq, (f16x8*)g.qimg);
+    // Launches of several query groups are bound by the matrix pipes and the vector issue beside them, not by HBM: they read
+    // the f16 image of the rows when the engine holds one (the values the pass converts in registers otherwise -- same
+    // products, same results; the conversion is not repeated by every group).  One group per launch: the f32 rows.
+    int NT0 = 1;
+    if (W == 256 && (g.n_cus & 7) == 0) NT0 = std::min(std::min(G, g.max_nt), g.n_cus >> 3);
+    bool image16 = W == 256 && NT0 > 1 && g.emb_f16 != nullptr;
+#ifdef MSR_DIAG
+    if (g_f32_dbg & (2048 | 1048576)) image16 = false;      // timing experiments: one group per launch / the f32 rows
+#endif
+    if (image16) build_qimg2_kernel<true, false><<<dim3((GF_KT * 256 * 4 + 255) / 256, G), 256, 0, stream>>>(qn, nq, (f16x8*)g.qimg);
+    else if (W == 256) build_qimg2_kernel<false><<<dim3((GF_KT * 256 * 4 + 255) / 256, G), 256, 0, stream>>>(qn, nq, (f16x8*)g.qimg);
     else build_qimg1_kernel<<<dim3((GF_KT * 128 * 4 + 255) / 256, G), 256, 0, stream>>>(qn, nq, (f16x8*)g.qimg);
     f16_margin_kernel<<<(nq + 3) / 4, 256, 0, stream>>>(qn, nq, g.err_max, g.margin);
     const float* margin = g.margin;
@@ -1076,11 +1124,12 @@ hipError_t msr_gemm_f32_pass(const GemmF32Index& g, const DenseIndex& ix, const 
     GemmF32Args a{};
     a.dbg = g_f32_dbg; a.nt = 1;
     a.E = (const char*)ix.emb; a.inv_pad = g.inv_pad; a.tile_row = g.tile_row;
-    bool tiled = W == 256 && g.emb_tiled != nullptr;
+    bool tiled = W == 256 && g.emb_tiled != nullptr && !image16;
 #ifdef MSR_DIAG
     if (g_f32_dbg & 8192) tiled = false;               // timing experiments: the row-major matrix
 #endif
     if (tiled) { a.E = (const char*)g.emb_tiled; a.tile_trow = g.tile_trow; }
+    if (image16) a.E = (const char*)g.emb_f16;
     a.n_rows = ix.n_chunks; a.tmax_t = g.tmax_t;
     // ---- pass 1 of every group: maxima of every ss-th tile -> emission thresholds ----
     a.t_first = ss / 2; a.t_stride = ss; a.t_count = n_s;
@@ -1088,7 +1137,7 @@ hipError_t msr_gemm_f32_pass(const GemmF32Index& g, const DenseIndex& ix, const 
         a.nt = std::min(NT, G - gi);
         a.qimg = (const char*)g.qimg + gi * qimg_bytes;
         if (ev && gi == 0 && (err = hipEventRecord(ev[0], stream)) != hipSuccess) return err;
-        if ((err = launch_f32(W, false, a, grid, stream, tiled)) != hipSuccess) return err;
+        if ((err = launch_f32(W, false, a, grid, stream, tiled, image16)) != hipSuccess) return err;
         if (ev && gi == 0 && (err = hipEventRecord(ev[1], stream)) != hipSuccess) return err;
         if ((err = msr_gemm_tmax(g.tmax_t, n_s, waves, W * a.nt, g.tmax + (size_t)gi * W * g.tmax_stride, g.tmax_stride, stream)) != hipSuccess) return err;
     }
@@ -1101,7 +1150,7 @@ hipError_t msr_gemm_f32_pass(const GemmF32Index& g, const DenseIndex& ix, const 
         a.qimg = (const char*)g.qimg + gi * qimg_bytes;
         a.thr = g.thr + gi * W; a.q_base = gi * W; a.append = gi > 0;
         if (ev && gi == 0 && (err = hipEventRecord(ev[2], stream)) != hipSuccess) return err;
-        if ((err = launch_f32(W, true, a, grid, stream, tiled)) != hipSuccess) return err;
+        if ((err = launch_f32(W, true, a, grid, stream, tiled, image16)) != hipSuccess) return err;
         if (ev && gi == 0 && (err = hipEventRecord(ev[3], stream)) != hipSuccess) return err;
         if ((err = msr_gemm_tmax(g.tmax_t, g.n_tiles, waves, W * a.nt, g.tmax + (size_t)gi * W * g.tmax_stride, g.tmax_stride, stream)) != hipSuccess) return err;
     }

@@ -321,8 +321,11 @@ struct GemmF32Index {
     int32_t max_nt;            // groups of 256 queries one launch of the 256-query kernel may serve (tmax_t holds 256 x this per row)
     const void* emb_tiled;     // fragment-order copy of the f32 rows for the 256-query kernel (nullptr: none), see msr_tile_rows
     const int32_t* tile_trow;  // [n_tiles] first row of each tile in that copy
+    const void* emb_f16;       // row-major f16 image of the rows (as the pass converts them; [n_chunks + 512][768], zero padded)
+                               // for launches of several query groups (nullptr: none), see msr_f16_rows
 };
 // emb_tiled <- fragment-order copy of emb: tile t's rows at tile_trow[t] (multiples of 16), 16-row groups x 24 K steps x 2 KB
+hipError_t msr_f16_rows(const float* emb, int64_t n_rows, int64_t n_pad, void* out, hipStream_t stream);
 hipError_t msr_tile_rows(const float* emb, const int32_t* tile_row, const int32_t* tile_trow, int n_tiles, void* emb_tiled,
                          hipStream_t stream);
 hipError_t msr_f16_row_error(const float* emb, const float* inv_norm, int64_t n_rows, uint32_t* err_max, hipStream_t stream);

@@ -1479,3 +1479,46 @@ def test_compact_rerank_exchange_equals_the_dense_halves(mods):
         assert torch.equal(cos.view(torch.int32), ref_cos.view(torch.int32))
     for e in engs:
         e.close()
+
+
+def test_multi_group_launches_on_the_f16_image_equal_the_f32_rows(mods):
+    """Engines for >= 512 queries per call serve launches of several 256-query groups from an f16 image of the rows -- the
+    values the f32 rows' pass converts in registers -- so that not every group converts them again.  Same products, same
+    thresholds, same candidates: the results of 300 / 600 / 1000 queries (2, 3 and 4 groups; launches of 2 + 1 and 4 groups) must
+    equal, bit for bit, those of an engine that declined the image (MSR_CFG_NO_ROW_COPY: f32 rows, converted in the kernel),
+    and the oracle's for queries of every group.  Rows are not unit norm; chunk-less documents, an exact hit, a zero query,
+    a last tile with a partly filled fragment."""
+    rng = np.random.default_rng(99)
+    n_docs = 50000
+    n = rng.integers(0, 8, size=n_docs)
+    n[-1] = 3
+    doc_off = np.zeros(n_docs + 1, np.int64); doc_off[1:] = np.cumsum(n)
+    C = int(doc_off[-1])
+    emb_t = torch.randn((C, 768), generator=torch.Generator().manual_seed(13))
+    emb_t /= emb_t.norm(dim=1, keepdim=True)
+    emb_t *= torch.empty(C, 1).uniform_(0.6, 1.8, generator=torch.Generator().manual_seed(14))   # (norms in [0.5, 2]: the default path)
+    emb = emb_t.numpy()
+    ix = mods["CorpusIndex"](doc_ids=np.arange(n_docs, dtype=np.int64), doc_off=doc_off.astype(np.int32),
+                             chunk_ids=np.arange(C, dtype=np.int64), emb=emb, total_docs=n_docs)
+    img = mods["DeviceEngine"](ix, max_queries=1024, max_k=100, rerank_max_docs=0)
+    raw = mods["DeviceEngine"](ix, max_queries=1024, max_k=100, rerank_max_docs=0, row_copy=False)
+    assert img.owned_bytes() - raw.owned_bytes() >= (C + 512) * 768 * 2          # the image (and the fragment-order copy)
+    assert img.row_copy_state() == "built" and raw.row_copy_state() == "declined"
+    q = rng.standard_normal((1000, 768)).astype(np.float32) * rng.uniform(0.5, 12, size=(1000, 1)).astype(np.float32)
+    q[0] = emb[4567] * 3.0
+    q[1] = 0.0
+    q[2:60] = emb[rng.integers(0, C, 58)] + 0.4 * q[2:60] / np.linalg.norm(q[2:60], axis=1, keepdims=True)
+    q[999] = emb[C - 1] * 0.5                                  # an exact hit in the last tile
+    for Q, k in ((300, 100), (600, 10), (1000, 100)):
+        a = [x.cpu().numpy() for x in img.dense_topk(q[:Q], k=k)]
+        assert img.dense_path() == 256
+        b = [x.cpu().numpy() for x in raw.dense_topk(q[:Q], k=k)]
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), (Q, k)
+        for i in sorted({0, 2, 59, 255, 256, Q // 2, Q - 1}):
+            oi, os_, oa = mods["dense_ref"].quick_search(emb, doc_off, q[i], k)
+            assert a[3][i] == len(oi)
+            np.testing.assert_allclose(a[1][i], os_, rtol=0, atol=1e-5)
+            ok = (a[0][i] == oi) | (np.abs(np.r_[np.diff(os_), 1.0]) <= 4e-6) | (np.abs(np.r_[1.0, np.diff(os_)]) <= 4e-6)
+            assert ok.all(), (Q, i)
+    img.close(); raw.close()
