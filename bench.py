@@ -911,7 +911,9 @@ def main():
                 # XCD's L2 for the other groups; msr_gemm_f32_topk) -- mirrors the engine's choice for this batch size
                 groups128 = min(8, max(Q, 128) // 128)
                 q_launch = 256 * max(1, min((min(Q, 128 * groups128) + 255) // 256, min(4, groups128 // 2)))
-            alg_bytes = n_ch * 768 * (2 if bf else 4) + (shard.n_docs + 1) * 4 + q_launch * 768 * 4
+            # launches of several 256-query groups read the engine's f16 image of the rows when it holds one (msr_row_image_state)
+            image16 = not bf and width == 256 and q_launch > 256 and eng.row_image_state() == "built"
+            alg_bytes = n_ch * 768 * (2 if bf or image16 else 4) + (shard.n_docs + 1) * 4 + q_launch * 768 * 4
             wide_kernel = q_launch > 32                         # 33..64 queries per sweep run on the K-split kernel
             k_ms, k_n = scan_ms, scan_n
             kname = ("dense_ksplit_kernel" if wide_kernel else "dense_scan_v2_kernel") + ("<bf16>" if bf else "")
@@ -929,9 +931,16 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes, "launches": k_n, "ms_per_launch": per_launch_ms}
         if args.workload != "bm25" and not gemm:
             roof["queries_per_launch"] = q_launch
-            if kname.startswith("gemm_stream256"):
+            if kname.startswith("gemm_stream256") and image16:
+                roof["rows_read_from"] = ("the engine's f16 image of the rows (launches of several 256-query groups: the values a one-group "
+                                          "launch converts from the f32 rows in registers -- same candidates, same results bit for bit; "
+                                          "1536 B per row, which is what algorithmic_bytes_per_launch counts here)")
+                roof["f16_matrix_TFLOPs"] = 2.0 * 768 * n_ch * q_launch / (per_launch_ms * 1e-3) / 1e12
+            elif kname.startswith("gemm_stream256"):
+                state = eng.row_copy_state()
                 roof["rows_read_from"] = ("the engine's fragment-order copy of the f32 matrix (the same values, laid out so that a load "
-                                          "instruction reads whole cache lines; + 3 % padding rows)")
+                                          "instruction reads whole cache lines; + 3 % padding rows)" if state == "built" else
+                                          f"the caller's row-major f32 matrix (fragment-order copy: {state})")
         if args.workload != "bm25" and args.dense_mode == "f32" and eng.scan_arith() == "f32" and q_launch > 32:
             # exact-f32 products at 64 queries per sweep: v_mfma_f32_16x16x4_f32 runs at the f32 vector rate
             # (157.3 TFLOP/s, MI355X_MICROARCH.md), which binds before HBM does (2 * 768 flop per row and query)

@@ -68,7 +68,8 @@ typedef struct msr_config {
 /* msr_config.flags */
 #define MSR_CFG_NO_ROW_COPY 1 /* do not build the fragment-order copy of the embedding matrix (msr_bind_chunks): the 256-query
                                  pass then reads the caller's row-major matrix (same results bit for bit, ~13 % slower pass,
-                                 half the embedding footprint) */
+                                 half the embedding footprint); also declines the f16 image of the rows that launches of
+                                 several query groups read (max_queries >= 512; msr_row_image_state) */
 
 /* BM25 parameters travel with the postings (bm25_indexer.py:57 k1=1.2, b=0.75). */
 typedef struct msr_rerank_params {
@@ -103,13 +104,21 @@ int msr_bind_postings(msr_engine* e, const int64_t* term_off, int64_t n_terms, c
  * the streaming pass: row-major, documents of <= 256 chunks, >= 64 row tiles) a copy of the matrix in the order the
  * 256-query pass loads it, 1.03 x n_chunks x 3072 bytes; the caller's matrix stays bound and is what
  * every other kernel reads, so it must stay alive.  SURVEY 8b's "the handle owns only small scratch" is deliberately not
- * kept here: the copy is a trade of HBM for bandwidth, with a switch (MSR_CFG_NO_ROW_COPY) and a fallback (msr_row_copy_state). */
+ * kept here: the copy is a trade of HBM for bandwidth, with a switch (MSR_CFG_NO_ROW_COPY) and a fallback (msr_row_copy_state).
+ * When cfg.max_queries >= 512 (calls that put several 256-query groups into one launch: those launches are bound by the
+ * matrix pipes, not by HBM) also an f16 image of the rows, (n_chunks + 512) x 1536 bytes: the values the 256-query pass
+ * otherwise converts in registers, group after group -- the same products, the same results bit for bit.  Launches of ONE
+ * group (<= 256 queries per call: the HBM-bound case) never read it; same switch, same fallback (msr_row_image_state). */
 int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks, const int32_t* doc_off,
                     int64_t n_docs, const float* inv_norm, void* stream);
 /* What became of that copy: 0 = not applicable (max_queries < 256 or the corpus does not qualify), 1 = built and used,
  * 2 = declined by MSR_CFG_NO_ROW_COPY, 3 = its allocation failed and the engine fell back to the row-major matrix (the bind
  * still succeeds).  -1: null handle. */
 int msr_row_copy_state(const msr_engine* e);
+/* The same for the f16 image of the rows that launches of several 256-query groups read: 0 = not applicable (max_queries < 512
+ * or the corpus does not qualify), 1 = built and used, 2 = declined by MSR_CFG_NO_ROW_COPY, 3 = its allocation failed (those
+ * launches then convert the f32 rows in registers as a single-group launch does).  -1: null handle. */
+int msr_row_image_state(const msr_engine* e);
 /* Device memory the handle owns right now, in bytes (scratch, tables built at bind, the copies above); the caller's bound
  * arrays are not included. */
 int64_t msr_owned_bytes(const msr_engine* e);

@@ -45,6 +45,7 @@ _SIGNATURES = {
     "msr_scan_width": (C.c_int, [_P]),
     "msr_dense_path": (C.c_int, [_P]),
     "msr_row_copy_state": (C.c_int, [_P]),
+    "msr_row_image_state": (C.c_int, [_P]),
     "msr_owned_bytes": (C.c_int64, [_P]),
     # include/msretr_encoder.h
     "msr_enc_layernorm": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, _P]),

@@ -87,6 +87,7 @@ struct msr_engine {
     int split_pending = 0;             // queries of an msr_dense_topk_begin whose msr_dense_topk_end has not come yet
     int row_copy_state = 0;            // fragment-order copy of the rows: 0 not wanted / not applicable, 1 built, 2 declined by
                                        // msr_config.flags, 3 allocation failed (the row-major instantiation of the kernel runs)
+    int row_image_state = 0;           // f16 image of the rows (launches of several query groups): the same four states
     int last_dense_width = 0;          // queries per pass over the matrix of the most recent msr_dense_topk call (msr_dense_path)
     // timing
     bool timing = false;
@@ -547,6 +548,7 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
     e->emb_bf16 = nullptr;
     free_gemm(e);
     free_gf(e);
+    e->row_copy_state = e->row_image_state = 0;              // (a re-bind that does not qualify reports "not applicable")
     // ---- row tiles for the GEMM paths: <= 256 rows, cut at document boundaries (a longer document: no GEMM paths) ----
     std::vector<int32_t> h_trow;                          // first row of each tile in the fragment-order copy (below): every
     int64_t n_trows = 0;                                  // tile starts at a multiple of 16 rows
@@ -652,13 +654,18 @@ extern "C" int msr_bind_chunks(msr_engine* e, const float* emb, int64_t n_chunks
         // again.  They read an f16 image of the rows instead -- the very values the pass converts in registers (round to
         // nearest, not normalised): same products, same candidates, same results; 1536 B per row.  Declined with the other
         // copy (MSR_CFG_NO_ROW_COPY) or when the allocation fails: those launches then convert as before.
-        if (max_nt >= 2 && !(e->cfg.flags & MSR_CFG_NO_ROW_COPY)) {
+        e->row_image_state = 0;
+        if (max_nt >= 2 && (e->cfg.flags & MSR_CFG_NO_ROW_COPY)) {
+            e->row_image_state = 2;
+        } else if (max_nt >= 2) {
             const size_t img_rows = (size_t)n_chunks + 512;
             if ((herr = alloc(&e->gf_emb_f16, img_rows * MSR_DIM * 2)) != hipSuccess) {
                 (void)hipGetLastError();
                 e->gf_emb_f16 = nullptr;
+                e->row_image_state = 3;
             } else {
                 HIP_TRY(e, msr_f16_rows(emb, n_chunks, (int64_t)img_rows, e->gf_emb_f16, st));
+                e->row_image_state = 1;
             }
         }
         e->gf = GemmF32Index{e->tile_row, n_tiles, e->n_cus, groups, e->gf_inv_pad, e->gf_qimg, e->gf_tmax_t, e->gf_tmax, stride,
@@ -743,6 +750,7 @@ extern "C" int64_t msr_owned_bytes(const msr_engine* e) {
 }
 
 extern "C" int msr_row_copy_state(const msr_engine* e) { return e ? e->row_copy_state : -1; }
+extern "C" int msr_row_image_state(const msr_engine* e) { return e ? e->row_image_state : -1; }
 
 extern "C" int msr_batch_width(const msr_engine* e) {
     if (!e || !e->have_chunks || !e->emb_bf16) return -1;

@@ -165,6 +165,11 @@ class DeviceEngine:
         """'none' (not applicable), 'built', 'declined' (row_copy=False) or 'alloc_failed' (fell back to the row-major matrix)."""
         return {0: "none", 1: "built", 2: "declined", 3: "alloc_failed"}.get(self.lib.msr_row_copy_state(self.handle), "?")
 
+    def row_image_state(self):
+        """The f16 image of the rows that launches of several 256-query groups read (max_queries >= 512): 'none', 'built',
+        'declined' or 'alloc_failed' (those launches then convert the f32 rows in registers, like a single-group launch)."""
+        return {0: "none", 1: "built", 2: "declined", 3: "alloc_failed"}.get(self.lib.msr_row_image_state(self.handle), "?")
+
     def owned_bytes(self):
         """Device bytes the handle owns (scratch, tables and copies built at bind); the bound index tensors are not included."""
         return int(self.lib.msr_owned_bytes(self.handle))

@@ -532,6 +532,7 @@ def test_streaming_pass_last_tile_with_a_partly_filled_fragment(mods):
         assert all(np.array_equal(a_[:100], b_) for a_, b_ in zip(g2, g))          # (exact f32 rescoring: the kernels agree bit for bit)
         owned_with_copy = eng.owned_bytes()
         assert eng.row_copy_state() == "built" and owned_with_copy > C * 768 * 4    # the handle owns the copy and says so
+        assert eng.row_image_state() == "none"                                      # (256 queries per call: one group per launch)
         eng.close()
         # ... and with the copy declined (MSR_CFG_NO_ROW_COPY; also what a failed allocation of the copy falls back to): the
         # same kernel reads the caller's row-major matrix, clamping the row index at the end of the matrix -- the same bits
@@ -1504,6 +1505,7 @@ def test_multi_group_launches_on_the_f16_image_equal_the_f32_rows(mods):
     raw = mods["DeviceEngine"](ix, max_queries=1024, max_k=100, rerank_max_docs=0, row_copy=False)
     assert img.owned_bytes() - raw.owned_bytes() >= (C + 512) * 768 * 2          # the image (and the fragment-order copy)
     assert img.row_copy_state() == "built" and raw.row_copy_state() == "declined"
+    assert img.row_image_state() == "built" and raw.row_image_state() == "declined"
     q = rng.standard_normal((1000, 768)).astype(np.float32) * rng.uniform(0.5, 12, size=(1000, 1)).astype(np.float32)
     q[0] = emb[4567] * 3.0
     q[1] = 0.0

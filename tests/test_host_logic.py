@@ -74,7 +74,7 @@ def test_create_rejects_bad_config_and_reports_why():
     assert lib.msr_create(C.byref(cfg), C.byref(h)) == -1
     cfg = _abi.MsrConfig(C.sizeof(_abi.MsrConfig), 0, 768, 8, 100, 100, 0, 0, 0x40)  # a flag bit this ABI does not know
     assert lib.msr_create(C.byref(cfg), C.byref(h)) == -1 and b"flag" in lib.msr_last_error(None)
-    assert lib.msr_owned_bytes(None) == -1 and lib.msr_row_copy_state(None) == -1
+    assert lib.msr_owned_bytes(None) == -1 and lib.msr_row_copy_state(None) == -1 and lib.msr_row_image_state(None) == -1
     assert lib.msr_destroy(None) == 0
 
 
