@@ -112,6 +112,48 @@ __global__ __launch_bounds__(BT_THREADS) void rescore_kernel(DenseIndex ix, cons
     }
 }
 
+// The same for candidates that come with the rows to look at (the f32 streaming pass: gemm_f32_cand_kernel): candidate slot
+// of query q owns rows[(q * row_cap + first + j) * row_stride], j < len, with first | len << 13 in cand_chunk[q][slot] on
+// entry -- a document's rows in DESCENDING order; walked from the back, so that the first arg-max is the lowest row as above.
+// Same arithmetic per row as rescore_kernel.  cand_chunk[q][slot] <- the arg-max row.
+__global__ __launch_bounds__(BT_THREADS) void rescore_rows_kernel(DenseIndex ix, const float* __restrict__ qn,
+                                                                   const int32_t* __restrict__ rows, int row_stride, int row_cap,
+                                                                   const int32_t* __restrict__ cand_n,
+                                                                   float* __restrict__ cand_score,
+                                                                   int32_t* __restrict__ cand_chunk) {
+    const int q = blockIdx.y, lane = threadIdx.x & 63;
+    const int cnt = cand_n[q];
+    if (cnt > MSR_SEL_CAP) return;                      // (overflow: no runs were written; rescore_final_kernel reports -1)
+    if ((int)(blockIdx.x * (BT_THREADS / 64) + (threadIdx.x >> 6)) >= cnt) return;
+    const f32x4* q4 = (const f32x4*)(qn + (size_t)q * MSR_DIM);
+    const f32x4 qa = q4[lane], qb = q4[lane + 64], qc = q4[lane + 128];
+    for (int slot = blockIdx.x * (BT_THREADS / 64) + (threadIdx.x >> 6); slot < cnt;
+         slot += gridDim.x * (BT_THREADS / 64)) {
+        const int fl = cand_chunk[(int64_t)q * MSR_SEL_CAP + slot];
+        const int first = fl & 8191;
+        int len = fl >> 13;
+        if (first + len > row_cap) len = row_cap - first;
+        float best = -__builtin_inff();
+        int64_t arg = -1;
+        for (int j = len - 1; j >= 0; --j) {
+            const int64_t c = rows[((int64_t)q * row_cap + first + j) * row_stride];
+            if (c < 0 || c >= ix.n_chunks) continue;    // (validated by the producer; never trusted as an address)
+            const f32x4* p = (const f32x4*)(ix.emb + (size_t)c * MSR_DIM);
+            const f32x4 a = p[lane], b = p[lane + 64], e = p[lane + 128];
+            float s = a.x * qa.x + a.y * qa.y + a.z * qa.z + a.w * qa.w;
+            s += b.x * qb.x + b.y * qb.y + b.z * qb.z + b.w * qb.w;
+            s += e.x * qc.x + e.y * qc.y + e.z * qc.z + e.w * qc.w;
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            s *= ix.inv_norm[c];
+            if (s > best) { best = s; arg = c; }
+        }
+        if (lane == 0) {
+            cand_score[(int64_t)q * MSR_SEL_CAP + slot] = best;
+            cand_chunk[(int64_t)q * MSR_SEL_CAP + slot] = (int32_t)arg;
+        }
+    }
+}
+
 // One workgroup per query: sort the rescored candidates by (score desc, doc asc) and emit the top-k.
 __global__ __launch_bounds__(1024) void rescore_final_kernel(const int32_t* __restrict__ cand_doc,
                                                               const float* __restrict__ cand_score,
@@ -170,12 +212,13 @@ __global__ __launch_bounds__(1024) void rescore_final_kernel(const int32_t* __re
 
 }  // namespace
 
-hipError_t msr_batch_rescore(const DenseIndex& ix, const float* qn, int nq, int k, int max_chunks, int32_t* cand_doc,
-                             float* cand_score, int32_t* cand_chunk, int32_t* cand_n, int32_t* out_doc, float* out_score,
-                             int32_t* out_chunk, int32_t* out_n, hipStream_t stream) {
+hipError_t msr_batch_rescore_rows(const DenseIndex& ix, const float* qn, int nq, int k, const int32_t* rows, int row_stride,
+                                  int row_cap, int32_t* cand_doc, float* cand_score, int32_t* cand_chunk, int32_t* cand_n,
+                                  int32_t* out_doc, float* out_score, int32_t* out_chunk, int32_t* out_n, hipStream_t stream) {
     if (nq <= 0) return hipSuccess;
-    rescore_kernel<<<dim3(rescore_grid_x(nq), (unsigned)nq), BT_THREADS, 0, stream>>>(ix, qn, max_chunks, cand_doc, cand_n, cand_score,
-                                                                    cand_chunk);
+    if (row_cap > 8192 || row_stride < 1) return hipErrorInvalidValue;
+    rescore_rows_kernel<<<dim3(rescore_grid_x(nq), (unsigned)nq), BT_THREADS, 0, stream>>>(ix, qn, rows, row_stride, row_cap, cand_n,
+                                                                                          cand_score, cand_chunk);
     rescore_final_kernel<<<nq, 1024, 0, stream>>>(cand_doc, cand_score, cand_chunk, cand_n, k, out_doc, out_score,
                                                   out_chunk, out_n);
     return hipGetLastError();

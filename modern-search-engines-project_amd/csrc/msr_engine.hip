@@ -1089,12 +1089,14 @@ extern "C" int msr_dense_topk_bf16(msr_engine* e, const float* q, int32_t n_quer
                 ev[0] = e->ev_start[3][e->ev_count[3]]; ev[1] = e->ev_stop[3][e->ev_count[3]];
                 ev[2] = e->ev_start[2][e->ev_count[2]]; ev[3] = e->ev_stop[2][e->ev_count[2]];
             }
-            HIP_TRY(e, msr_gemm_candidates(e->gemm, e->dense, e->gm_qn, nq, k, e->bf_margin, e->bt_cand_doc, e->bt_cand_n,
-                                           timed ? ev : nullptr, st));
+            // (candidates with the runs of their emitted rows: bt_cand_chunk carries first | len << 13 in, the arg-max row out)
+            HIP_TRY(e, msr_gemm_candidates(e->gemm, e->dense, e->gm_qn, nq, k, e->bf_margin, e->bt_cand_doc, e->bt_cand_chunk,
+                                           e->bt_cand_n, timed ? ev : nullptr, st));
             if (timed) { e->ev_count[2]++; e->ev_count[3]++; }
-            HIP_TRY(e, msr_batch_rescore(e->dense, e->gm_qn, nq, k, 0, e->bt_cand_doc, e->bt_cand_score, e->bt_cand_chunk,
-                                         e->bt_cand_n, out_doc + (int64_t)q0 * k, out_score + (int64_t)q0 * k,
-                                         out_chunk ? out_chunk + (int64_t)q0 * k : nullptr, out_n + q0, st));
+            HIP_TRY(e, msr_batch_rescore_rows(e->dense, e->gm_qn, nq, k, (const int32_t*)e->gemm.pairs, 2, msr_gemm_pair_cap(),
+                                              e->bt_cand_doc, e->bt_cand_score, e->bt_cand_chunk, e->bt_cand_n,
+                                              out_doc + (int64_t)q0 * k, out_score + (int64_t)q0 * k,
+                                              out_chunk ? out_chunk + (int64_t)q0 * k : nullptr, out_n + q0, st));
         }
         return MSR_OK;
     }

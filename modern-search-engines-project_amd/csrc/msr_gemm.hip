@@ -208,13 +208,20 @@ __global__ __launch_bounds__(256) void gemm_bucket_kernel(const int4* __restrict
 // maximum -> candidate list for the exact f32 rescoring (msr_batch.hip).  Overflow anywhere: cand_n = MSR_SEL_CAP + 1,
 // which rescore_final_kernel reports as out_n = -1 (rerun on the exact path).
 constexpr int GM_PAIR_CAP = 4096;
-__global__ __launch_bounds__(1024) void gemm_cand_kernel(const int2* __restrict__ pairs, int32_t* __restrict__ pair_n,
-                                                          const int32_t* __restrict__ chunk_doc,
+// Every candidate also gets the run of ITS emitted rows (cand_first_len[slot] = first | len << 13 into pairs[q][.].x, which
+// is rewritten in (document, score) order): msr_batch_rescore_rows recomputes only those -- the arg-max row of a document
+// whose exact max-cosine reaches the exact k-th score has an approximate score >= the bucket's bound, so it is among them
+// (the argument in msr_gemm_f32.hip, gemm_f32_cand_kernel).  Both sorts carry a 32-bit payload for that.
+static_assert(GM_PAIR_CAP <= (1 << 13), "cand_first_len packs first and len into 13 bits each");
+__global__ __launch_bounds__(1024) void gemm_cand_kernel(int2* __restrict__ pairs, int32_t* __restrict__ pair_n,
+                                                          const int32_t* __restrict__ chunk_doc, int64_t n_rows,
                                                           const int32_t* __restrict__ wg_count, int n_wg, int wg_cap,
                                                           const int32_t* __restrict__ flag, int k,
                                                           const float* __restrict__ margin,
-                                                          int32_t* __restrict__ cand_doc, int32_t* __restrict__ cand_n) {
+                                                          int32_t* __restrict__ cand_doc, int32_t* __restrict__ cand_first_len,
+                                                          int32_t* __restrict__ cand_n) {
     __shared__ uint64_t key[GM_PAIR_CAP];
+    __shared__ uint32_t pay[GM_PAIR_CAP];               // sort 1: the entry's row; sort 2: the head's first | len << 13
     __shared__ int s_heads, s_over;
     const int q = blockIdx.x, t = threadIdx.x;
     const int raw = pair_n[q];
@@ -240,7 +247,10 @@ __global__ __launch_bounds__(1024) void gemm_cand_kernel(const int2* __restrict_
                     const int p = i | j;
                     const bool desc = (i & kk) == 0;
                     const uint64_t x = key[i], y = key[p];
-                    if (desc ? x < y : x > y) { key[i] = y; key[p] = x; }
+                    if (desc ? x < y : x > y) {
+                        key[i] = y; key[p] = x;
+                        const uint32_t v = pay[i]; pay[i] = pay[p]; pay[p] = v;
+                    }
                 }
                 __syncthreads();
             }
@@ -248,30 +258,45 @@ __global__ __launch_bounds__(1024) void gemm_cand_kernel(const int2* __restrict_
     // (1) by (document, score) descending: the first entry of a document's run is its maximum
     for (int i = t; i < P; i += 1024) {
         uint64_t kk = 0;
+        uint32_t row = 0;
         if (i < raw) {
             const int2 e = pairs[(size_t)q * GM_PAIR_CAP + i];
-            kk = ((uint64_t)(uint32_t)(chunk_doc[e.x] + 1) << 32) | msr_ord32(__int_as_float(e.y));   // doc + 1: 0 is the pad key
+            if (e.x >= 0 && e.x < n_rows) {                 // (a row index is never trusted as an address)
+                kk = ((uint64_t)(uint32_t)(chunk_doc[e.x] + 1) << 32) | msr_ord32(__int_as_float(e.y));   // doc + 1: 0 is the pad key
+                row = (uint32_t)e.x;
+            }
         }
-        key[i] = kk;
+        key[i] = kk; pay[i] = row;
     }
     __syncthreads();
     sort_desc();
-    // (2) heads only, keyed by (score, ~document); everything else becomes the pad key
+    // (2) heads only, keyed by (score, ~document), with the run of the document's entries as payload; everything else
+    // becomes the pad key.  The rows go back to pairs[q][.].x in the order of sort 1 (a document's rows adjacent).
     uint64_t mine[GM_PAIR_CAP / 1024];
+    uint32_t mine_run[GM_PAIR_CAP / 1024];
 #pragma unroll
     for (int u = 0; u < GM_PAIR_CAP / 1024; ++u) {
         const int i = t + u * 1024;
         uint64_t kk = 0;
-        if (i < P && key[i] != 0 && (i == 0 || (key[i] >> 32) != (key[i - 1] >> 32)))
-            kk = ((uint64_t)(uint32_t)key[i] << 32) | (uint32_t)~(uint32_t)((key[i] >> 32) - 1);
-        mine[u] = kk;
+        uint32_t run = 0;
+        if (i < P && key[i] != 0) {
+            pairs[(size_t)q * GM_PAIR_CAP + i].x = (int32_t)pay[i];
+            const uint32_t d = (uint32_t)(key[i] >> 32);
+            if (i == 0 || (uint32_t)(key[i - 1] >> 32) != d) {
+                kk = ((uint64_t)(uint32_t)key[i] << 32) | (uint32_t)~(uint32_t)(d - 1);
+                int len = 1;
+                while (i + len < P && (uint32_t)(key[i + len] >> 32) == d) ++len;
+                run = (uint32_t)i | ((uint32_t)len << 13);
+            }
+        }
+        mine[u] = kk; mine_run[u] = run;
     }
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < GM_PAIR_CAP / 1024; ++u) {
         const int i = t + u * 1024;
         if (i < P) {
-            key[i] = mine[u];
+            key[i] = mine[u]; pay[i] = mine_run[u];
             if (mine[u]) atomicAdd(&s_heads, 1);
         }
     }
@@ -287,7 +312,10 @@ __global__ __launch_bounds__(1024) void gemm_cand_kernel(const int2* __restrict_
     for (int i = t; i < heads; i += 1024)                                   // sorted: the kept ones are a prefix
         if (msr_unord32((uint32_t)(key[i] >> 32)) >= cut) {
             atomicAdd(&s_keep, 1);
-            if (i < MSR_SEL_CAP) cand_doc[(size_t)q * MSR_SEL_CAP + i] = (int32_t)~(uint32_t)key[i];
+            if (i < MSR_SEL_CAP) {
+                cand_doc[(size_t)q * MSR_SEL_CAP + i] = (int32_t)~(uint32_t)key[i];
+                cand_first_len[(size_t)q * MSR_SEL_CAP + i] = (int32_t)pay[i];
+            }
         }
     __syncthreads();
     if (t == 0) { cand_n[q] = s_keep; pair_n[q] = 0; }
@@ -334,9 +362,9 @@ hipError_t msr_gemm_bucket(const void* wvbuf, int wv_cap, const int32_t* wv_coun
 void msr_gemm_set_dbg(int v) { g_gemm_dbg = v; }
 
 // The whole batched candidate path for nq <= g.max_queries queries (see the header of this file); ends with cand_doc /
-// cand_n filled for msr_batch_rescore.  qn: normalised f32 queries [nq][768].
+// cand_first_len / cand_n filled for msr_batch_rescore_rows.  qn: normalised f32 queries [nq][768].
 hipError_t msr_gemm_candidates(const GemmIndex& g, const DenseIndex& ix, const float* qn, int nq, int k, const float* margin,
-                               int32_t* cand_doc, int32_t* cand_n, hipEvent_t* ev, hipStream_t stream) {
+                               int32_t* cand_doc, int32_t* cand_first_len, int32_t* cand_n, hipEvent_t* ev, hipStream_t stream) {
     const int nq_pad = (nq + 255) / 256 * 256;
     const int nt = nq_pad / 256;
     if (nq <= 0 || nq_pad > g.max_queries || k < 1 || g.n_tiles < 2 * k) return hipErrorInvalidValue;
@@ -375,7 +403,7 @@ hipError_t msr_gemm_candidates(const GemmIndex& g, const DenseIndex& ix, const f
     // ---- finish: bucket, per-document maxima, candidates ----
     gemm_bucket_kernel<<<dim3(2, (unsigned)grid * 8), 256, 0, stream>>>((const int4*)g.wgbuf, g.wv_cap, g.wv_count, g.thr2,
                                                                        (int2*)g.pairs, GM_PAIR_CAP, g.pair_n);
-    gemm_cand_kernel<<<nq, 1024, 0, stream>>>((const int2*)g.pairs, g.pair_n, ix.chunk_doc, g.wv_count, grid * 8, g.wv_cap,
-                                              g.flag, k, margin, cand_doc, cand_n);
+    gemm_cand_kernel<<<nq, 1024, 0, stream>>>((int2*)g.pairs, g.pair_n, ix.chunk_doc, ix.n_chunks, g.wv_count, grid * 8, g.wv_cap,
+                                              g.flag, k, margin, cand_doc, cand_first_len, cand_n);
     return hipGetLastError();
 }

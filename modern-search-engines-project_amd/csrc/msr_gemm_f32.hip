@@ -11,8 +11,8 @@
 // for the normalised query (f16_margin_kernel); |s^ - s| <= eps_q = dE (1 + dq) + dq (Cauchy-Schwarz twice, the argument
 // of msr_batch.hip).  With t^ the k-th largest per-document s^, every document of the exact top-k has
 // s^ >= t^ - 2 eps_q, so keeping everything above (a lower bound of t^) - margin_q, margin_q = 2 eps_q + 1e-4, loses
-// nothing; the survivors' cosines are then recomputed in plain f32 from the f32 rows (msr_batch_rescore) and sorted
-// exactly.  Typical margin: 1.1e-3.  Every RETURNED score is an exact f32 cosine.
+// nothing; the survivors' cosines are then recomputed in plain f32 from the f32 rows (msr_batch_rescore_rows: the emitted
+// rows of each candidate document) and sorted exactly.  Typical margin: 1.1e-3.  Every RETURNED score is an exact f32 cosine.
 //
 // No score matrix, no score rows: row tiles (<= 256 rows) are cut at document boundaries, so the k-th largest TILE
 // MAXIMUM is attained by k different documents -- a lower bound of t^.  Pass 1 (every ss-th tile) computes tile maxima
@@ -898,16 +898,24 @@ __global__ __launch_bounds__(256) void f16_margin_kernel(const float* __restrict
     }
 }
 
-// One workgroup per query: entries (row, approximate score) -> the distinct documents they belong to = the candidates
-// whose exact f32 cosines msr_batch_rescore computes.  Overflow on the way: no candidates and gate[q / 64] |= 1 -- one
+// One workgroup per query: entries (row, approximate score) -> the distinct documents they belong to = the candidates, each
+// with the run of ITS emitted rows: the entries are sorted by (document, row) and the rows written back over pairs[q][.].x in
+// that order; cand_first_len[slot] = first | len << 13 names the candidate's run.  msr_batch_rescore_rows computes the exact
+// f32 cosines of exactly those rows.  That is enough: a row whose exact cosine is >= the exact k-th document score sigma has
+// an approximate score >= sigma - eps >= thr2, so it was emitted -- for every document with max-cosine >= sigma the arg-max
+// row (and every row tied with it) is among its emitted rows and the document's score comes out exact; a document below
+// sigma gets a score <= its true one and stays below.  (Rescoring all rows of each candidate document, as rounds 2-4 did,
+// read ~5 x the bytes.)  Overflow on the way: no candidates and gate[q / 64] |= 1 -- one
 // gate word per slice of 64 queries, the unit of the caller's gated sweeps, so a query with a huge tie group sends its own
 // slice back to the sweeps, not the whole call (an overflowing wave buffer concerns every query: all slices).
-__global__ __launch_bounds__(1024) void gemm_f32_cand_kernel(const int2* __restrict__ pairs, int32_t* __restrict__ pair_n,
+static_assert(GF_PAIR_CAP <= (1 << 13), "cand_first_len packs first and len into 13 bits each");
+__global__ __launch_bounds__(1024) void gemm_f32_cand_kernel(int2* __restrict__ pairs, int32_t* __restrict__ pair_n,
                                                               const int32_t* __restrict__ chunk_doc, int64_t n_rows,
                                                               const int32_t* __restrict__ wv_count, int n_waves, int wv_cap,
                                                               const int32_t* __restrict__ flag, int32_t* __restrict__ cand_doc,
+                                                              int32_t* __restrict__ cand_first_len,
                                                               int32_t* __restrict__ cand_n, int32_t* __restrict__ gate) {
-    __shared__ uint32_t key[GF_PAIR_CAP];
+    __shared__ uint64_t key[GF_PAIR_CAP];               // (document + 1) << 32 | row; 0 = pad / an entry that names no row
     __shared__ int s_over, s_n;
     const int q = blockIdx.x, t = threadIdx.x;
     const int raw = pair_n[q];
@@ -924,10 +932,11 @@ __global__ __launch_bounds__(1024) void gemm_f32_cand_kernel(const int2* __restr
     int P = 64;
     while (P < raw) P <<= 1;
     for (int i = t; i < P; i += 1024) {
-        uint32_t kk = 0u;                               // (pad key)
+        uint64_t kk = 0u;                               // (pad key)
         if (i < raw) {
             const int64_t row = pairs[(size_t)q * GF_PAIR_CAP + i].x;
-            if (row >= 0 && row < n_rows) kk = (uint32_t)chunk_doc[row] + 1u;   // (a row index is never trusted as an address)
+            if (row >= 0 && row < n_rows)               // (a row index is never trusted as an address)
+                kk = ((uint64_t)((uint32_t)chunk_doc[row] + 1u) << 32) | (uint32_t)row;
         }
         key[i] = kk;
     }
@@ -938,13 +947,25 @@ __global__ __launch_bounds__(1024) void gemm_f32_cand_kernel(const int2* __restr
                 const int i = ((idx & ~(j - 1)) << 1) | (idx & (j - 1));
                 const int p = i | j;
                 const bool desc = (i & kk) == 0;
-                const uint32_t a = key[i], b = key[p];
+                const uint64_t a = key[i], b = key[p];
                 if (desc ? a < b : a > b) { key[i] = b; key[p] = a; }
             }
             __syncthreads();
         }
-    for (int i = t; i < P; i += 1024)
-        if (key[i] != 0 && (i == 0 || key[i] != key[i - 1])) cand_doc[(size_t)q * MSR_SEL_CAP + atomicAdd(&s_n, 1)] = (int32_t)(key[i] - 1u);
+    // (descending: the pads end up behind the entries; a document's rows are adjacent, highest row first)
+    for (int i = t; i < P; i += 1024) {
+        const uint64_t kk = key[i];
+        if (kk == 0) continue;
+        pairs[(size_t)q * GF_PAIR_CAP + i].x = (int32_t)(uint32_t)kk;
+        const uint32_t d = (uint32_t)(kk >> 32);
+        if (i == 0 || (uint32_t)(key[i - 1] >> 32) != d) {
+            int len = 1;
+            while (i + len < P && (uint32_t)(key[i + len] >> 32) == d) ++len;
+            const int slot = atomicAdd(&s_n, 1);
+            cand_doc[(size_t)q * MSR_SEL_CAP + slot] = (int32_t)(d - 1u);
+            cand_first_len[(size_t)q * MSR_SEL_CAP + slot] = i | (len << 13);
+        }
+    }
     __syncthreads();
     if (t == 0) { cand_n[q] = s_n; pair_n[q] = 0; }
 }
@@ -1185,11 +1206,12 @@ hipError_t msr_gemm_f32_finish(const GemmF32Index& g, const DenseIndex& ix, cons
         if ((err = hipGetLastError()) != hipSuccess) return err;
     }
     if ((err = msr_gemm_bucket(g.wvbuf, wv_cap, g.wv_count, grid * waves, g.thr2, g.pairs, g.pair_n, stream)) != hipSuccess) return err;
-    gemm_f32_cand_kernel<<<nq, 1024, 0, stream>>>((const int2*)g.pairs, g.pair_n, ix.chunk_doc, ix.n_chunks, g.wv_count, grid * waves,
-                                                  wv_cap, g.flag, g.cand_doc, g.cand_n, gate);
+    // candidates with the runs of their emitted rows (cand_chunk carries first | len << 13 in, the arg-max row out)
+    gemm_f32_cand_kernel<<<nq, 1024, 0, stream>>>((int2*)g.pairs, g.pair_n, ix.chunk_doc, ix.n_chunks, g.wv_count, grid * waves,
+                                                  wv_cap, g.flag, g.cand_doc, g.cand_chunk, g.cand_n, gate);
     if ((err = hipGetLastError()) != hipSuccess) return err;
-    return msr_batch_rescore(ix, qn, nq, k, 0, g.cand_doc, g.cand_score, g.cand_chunk, g.cand_n, out_doc, out_score, out_chunk,
-                             out_n, stream);
+    return msr_batch_rescore_rows(ix, qn, nq, k, (const int32_t*)g.pairs, 2, GF_PAIR_CAP, g.cand_doc, g.cand_score, g.cand_chunk,
+                                  g.cand_n, out_doc, out_score, out_chunk, out_n, stream);
 }
 
 hipError_t msr_gemm_f32_topk(const GemmF32Index& g, const DenseIndex& ix, const float* qn, int nq, int k,

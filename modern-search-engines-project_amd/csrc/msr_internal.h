@@ -268,10 +268,11 @@ hipError_t msr_unit_bf16_rows(const float* src, const float* inv_norm, int64_t n
 // margin[q] = 2 (dE (1 + dq) + dq) + slack from the MEASURED rounding errors of the image (err_max) and of query q
 hipError_t msr_batch_margin(const float* qn, int nq, const uint32_t* err_max, float* margin, hipStream_t stream);
 // qn: [nq][768] normalised f32 queries, nq <= g.max_queries.  Fills cand_doc[q][MSR_SEL_CAP] / cand_n[q] (cand_n =
-// MSR_SEL_CAP + 1: overflow, rerun that query on the exact path) for msr_batch_rescore.  ev (nullable): 4 events recorded
-// around the sample pass (0, 1) and the emit pass (2, 3).
+// MSR_SEL_CAP + 1: overflow, rerun that query on the exact path) and cand_first_len[q][MSR_SEL_CAP] (the run of the
+// candidate's emitted rows in g.pairs: first | len << 13, msr_gemm_pair_cap() entries of 2 words per query) for
+// msr_batch_rescore_rows.  ev (nullable): 4 events recorded around the sample pass (0, 1) and the emit pass (2, 3).
 hipError_t msr_gemm_candidates(const GemmIndex& g, const DenseIndex& ix, const float* qn, int nq, int k, const float* margin,
-                               int32_t* cand_doc, int32_t* cand_n, hipEvent_t* ev,
+                               int32_t* cand_doc, int32_t* cand_first_len, int32_t* cand_n, hipEvent_t* ev,
                                hipStream_t stream);
 
 // Rows a workgroup of the 256-query streaming kernel loads per tile visit, from the tile's first row on and whatever the
@@ -351,10 +352,12 @@ hipError_t msr_gemm_f32_finish(const GemmF32Index& g, const DenseIndex& ix, cons
                                hipStream_t stream);
 
 // ---- K5: batched bf16 candidate scan finished exactly in f32 (msr_batch.hip) -----------------------
-// exact f32 rescoring + final sort of candidate lists that are already filled (cand_n zeroed on return)
-hipError_t msr_batch_rescore(const DenseIndex& ix, const float* qn, int nq, int k, int max_chunks, int32_t* cand_doc,
-                             float* cand_score, int32_t* cand_chunk, int32_t* cand_n, int32_t* out_doc, float* out_score,
-                             int32_t* out_chunk, int32_t* out_n, hipStream_t stream);
+// exact f32 rescoring + final sort of candidate lists that are already filled (cand_n zeroed on return); the candidates name
+// the rows to rescore (row j of candidate slot: rows[(q * row_cap + first + j) * row_stride], first | len << 13 in
+// cand_chunk[q][slot] on entry; cand_chunk <- the arg-max row): the finish of both streaming passes (f32 rows, bf16 image).
+hipError_t msr_batch_rescore_rows(const DenseIndex& ix, const float* qn, int nq, int k, const int32_t* rows, int row_stride,
+                                  int row_cap, int32_t* cand_doc, float* cand_score, int32_t* cand_chunk, int32_t* cand_n,
+                                  int32_t* out_doc, float* out_score, int32_t* out_chunk, int32_t* out_n, hipStream_t stream);
 hipError_t msr_batch_finish(const DenseIndex& ix, const float* qn, int nq, int k, int max_chunks, const float* margin,
                             const float* scores, const float* top_score, const int32_t* top_n, int32_t* cand_doc,
                             float* cand_score, int32_t* cand_chunk, int32_t* cand_n, int32_t* out_doc,

@@ -607,6 +607,53 @@ def test_streaming_pass_vs_oracle_and_query_groups(mods):
     eng.close()
 
 
+def test_streaming_finish_rescores_the_emitted_rows_only(mods):
+    """The streaming pass' finish recomputes in f32 only the rows the pass emitted for a candidate document (not all of its
+    rows): the scores, the order and the FIRST arg-max row must still be the oracle's.  Documents built to stress that: one
+    with two identical best rows (rows 1 and 3 of 5: the lower one wins), one whose best row is its last, one of 200 rows with
+    a single good row in the middle; queries are those rows, scaled; both kernel widths (128 and 256 queries per pass), a
+    batch of 300 on an engine that puts two query groups into one launch (the f16 image), and the bf16-candidate path."""
+    rng = np.random.default_rng(17)
+    n_docs = 40000
+    n = rng.integers(1, 8, size=n_docs)
+    n[100] = 5; n[200] = 4; n[300] = 200
+    doc_off = np.zeros(n_docs + 1, np.int64); doc_off[1:] = np.cumsum(n)
+    C = int(doc_off[-1])
+    emb = rng.standard_normal((C, 768)).astype(np.float32)
+    emb /= np.linalg.norm(emb, axis=1, keepdims=True)
+    a, b, c = int(doc_off[100]), int(doc_off[200]), int(doc_off[300])
+    emb[a + 3] = emb[a + 1]                                   # an exact tie inside document 100
+    ix = mods["CorpusIndex"](doc_ids=np.arange(n_docs, dtype=np.int64), doc_off=doc_off.astype(np.int32),
+                             chunk_ids=np.arange(C, dtype=np.int64), emb=emb, total_docs=n_docs)
+    q = rng.standard_normal((300, 768)).astype(np.float32)
+    q[0] = emb[a + 1] * 2.5                                   # both copies score 1.0
+    q[1] = emb[b + 3] * 0.7                                   # the last row of document 200
+    q[2] = emb[c + 117] * 4.0                                 # one row of the 200-row document
+    q[3] = emb[a + 1] + 0.3 * q[3] / np.linalg.norm(q[3])     # near the tied pair: still tied with each other
+    pick = [0, 1, 2, 3, 50, 99]
+    for max_q, Q, width in ((64, 100, 128), (256, 200, 256), (512, 300, 256)):
+        eng = mods["DeviceEngine"](ix, max_queries=max_q, max_k=100, rerank_max_docs=0)
+        assert eng.scan_width() == width
+        got = eng.dense_topk(q[:Q], k=100)
+        assert eng.dense_path() == width
+        _check_dense(mods, eng, doc_off, emb, q[pick], 100, 0, [x[pick] for x in got])
+        doc, score, chunk, _ = [x.cpu().numpy() for x in got]
+        assert doc[0, 0] == 100 and chunk[0, 0] == a + 1 and abs(score[0, 0] - 1.0) <= 1e-6      # first arg-max of the tie
+        assert doc[1, 0] == 200 and chunk[1, 0] == b + 3
+        assert doc[2, 0] == 300 and chunk[2, 0] == c + 117
+        assert doc[3, 0] == 100 and chunk[3, 0] == a + 1
+        if max_q == 512:
+            # the batched path (bf16 candidates, K5) finishes the same way: the emitted rows of each candidate, in exact f32
+            eng.enable_bf16()
+            assert eng.batch_gemm_ok()
+            got = eng.dense_topk_batched(q[:Q], k=100)
+            _check_dense(mods, eng, doc_off, emb, q[pick], 100, 0, [x[pick] for x in got])
+            doc, score, chunk, _ = [x.cpu().numpy() for x in got]
+            assert [int(doc[i, 0]) for i in range(4)] == [100, 200, 300, 100]
+            assert [int(chunk[i, 0]) for i in range(4)] == [a + 1, b + 3, c + 117, a + 1]
+        eng.close()
+
+
 def test_dense_cosine_golden(mods):
     """One chunk per document: the engine's scores are the reference's cosine_similarity values."""
     z = np.load(os.path.join(G, "cosine.npz"))
