@@ -114,7 +114,8 @@ __global__ __launch_bounds__(BT_THREADS) void rescore_kernel(DenseIndex ix, cons
 
 // The same for candidates that come with the rows to look at (the f32 streaming pass: gemm_f32_cand_kernel): candidate slot
 // of query q owns rows[(q * row_cap + first + j) * row_stride], j < len, with first | len << 13 in cand_chunk[q][slot] on
-// entry -- a document's rows in DESCENDING order; walked from the back, so that the first arg-max is the lowest row as above.
+// entry -- a document's rows in any order (the f32 pass hands them over in descending order and they are walked from the
+// back; the bf16 pass orders them by approximate score): the arg-max is the LOWEST row among equal maxima, as above.
 // Same arithmetic per row as rescore_kernel.  cand_chunk[q][slot] <- the arg-max row.
 __global__ __launch_bounds__(BT_THREADS) void rescore_rows_kernel(DenseIndex ix, const float* __restrict__ qn,
                                                                    const int32_t* __restrict__ rows, int row_stride, int row_cap,
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(BT_THREADS) void rescore_rows_kernel(DenseIndex ix,
             s += e.x * qc.x + e.y * qc.y + e.z * qc.z + e.w * qc.w;
             for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
             s *= ix.inv_norm[c];
-            if (s > best) { best = s; arg = c; }
+            if (s > best || (s == best && c < arg)) { best = s; arg = c; }   // (the FIRST arg-max, whatever the order of the run)
         }
         if (lane == 0) {
             cand_score[(int64_t)q * MSR_SEL_CAP + slot] = best;
