@@ -935,7 +935,13 @@ def main():
                 roof["rows_read_from"] = ("the engine's f16 image of the rows (launches of several 256-query groups: the values a one-group "
                                           "launch converts from the f32 rows in registers -- same candidates, same results bit for bit; "
                                           "1536 B per row, which is what algorithmic_bytes_per_launch counts here)")
-                roof["f16_matrix_TFLOPs"] = 2.0 * 768 * n_ch * q_launch / (per_launch_ms * 1e-3) / 1e12
+                # such a launch is bound by the matrix pipes (2 * 768 flop per row and query on v_mfma_f32_16x16x32_f16; the dense
+                # f16 peak is the bf16 one), not by HBM: 7.7 GB in ~4 / ~8 ms
+                flops = 2.0 * 768 * n_ch * q_launch
+                tf = flops / (per_launch_ms * 1e-3) / 1e12
+                roof.update({"bound": "mfma", "achieved": tf, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": tf / BF16_MFMA_PEAK_TFLOPS, "algorithmic_flops_per_launch": flops,
+                             "hbm_GBps_algorithmic": achieved})
             elif kname.startswith("gemm_stream256"):
                 state = eng.row_copy_state()
                 roof["rows_read_from"] = ("the engine's fragment-order copy of the f32 matrix (the same values, laid out so that a load "
