@@ -386,7 +386,8 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t u) {
 // F16I = true (with BF16 = true, which stands for the data path of a row-major 16-bit image): the image holds the f32 rows
 // AS THE f32 PASS CONVERTS THEM (f16, round to nearest, not normalised) -- the products, thresholds, margins and emitted entries
 // are those of the f32 rows' pass bit for bit; only the conversion is not done again by every query group of a launch.  f16
-// matrix instructions, the rows' inverse norms in the epilogue and per-wave tile maxima as on the f32 rows.
+// matrix instructions and the rows' inverse norms in the epilogue as on the f32 rows, the waves' tile maxima joined in LDS as
+// on the bf16 image.
 template <bool EMIT, bool BF16, bool TILED = false, bool NTL = false, bool F16I = false>
 __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args a) {
     static_assert(!F16I || (BF16 && !TILED && !NTL), "the f16 image takes the 16-bit image's data path");
@@ -460,8 +461,9 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_stream256_kernel(GemmF32Args 
     // eight waves' maxima of a (tile, query) are joined in LDS (atomic max on order-preserving keys; two sets, by tile
     // parity) and written as ONE row of 256 per tile -- after the first barrier of the NEXT tile, which every wave passes
     // only with its epilogue behind it.  f32 rows (160 MB per 256-query pass, 1 % of its traffic): every wave stores its own
-    // row as before -- the join costs the pass 1.3 % and saves the transposing kernel the same.
-    constexpr bool JOIN = BF16 && !F16I;
+    // row as before -- the join costs the pass 1.3 % and saves the transposing kernel the same.  The f16 image of the rows
+    // (launches of several query groups) joins like the bf16 image: the maximum of the same values either way.
+    constexpr bool JOIN = BF16;
     uint32_t* tmx = (uint32_t*)(smem + G2_TMX);
     if (JOIN) tmx[tid] = 0u;                            // (512 threads, 2 x 256 keys; 0 orders below every float)
     auto flush_tmax = [&](int tile_j, int par) {        // wave w: queries 32 w .. + 31 of the tile whose maxima sit in set par
@@ -1151,6 +1153,7 @@ hipError_t msr_gemm_f32_pass(const GemmF32Index& g, const DenseIndex& ix, const 
 #endif
     if (tiled) { a.E = (const char*)g.emb_tiled; a.tile_trow = g.tile_trow; }
     if (image16) a.E = (const char*)g.emb_f16;
+    const int tmax_parts = image16 ? 1 : waves;         // (the 16-bit image's data path joins the waves' tile maxima in LDS: one row per tile)
     a.n_rows = ix.n_chunks; a.tmax_t = g.tmax_t;
     // ---- pass 1 of every group: maxima of every ss-th tile -> emission thresholds ----
     a.t_first = ss / 2; a.t_stride = ss; a.t_count = n_s;
@@ -1160,7 +1163,7 @@ hipError_t msr_gemm_f32_pass(const GemmF32Index& g, const DenseIndex& ix, const 
         if (ev && gi == 0 && (err = hipEventRecord(ev[0], stream)) != hipSuccess) return err;
         if ((err = launch_f32(W, false, a, grid, stream, tiled, image16)) != hipSuccess) return err;
         if (ev && gi == 0 && (err = hipEventRecord(ev[1], stream)) != hipSuccess) return err;
-        if ((err = msr_gemm_tmax(g.tmax_t, n_s, waves, W * a.nt, g.tmax + (size_t)gi * W * g.tmax_stride, g.tmax_stride, stream)) != hipSuccess) return err;
+        if ((err = msr_gemm_tmax(g.tmax_t, n_s, tmax_parts, W * a.nt, g.tmax + (size_t)gi * W * g.tmax_stride, g.tmax_stride, stream)) != hipSuccess) return err;
     }
     if ((err = msr_gemm_kth(g.tmax, n_s, g.tmax_stride, nq, W * G, k, margin, g.thr, g.flag, stream)) != hipSuccess) return err;
     // ---- pass 2 of every group: maxima of all tiles + the entries at or above the threshold (one set of wave buffers) ----
@@ -1173,7 +1176,7 @@ hipError_t msr_gemm_f32_pass(const GemmF32Index& g, const DenseIndex& ix, const 
         if (ev && gi == 0 && (err = hipEventRecord(ev[2], stream)) != hipSuccess) return err;
         if ((err = launch_f32(W, true, a, grid, stream, tiled, image16)) != hipSuccess) return err;
         if (ev && gi == 0 && (err = hipEventRecord(ev[3], stream)) != hipSuccess) return err;
-        if ((err = msr_gemm_tmax(g.tmax_t, g.n_tiles, waves, W * a.nt, g.tmax + (size_t)gi * W * g.tmax_stride, g.tmax_stride, stream)) != hipSuccess) return err;
+        if ((err = msr_gemm_tmax(g.tmax_t, g.n_tiles, tmax_parts, W * a.nt, g.tmax + (size_t)gi * W * g.tmax_stride, g.tmax_stride, stream)) != hipSuccess) return err;
     }
     if ((err = msr_gemm_kth(g.tmax, g.n_tiles, g.tmax_stride, nq, W * G, k, margin, g.thr2, nullptr, stream)) != hipSuccess) return err;
     // (sharded callers: what this shard can vouch for towards the k-th score over all shards, see msr_internal.h)
