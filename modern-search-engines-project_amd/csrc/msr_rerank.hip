@@ -31,8 +31,10 @@ constexpr int RR_MAXM = 1024;
 // sharded run has work for -- 2 M waves per 2048-query step at N = 8, most of which only wrote zeros: 2.2 ms instead of 0.7;
 // workgroups of several waves sharing a block lose 12 % on the unsharded corpus, where every slot is work: a workgroup
 // keeps its place on the CU until its slowest wave is done.)
+// SLOTS = 1 (calls of a few queries, no records): one wave per candidate slot -- a single query has 1000 slots, i.e. 125 waves
+// of 8 slots each on a chip with room for thousands; its gather took 43 us of one after the other.
 constexpr int RC_SLOTS = 8;
-template <bool TILED>
+template <bool TILED, int SLOTS = RC_SLOTS>
 __global__ __launch_bounds__(64) void rerank_cos_kernel(DenseIndex ix, const int32_t* __restrict__ url_group,
                                                          const float* __restrict__ qn,
                                                          const int32_t* __restrict__ cand_doc,
@@ -45,14 +47,14 @@ __global__ __launch_bounds__(64) void rerank_cos_kernel(DenseIndex ix, const int
     // (one contiguous array: q_per_block >= the number of queries; the blocks of an all-to-all send buffer: see msretr.h).
     // RECORDS (rec.out != null): nothing is written for the slots this shard does not own; an owned slot becomes a 16-word
     // record [slot, rows, url group + 2, first row, cos x 10, query, 0] at the place rerank_plan_kernel counted out for it.
-    const int q = blockIdx.y, m0 = blockIdx.x * RC_SLOTS, lane = threadIdx.x;
+    const int q = blockIdx.y, m0 = blockIdx.x * SLOTS, lane = threadIdx.x;
     const bool records = rec.out != nullptr;
     cos_out += (int64_t)(q / q_per_block) * block_stride + (int64_t)(q % q_per_block) * max_cand * RR_MAXC;
     meta += (int64_t)(q / q_per_block) * block_stride + (int64_t)(q % q_per_block) * max_cand * 3;
     int d_mine = -1;
     {
         const int m = m0 + lane;
-        const bool slot = lane < RC_SLOTS && m < max_cand;
+        const bool slot = lane < SLOTS && m < max_cand;
         if (slot && m < cand_n[q]) d_mine = cand_doc[(int64_t)q * max_cand + m] - doc_base;
         const bool own = d_mine >= 0 && d_mine < ix.n_docs;
         if (!own) d_mine = -1;
@@ -570,6 +572,16 @@ hipError_t msr_rerank_gather(const DenseIndex& ix, const int32_t* url_group, con
                              int64_t block_stride, const RerankRecords& rec, hipStream_t stream) {
     if (nq <= 0) return hipSuccess;
     if (max_cand <= 0 || max_cand > RR_MAXM || max_chunks <= 0 || max_chunks > RR_MAXC || q_per_block < 1) return hipErrorInvalidValue;
+    if (rec.out == nullptr && (int64_t)nq * max_cand <= 16384) {      // a few queries: one wave per slot
+        dim3 grid1((unsigned)max_cand, (unsigned)nq);
+        if (ix.layout == 1)
+            rerank_cos_kernel<true, 1><<<grid1, 64, 0, stream>>>(ix, url_group, qn, cand_doc, cand_n, max_cand, doc_base,
+                                                                 row_base, max_chunks, cos_out, meta, q_per_block, block_stride, rec);
+        else
+            rerank_cos_kernel<false, 1><<<grid1, 64, 0, stream>>>(ix, url_group, qn, cand_doc, cand_n, max_cand, doc_base,
+                                                                  row_base, max_chunks, cos_out, meta, q_per_block, block_stride, rec);
+        return hipGetLastError();
+    }
     dim3 grid((unsigned)((max_cand + RC_SLOTS - 1) / RC_SLOTS), (unsigned)nq);
     if (ix.layout == 1)
         rerank_cos_kernel<true><<<grid, 64, 0, stream>>>(ix, url_group, qn, cand_doc, cand_n, max_cand, doc_base,
