@@ -462,3 +462,59 @@ def test_native_line_formatter_equals_python_format():
                   for q in range(Q) for r in range(n[q])).encode()
     assert got == exp
     assert lf.format([], np.zeros((0, 0), np.int32), np.zeros((0, 0)), np.zeros(0, np.int32)) == b""
+
+
+def test_emitted_rows_suffice_for_the_exact_top_k():
+    """The invariant behind the streaming passes' finish (msr_batch_rescore_rows recomputes only the rows the
+    pass emitted for a candidate document), checked on the CPU with the pass' own arithmetic restated in numpy: products of
+    f16(e) and f16(q^) accumulated in f32, the measured margin 2 (dE (1 + dq) + dq) + 1e-4, the bucket's bound = (k-th largest
+    TILE maximum) - margin.  For every document whose exact max-cosine reaches the exact k-th document score: its arg-max row
+    -- every row tied with it -- is among the emitted rows, so the maximum over the emitted rows IS the document's score; for
+    every other document the maximum over its emitted rows cannot lift it above the k-th."""
+    rng = np.random.default_rng(5)
+    n_docs, k = 14000, 100
+    n = rng.integers(1, 9, size=n_docs)
+    off = np.zeros(n_docs + 1, np.int64); off[1:] = np.cumsum(n)
+    C = int(off[-1])
+    chunk_doc = np.repeat(np.arange(n_docs), n)
+    emb = rng.standard_normal((C, 768)).astype(np.float32)
+    emb *= (rng.uniform(0.6, 1.8, size=(C, 1)) / np.linalg.norm(emb, axis=1, keepdims=True)).astype(np.float32)
+    emb[off[77] + 2] = emb[off[77]]                            # two identical rows inside one document
+    inv = (1.0 / np.linalg.norm(emb.astype(np.float64), axis=1)).astype(np.float32)
+    e16 = emb.astype(np.float16).astype(np.float32)
+    dE = float(np.max(np.linalg.norm((emb - e16).astype(np.float64), axis=1) * inv))
+    # row tiles of <= 256 rows cut at document boundaries (the k-th largest tile maximum is attained by k documents)
+    tiles, start = [], 0
+    for d in range(n_docs):
+        if off[d + 1] - off[start] > 256:
+            tiles.append((off[start], off[d])); start = d
+    tiles.append((off[start], off[n_docs]))
+    assert len(tiles) >= 2 * k
+    for trial in range(6):
+        q = rng.standard_normal(768).astype(np.float32)
+        if trial == 0:
+            q = emb[off[77]] * 3.0                             # the tied pair is the best document
+        if trial == 1:
+            q = emb[rng.integers(0, C)] + 0.5 * q / np.linalg.norm(q)
+        qn = (q / np.linalg.norm(q.astype(np.float64))).astype(np.float32)
+        q16 = qn.astype(np.float16).astype(np.float32)
+        dq = float(np.linalg.norm((qn - q16).astype(np.float64)))
+        margin = 2.0 * (dE * (1.0 + dq) + dq) + 1e-4
+        approx = (e16 @ q16) * inv                             # the pass' scores (f32 accumulation of f16 products)
+        exact = (emb @ qn) * inv                               # what the finish recomputes
+        assert np.abs(approx - exact).max() <= 0.5 * margin    # the measured bound holds
+        tmax = np.array([approx[a:b].max() for a, b in tiles])
+        bound = np.sort(tmax)[-k] - margin                     # thr2
+        emitted = approx >= bound
+        doc_exact = np.maximum.reduceat(exact, off[:-1])
+        doc_emit = np.full(n_docs, -np.inf, np.float32)
+        np.maximum.at(doc_emit, chunk_doc[emitted], exact[emitted])
+        sigma = np.sort(doc_exact)[-k]
+        top = doc_exact >= sigma
+        assert np.array_equal(doc_emit[top], doc_exact[top])                  # exact scores for everything that can be returned
+        assert np.all(doc_emit[~top] <= doc_exact[~top]) and np.all(doc_emit[~top] < sigma)
+        for d in np.nonzero(top)[0]:                           # ... and the FIRST arg-max row is among the emitted ones
+            rows = np.arange(off[d], off[d + 1])
+            first = rows[np.argmax(exact[rows])]
+            assert emitted[first]
+        assert emitted.sum() < 40 * k                          # (the filter filters: a few rows per candidate)
